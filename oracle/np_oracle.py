@@ -1,0 +1,683 @@
+"""TEST INFRASTRUCTURE ONLY -- float64 NumPy restatement of the reference hot path.
+
+Every function cites the reference lines it follows (paths relative to the
+reference checkout).  ``[UPSTREAM]`` marks behaviour of gym-pybullet-drones /
+pybullet, which are NOT in the reference tree and not installable here; those
+functions follow the specification recorded in SURVEY.md section 3.4 and their
+parity against real PyBullet is UNPINNED.  Everything restated from in-tree files
+is pinned by ``tests/golden/*.npz`` (minted from the reference by
+``tests/golden/mint_golden.py``).
+
+All functions are batched over leading axes and compute in float64.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# drone constants  ([UPSTREAM] cf2p.urdf / cf2x.urdf; cross-checked against
+# utils/graph_fedce.py:9 and model/dynamics.py:38-39)
+# --------------------------------------------------------------------------------------
+
+
+@dataclass
+class DroneConsts:
+    M: float = 0.027
+    L: float = 0.0397
+    KF: float = 3.16e-10
+    KM: float = 7.94e-12
+    J: tuple = (2.3951e-5, 2.3951e-5, 3.2347e-5)  # cf2p
+    G: float = 9.8
+    THRUST2WEIGHT: float = 2.25
+    DRAG: tuple = (9.1785e-7, 9.1785e-7, 10.311e-7)
+    MODEL: str = "cf2p"
+    GRAVITY: float = field(init=False)
+    HOVER_RPM: float = field(init=False)
+    MAX_RPM: float = field(init=False)
+    MAX_THRUST: float = field(init=False)
+    MAX_XY_TORQUE: float = field(init=False)
+    MAX_Z_TORQUE: float = field(init=False)
+
+    def __post_init__(self):
+        # [UPSTREAM] BaseAviary.__init__
+        self.GRAVITY = self.G * self.M
+        self.HOVER_RPM = np.sqrt(self.GRAVITY / (4 * self.KF))
+        self.MAX_RPM = np.sqrt((self.THRUST2WEIGHT * self.GRAVITY) / (4 * self.KF))
+        self.MAX_THRUST = 4 * self.KF * self.MAX_RPM ** 2
+        if self.MODEL == "cf2x":
+            self.MAX_XY_TORQUE = (2 * self.L * self.KF * self.MAX_RPM ** 2) / np.sqrt(2)
+        else:
+            self.MAX_XY_TORQUE = self.L * self.KF * self.MAX_RPM ** 2
+        self.MAX_Z_TORQUE = 2 * self.KM * self.MAX_RPM ** 2
+
+
+CF2P = DroneConsts()
+CF2X = DroneConsts(J=(1.4e-5, 1.4e-5, 2.17e-5), MODEL="cf2x")
+
+# --------------------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------------------
+
+
+def cross(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.stack([a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1],
+                     a[..., 2] * b[..., 0] - a[..., 0] * b[..., 2],
+                     a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]], axis=-1)
+
+
+def norm(a):
+    return np.sqrt(np.sum(np.asarray(a, dtype=np.float64) ** 2, axis=-1))
+
+
+def matvec(R, v):
+    return np.einsum("...ij,...j->...i", R, v)
+
+
+def matTvec(R, v):
+    return np.einsum("...ji,...j->...i", R, v)
+
+
+def quat_to_rotmat_scipy(q):
+    """scipy ``Rotation.from_quat(q).as_matrix()`` (normalising, xyzw) as used by
+    utils/model_conversions.py:110."""
+    q = np.asarray(q, dtype=np.float64)
+    q = q / norm(q)[..., None]
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    x2, y2, z2, w2 = x * x, y * y, z * z, w * w
+    xy, zw, xz, yw, yz, xw = x * y, z * w, x * z, y * w, y * z, x * w
+    R = np.empty(q.shape[:-1] + (3, 3))
+    R[..., 0, 0] = x2 - y2 - z2 + w2
+    R[..., 1, 0] = 2 * (xy + zw)
+    R[..., 2, 0] = 2 * (xz - yw)
+    R[..., 0, 1] = 2 * (xy - zw)
+    R[..., 1, 1] = -x2 + y2 - z2 + w2
+    R[..., 2, 1] = 2 * (yz + xw)
+    R[..., 0, 2] = 2 * (xz + yw)
+    R[..., 1, 2] = 2 * (yz - xw)
+    R[..., 2, 2] = -x2 - y2 + z2 + w2
+    return R
+
+
+def quat_to_rotmat_bullet(q):
+    """[UPSTREAM] ``p.getMatrixFromQuaternion`` (btMatrix3x3::setRotation: s = 2/|q|^2)."""
+    q = np.asarray(q, dtype=np.float64)
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    d = x * x + y * y + z * z + w * w
+    s = 2.0 / d
+    xs, ys, zs = x * s, y * s, z * s
+    wx, wy, wz = w * xs, w * ys, w * zs
+    xx, xy, xz = x * xs, x * ys, x * zs
+    yy, yz, zz = y * ys, y * zs, z * zs
+    R = np.empty(q.shape[:-1] + (3, 3))
+    R[..., 0, 0] = 1.0 - (yy + zz)
+    R[..., 0, 1] = xy - wz
+    R[..., 0, 2] = xz + wy
+    R[..., 1, 0] = xy + wz
+    R[..., 1, 1] = 1.0 - (xx + zz)
+    R[..., 1, 2] = yz - wx
+    R[..., 2, 0] = xz - wy
+    R[..., 2, 1] = yz + wx
+    R[..., 2, 2] = 1.0 - (xx + yy)
+    return R
+
+
+def quat_from_euler_bullet(rpy):
+    """[UPSTREAM] ``p.getQuaternionFromEuler`` (btQuaternion::setEulerZYX), xyzw."""
+    rpy = np.asarray(rpy, dtype=np.float64)
+    hr, hp, hy = rpy[..., 0] * 0.5, rpy[..., 1] * 0.5, rpy[..., 2] * 0.5
+    cr, sr, cp, sp, cy, sy = np.cos(hr), np.sin(hr), np.cos(hp), np.sin(hp), np.cos(hy), np.sin(hy)
+    return np.stack([sr * cp * cy - cr * sp * sy,
+                     cr * sp * cy + sr * cp * sy,
+                     cr * cp * sy - sr * sp * cy,
+                     cr * cp * cy + sr * sp * sy], axis=-1)
+
+
+def euler_from_quat_bullet(q):
+    """[UPSTREAM] ``p.getEulerFromQuaternion``: ZYX with the
+    +-0.99999 gimbal branches."""
+    q = np.asarray(q, dtype=np.float64)
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    sqx, sqy, sqz, squ = x * x, y * y, z * z, w * w
+    sarg = -2.0 * (x * z - w * y)
+    roll = np.arctan2(2 * (y * z + w * x), squ - sqx - sqy + sqz)
+    pitch = np.arcsin(np.clip(sarg, -1.0, 1.0))
+    yaw = np.arctan2(2 * (x * y + w * z), squ + sqx - sqy - sqz)
+    lo = sarg <= -0.99999
+    hi = sarg >= 0.99999
+    roll = np.where(lo | hi, 0.0, roll)
+    pitch = np.where(lo, -0.5 * np.pi, np.where(hi, 0.5 * np.pi, pitch))
+    yaw = np.where(lo, 2 * np.arctan2(x, -y), np.where(hi, 2 * np.arctan2(-x, y), yaw))
+    return np.stack([roll, pitch, yaw], axis=-1)
+
+
+# --------------------------------------------------------------------------------------
+# a1-a4: [UPSTREAM] BaseAviary.step / _dynamics / _integrateQ / _drag  
+# --------------------------------------------------------------------------------------
+
+
+def rotor_wrench(rpm, c: DroneConsts):
+    """[UPSTREAM] _dynamics: total thrust (body z) and body torques from 4 RPM."""
+    rpm = np.asarray(rpm, dtype=np.float64)
+    forces = rpm ** 2 * c.KF
+    thrust = forces[..., 0] + forces[..., 1] + forces[..., 2] + forces[..., 3]
+    zt = rpm ** 2 * c.KM
+    tz = -zt[..., 0] + zt[..., 1] - zt[..., 2] + zt[..., 3]
+    if c.MODEL == "cf2x":
+        tx = (forces[..., 0] + forces[..., 1] - forces[..., 2] - forces[..., 3]) * (c.L / np.sqrt(2))
+        ty = (-forces[..., 0] + forces[..., 1] + forces[..., 2] - forces[..., 3]) * (c.L / np.sqrt(2))
+    else:  # cf2p
+        tx = (forces[..., 1] - forces[..., 3]) * c.L
+        ty = (-forces[..., 0] + forces[..., 2]) * c.L
+    return thrust, np.stack([tx, ty, tz], axis=-1)
+
+
+def integrate_q(quat, omega, dt):
+    """[UPSTREAM] BaseAviary._integrateQ: exact exponential for constant body rate."""
+    quat = np.asarray(quat, dtype=np.float64)
+    omega = np.asarray(omega, dtype=np.float64)
+    on = norm(omega)
+    p, q, r = omega[..., 0], omega[..., 1], omega[..., 2]
+    still = np.isclose(on, 0.0)
+    on_safe = np.where(still, 1.0, on)
+    theta = on_safe * dt / 2
+    ct = np.cos(theta)
+    k = (2.0 / on_safe) * np.sin(theta) * 0.5
+    x, y, z, w = quat[..., 0], quat[..., 1], quat[..., 2], quat[..., 3]
+    # lambda_ = .5*[[0,r,-q,p],[-r,0,p,q],[q,-p,0,r],[-p,-q,-r,0]]
+    nx = ct * x + k * (r * y - q * z + p * w)
+    ny = ct * y + k * (-r * x + p * z + q * w)
+    nz = ct * z + k * (q * x - p * y + r * w)
+    nw = ct * w + k * (-p * x - q * y - r * z)
+    out = np.stack([nx, ny, nz, nw], axis=-1)
+    return np.where(still[..., None], quat, out)
+
+
+def dyn_derivative(pos, quat, vel, rates, rpm, c: DroneConsts, drag_rpm=None):
+    """Continuous-time derivative of the 13-state used by the RK4 integrator
+    (same force/torque model as [UPSTREAM] _dynamics; qdot = Lambda(omega) q)."""
+    R = quat_to_rotmat_bullet(quat)
+    thrust, torques = rotor_wrench(rpm, c)
+    force_w = R[..., :, 2] * thrust[..., None]
+    force_w[..., 2] -= c.GRAVITY
+    if drag_rpm is not None:
+        force_w = force_w + drag_force_world(vel, drag_rpm, c)
+    J = np.asarray(c.J)
+    torques = torques - cross(rates, J * rates)
+    rates_dot = torques / J
+    acc = force_w / c.M
+    p, q, r = rates[..., 0], rates[..., 1], rates[..., 2]
+    x, y, z, w = quat[..., 0], quat[..., 1], quat[..., 2], quat[..., 3]
+    qdot = 0.5 * np.stack([r * y - q * z + p * w,
+                           -r * x + p * z + q * w,
+                           q * x - p * y + r * w,
+                           -p * x - q * y - r * z], axis=-1)
+    return vel, qdot, acc, rates_dot
+
+
+def drag_force_world(vel, rpm_prev, c: DroneConsts):
+    """[UPSTREAM] BaseAviary._drag: body force R^T(-c * sum(2 pi rpm/60) * v_world)
+    applied in the link frame, i.e. world force = -c (.) sum(2 pi rpm / 60) (.) v_world.
+    ``rpm_prev`` is the PREVIOUS step's clipped action."""
+    rpm_prev = np.asarray(rpm_prev, dtype=np.float64)
+    s = np.sum(2 * np.pi * rpm_prev / 60, axis=-1)
+    return -np.asarray(c.DRAG) * s[..., None] * np.asarray(vel, dtype=np.float64)
+
+
+def dyn_step_euler(pos, quat, vel, rates, rpm, dt, c: DroneConsts, drag_rpm=None):
+    """[UPSTREAM] BaseAviary._dynamics (Physics.DYN): explicit Euler on (v, omega),
+    then p with the NEW v, q with the NEW omega.  ``drag_rpm`` (build extension
+    DYN_DRAG) adds the _drag force computed from the previous clipped action."""
+    R = quat_to_rotmat_bullet(quat)
+    thrust, torques = rotor_wrench(rpm, c)
+    force_w = R[..., :, 2] * thrust[..., None]          # R @ [0,0,thrust]
+    force_w[..., 2] -= c.GRAVITY
+    if drag_rpm is not None:
+        force_w = force_w + drag_force_world(vel, drag_rpm, c)
+    J = np.asarray(c.J)
+    torques = torques - cross(rates, J * rates)
+    rates_dot = torques / J                             # J_INV @ torques (diagonal J)
+    acc = force_w / c.M
+    vel = vel + dt * acc
+    rates = rates + dt * rates_dot
+    pos = pos + dt * vel
+    quat = integrate_q(quat, rates, dt)
+    ang_v_world = matvec(R, rates)                      # resetBaseVelocity(..., R_old @ rpy_rates)
+    return pos, quat, vel, rates, ang_v_world
+
+
+def dyn_step_rk4(pos, quat, vel, rates, rpm, dt, c: DroneConsts, drag_rpm=None):
+    """Classical RK4 on the 13-state (north_star integrator; not in upstream).
+    Quaternion re-normalised after the step."""
+    def f(s):
+        return dyn_derivative(s[0], s[1], s[2], s[3], rpm, c, drag_rpm)
+
+    s0 = (pos, quat, vel, rates)
+    k1 = f(s0)
+    k2 = f(tuple(a + 0.5 * dt * k for a, k in zip(s0, k1)))
+    k3 = f(tuple(a + 0.5 * dt * k for a, k in zip(s0, k2)))
+    k4 = f(tuple(a + dt * k for a, k in zip(s0, k3)))
+    out = [a + (dt / 6.0) * (b1 + 2 * b2 + 2 * b3 + b4) for a, b1, b2, b3, b4 in zip(s0, k1, k2, k3, k4)]
+    out[1] = out[1] / norm(out[1])[..., None]
+    ang_v_world = matvec(quat_to_rotmat_bullet(out[1]), out[3])
+    return out[0], out[1], out[2], out[3], ang_v_world
+
+
+class AviaryOracle:
+    """[UPSTREAM] CtrlAviary / BaseAviary state machine (step, obs packing), batched
+    over n drones.  physics in {"dyn", "dyn_drag"}, integrator in {"euler", "rk4"}."""
+
+    def __init__(self, init_xyzs, init_rpys, consts: DroneConsts = CF2P, pyb_freq=240, ctrl_freq=240,
+                 physics="dyn", integrator="euler"):
+        if pyb_freq % ctrl_freq != 0:
+            raise ValueError("pyb_freq must be a multiple of ctrl_freq")  # [UPSTREAM] BaseAviary.__init__
+        self.c = consts
+        self.PYB_FREQ, self.CTRL_FREQ = pyb_freq, ctrl_freq
+        self.PYB_STEPS_PER_CTRL = pyb_freq // ctrl_freq
+        self.PYB_TIMESTEP = 1.0 / pyb_freq
+        self.CTRL_TIMESTEP = 1.0 / ctrl_freq
+        self.physics, self.integrator = physics, integrator
+        self.init_xyzs = np.array(init_xyzs, dtype=np.float64).reshape(-1, 3)
+        self.init_rpys = np.array(init_rpys, dtype=np.float64).reshape(-1, 3)
+        self.reset()
+
+    def reset(self):
+        """[UPSTREAM] _housekeeping + _updateAndStoreKinematicInformation."""
+        n = self.init_xyzs.shape[0]
+        self.pos = self.init_xyzs.copy()
+        self.quat = quat_from_euler_bullet(self.init_rpys)
+        self.vel = np.zeros((n, 3))
+        self.rates = np.zeros((n, 3))
+        self.ang_v = np.zeros((n, 3))
+        self.last_clipped_action = np.zeros((n, 4))
+        return self.obs()
+
+    def obs(self):
+        """[UPSTREAM] _getDroneStateVector: pos3 | quat4 xyzw | rpy3 | vel3 | ang_v3 | last_clipped_action4."""
+        return np.concatenate([self.pos, self.quat, euler_from_quat_bullet(self.quat), self.vel, self.ang_v,
+                               self.last_clipped_action], axis=-1)
+
+    def step(self, action):
+        clipped = np.clip(np.asarray(action, dtype=np.float64).reshape(-1, 4), 0, self.c.MAX_RPM)
+        stepf = dyn_step_euler if self.integrator == "euler" else dyn_step_rk4
+        for _ in range(self.PYB_STEPS_PER_CTRL):
+            drag_rpm = self.last_clipped_action if self.physics == "dyn_drag" else None
+            self.pos, self.quat, self.vel, self.rates, self.ang_v = stepf(
+                self.pos, self.quat, self.vel, self.rates, clipped, self.PYB_TIMESTEP, self.c, drag_rpm)
+            self.last_clipped_action = clipped
+        return self.obs()
+
+
+# --------------------------------------------------------------------------------------
+# a10: trajectories/Lemniscate.py:32-63
+# --------------------------------------------------------------------------------------
+
+
+def lemniscate(t, a, omega, center, yaw_rate, phase_shift):
+    """Lemniscate.__call__ -> (pos, vel, acc, yaw, yaw_rate_out), batched over params."""
+    a = np.asarray(a, dtype=np.float64)
+    omega = np.asarray(omega, dtype=np.float64)
+    center = np.asarray(center, dtype=np.float64)
+    yaw_rate = np.asarray(yaw_rate, dtype=np.float64)
+    th = t * omega + phase_shift
+    s, c = np.sin(th), np.cos(th)
+    z = np.zeros_like(th)
+    pos = np.stack([center[..., 0] + (a * s * c) / (1 + s ** 2),
+                    center[..., 1] + (a * c) / (1 + s ** 2),
+                    center[..., 2] + z], axis=-1)
+    vel = np.stack([-a * omega * (s ** 4 + s ** 2 + (s ** 2 - 1) * c ** 2) / (s ** 2 + 1) ** 2,
+                    -a * omega * s * (s ** 2 + 2 * c ** 2 + 1) / (s ** 2 + 1) ** 2,
+                    z], axis=-1)
+    acc = np.stack([4 * a * omega ** 2 * np.sin(2 * th) * (3 * np.cos(2 * th) + 7) / (np.cos(2 * th) - 3) ** 3,
+                    a * omega ** 2 * c * (44 * np.cos(2 * th) + np.cos(4 * th) - 21) / (np.cos(2 * th) - 3) ** 3,
+                    z], axis=-1)
+    yaw = np.pi * np.sin(yaw_rate * t)
+    yaw_dot = np.pi * yaw_rate * np.cos(yaw_rate * t)
+    return pos, vel, acc, yaw, yaw_dot
+
+
+# --------------------------------------------------------------------------------------
+# a9: utils/model_conversions.py:69-103
+# --------------------------------------------------------------------------------------
+
+
+def _mixer(c: DroneConsts):
+    r = c.KM / c.KF
+    return np.array([[1.0, 1.0, 1.0, 1.0],
+                     [0.0, c.L, 0.0, -c.L],
+                     [-c.L, 0.0, c.L, 0.0],
+                     [-r, r, -r, r]])
+
+
+def action_to_input(action, c: DroneConsts, cap_rpm=True):
+    """model_conversions.py:69-83."""
+    action = np.asarray(action, dtype=np.float64)
+    if cap_rpm:
+        action = np.clip(action, 0, c.MAX_RPM)
+    return np.einsum("ij,...j->...i", _mixer(c), c.KF * action ** 2)
+
+
+def input_to_action(u, c: DroneConsts):
+    """model_conversions.py:85-103 (MAX_THRUST used as a per-motor clip, as in the reference)."""
+    u = np.array(u, dtype=np.float64)
+    u[..., 0] = np.clip(u[..., 0], 0, None)
+    thrusts = np.einsum("ij,...j->...i", np.linalg.inv(_mixer(c)), u)
+    thrusts = np.clip(thrusts, 9440.3 ** 2 * c.KF, c.MAX_THRUST)
+    return np.sqrt(thrusts / c.KF)
+
+
+# --------------------------------------------------------------------------------------
+# a7, a8: utils/model_conversions.py:105-114, control/geometric.py:59-115
+# --------------------------------------------------------------------------------------
+
+GEO_GAINS = dict(Kp=(2.25, 2.25, 2.25), Kv=(3.5, 3.5, 3.5), KR=(125.0, 125.0, 125.0), Kw=(10.0, 10.0, 10.0),
+                 g=9.81, max_tilt=40 * np.pi / 180)  # control/geometric.py:14-23
+
+
+def obs_to_geo_model(obs):
+    """model_conversions.py:105-114 -> (p, R, v_world, w)."""
+    obs = np.asarray(obs, dtype=np.float64)
+    return obs[..., 0:3], quat_to_rotmat_scipy(obs[..., 3:7]), obs[..., 10:13], obs[..., 13:16]
+
+
+def geometric_compute(obs, p_des, v_des, a_des, yaw_des, yawrate_des, c: DroneConsts = CF2P, gains=None,
+                      return_omegas=False):
+    """GeometricControl.compute (control/geometric.py:59-115), quirks kept:
+    g = 9.81 (:20); obs[13:16] used as body rate (:63); R_des.transpose(0,1) is a no-op on
+    ndarrays so w_des_hat = R_des @ R_dot_des (:102); f_des_dot uses Kp and body v (:96)."""
+    gn = dict(GEO_GAINS)
+    if gains:
+        gn.update(gains)
+    Kp, Kv, KR, Kw = (np.asarray(gn[k], dtype=np.float64) for k in ("Kp", "Kv", "KR", "Kw"))
+    g, max_tilt = gn["g"], gn["max_tilt"]
+    m, J = c.M, np.asarray(c.J, dtype=np.float64)
+    p, R, v_world, w = obs_to_geo_model(obs)
+    p_des, v_des, a_des = (np.asarray(x, dtype=np.float64) for x in (p_des, v_des, a_des))
+    yaw_des = np.asarray(yaw_des, dtype=np.float64)
+    yawrate_des = np.asarray(yawrate_des, dtype=np.float64)
+    e3 = np.array([0.0, 0.0, 1.0])
+
+    v = matTvec(R, v_world)                                                     # :70
+    RTvd = matTvec(R, v_des)
+    f_b = (matTvec(R, m * g * e3 * np.ones_like(p)) - m * matTvec(R, Kp * (p - p_des))
+           - m * Kv * (v - RTvd) + m * (matTvec(R, a_des) - cross(w, RTvd)))    # :73-74  (w_hat @ x = w x x)
+    f_w = matvec(R, f_b)                                                        # :75
+    fn = norm(f_w)
+    tilt = np.arccos(f_w[..., 2] / fn)                                          # :79
+    xy_mag = norm(f_w[..., :2])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        scale = f_w[..., 2] * np.tan(max_tilt) / xy_mag                         # :81-83
+    clamp = tilt > max_tilt
+    f_w = f_w.copy()
+    f_w[..., 0] = np.where(clamp, f_w[..., 0] * scale, f_w[..., 0])             # :84
+    f_w[..., 1] = np.where(clamp, f_w[..., 1] * scale, f_w[..., 1])
+    f_b = matTvec(R, f_w)                                                       # :85
+    fn = norm(f_w)
+
+    z = np.zeros_like(yaw_des)
+    b1c = np.stack([np.cos(yaw_des), np.sin(yaw_des), z], axis=-1)              # :88
+    b3d = f_w / fn[..., None]
+    c1 = cross(b3d, b1c)
+    b2d = c1 / norm(c1)[..., None]
+    c2 = cross(b2d, b3d)
+    b1d = c2 / norm(c2)[..., None]
+    R_des = np.stack([b1d, b2d, b3d], axis=-1)                                  # columns (:92)
+
+    b1c_dot = np.stack([-np.sin(yaw_des) * yawrate_des, np.cos(yaw_des) * yawrate_des, z], axis=-1)  # :95
+    f_dot_w = m * matvec(R, Kp * (v - RTvd)) / fn[..., None]                    # :96
+    b3d_dot = cross(cross(b3d, f_dot_w), b3d)                                   # :97
+    inner = (cross(b1c_dot, b3d) + cross(b1c, b3d_dot)) / norm(cross(b1c, b3d))[..., None]
+    b2d_dot = cross(cross(b2d, inner), b2d)                                     # :98-99
+    b1d_dot = cross(b3d_dot, b2d) + cross(b3d, b2d_dot)                         # :100
+    R_dot_des = np.stack([b1d_dot, b2d_dot, b3d_dot], axis=-1)
+    W = np.einsum("...ij,...jk->...ik", R_des, R_dot_des)                       # :102 (no-op transpose)
+    w_des = np.stack([W[..., 2, 1], W[..., 0, 2], W[..., 1, 0]], axis=-1)       # :103
+
+    if return_omegas:
+        force = np.sum(f_w * R[..., :, 2], axis=-1)                             # :107
+        return force, w_des, R_des
+
+    E = np.einsum("...ji,...jk->...ik", R_des, R) - np.einsum("...ji,...jk->...ik", R, R_des)
+    vee = np.stack([-E[..., 1, 2], E[..., 0, 2], -E[..., 0, 1]], axis=-1)       # :36-44
+    e_R = 0.5 * KR * vee                                                        # :109
+    torque = J * (-e_R - Kw * (w - matTvec(R, matvec(R_des, w_des)))) - cross(w, J * w)  # :110-111
+    u = np.concatenate([np.maximum(0.0, f_b[..., 2:3]), torque], axis=-1)       # :114
+    return input_to_action(u, c)                                                # :115
+
+
+# --------------------------------------------------------------------------------------
+# a5: model/dynamics.py:83-106
+# --------------------------------------------------------------------------------------
+
+
+def quadrotor_dynamics(state18, u4, m=6.77, J=(1.05, 1.05, 2.05), g=9.81):
+    """QuadrotorDynamics.dynamics -> 12 floats (x_dot=v, "R_dot"=w, v_dot, w_dot).
+    Defaults are the Hummingbird constants (:24-28); after load_env_params the
+    reference keeps the STALE Hummingbird J (:18) but takes m, g from the env."""
+    s = np.asarray(state18, dtype=np.float64)
+    u = np.asarray(u4, dtype=np.float64)
+    R = s[..., 3:12].reshape(s.shape[:-1] + (3, 3))
+    v, w = s[..., 12:15], s[..., 15:18]
+    J = np.asarray(J, dtype=np.float64)
+    v_dot = R[..., :, 2] * (u[..., 0:1] / m)
+    v_dot = v_dot.copy()
+    v_dot[..., 2] -= g
+    w_dot = (u[..., 1:4] - cross(w, J * w)) / J
+    return np.concatenate([v, w, v_dot, w_dot], axis=-1)
+
+
+# --------------------------------------------------------------------------------------
+# obs -> linear-model state  (utils/model_conversions.py:20-58, :137-143)
+# --------------------------------------------------------------------------------------
+
+
+def obs_to_lin_model(obs, dim, c: DroneConsts = CF2P):
+    obs = np.asarray(obs, dtype=np.float64)
+    rpy, vel, pos, angv = obs[..., 7:10], obs[..., 10:13], obs[..., 0:3], obs[..., 13:16]
+    if dim == 12:
+        return np.concatenate([rpy, angv, vel, pos], axis=-1)
+    if dim == 9:
+        return np.concatenate([rpy, vel, pos], axis=-1)
+    if dim == 10:
+        thrust = np.sum(c.KF * obs[..., 16:20] ** 2, axis=-1, keepdims=True)    # calc_z_thrust
+        return np.concatenate([rpy, thrust, vel, pos], axis=-1)
+    raise ValueError("Invalid dim for linear model")
+
+
+# --------------------------------------------------------------------------------------
+# a11-a14: cbf/cbf.py rows in closed form (pinned against the dense
+# reference construction by tests/golden/cbf_rows_*.npz)
+# --------------------------------------------------------------------------------------
+
+
+def place_poles_chain(poles):
+    """cbf/cbf.py:115-124: Kcbf = place_poles(chain of integrators) = ascending
+    coefficients of prod(s - p_i) without the leading 1."""
+    co = np.poly(np.asarray(poles, dtype=np.float64))  # descending, leading 1
+    return co[1:][::-1].copy()
+
+
+def _cbf_pair_terms(xi, xj, xi_des, xj_des, order, Ds, zscale, Kcbf, m, g):
+    """Closed form of custom_hdots (:135-178) + custom_control_affine_terms (:194-283) for
+    the hover linearisations (model/linear_omega.py:46-53, linear_yank_omega.py:45-51).
+    Returns (h_ij, Lg[4]) with G_ij[4i:4i+4] = -Lg, G_ij[4j:4j+4] = +Lg."""
+    c4 = zscale ** 4
+    e = xi[..., -3:] - xj[..., -3:]
+    ex, ey, ez = e[..., 0], e[..., 1], e[..., 2]
+    s = ex * ex + ey * ey
+    h = s * s + (ez / zscale) ** 4 - Ds ** 4
+    gx, gy, gz = 4 * ex * s, 4 * ey * s, 4 * ez ** 3 / c4
+    Hxx, Hxy, Hyy, Hzz = 12 * ex * ex + 4 * ey * ey, 8 * ex * ey, 4 * ex * ex + 12 * ey * ey, 12 * ez * ez / c4
+    hi = xi - xi_des
+    hj = xj - xj_des
+    d = hi - hj
+    if order == 2:
+        dr, dp = d[..., 0], d[..., 1]
+        dvx, dvy, dvz = d[..., 3], d[..., 4], d[..., 5]
+        dax, day, daz = g * dp, -g * dr, 0.0 * dr
+        hdot = gx * dvx + gy * dvy + gz * dvz
+        quad = Hxx * dvx * dvx + 2 * Hxy * dvx * dvy + Hyy * dvy * dvy + Hzz * dvz * dvz
+        Lf2 = gx * dax + gy * day + gz * daz + quad
+        hij = Kcbf[0] * h + Kcbf[1] * hdot + Lf2
+        zero = 0.0 * gz
+        Lg = np.stack([gz / m, zero, zero, zero], axis=-1)
+        return hij, Lg
+    if order == 3:
+        dr, dp, dF = d[..., 0], d[..., 1], d[..., 3]
+        dvx, dvy, dvz = d[..., 4], d[..., 5], d[..., 6]
+        dax, day, daz = g * dp, -g * dr, dF / m
+        hdot = gx * dvx + gy * dvy + gz * dvz
+        # custom_hdots i == 2 uses hard-coded slots 6,7,8 = (vz, x, y) of the 10-state (:158-169):
+        # dhdx picks (A xhat)[6,7,8] = (dF/m, dvx, dvy); d2h likewise.
+        w0, w1, w2 = dF / m, dvx, dvy
+        A2 = g * (gy * dp - gz * dr)       # dhdx@A@Axhat with dhde on slots 6,7,8: A[7,4]*(A xhat)[4] etc.
+        hddot_ref = A2 + (Hxx * w0 * w0 + 2 * Hxy * w0 * w1 + Hyy * w1 * w1 + Hzz * w2 * w2)
+        Hdv_da = (Hxx * dvx * dax + Hxy * (dvx * day + dvy * dax) + Hyy * dvy * day + Hzz * dvz * daz)
+        T = (24 * ex * dvx ** 3 + 24 * ey * dvx ** 2 * dvy + 24 * ex * dvx * dvy ** 2 + 24 * ey * dvy ** 3
+             + (24 * ez / c4) * dvz ** 3)
+        Lf3 = 3 * Hdv_da + T
+        hij = Kcbf[0] * h + Kcbf[1] * hdot + Kcbf[2] * hddot_ref + Lf3
+        Lg = np.stack([gz / m, -g * gy, g * gx, 0.0 * gz], axis=-1)
+        return hij, Lg
+    raise ValueError("order must be 2 or 3")
+
+
+def cbf_rows(x, xdes, order, Kcbf, umax, safety_radius, zscale, c: DroneConsts = CF2P, x_obs=None, obs_r=None,
+             Fmin=None, Fmax=None):
+    """CBF._build_ineq_const (cbf/cbf.py:308-367) for ONE env: x, xdes [N, xdim] ->
+    (G [m, 4N], h [m]) in the reference's row order: pairs (i<j lexicographic) | +I | -I |
+    (order 3: 2 force rows per agent) | obstacles agent-major."""
+    x = np.asarray(x, dtype=np.float64)
+    xdes = np.asarray(xdes, dtype=np.float64)
+    N, xdim = x.shape
+    Kcbf = np.asarray(Kcbf, dtype=np.float64)
+    rows_G, rows_h = [], []
+    for i in range(N - 1):
+        for j in range(i + 1, N):
+            hij, Lg = _cbf_pair_terms(x[i], x[j], xdes[i], xdes[j], order, 2 * safety_radius, zscale, Kcbf, c.M, c.G)
+            Gij = np.zeros(4 * N)
+            Gij[4 * i:4 * i + 4] = -Lg
+            Gij[4 * j:4 * j + 4] = Lg
+            rows_G.append(Gij)
+            rows_h.append(hij)
+    G = np.array(rows_G).reshape(-1, 4 * N)
+    h = np.array(rows_h).reshape(-1)
+    if umax is not None:                                                       # :400-412
+        G = np.vstack([G, np.eye(4 * N), -np.eye(4 * N)])
+        h = np.hstack([h, np.tile(np.asarray(umax, dtype=np.float64), 2 * N)])
+    if order == 3:                                                             # :446-464 (quirk: column 4i+3)
+        Fmin = -c.M * c.G if Fmin is None else Fmin
+        Fmax = c.MAX_THRUST if Fmax is None else Fmax
+        for i in range(N):
+            Gi = np.zeros((2, 4 * N))
+            Gi[0, 4 * i + 3] = 1
+            Gi[1, 4 * i + 3] = -1
+            hi = np.array([Kcbf[-1] * (Fmax - x[i, 3]), Kcbf[-1] * (x[i, 3] - Fmin)])
+            G = np.vstack([G, Gi])
+            h = np.hstack([h, hi])
+    if x_obs is not None and obs_r is not None and len(obs_r) > 0:             # :369-398
+        x_obs = np.asarray(x_obs, dtype=np.float64).reshape(len(obs_r), -1, 3)
+        Go = np.zeros((N * len(obs_r), 4 * N))
+        ho = np.zeros(N * len(obs_r))
+        for i in range(N):
+            for j, r in enumerate(obs_r):
+                xo = np.zeros(xdim)
+                xo[-3:] = x_obs[j][0]
+                hij, Lg = _cbf_pair_terms(x[i], xo, xdes[i], xo, order, safety_radius + r, zscale, Kcbf, c.M, c.G)
+                Go[i * len(obs_r) + j, 4 * i:4 * i + 4] = -Lg
+                ho[i * len(obs_r) + j] = hij
+        G = np.vstack([G, Go])
+        h = np.hstack([h, ho])
+    return G, h
+
+
+# --------------------------------------------------------------------------------------
+# a15: cbf/qptracker.py:86-114 -- min 1/2|u|^2 - uhat^T u  s.t. G u <= h
+# cvxopt (interior point) is absent here: QP *solution* parity is UNPINNED against cvxopt;
+# the problem is strictly convex so the minimiser is unique and this exact active-set
+# solver is the oracle.  Infeasible / failure -> (False, None) -> caller keeps uhat
+# (qptracker.py:30-34).
+# --------------------------------------------------------------------------------------
+
+
+def qp_project(uhat, G, h, tol=1e-10, max_iter=None):
+    """Goldfarb-Idnani style dual active-set for  min 1/2|u - uhat|^2  s.t. G u <= h.
+    Returns (success, u, lam)."""
+    uhat = np.asarray(uhat, dtype=np.float64).reshape(-1)
+    G = np.asarray(G, dtype=np.float64)
+    h = np.asarray(h, dtype=np.float64)
+    m = G.shape[0]
+    if max_iter is None:
+        max_iter = 20 * (m + 10)
+    u = uhat.copy()
+    active = []
+    lam = np.zeros(0)
+    for _ in range(max_iter):
+        viol = G @ u - h
+        scale = np.maximum(1.0, np.abs(h))
+        k = int(np.argmax(viol / scale))
+        if viol[k] <= tol * scale[k]:
+            full = np.zeros(m)
+            full[active] = lam
+            return True, u, full
+        # add constraint k: move along z (primal) / r (dual) as in Goldfarb-Idnani with H = I
+        gk = G[k]
+        lam_k = 0.0
+        while True:
+            if active:
+                Na = G[active].T                      # n x q
+                M = Na.T @ Na
+                try:
+                    r = np.linalg.solve(M, Na.T @ gk)
+                except np.linalg.LinAlgError:
+                    r = np.linalg.lstsq(M, Na.T @ gk, rcond=None)[0]
+                z = gk - Na @ r
+            else:
+                r = np.zeros(0)
+                z = gk.copy()
+            zz = z @ z
+            # dual step length
+            t1, drop = np.inf, -1
+            for idx in range(len(active)):
+                if r[idx] > 1e-14:
+                    cand = lam[idx] / r[idx]
+                    if cand < t1:
+                        t1, drop = cand, idx
+            if zz > 1e-18 * max(1.0, gk @ gk):
+                t2 = (gk @ u - h[k]) / zz
+            else:
+                t2 = np.inf
+            t = min(t1, t2)
+            if not np.isfinite(t):
+                return False, None, None              # infeasible
+            if t2 == np.inf:                          # dual step only
+                lam = lam - t * r
+                lam_k += t
+                active.pop(drop)
+                lam = np.delete(lam, drop)
+                continue
+            u = u - t * z
+            lam = lam - t * r
+            lam_k += t
+            if t == t2:
+                active.append(k)
+                lam = np.append(lam, lam_k)
+                break
+            active.pop(drop)
+            lam = np.delete(lam, drop)
+    return False, None, None
+
+
+def cbf_filter(x, xdes, u_nominal, order, Kcbf, umax, safety_radius, zscale, c: DroneConsts = CF2P, x_obs=None,
+               obs_r=None):
+    """DroneQPTracker.compute_control (qptracker.py:22-34) for ONE env, given linear-model
+    states x [N, xdim].  Returns (u [N,4], status) with status 0 = ok, 1 = fallback."""
+    G, h = cbf_rows(x, xdes, order, Kcbf, umax, safety_radius, zscale, c, x_obs, obs_r)
+    u_nominal = np.asarray(u_nominal, dtype=np.float64)
+    ok, u, _ = qp_project(u_nominal.reshape(-1), G, h)
+    if not ok:
+        return u_nominal.copy(), 1
+    return u.reshape(u_nominal.shape), 0

@@ -1,0 +1,298 @@
+#!/usr/bin/env python3
+"""Mint golden input/output vectors from the reference's own NumPy code.
+
+Run ONLY in the build container (the reference lives at /root/reference there and
+does not travel to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/mint_golden.py
+
+The reference packages cannot be imported as packages (utils/__init__ pulls in
+gym_pybullet_drones, cbf pulls in cvxopt; neither is installed), so single files are
+loaded BY PATH with synthetic parent packages and a placeholder ``cvxopt`` module
+(only G,h are built, qp() is never called).  See SURVEY.md section 8c.
+
+Outputs: tests/golden/*.npz -- data only (inputs, expected outputs, seeds, versions).
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import scipy
+from scipy.spatial.transform import Rotation
+
+REF = os.environ.get("MDS_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+
+
+def load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def load_reference():
+    mc = load("utils.model_conversions", REF + "/utils/model_conversions.py")
+    u = types.ModuleType("utils")
+    u.__path__ = []
+    for k in dir(mc):
+        if not k.startswith("_"):
+            setattr(u, k, getattr(mc, k))
+    u.model_conversions = mc
+    sys.modules["utils"] = u
+    c = types.ModuleType("control")
+    c.__path__ = [REF + "/control"]
+    sys.modules["control"] = c
+    load("control.base_controller", REF + "/control/base_controller.py")
+    geo = load("control.geometric", REF + "/control/geometric.py")
+    lem = load("ref_lem", REF + "/trajectories/Lemniscate.py")
+    dyn = load("ref_dyn", REF + "/model/dynamics.py")
+    cv = types.ModuleType("cvxopt")
+    cv.matrix = None
+    cv.solvers = types.SimpleNamespace(options={})
+    sys.modules["cvxopt"] = cv
+    cbf = load("ref_cbf", REF + "/cbf/cbf.py")
+    lin_o = load("ref_lin_omega", REF + "/model/linear_omega.py")
+    lin_yo = load("ref_lin_yank_omega", REF + "/model/linear_yank_omega.py")
+    return dict(mc=mc, geo=geo, lem=lem, dyn=dyn, cbf=cbf, lin_o=lin_o, lin_yo=lin_yo)
+
+
+class Env:  # mock env, precedent: utils/env_builder.py:4-10
+    pass
+
+
+def make_env():
+    env = Env()
+    env.M = 0.027
+    env.G = 9.8
+    env.L = 0.0397
+    env.KF = 3.16e-10
+    env.KM = 7.94e-12
+    env.J = np.diag([2.3951e-5, 2.3951e-5, 3.2347e-5])
+    env.CTRL_TIMESTEP = 0.01
+    env.PYB_FREQ = 100
+    env.MAX_RPM = np.sqrt(2.25 * env.M * env.G / (4 * env.KF))
+    env.MAX_THRUST = 4 * env.KF * env.MAX_RPM ** 2
+    return env
+
+
+META = dict(numpy=np.__version__, scipy=scipy.__version__)
+
+
+def random_obs(rng, n, pos_c, vel_c, euler_max=0.6, w_max=1.0, pos_noise=0.3, vel_noise=0.5):
+    obs = np.zeros((n, 20))
+    obs[:, 0:3] = pos_c + rng.normal(size=(n, 3)) * pos_noise
+    eul = rng.uniform(-euler_max, euler_max, size=(n, 3))
+    obs[:, 3:7] = Rotation.from_euler("xyz", eul).as_quat()
+    obs[:, 7:10] = eul
+    obs[:, 10:13] = vel_c + rng.normal(size=(n, 3)) * vel_noise
+    obs[:, 13:16] = rng.uniform(-w_max, w_max, size=(n, 3))
+    obs[:, 16:20] = 14468.0 * (1 + 0.05 * rng.normal(size=(n, 4)))
+    return obs
+
+
+def mint_lemniscate(ref):
+    Lem = ref["lem"].Lemniscate
+    params = [dict(a=1.0, omega=1.5, center=np.array([0, 0, 0.5]), yaw_rate=0.3, phase_shift=0.0),
+              dict(a=1.0, omega=1.5, center=np.array([0.2, -0.1, 0.5]), yaw_rate=0.0, phase_shift=-np.pi / 4 * 3),
+              dict(a=0.7, omega=0.5, center=np.array([-1.0, 2.0, 1.5]), yaw_rate=0.11, phase_shift=2 * np.pi * 5 / 8.25)]
+    ts = np.linspace(0, 30, 301)
+    out = np.zeros((len(params), len(ts), 11))
+    for k, p in enumerate(params):
+        tr = Lem(**p)
+        for i, t in enumerate(ts):
+            pos, vel, acc, yaw, om = tr(t)
+            out[k, i] = np.hstack([pos, vel, acc, yaw, om])
+    P = np.array([[p["a"], p["omega"], *p["center"], p["yaw_rate"], p["phase_shift"]] for p in params])
+    spot = Lem(center=np.array([0, 0, .5]), omega=1.5, yaw_rate=0.3)(0.37)
+    np.savez_compressed(OUT + "/lemniscate.npz", params=P, ts=ts, out=out, spot=np.hstack(spot), **META)
+    print("lemniscate", out.shape, "spot", np.hstack(spot))
+
+
+def mint_geometric(ref):
+    env = make_env()
+    Lem = ref["lem"].Lemniscate
+    G = ref["geo"].GeometricControl
+    rng = np.random.default_rng(0)
+    n_rand, n_tilt, n_clip = 320, 32, 32
+    obs_list, des_list = [], []
+    traj = Lem(center=np.array([0, 0, .5]), omega=1.5, yaw_rate=0.3)
+    # (a) random states near the trajectory
+    for k in range(n_rand):
+        t = rng.uniform(0, 20)
+        pos, vel, acc, yaw, om = traj(t)
+        o = random_obs(rng, 1, pos, vel)[0]
+        obs_list.append(o)
+        des_list.append(np.hstack([pos, vel, acc, yaw, om]))
+    # (b) tilt-clamp cases: large lateral position error
+    for k in range(n_tilt):
+        t = rng.uniform(0, 20)
+        pos, vel, acc, yaw, om = traj(t)
+        o = random_obs(rng, 1, pos + np.array([rng.uniform(3, 8) * rng.choice([-1, 1]), rng.uniform(-6, 6), 0.0]),
+                       vel)[0]
+        obs_list.append(o)
+        des_list.append(np.hstack([pos, vel, acc, yaw, om]))
+    # (c) min-thrust / negative-thrust clip: far ABOVE the target, moving up fast, flipped attitude
+    for k in range(n_clip):
+        t = rng.uniform(0, 20)
+        pos, vel, acc, yaw, om = traj(t)
+        o = random_obs(rng, 1, pos + np.array([0.0, 0.0, rng.uniform(4, 12)]), vel + np.array([0, 0, 3.0]),
+                       euler_max=1.4, w_max=6.0)[0]
+        obs_list.append(o)
+        des_list.append(np.hstack([pos, vel, acc, yaw, om]))
+    obs = np.array(obs_list)
+    des = np.array(des_list)
+    n = obs.shape[0]
+    rpm = np.zeros((n, 4))
+    force = np.zeros(n)
+    w_des = np.zeros((n, 3))
+    R_des = np.zeros((n, 3, 3))
+    for i in range(n):
+        ctrl = G(env)
+        ctrl.set_desired_trajectory(0, des[i, 0:3].copy(), des[i, 3:6].copy(), des[i, 6:9].copy(), des[i, 9], des[i, 10])
+        rpm[i] = ctrl.compute(obs[i].copy())
+        f, w, Rd = ctrl.compute(obs[i].copy(), return_omegas=True)
+        force[i], w_des[i], R_des[i] = f, w, Rd
+    # spot value of SURVEY.md 8c (G1)
+    rng1 = np.random.default_rng(1)
+    pos, vel, acc, yaw, om = traj(0.37)
+    so = np.zeros(20)
+    so[:3] = pos + rng1.normal(size=3) * 0.05
+    so[3:7] = Rotation.from_euler('xyz', [0.1, -0.07, 0.2]).as_quat()
+    so[10:13] = vel + rng1.normal(size=3) * 0.05
+    so[13:16] = rng1.normal(size=3) * 0.2
+    ctrl = G(env)
+    ctrl.set_desired_trajectory(0, pos, vel, acc, yaw, om)
+    spot_rpm = ctrl.compute(so.copy())
+    _, spot_w, _ = ctrl.compute(so.copy(), return_omegas=True)
+    np.savez_compressed(OUT + "/geometric_compute.npz", obs=obs, des=des, rpm=rpm, force=force, w_des=w_des, R_des=R_des,
+             spot_obs=so, spot_des=np.hstack([pos, vel, acc, yaw, om]), spot_rpm=spot_rpm, spot_w_des=spot_w,
+             n_rand=n_rand, n_tilt=n_tilt, n_clip=n_clip, **META)
+    lo = 9440.3
+    print("geometric", n, "spot", spot_rpm, spot_w, "minclip rows:", int((np.abs(rpm - lo) < 1e-6).any(axis=1).sum()),
+          "maxclip rows:", int((rpm > 43000).any(axis=1).sum()))
+
+
+def mint_mixer(ref):
+    env = make_env()
+    mc = ref["mc"]
+    rng = np.random.default_rng(2)
+    n = 128
+    u = np.zeros((n, 4))
+    u[:, 0] = rng.uniform(-0.1, 0.8, size=n)
+    u[:, 1:3] = rng.normal(size=(n, 2)) * 2e-3
+    u[:, 3] = rng.normal(size=n) * 5e-4
+    rpm = np.array([mc.input_to_action(env, ui.copy()) for ui in u])
+    act = rng.uniform(-2000, 26000, size=(n, 4))
+    u_back = np.array([mc.action_to_input(env, a.copy()) for a in act])
+    u_back_nocap = np.array([mc.action_to_input(env, a.copy(), cap_rpm=False) for a in act])
+    obs = random_obs(rng, 64, np.zeros(3), np.zeros(3))
+    lin9 = np.array([mc.obs_to_lin_model(o, dim=9) for o in obs])
+    lin10 = np.array([mc.obs_to_lin_model(o, dim=10, env=env) for o in obs])
+    lin12 = np.array([mc.obs_to_lin_model(o, dim=12) for o in obs])
+    geo18 = np.array([mc.obs_to_geo_model(o) for o in obs])
+    np.savez_compressed(OUT + "/mixer.npz", u=u, rpm=rpm, act=act, u_back=u_back, u_back_nocap=u_back_nocap, obs=obs, lin9=lin9,
+             lin10=lin10, lin12=lin12, geo18=geo18, **META)
+    print("mixer", rpm.shape)
+
+
+def mint_dynamics(ref):
+    env = make_env()
+    Q = ref["dyn"].QuadrotorDynamics
+    rng = np.random.default_rng(3)
+    n = 128
+    state = np.zeros((n, 18))
+    state[:, 0:3] = rng.normal(size=(n, 3))
+    state[:, 3:12] = Rotation.from_euler("xyz", rng.uniform(-1, 1, size=(n, 3))).as_matrix().reshape(n, 9)
+    state[:, 12:15] = rng.normal(size=(n, 3))
+    state[:, 15:18] = rng.normal(size=(n, 3)) * 2
+    u = np.zeros((n, 4))
+    u[:, 0] = rng.uniform(0, 100, size=n)
+    u[:, 1:] = rng.normal(size=(n, 3)) * 0.5
+    q = Q(sim_freq=100)
+    out_hb = np.array([q.dynamics(0.0, s, ui) for s, ui in zip(state, u)])
+    q2 = Q(sim_freq=100)
+    q2.load_env_params(env)  # stale-J quirk: m,g from env, J stays Hummingbird
+    u2 = u.copy()
+    u2[:, 0] = rng.uniform(0, 0.6, size=n)
+    u2[:, 1:] *= 1e-3
+    out_env = np.array([q2.dynamics(0.0, s, ui) for s, ui in zip(state, u2)])
+    step_raises = False
+    try:
+        q.step(u[0])
+    except ValueError:
+        step_raises = True
+    np.savez_compressed(OUT + "/dynamics_deriv.npz", state=state, u=u, out_hb=out_hb, u_env=u2, out_env=out_env,
+             env_m=q2.m, env_g=q2.g, env_J=np.diag(q2.J), step_raises=step_raises, **META)
+    print("dynamics", out_hb.shape, "step() raises:", step_raises)
+
+
+def mint_cbf(ref):
+    env = make_env()
+    cbf = ref["cbf"]
+    rng = np.random.default_rng(4)
+    for order, Model, poles, xdim, sr, zs in (
+            (2, ref["lin_o"].LinearizedOmegaModel, np.array([-2.2, -2.4]), 9, 0.1, 1.0),
+            (3, ref["lin_yo"].LinearizedYankOmegaModel, np.array([-3.0, -3.6, -5.6]), 10, 0.125, 2.0)):
+        cases = {}
+        idx = 0
+        raises_when_nobs_gt_n = False
+        for N in (2, 3, 7, 16):
+            for N_obs in (0, 1, 4):
+                models = [Model(env) for _ in range(N)]
+                d = cbf.DroneCBF(env, models, safety_radius=sr, zscale=zs, order=order, cbf_poles=poles)
+                x = np.zeros((N, xdim))
+                x[:, 0:3] = rng.uniform(-0.4, 0.4, size=(N, 3))
+                if order == 3:
+                    x[:, 3] = env.M * env.G * (1 + 0.2 * rng.normal(size=N))
+                x[:, -6:-3] = rng.normal(size=(N, 3)) * 0.7
+                x[:, -3:] = rng.uniform(-0.8, 0.8, size=(N, 3)) + np.array([0, 0, 0.5])
+                xdes = np.zeros((N, xdim))
+                xdes[:, 2] = rng.uniform(-1, 1, size=N)
+                if order == 3:
+                    xdes[:, 3] = env.M * env.G
+                xdes[:, -6:-3] = rng.normal(size=(N, 3)) * 0.5
+                xdes[:, -3:] = x[:, -3:] + rng.normal(size=(N, 3)) * 0.1
+                d.set_xdes(xdes)
+                if N_obs:
+                    x_obs = np.zeros((N_obs, order, 3))
+                    x_obs[:, 0, :] = rng.uniform(-0.6, 0.6, size=(N_obs, 3)) + np.array([0, 0, 0.5])
+                    obs_r = list(rng.uniform(0.05, 0.2, size=N_obs))
+                    try:
+                        G, h = d._build_ineq_const(x.copy(), False, list(x_obs), obs_r)
+                    except ValueError:
+                        # reference quirk: getABij(i, j) indexes the AGENT block j for obstacle j
+                        # (cbf/cbf.py:388,180-192) -> N_obs > N raises.  Recorded, case skipped.
+                        assert N_obs > N
+                        raises_when_nobs_gt_n = True
+                        continue
+                else:
+                    x_obs = np.zeros((0, order, 3))
+                    obs_r = []
+                    G, h = d._build_ineq_const(x.copy(), False, None, None)
+                cases[f"c{idx}_x"] = x
+                cases[f"c{idx}_xdes"] = xdes
+                cases[f"c{idx}_xobs"] = x_obs
+                cases[f"c{idx}_obsr"] = np.array(obs_r)
+                cases[f"c{idx}_G"] = G
+                cases[f"c{idx}_h"] = h
+                idx += 1
+                Kcbf = np.asarray(d.Kcbf).reshape(-1)
+                umax = np.asarray(d.umax)
+        np.savez_compressed(OUT + f"/cbf_rows_o{order}.npz", n_cases=idx, order=order, poles=poles, Kcbf=Kcbf, umax=umax,
+                 safety_radius=sr, zscale=zs, Fmin=-env.M * env.G, Fmax=env.MAX_THRUST,
+                 raises_when_nobs_gt_n=raises_when_nobs_gt_n, **cases, **META)
+        print("cbf order", order, "cases", idx, "Kcbf", Kcbf, "umax", umax, "last G", G.shape)
+
+
+if __name__ == "__main__":
+    ref = load_reference()
+    mint_lemniscate(ref)
+    mint_geometric(ref)
+    mint_mixer(ref)
+    mint_dynamics(ref)
+    mint_cbf(ref)

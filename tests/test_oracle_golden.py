@@ -1,0 +1,124 @@
+"""Pin the float64 oracle against golden vectors minted from the reference's own NumPy
+code (tests/golden/mint_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+def test_lemniscate_matches_reference():
+    d = load("lemniscate.npz")
+    P, ts, ref = d["params"], d["ts"], d["out"]
+    for k in range(P.shape[0]):
+        for i, t in enumerate(ts):
+            pos, vel, acc, yaw, om = O.lemniscate(t, P[k, 0], P[k, 1], P[k, 2:5], P[k, 5], P[k, 6])
+            got = np.hstack([pos, vel, acc, yaw, om])
+            np.testing.assert_allclose(got, ref[k, i], rtol=0, atol=1e-12)
+    # SURVEY.md 8c spot value
+    pos, vel, acc, yaw, om = O.lemniscate(0.37, 1.0, 1.5, np.array([0, 0, .5]), 0.3, 0.0)
+    np.testing.assert_allclose(np.hstack([pos, vel, acc, yaw, om]), d["spot"], atol=1e-14)
+    np.testing.assert_allclose(pos, [0.3505205637, 0.6651959776, 0.5], atol=1e-9)
+
+
+def test_lemniscate_batched_params():
+    d = load("lemniscate.npz")
+    P, ts, ref = d["params"], d["ts"], d["out"]
+    pos, vel, acc, yaw, om = O.lemniscate(ts[37], P[:, 0], P[:, 1], P[:, 2:5], P[:, 5], P[:, 6])
+    got = np.concatenate([pos, vel, acc, yaw[:, None], om[:, None]], axis=-1)
+    np.testing.assert_allclose(got, ref[:, 37], atol=1e-12)
+
+
+def test_geometric_compute_matches_reference():
+    d = load("geometric_compute.npz")
+    obs, des = d["obs"], d["des"]
+    rpm = O.geometric_compute(obs, des[:, 0:3], des[:, 3:6], des[:, 6:9], des[:, 9], des[:, 10])
+    np.testing.assert_allclose(rpm, d["rpm"], rtol=1e-11, atol=1e-7)
+    f, w, Rd = O.geometric_compute(obs, des[:, 0:3], des[:, 3:6], des[:, 6:9], des[:, 9], des[:, 10],
+                                   return_omegas=True)
+    np.testing.assert_allclose(f, d["force"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(w, d["w_des"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(Rd, d["R_des"], rtol=0, atol=1e-12)
+    # both quirk-sensitive spot values from SURVEY.md 8c
+    so, sd = d["spot_obs"], d["spot_des"]
+    r1 = O.geometric_compute(so, sd[0:3], sd[3:6], sd[6:9], sd[9], sd[10])
+    np.testing.assert_allclose(r1, [14426.96568, 14788.12966, 11884.78050, 16030.20029], atol=1e-4)
+    _, w1, _ = O.geometric_compute(so, sd[0:3], sd[3:6], sd[6:9], sd[9], sd[10], return_omegas=True)
+    np.testing.assert_allclose(w1, [0.5956908439, -0.0106877434, 0.7451911107], atol=1e-9)
+
+
+def test_geometric_golden_covers_clamp_and_clip():
+    d = load("geometric_compute.npz")
+    rpm = d["rpm"]
+    lo = 9440.3
+    assert (np.abs(rpm - lo) < 1e-6).any(axis=1).sum() >= 16          # min-thrust clip exercised
+    assert (np.abs(rpm - lo) > 1.0).all(axis=1).sum() >= 64           # and plenty of unclipped rows
+    # tilt clamp rows: recompute the pre-clamp tilt with the oracle pieces
+    obs, des = d["obs"], d["des"]
+    n_rand, n_tilt = int(d["n_rand"]), int(d["n_tilt"])
+    f, _, Rd = O.geometric_compute(obs[n_rand:n_rand + n_tilt], des[n_rand:n_rand + n_tilt, 0:3],
+                                   des[n_rand:n_rand + n_tilt, 3:6], des[n_rand:n_rand + n_tilt, 6:9],
+                                   des[n_rand:n_rand + n_tilt, 9], des[n_rand:n_rand + n_tilt, 10], return_omegas=True)
+    tilt = np.arccos(np.abs(Rd[:, 2, 2]))
+    assert (np.abs(tilt - 40 * np.pi / 180) < 1e-9).sum() >= 16      # clamped exactly to 40 deg
+
+
+def test_mixer_matches_reference():
+    d = load("mixer.npz")
+    np.testing.assert_allclose(O.input_to_action(d["u"], O.CF2P), d["rpm"], rtol=1e-12, atol=1e-8)
+    np.testing.assert_allclose(O.action_to_input(d["act"], O.CF2P), d["u_back"], rtol=1e-13, atol=1e-18)
+    np.testing.assert_allclose(O.action_to_input(d["act"], O.CF2P, cap_rpm=False), d["u_back_nocap"], rtol=1e-13,
+                               atol=1e-18)
+
+
+def test_obs_conversions_match_reference():
+    d = load("mixer.npz")
+    obs = d["obs"]
+    np.testing.assert_allclose(O.obs_to_lin_model(obs, 9), d["lin9"], atol=0)
+    np.testing.assert_allclose(O.obs_to_lin_model(obs, 10), d["lin10"], rtol=1e-14)
+    np.testing.assert_allclose(O.obs_to_lin_model(obs, 12), d["lin12"], atol=0)
+    p, R, v, w = O.obs_to_geo_model(obs)
+    got = np.concatenate([p, R.reshape(-1, 9), v, w], axis=-1)
+    np.testing.assert_allclose(got, d["geo18"], atol=1e-15)
+    with pytest.raises(ValueError):
+        O.obs_to_lin_model(obs, 7)
+
+
+def test_quadrotor_dynamics_matches_reference():
+    d = load("dynamics_deriv.npz")
+    np.testing.assert_allclose(O.quadrotor_dynamics(d["state"], d["u"]), d["out_hb"], rtol=1e-13, atol=1e-13)
+    # stale-J quirk: after load_env_params J is still the Hummingbird one
+    np.testing.assert_allclose(d["env_J"], [1.05, 1.05, 2.05])
+    got = O.quadrotor_dynamics(d["state"], d["u_env"], m=float(d["env_m"]), g=float(d["env_g"]), J=d["env_J"])
+    np.testing.assert_allclose(got, d["out_env"], rtol=1e-13, atol=1e-13)
+    assert bool(d["step_raises"])  # QuadrotorDynamics.step() raises ValueError in the reference
+
+
+@pytest.mark.parametrize("order", [2, 3])
+def test_cbf_rows_match_reference(order):
+    d = load(f"cbf_rows_o{order}.npz")
+    Kcbf = d["Kcbf"]
+    np.testing.assert_allclose(O.place_poles_chain(d["poles"]), Kcbf, rtol=1e-10)
+    assert bool(d["raises_when_nobs_gt_n"])
+    for k in range(int(d["n_cases"])):
+        x, xdes, xobs, obsr = d[f"c{k}_x"], d[f"c{k}_xdes"], d[f"c{k}_xobs"], d[f"c{k}_obsr"]
+        Gr, hr = d[f"c{k}_G"], d[f"c{k}_h"]
+        G, h = O.cbf_rows(x, xdes, order, Kcbf, d["umax"], float(d["safety_radius"]), float(d["zscale"]), O.CF2P,
+                          xobs if len(obsr) else None, list(obsr) if len(obsr) else None,
+                          Fmin=float(d["Fmin"]), Fmax=float(d["Fmax"]))
+        assert G.shape == Gr.shape and h.shape == hr.shape
+        np.testing.assert_allclose(G, Gr, rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(h, hr, rtol=1e-10, atol=1e-9)
+
+
+def test_place_poles_known_values():
+    np.testing.assert_allclose(O.place_poles_chain([-2.2, -2.4]), [5.28, 4.6], rtol=1e-12)
+    np.testing.assert_allclose(O.place_poles_chain([-3.0, -3.6, -5.6]), [60.48, 47.76, 12.2], rtol=1e-12)
+    np.testing.assert_allclose(O.place_poles_chain([-2.2, -2.4, -2.6]), [13.728, 17.24, 7.2], rtol=1e-12)
