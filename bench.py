@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: drone-steps/sec of the fused (trajectory -> geometric controller
+-> mixer -> physics step -> observation) kernel, plus the achieved algorithmic HBM bandwidth
+against the MI355X roofline and a CPU baseline (the float64 oracle) timed in the same run.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torchrun)
+
+A "step" is one control step of EVERY drone of the workload (one kernel launch).  Default
+workload = BASELINE.json configs[2] ("C3": 65 536 envs x 8 drones, Lemniscate tracking), the
+configuration the metric's targets (>= 50 M drone-steps/s at >= 60 % of HBM roofline, 1/2/4/8
+GPU scaling) are quoted on; --workload c2 selects configs[1] (4 096 x 4), whose 3.5 MB working
+set is launch-latency bound.  Each rank owns its own envs (weak scaling, no collective on the
+data path).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (envs per GPU, drones per env, phase rule, description)
+    "c3": (65536, 8, "c3", "C3: 65536 envs x 8 drones per GPU, Lemniscate tracking, fused traj+geometric+DYN step, obs every step"),
+    "c2": (4096, 4, "c2", "C2: 4096 envs x 4 drones per GPU, geometric controller free flight, fused step, obs every step"),
+}
+BYTES_PER_DRONE_STEP = 212          # R state 52 + R traj params 28 + W state 52 + W obs 80
+HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_inputs(E, D, phase, seed):
+    """SURVEY.md 8d synthetic generator (same as tests/helpers.c2_setup)."""
+    rng = np.random.default_rng(seed)
+    cen = np.zeros((E, D, 3))
+    cen[..., :2] = rng.uniform(-5, 5, size=(E, 1, 2))
+    cen[..., 2] = 0.5
+    ang = 2 * np.pi * np.arange(D) / D
+    xyz = cen.copy()
+    xyz[..., 0] += np.sin(ang)
+    xyz[..., 1] += np.cos(ang)
+    P = np.zeros((E, D, 7))
+    P[..., 0], P[..., 1], P[..., 2:5] = 1.0, 1.5, cen
+    P[..., 6] = -(np.pi / 4) * (np.arange(D) - 1) if phase == "c2" else 2 * np.pi * np.arange(D) / (D + 0.25)
+    return xyz, np.zeros((E, D, 3)), P
+
+
+def dist_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def dist_init(backend):
+    import torch.distributed as dist
+    rank, local_rank, world = dist_env()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def max_over_ranks(value, world, device):
+    """Elapsed time of the slowest rank (the contract's MAX over ranks)."""
+    if world == 1:
+        return value
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def cpu_baseline(D, phase, budget_s=15.0):
+    """The float64 NumPy oracle (a restatement of the reference path, kind "port") on a bounded
+    sample of the same workload: 512 envs, as many control steps as fit in ~budget_s."""
+    from oracle import np_oracle as O
+    E = 512
+    xyz, rpy, P = make_inputs(E, D, phase, 123)
+    n = E * D
+    Pf = P.reshape(-1, 7)
+    ora = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), pyb_freq=100, ctrl_freq=100)
+    obs = ora.step(np.zeros((n, 4)))
+    t, steps = 0.0, 0
+    t0 = time.perf_counter()
+    while True:
+        pos, vel, acc, yaw, yd = O.lemniscate(t, Pf[:, 0], Pf[:, 1], Pf[:, 2:5], Pf[:, 5], Pf[:, 6])
+        obs = ora.step(O.geometric_compute(obs, pos, vel, acc, yaw, yd))
+        t += ora.CTRL_TIMESTEP
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 2000:
+            break
+    return {"value": n * steps / el, "unit": "drone-steps/s", "cores": 1, "kind": "port",
+            "sample": f"float64 NumPy oracle (vectorised), {E} envs x {D} drones x {steps} control steps in {el:.1f} s"}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--dtype", default="float32", choices=["float32", "float64", "float16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--python-loop", action="store_true", help="issue each step from Python (env.step_geometric) instead of the C rollout loop")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU tests of the N>1 path")
+    args = ap.parse_args(argv)
+
+    E, D, phase, desc = WORKLOADS[args.workload]
+    import torch
+
+    if args.dry_run_cpu:
+        rank, local_rank, world = dist_init("gloo")
+        device = torch.device("cpu")
+        barrier(world)
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))          # stand-in work; the slowest rank defines the time
+        barrier(world)
+        elapsed = max_over_ranks(time.perf_counter() - t0, world, device)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "elapsed": elapsed, "ranks_seen": world}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return 0
+
+    rank, local_rank, world = dist_init("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import __graft_entry__
+    if not os.path.exists(__graft_entry__.LIB):
+        if rank == 0:
+            __graft_entry__.build()
+        barrier(world)
+    from multidronesim_amd.envs.CtrlAviary import CtrlAviary, DroneModel, Physics
+
+    xyz, rpy, P = make_inputs(E, D, phase, 1000 + rank)          # every rank owns different envs
+    env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN,
+                     pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=args.dtype, device=local_rank)
+    env.set_trajectories(P)
+    env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=device))     # EnvGeometric.py:431
+    dt = env.CTRL_TIMESTEP
+
+    def run(t0, k):
+        if args.python_loop:
+            t = t0
+            for _ in range(k):
+                env.step_geometric(t)
+                t += dt
+        else:
+            env.rollout_geometric(t0, k, want_obs=True, obs_every_step=True)
+
+    run(0.0, args.warmup)
+    torch.cuda.synchronize(device)
+    barrier(world)
+    torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    wall0 = time.perf_counter()
+    ev0.record(torch.cuda.current_stream(device))       # same stream the kernels are enqueued on
+    run(args.warmup * dt, args.steps)
+    ev1.record(torch.cuda.current_stream(device))
+    torch.cuda.synchronize(device)
+    barrier(world)
+    wall = time.perf_counter() - wall0
+    dev_ms = ev0.elapsed_time(ev1)
+    elapsed = max_over_ranks(wall, world, device)
+    dev_ms_max = max_over_ranks(dev_ms, world, device)
+
+    obs = env._obs
+    ok = bool(torch.isfinite(obs).all().item()) and abs(float(obs[..., 3:7].norm(dim=-1).mean().item()) - 1.0) < 1e-3
+    n_local = E * D
+    total_units = n_local * world * args.steps
+    value = total_units / elapsed
+    kernel_us = dev_ms * 1e3 / args.steps                   # average launch-to-launch duration on the stream (HIP events)
+    achieved = BYTES_PER_DRONE_STEP * n_local / (kernel_us * 1e-6) / 1e9
+    line = {
+        "metric": "drone-steps/sec (whole node) at N_envs x N_drones; achieved HBM GB/s vs roofline",
+        "value": value, "unit": "drone-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"float32": "f32", "float64": "f64", "float16": "f16-storage/f32-math"}[args.dtype], "data": "synthetic",
+        "config": {"workload": desc, "envs_per_gpu": E, "drones_per_env": D, "pyb_freq": 100, "ctrl_freq": 100,
+                   "physics": "DYN (explicit Euler)", "parallelism": f"env-shard x{world}, no collective",
+                   "launch": "python" if args.python_loop else "C rollout loop"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": None, "kernel": "k_step_geometric<float,float,true,false>", "kernel_us": kernel_us,
+                     "bytes_per_launch": BYTES_PER_DRONE_STEP * n_local},
+        "device_ms_per_step_max_rank": dev_ms_max / args.steps, "state_sane": ok,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(D, phase, args.cpu_budget)
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    env.close()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

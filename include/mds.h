@@ -1,0 +1,172 @@
+/* libmds -- C-ABI of the MI355X-native batched multi-drone step.
+ *
+ * This is the drop-in boundary for the ONE hot path of JasonTStanley/MultiDroneSim: the
+ * per-drone physics step the reference delegates to gym-pybullet-drones'
+ * BaseAviary.step/_dynamics (PyBullet, CPU) plus the reference's per-drone trajectory
+ * sampling, geometric controller, RPM mixer and ECBF safety filter.  The reference has no
+ * FFI layer of its own (pure Python); each entry point below names the reference
+ * interface it replaces (paths relative to the reference checkout; [UPSTREAM] =
+ * gym-pybullet-drones, not in the tree -- see SURVEY.md 3.4).
+ *
+ * Conventions
+ *   - n = num_envs * num_drones "drones"; drone d of env e has flat index e*num_drones + d.
+ *   - "dev" pointers are device (HBM) pointers owned by the caller (e.g. PyTorch-ROCm
+ *     tensors); their element type is the handle's storage dtype (mds_dtype): float for
+ *     MDS_F32, double for MDS_F64, IEEE half for MDS_F16 (fp16 storage, fp32 arithmetic).
+ *   - "host" pointers are host double arrays (set-up / inspection only, never hot path).
+ *   - `stream` is a hipStream_t (NULL = default stream).  Hot-path calls only enqueue
+ *     work on it and return; they never synchronise, allocate or copy.
+ *   - Every call returns MDS_OK (0) or a negative mds_status; nothing throws or aborts
+ *     across the ABI.  mds_strerror() names a status, mds_last_error() adds HIP detail.
+ *   - A handle is not re-entrant (one simulation thread, as PIDEnv.py:99-103); distinct
+ *     handles (one per GPU / process) are independent.
+ *   - The library owns only the handle and its internal SoA state / parameter planes.
+ */
+#ifndef MDS_H
+#define MDS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDS_VERSION 100 /* 0.1.0 */
+#define MDS_OBS_DIM 20  /* [UPSTREAM] _getDroneStateVector */
+#define MDS_ACT_DIM 4
+#define MDS_STATE_DIM 13 /* pos3 | quat4 xyzw | vel3 (world) | body rates3 */
+#define MDS_DES_DIM 11   /* pos3 | vel3 | acc3 | yaw | yaw_rate  (Lemniscate.__call__ 5-tuple, flattened) */
+#define MDS_LEM_DIM 7    /* a | omega | centre3 | yaw_rate | phase_shift  (Lemniscate.__init__) */
+#define MDS_GEO_AUX_DIM 13 /* force | w_des3 | R_des9 row-major  (GeometricControl.compute(return_omegas=True)) */
+
+typedef enum mds_status {
+  MDS_OK = 0,
+  MDS_EINVAL = -1,      /* bad argument (null pointer, size, enum) */
+  MDS_ENOMEM = -2,      /* hipMalloc failed */
+  MDS_EHIP = -3,        /* a HIP runtime call failed; see mds_last_error() */
+  MDS_EALIGN = -4,      /* a device pointer is not 16-byte aligned */
+  MDS_ESTATE = -5,      /* call not valid in the handle's state (e.g. no trajectory set) */
+  MDS_EUNSUPPORTED = -6 /* combination not built (e.g. order-3 CBF with fp16 storage) */
+} mds_status;
+
+typedef enum mds_dtype { MDS_F32 = 0, MDS_F64 = 1, MDS_F16 = 2 } mds_dtype;
+typedef enum mds_physics { MDS_PHYSICS_DYN = 0, MDS_PHYSICS_DYN_DRAG = 1 } mds_physics;
+typedef enum mds_integrator { MDS_INTEGRATOR_EULER = 0, MDS_INTEGRATOR_RK4 = 1 } mds_integrator;
+typedef enum mds_drone_model { MDS_CF2X = 0, MDS_CF2P = 1 } mds_drone_model;
+
+/* Constructor arguments of [UPSTREAM] CtrlAviary as the reference passes them
+ * (PIDEnv.py:106-116, simulations/EnvGeometric.py:89-100) plus the batch axis. */
+typedef struct mds_config {
+  int32_t num_envs;
+  int32_t num_drones;   /* per env */
+  int32_t dtype;        /* mds_dtype */
+  int32_t physics;      /* mds_physics; [UPSTREAM] Physics.DYN (+ _drag) */
+  int32_t integrator;   /* mds_integrator; EULER = [UPSTREAM] _dynamics semantics */
+  int32_t drone_model;  /* mds_drone_model: selects the torque mixing of _dynamics */
+  int32_t pyb_freq;     /* must be a multiple of ctrl_freq ([UPSTREAM] BaseAviary.__init__) */
+  int32_t ctrl_freq;
+  int32_t device;       /* HIP device ordinal */
+  int32_t reserved;
+  /* urdf constants ([UPSTREAM] _parseURDFParameters) */
+  double M, L, KF, KM, J[3], G, thrust2weight, drag_coeff[3];
+} mds_config;
+
+/* control/geometric.py:14-23 */
+typedef struct mds_geometric_gains {
+  double Kp[3], Kv[3], KR[3], Kw[3];
+  double g;              /* 9.81 in the reference (env.G is 9.8) */
+  double max_tilt_angle; /* rad */
+} mds_geometric_gains;
+
+typedef struct mds_handle mds_handle;
+
+int mds_version(void);
+const char* mds_strerror(int status);
+const char* mds_last_error(void);
+
+/* Fills cfg with the CF2P / CF2X constants and the reference's defaults
+ * (PIDEnv.py:18-29: pyb = ctrl = 100 Hz... callers override). */
+int mds_default_config(int drone_model, mds_config* cfg);
+int mds_default_geometric_gains(mds_geometric_gains* gains);
+
+/* [UPSTREAM] CtrlAviary.__init__ / close().  State starts at the origin with identity
+ * attitude; call mds_reset. */
+int mds_create(const mds_config* cfg, mds_handle** out);
+int mds_destroy(mds_handle* h);
+
+/* Derived attributes the reference reads off `env` (SURVEY.md 3.4 census):
+ * out[0..7] = GRAVITY(M*G), HOVER_RPM, MAX_RPM, MAX_THRUST, MAX_XY_TORQUE, MAX_Z_TORQUE,
+ *             CTRL_TIMESTEP, PYB_TIMESTEP */
+int mds_get_derived(const mds_handle* h, double out[8]);
+
+/* [UPSTREAM] BaseAviary.reset()/_housekeeping: pose from initial_xyzs / initial_rpys
+ * (host double [n,3] each), zero velocities, zero last action. */
+int mds_reset(mds_handle* h, const double* xyz_host, const double* rpy_host, void* stream);
+
+/* Test / checkpoint access to the 13-float state in the WORLD frame (host double [n,13]).
+ * Synchronises the stream. */
+int mds_get_state(mds_handle* h, double* state_host, void* stream);
+int mds_set_state(mds_handle* h, const double* state_host, void* stream);
+
+/* Local-frame origin per drone (host double [n,3]); positions are stored relative to it so
+ * that fp32 storage keeps ~1e-7 m resolution far from the world origin.  Re-bases the
+ * stored state; observations are always world-frame.  mds_set_lemniscate sets it to the
+ * trajectory centre. */
+int mds_set_origin(mds_handle* h, const double* origin_host, void* stream);
+
+/* [UPSTREAM] BaseAviary._computeObs(): obs_dev [n,20] from the current state.  obs[16:20]
+ * is the last clipped action of the most recent mds_step* call (zeros after reset). */
+int mds_get_obs(mds_handle* h, void* obs_dev, void* stream);
+
+/* [UPSTREAM] BaseAviary.step(action) for every drone: clip RPM to [0, MAX_RPM],
+ * pyb_freq/ctrl_freq physics substeps of _dynamics (+_drag), pack the 20-float obs.
+ * Call sites replaced: simulations/EnvGeometric.py:469, PIDEnv.py:176.
+ * action_dev [n,4] RPM, obs_dev [n,20] (may be NULL: state only). */
+int mds_step(mds_handle* h, const void* action_dev, void* obs_dev, void* stream);
+
+/* trajectories/Lemniscate.py:14-30: one Lemniscate per drone, params_host double [n,7] =
+ * (a, omega, centre_x, centre_y, centre_z, yaw_rate, phase_shift). */
+int mds_set_lemniscate(mds_handle* h, const double* params_host, void* stream);
+int mds_set_geometric_gains(mds_handle* h, const mds_geometric_gains* gains);
+
+/* One fused control step of simulations/EnvGeometric.py:434-469 for every drone:
+ * trajs[j](t) -> GeometricControl.compute(obs[j]) -> input_to_action -> env.step(action),
+ * with no action / observation round trip through HBM.
+ * obs_dev [n,20] or NULL; action_dev [n,4] (the unclipped controller RPM) or NULL. */
+int mds_step_geometric(mds_handle* h, double t, void* obs_dev, void* action_dev, void* stream);
+
+/* n_steps consecutive mds_step_geometric calls at t0, t0+dt, ... enqueued from C (dt =
+ * CTRL_TIMESTEP, accumulated like the reference loop, EnvGeometric.py:473).  obs_dev (or
+ * NULL) receives the observation of EVERY step (same buffer, overwritten) when
+ * obs_every_step != 0, else only the last step's. */
+int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs_dev, int obs_every_step, void* stream);
+
+/* ---- stand-alone per-drone operators (same arithmetic as the fused path) ---------------- */
+
+/* trajectories/Lemniscate.py:32-63 `__call__(t)`: des_dev [n,11] world frame, using the
+ * handle's trajectories. */
+int mds_lemniscate_eval(mds_handle* h, double t, void* des_dev, void* stream);
+
+/* control/geometric.py:59-115 `GeometricControl.compute(obs)` after
+ * set_desired_trajectory(...): obs_dev [n,20], des_dev [n,11] -> rpm_dev [n,4]
+ * (input_to_action applied, utils/model_conversions.py:85-103).  If aux_dev != NULL also
+ * writes the return_omegas=True triple (force, w_des, R_des) as [n,13]. */
+int mds_geometric_compute(mds_handle* h, const void* obs_dev, const void* des_dev, void* rpm_dev, void* aux_dev,
+                          void* stream);
+
+/* utils/model_conversions.py:85-103 / :69-83 */
+int mds_input_to_action(mds_handle* h, const void* u_dev /*[n,4]*/, void* rpm_dev /*[n,4]*/, void* stream);
+int mds_action_to_input(mds_handle* h, const void* rpm_dev /*[n,4]*/, int cap_rpm, void* u_dev /*[n,4]*/, void* stream);
+
+/* model/dynamics.py:83-106 `QuadrotorDynamics.dynamics(t, state, u)`: state_dev [count,18]
+ * (p, R row-major, v, w), u_dev [count,4] (thrust, torques) -> out_dev [count,12].
+ * m, J, g are that class's own constants (Hummingbird defaults :24-28; J stays the stale
+ * Hummingbird one after load_env_params, :18).  dtype = element type of the buffers. */
+int mds_quadrotor_dynamics(int dtype, int count, const void* state_dev, const void* u_dev, double m, const double J[3],
+                           double g, void* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDS_H */

@@ -1,0 +1,151 @@
+"""PIDEnv.py of the reference: ``MultiDroneEnv`` -- a threaded hover service around
+CtrlAviary with mutable ``TARGET_POSITIONS`` (PIDEnv.py:31-187).
+
+Same constructor, ``threaded_sim() / run_sim() / sim_step(i) / stop()`` and attributes.  The
+per-drone set-point controller runs on the GPU fused with the physics step: each drone
+tracks a zero-amplitude Lemniscate centred on its target (pos = target, vel = acc = 0), i.e.
+the reference's own GeometricControl regulating to TARGET_POSITIONS.  ([UPSTREAM]
+DSLPIDControl, which the reference instantiates at PIDEnv.py:124-134, is not in the
+reference tree; porting it is listed under "next" in DESIGN.md.)  The reference's latent bugs
+(module-global ARGS, 20-vector unpacked into 4 names, missing ``logging`` import) are not
+reproduced."""
+from __future__ import annotations
+
+import argparse
+import logging
+import threading
+import time
+
+import numpy as np
+
+from .envs.CtrlAviary import CtrlAviary
+from .utils.enums import DroneModel, Physics
+from .utils.utils import sync
+
+DEFAULT_DRONES = DroneModel("cf2p")
+DEFAULT_PHYSICS = Physics("pyb")
+DEFAULT_GUI = True
+DEFAULT_PLOT = False
+DEFAULT_RECORD = False
+DEFAULT_USER_DEBUG_GUI = False
+DEFAULT_SIMULATION_FREQ_HZ = 100
+DEFAULT_CONTROL_FREQ_HZ = 100
+DEFAULT_DURATION_SEC = None
+DEFAULT_OUTPUT_FOLDER = 'results'
+DEFAULT_NUM_DRONES = 2
+
+
+class MultiDroneEnv(object):
+    def build_args(self, kwargs):
+        args = {}
+        args['drone'] = DEFAULT_DRONES
+        args['num_drones'] = DEFAULT_NUM_DRONES
+        args['physics'] = DEFAULT_PHYSICS
+        args['gui'] = DEFAULT_GUI
+        args['plot'] = DEFAULT_PLOT
+        args['user_debug_gui'] = DEFAULT_USER_DEBUG_GUI
+        args['simulation_freq_hz'] = DEFAULT_SIMULATION_FREQ_HZ
+        args['control_freq_hz'] = DEFAULT_CONTROL_FREQ_HZ
+        args['duration_sec'] = None
+        args['output_folder'] = DEFAULT_OUTPUT_FOLDER
+        args['init_rad'] = 1.0
+        args['num_envs'] = 1          # batch axis (build extension)
+        args['realtime'] = True       # sync() to wall-clock like the reference (PIDEnv.py:179)
+        for key, value in kwargs.items():
+            if key in args:
+                args[key] = value
+            else:
+                logging.warning(f"Skipping invalid argument: {key} in creation of MultiDroneEnv,"
+                                f" must be from list {args.keys()}")
+        return argparse.Namespace(**args)
+
+    def __init__(self, INIT_XYZS=None, INIT_RPYS=None, TARGET_POSITIONS=None, TARGET_RPYS=None, args=None, **kwargs):
+        self.args = self.build_args(kwargs) if args is None else args
+        a = self.args
+        for k, v in (("num_envs", 1), ("realtime", True), ("init_rad", 1.0), ("duration_sec", None)):
+            if not hasattr(a, k):
+                setattr(a, k, v)
+        starting_target_offset = 1
+        if INIT_XYZS is None:
+            INIT_XYZS = np.zeros((a.num_drones, 3))
+            for i in range(1, a.num_drones):
+                INIT_XYZS[i, 0] = a.init_rad * np.cos((i / a.num_drones) * 2 * np.pi)
+                INIT_XYZS[i, 1] = a.init_rad * np.sin((i / a.num_drones) * 2 * np.pi)
+                INIT_XYZS[i, 2] = 0.0
+        if INIT_RPYS is None:
+            INIT_RPYS = np.zeros((a.num_drones, 3))
+        if TARGET_POSITIONS is None:
+            TARGET_POSITIONS = np.array(INIT_XYZS, dtype=np.float64).copy()
+            TARGET_POSITIONS[..., 2] += starting_target_offset
+        if TARGET_RPYS is None:
+            TARGET_RPYS = np.zeros((a.num_drones, 3))
+        self.INIT_XYZS = INIT_XYZS
+        self.INIT_RPYS = INIT_RPYS
+        self.TARGET_POSITIONS = TARGET_POSITIONS
+        self.TARGET_RPYS = TARGET_RPYS
+        self.ctrl = []
+        self.env = None
+        self.action = None
+        self.obs = None
+        self.stop_cmd = False
+        self._sent_targets = None
+
+    def threaded_sim(self):
+        self.stop_cmd = False
+        t = threading.Thread(target=self.run_sim)
+        t.start()
+        return t
+
+    def _push_targets(self):
+        """Targets are copied to the device at a step boundary (the reference's REPL thread
+        writes TARGET_POSITIONS unsynchronised, PIDEnv.py:206; here a change takes effect at the
+        next step)."""
+        tp = np.array(self.TARGET_POSITIONS, dtype=np.float64)
+        if self._sent_targets is not None and np.array_equal(tp, self._sent_targets):
+            return
+        env = self.env
+        P = np.zeros((env.NUM_ENVS, env.NUM_DRONES, 7))
+        P[..., 1] = 1.0
+        P[..., 2:5] = tp
+        env.set_trajectories(P)
+        self._sent_targets = tp.copy()
+
+    def run_sim(self):
+        args = self.args
+        env = CtrlAviary(drone_model=args.drone, num_drones=args.num_drones, initial_xyzs=self.INIT_XYZS,
+                         initial_rpys=self.INIT_RPYS, physics=args.physics, pyb_freq=args.simulation_freq_hz,
+                         ctrl_freq=args.control_freq_hz, gui=args.gui, user_debug_gui=args.user_debug_gui,
+                         output_folder=args.output_folder, num_envs=args.num_envs)
+        self.env = env
+        self.PYB_CLIENT = self.env.getPyBulletClient()
+        self.DRONE_IDS = self.env.getDroneIds()
+        self.env._showDroneLocalAxes(0)
+        self.START = time.time()
+        self.action = np.zeros((args.num_drones, 4)) if args.num_envs == 1 else np.zeros((args.num_envs, args.num_drones, 4))
+        self.obs, _, _, _, _ = self.env.step(self.action)
+        if args.duration_sec is not None:
+            CTRL_STEPS = int(args.duration_sec * self.env.CTRL_FREQ)
+            for i in range(CTRL_STEPS):
+                self.sim_step(i)
+        else:
+            i = 0
+            while not self.stop_sim(i):
+                self.sim_step(i)
+                i += 1
+        self.env.close()
+
+    def sim_step(self, i):
+        self._push_targets()
+        obs, act = self.env.step_geometric(i * self.env.CTRL_TIMESTEP, return_action=True)
+        self.obs = obs
+        self.action = act
+        if self.args.realtime:
+            sync(i, self.START, self.env.CTRL_TIMESTEP)
+
+    def stop_sim(self, i):
+        if i * self.env.CTRL_TIMESTEP > 1000:
+            return True
+        return self.stop_cmd
+
+    def stop(self):
+        self.stop_cmd = True

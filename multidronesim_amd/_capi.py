@@ -1,0 +1,104 @@
+"""ctypes binding of libmds.so (include/mds.h).  Thin: argument marshalling and status
+checks only -- all arithmetic lives in the HIP kernels.  There is NO fallback: if the
+shared library is missing or a call fails, this raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmds.so")
+
+MDS_OK = 0
+MDS_F32, MDS_F64, MDS_F16 = 0, 1, 2
+MDS_PHYSICS_DYN, MDS_PHYSICS_DYN_DRAG = 0, 1
+MDS_INTEGRATOR_EULER, MDS_INTEGRATOR_RK4 = 0, 1
+MDS_CF2X, MDS_CF2P = 0, 1
+OBS_DIM, ACT_DIM, STATE_DIM, DES_DIM, LEM_DIM, GEO_AUX_DIM = 20, 4, 13, 11, 7, 13
+
+
+class MdsConfig(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("num_drones", C.c_int32), ("dtype", C.c_int32), ("physics", C.c_int32),
+                ("integrator", C.c_int32), ("drone_model", C.c_int32), ("pyb_freq", C.c_int32),
+                ("ctrl_freq", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32),
+                ("M", C.c_double), ("L", C.c_double), ("KF", C.c_double), ("KM", C.c_double), ("J", C.c_double * 3),
+                ("G", C.c_double), ("thrust2weight", C.c_double), ("drag_coeff", C.c_double * 3)]
+
+
+class MdsGeometricGains(C.Structure):
+    _fields_ = [("Kp", C.c_double * 3), ("Kv", C.c_double * 3), ("KR", C.c_double * 3), ("Kw", C.c_double * 3),
+                ("g", C.c_double), ("max_tilt_angle", C.c_double)]
+
+
+class MdsError(RuntimeError):
+    def __init__(self, status, where, detail):
+        super().__init__(f"{where}: {detail} (mds_status {status})")
+        self.status = status
+
+
+_P = C.c_void_p
+_PD = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); mirrors include/mds.h one to one
+PROTOTYPES = {
+    "mds_version": (C.c_int, []),
+    "mds_strerror": (C.c_char_p, [C.c_int]),
+    "mds_last_error": (C.c_char_p, []),
+    "mds_default_config": (C.c_int, [C.c_int, C.POINTER(MdsConfig)]),
+    "mds_default_geometric_gains": (C.c_int, [C.POINTER(MdsGeometricGains)]),
+    "mds_create": (C.c_int, [C.POINTER(MdsConfig), C.POINTER(_P)]),
+    "mds_destroy": (C.c_int, [_P]),
+    "mds_get_derived": (C.c_int, [_P, _PD]),
+    "mds_reset": (C.c_int, [_P, _PD, _PD, _P]),
+    "mds_get_state": (C.c_int, [_P, _PD, _P]),
+    "mds_set_state": (C.c_int, [_P, _PD, _P]),
+    "mds_set_origin": (C.c_int, [_P, _PD, _P]),
+    "mds_get_obs": (C.c_int, [_P, _P, _P]),
+    "mds_step": (C.c_int, [_P, _P, _P, _P]),
+    "mds_set_lemniscate": (C.c_int, [_P, _PD, _P]),
+    "mds_set_geometric_gains": (C.c_int, [_P, C.POINTER(MdsGeometricGains)]),
+    "mds_step_geometric": (C.c_int, [_P, C.c_double, _P, _P, _P]),
+    "mds_rollout_geometric": (C.c_int, [_P, C.c_double, C.c_int, _P, C.c_int, _P]),
+    "mds_lemniscate_eval": (C.c_int, [_P, C.c_double, _P, _P]),
+    "mds_geometric_compute": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "mds_input_to_action": (C.c_int, [_P, _P, _P, _P]),
+    "mds_action_to_input": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "mds_quadrotor_dynamics": (C.c_int, [C.c_int, C.c_int, _P, _P, C.c_double, _PD, C.c_double, _P, _P]),
+}
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """dlopen libmds.so and bind every prototype.  Raises (never falls back) when the
+    library has not been built -- run ``python -c 'import __graft_entry__ as g; g.build()'``."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise MdsError(-1, "load_library", f"{p} not found: the HIP extension is not built (no CPU fallback exists)")
+    try:
+        import torch  # noqa: F401  -- loads torch's bundled libamdhip64 first so both share one HIP runtime
+    except Exception:  # pragma: no cover - torch is only needed for device tensors
+        pass
+    lib = C.CDLL(p)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(status: int, where: str):
+    if status != MDS_OK:
+        lib = load_library()
+        detail = lib.mds_strerror(status).decode()
+        extra = lib.mds_last_error().decode()
+        raise MdsError(status, where, f"{detail}; {extra}" if extra else detail)
+
+
+def as_double_ptr(arr):
+    return arr.ctypes.data_as(_PD)

@@ -1,0 +1,29 @@
+"""Device-tensor plumbing (PyTorch-ROCm is used for buffers and streams only)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+
+TORCH_DTYPE = {capi.MDS_F32: torch.float32, capi.MDS_F64: torch.float64, capi.MDS_F16: torch.float16}
+DTYPE_BY_NAME = {"float32": capi.MDS_F32, "fp32": capi.MDS_F32, "f32": capi.MDS_F32, torch.float32: capi.MDS_F32,
+                 "float64": capi.MDS_F64, "fp64": capi.MDS_F64, "f64": capi.MDS_F64, torch.float64: capi.MDS_F64,
+                 "float16": capi.MDS_F16, "fp16": capi.MDS_F16, "f16": capi.MDS_F16, torch.float16: capi.MDS_F16}
+
+
+def require_gpu(device_index: int) -> torch.device:
+    if not torch.cuda.is_available():
+        raise capi.MdsError(-3, "multidronesim_amd", "no HIP device visible: the batched step only runs on a GPU "
+                            "(there is no CPU fallback)")
+    return torch.device("cuda", device_index)
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def to_device(x, device, dtype) -> torch.Tensor:
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(device)

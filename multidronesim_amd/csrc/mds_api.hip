@@ -1,0 +1,395 @@
+// C-ABI of libmds (include/mds.h): handle management, constant set-up in double, dtype
+// dispatch and kernel launches.  No torch types, no exceptions across the boundary.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/mds.h"
+#include "mds_consts.hpp"
+#include "mds_kernels.hip"
+
+using namespace mds;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail_hip(hipError_t e, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return MDS_EHIP;
+}
+int fail(int code, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s", what);
+  return code;
+}
+
+#define MDS_HIP(call)                          \
+  do {                                         \
+    hipError_t e__ = (call);                   \
+    if (e__ != hipSuccess) return fail_hip(e__, #call); \
+  } while (0)
+
+size_t elem_size(int dtype) { return dtype == MDS_F64 ? 8 : (dtype == MDS_F16 ? 2 : 4); }
+size_t comp_size(int dtype) { return dtype == MDS_F64 ? 8 : 4; }
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+struct mds_handle {
+  mds_config cfg;
+  mds_geometric_gains gains;
+  int n;
+  size_t ld;           // plane stride (elements)
+  void* state;         // S [13][ld]
+  void* origin;        // T [3][ld]
+  void* last_rpm;      // T [4][ld]
+  void* lem;           // T [7][ld]
+  double* scratch;     // double [n*20] device staging for host<->device set-up calls
+  bool has_traj;
+  Consts<float> cf;
+  Consts<double> cd;
+};
+
+// dispatch on the handle dtype: F32 -> <float,float>, F64 -> <double,double>, F16 -> <float,half_t>
+#define MDS_DISPATCH(h, EXPR)                                               \
+  do {                                                                      \
+    if ((h)->cfg.dtype == MDS_F32) {                                        \
+      typedef float T; typedef float S; const Consts<T>& C = (h)->cf; (void)C; EXPR; \
+    } else if ((h)->cfg.dtype == MDS_F64) {                                 \
+      typedef double T; typedef double S; const Consts<T>& C = (h)->cd; (void)C; EXPR; \
+    } else {                                                                \
+      typedef float T; typedef half_t S; const Consts<T>& C = (h)->cf; (void)C; EXPR; \
+    }                                                                       \
+  } while (0)
+
+static inline dim3 grid_for(int n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+extern "C" {
+
+int mds_version(void) { return MDS_VERSION; }
+
+const char* mds_strerror(int status) {
+  switch (status) {
+    case MDS_OK: return "ok";
+    case MDS_EINVAL: return "invalid argument";
+    case MDS_ENOMEM: return "out of device memory";
+    case MDS_EHIP: return "HIP runtime error";
+    case MDS_EALIGN: return "device pointer not 16-byte aligned";
+    case MDS_ESTATE: return "call not valid in this handle state";
+    case MDS_EUNSUPPORTED: return "unsupported combination";
+    default: return "unknown status";
+  }
+}
+
+const char* mds_last_error(void) { return g_err; }
+
+int mds_default_config(int drone_model, mds_config* cfg) {
+  if (!cfg || (drone_model != MDS_CF2X && drone_model != MDS_CF2P)) return fail(MDS_EINVAL, "mds_default_config");
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->num_envs = 1;
+  cfg->num_drones = 2;           // PIDEnv.py:29
+  cfg->dtype = MDS_F32;
+  cfg->physics = MDS_PHYSICS_DYN;
+  cfg->integrator = MDS_INTEGRATOR_EULER;
+  cfg->drone_model = drone_model;
+  cfg->pyb_freq = 100;           // PIDEnv.py:24-25
+  cfg->ctrl_freq = 100;
+  cfg->M = 0.027;
+  cfg->L = 0.0397;
+  cfg->KF = 3.16e-10;
+  cfg->KM = 7.94e-12;
+  if (drone_model == MDS_CF2P) {
+    cfg->J[0] = 2.3951e-5; cfg->J[1] = 2.3951e-5; cfg->J[2] = 3.2347e-5;
+  } else {
+    cfg->J[0] = 1.4e-5; cfg->J[1] = 1.4e-5; cfg->J[2] = 2.17e-5;
+  }
+  cfg->G = 9.8;
+  cfg->thrust2weight = 2.25;
+  cfg->drag_coeff[0] = 9.1785e-7; cfg->drag_coeff[1] = 9.1785e-7; cfg->drag_coeff[2] = 10.311e-7;
+  return MDS_OK;
+}
+
+int mds_default_geometric_gains(mds_geometric_gains* g) {
+  if (!g) return fail(MDS_EINVAL, "mds_default_geometric_gains");
+  for (int k = 0; k < 3; ++k) {
+    g->Kp[k] = 2.25; g->Kv[k] = 3.5; g->KR[k] = 125.0; g->Kw[k] = 10.0;   // control/geometric.py:14-17
+  }
+  g->g = 9.81;                                                             // :20
+  g->max_tilt_angle = 40.0 * M_PI / 180.0;                                 // :23
+  return MDS_OK;
+}
+
+int mds_create(const mds_config* cfg, mds_handle** out) {
+  if (!cfg || !out) return fail(MDS_EINVAL, "mds_create: null argument");
+  *out = nullptr;
+  if (cfg->num_envs <= 0 || cfg->num_drones <= 0) return fail(MDS_EINVAL, "mds_create: num_envs/num_drones must be > 0");
+  if ((long long)cfg->num_envs * cfg->num_drones > (1LL << 30)) return fail(MDS_EINVAL, "mds_create: too many drones");
+  if (cfg->dtype < MDS_F32 || cfg->dtype > MDS_F16) return fail(MDS_EINVAL, "mds_create: dtype");
+  if (cfg->physics != MDS_PHYSICS_DYN && cfg->physics != MDS_PHYSICS_DYN_DRAG) return fail(MDS_EINVAL, "mds_create: physics");
+  if (cfg->integrator != MDS_INTEGRATOR_EULER && cfg->integrator != MDS_INTEGRATOR_RK4) return fail(MDS_EINVAL, "mds_create: integrator");
+  if (cfg->drone_model != MDS_CF2X && cfg->drone_model != MDS_CF2P) return fail(MDS_EINVAL, "mds_create: drone_model");
+  if (cfg->ctrl_freq <= 0 || cfg->pyb_freq <= 0 || cfg->pyb_freq % cfg->ctrl_freq != 0)
+    return fail(MDS_EINVAL, "mds_create: pyb_freq must be a positive multiple of ctrl_freq");
+  if (!(cfg->M > 0) || !(cfg->KF > 0) || !(cfg->KM > 0) || !(cfg->L > 0) || !(cfg->J[0] > 0) || !(cfg->J[1] > 0) || !(cfg->J[2] > 0))
+    return fail(MDS_EINVAL, "mds_create: non-positive drone constant");
+  MDS_HIP(hipSetDevice(cfg->device));
+  mds_handle* h = new (std::nothrow) mds_handle();
+  if (!h) return fail(MDS_ENOMEM, "mds_create: host allocation");
+  h->cfg = *cfg;
+  mds_default_geometric_gains(&h->gains);
+  h->n = cfg->num_envs * cfg->num_drones;
+  h->ld = ((size_t)h->n + 255) / 256 * 256;
+  h->has_traj = false;
+  fill_consts(h->cfg, h->gains, h->cf);
+  fill_consts(h->cfg, h->gains, h->cd);
+  const size_t es = elem_size(cfg->dtype), cs = comp_size(cfg->dtype);
+  h->state = h->origin = h->last_rpm = h->lem = nullptr;
+  h->scratch = nullptr;
+  hipError_t e = hipMalloc(&h->state, 13 * h->ld * es);
+  if (e == hipSuccess) e = hipMalloc(&h->origin, 3 * h->ld * cs);
+  if (e == hipSuccess) e = hipMalloc(&h->last_rpm, 4 * h->ld * cs);
+  if (e == hipSuccess) e = hipMalloc(&h->lem, 7 * h->ld * cs);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->scratch, (size_t)h->n * 20 * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(h->state, 0, 13 * h->ld * es);
+  if (e == hipSuccess) e = hipMemset(h->origin, 0, 3 * h->ld * cs);
+  if (e == hipSuccess) e = hipMemset(h->last_rpm, 0, 4 * h->ld * cs);
+  if (e == hipSuccess) e = hipMemset(h->lem, 0, 7 * h->ld * cs);
+  if (e != hipSuccess) {
+    mds_destroy(h);
+    return e == hipErrorOutOfMemory ? fail(MDS_ENOMEM, "mds_create: hipMalloc") : fail_hip(e, "mds_create");
+  }
+  // identity attitude
+  {
+    const size_t nbytes = (size_t)h->n * 6 * sizeof(double);
+    MDS_HIP(hipMemset(h->scratch, 0, nbytes));
+    MDS_DISPATCH(h, (k_reset<T, S><<<grid_for(h->n, 256), 256, 0, 0>>>(h->n, h->ld, h->scratch, h->scratch + (size_t)3 * h->n,
+                                                                         (const T*)h->origin, (S*)h->state, (T*)h->last_rpm)));
+    MDS_HIP(hipGetLastError());
+    MDS_HIP(hipDeviceSynchronize());
+  }
+  *out = h;
+  return MDS_OK;
+}
+
+int mds_destroy(mds_handle* h) {
+  if (!h) return MDS_OK;
+  if (h->state) (void)hipFree(h->state);
+  if (h->origin) (void)hipFree(h->origin);
+  if (h->last_rpm) (void)hipFree(h->last_rpm);
+  if (h->lem) (void)hipFree(h->lem);
+  if (h->scratch) (void)hipFree(h->scratch);
+  delete h;
+  return MDS_OK;
+}
+
+int mds_get_derived(const mds_handle* h, double out[8]) {
+  if (!h || !out) return fail(MDS_EINVAL, "mds_get_derived");
+  const mds_config& c = h->cfg;
+  const double grav = c.G * c.M;
+  const double max_rpm = sqrt(c.thrust2weight * grav / (4 * c.KF));
+  out[0] = grav;
+  out[1] = sqrt(grav / (4 * c.KF));
+  out[2] = max_rpm;
+  out[3] = 4 * c.KF * max_rpm * max_rpm;
+  out[4] = c.drone_model == MDS_CF2X ? (2 * c.L * c.KF * max_rpm * max_rpm) / sqrt(2.0) : c.L * c.KF * max_rpm * max_rpm;
+  out[5] = 2 * c.KM * max_rpm * max_rpm;
+  out[6] = 1.0 / c.ctrl_freq;
+  out[7] = 1.0 / c.pyb_freq;
+  return MDS_OK;
+}
+
+int mds_reset(mds_handle* h, const double* xyz, const double* rpy, void* stream) {
+  if (!h || !xyz || !rpy) return fail(MDS_EINVAL, "mds_reset: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nb = (size_t)h->n * 3 * sizeof(double);
+  MDS_HIP(hipMemcpyAsync(h->scratch, xyz, nb, hipMemcpyHostToDevice, st));
+  MDS_HIP(hipMemcpyAsync(h->scratch + (size_t)3 * h->n, rpy, nb, hipMemcpyHostToDevice, st));
+  MDS_DISPATCH(h, (k_reset<T, S><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, h->ld, h->scratch, h->scratch + (size_t)3 * h->n,
+                                                                        (const T*)h->origin, (S*)h->state, (T*)h->last_rpm)));
+  MDS_HIP(hipGetLastError());
+  MDS_HIP(hipStreamSynchronize(st));   // host buffers may be reused by the caller
+  return MDS_OK;
+}
+
+int mds_get_state(mds_handle* h, double* out, void* stream) {
+  if (!h || !out) return fail(MDS_EINVAL, "mds_get_state: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  MDS_DISPATCH(h, (k_get_state<T, S><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, h->ld, (const S*)h->state, (const T*)h->origin,
+                                                                            h->scratch)));
+  MDS_HIP(hipGetLastError());
+  MDS_HIP(hipMemcpyAsync(out, h->scratch, (size_t)h->n * 13 * sizeof(double), hipMemcpyDeviceToHost, st));
+  MDS_HIP(hipStreamSynchronize(st));
+  return MDS_OK;
+}
+
+int mds_set_state(mds_handle* h, const double* in, void* stream) {
+  if (!h || !in) return fail(MDS_EINVAL, "mds_set_state: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  MDS_HIP(hipMemcpyAsync(h->scratch, in, (size_t)h->n * 13 * sizeof(double), hipMemcpyHostToDevice, st));
+  MDS_DISPATCH(h, (k_set_state<T, S><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, h->ld, h->scratch, (const T*)h->origin,
+                                                                            (S*)h->state)));
+  MDS_HIP(hipGetLastError());
+  MDS_HIP(hipStreamSynchronize(st));
+  return MDS_OK;
+}
+
+int mds_set_origin(mds_handle* h, const double* origin, void* stream) {
+  if (!h || !origin) return fail(MDS_EINVAL, "mds_set_origin: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  MDS_HIP(hipMemcpyAsync(h->scratch, origin, (size_t)h->n * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+  MDS_DISPATCH(h, (k_set_origin<T, S><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, h->ld, h->scratch, (T*)h->origin, (S*)h->state)));
+  MDS_HIP(hipGetLastError());
+  MDS_HIP(hipStreamSynchronize(st));
+  return MDS_OK;
+}
+
+int mds_get_obs(mds_handle* h, void* obs, void* stream) {
+  if (!h || !obs) return fail(MDS_EINVAL, "mds_get_obs: null argument");
+  if (!aligned16(obs)) return fail(MDS_EALIGN, "mds_get_obs: obs_dev");
+  hipStream_t st = (hipStream_t)stream;
+  MDS_DISPATCH(h, (k_get_obs<T, S><<<grid_for(h->n, kBlock), kBlock, 0, st>>>(h->n, h->ld, (const S*)h->state, (const T*)h->origin,
+                                                                                (const T*)h->last_rpm, (S*)obs)));
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_step(mds_handle* h, const void* action, void* obs, void* stream) {
+  if (!h || !action) return fail(MDS_EINVAL, "mds_step: null argument");
+  if (!aligned16(action) || !aligned16(obs)) return fail(MDS_EALIGN, "mds_step: action_dev/obs_dev");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid = grid_for(h->n, kBlock);
+  if (obs) {
+    MDS_DISPATCH(h, (k_step<T, S, true><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, (S*)h->state, (const T*)h->origin, (T*)h->last_rpm,
+                                                                  (const S*)action, (S*)obs)));
+  } else {
+    MDS_DISPATCH(h, (k_step<T, S, false><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, (S*)h->state, (const T*)h->origin, (T*)h->last_rpm,
+                                                                   (const S*)action, (S*)nullptr)));
+  }
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_set_lemniscate(mds_handle* h, const double* params, void* stream) {
+  if (!h || !params) return fail(MDS_EINVAL, "mds_set_lemniscate: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int n = h->n;
+  // re-base the local frame onto the trajectory centres (host gathers them from params)
+  double* centres = new (std::nothrow) double[(size_t)n * 3];
+  if (!centres) return fail(MDS_ENOMEM, "mds_set_lemniscate: host allocation");
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) centres[(size_t)3 * i + k] = params[(size_t)7 * i + 2 + k];
+  int rc = mds_set_origin(h, centres, stream);
+  delete[] centres;
+  if (rc != MDS_OK) return rc;
+  MDS_HIP(hipMemcpyAsync(h->scratch, params, (size_t)n * 7 * sizeof(double), hipMemcpyHostToDevice, st));
+  MDS_DISPATCH(h, (k_set_planes<T><<<grid_for(n, 256), 256, 0, st>>>(n, h->ld, 7, h->scratch, (T*)h->lem)));
+  MDS_HIP(hipGetLastError());
+  MDS_HIP(hipStreamSynchronize(st));
+  h->has_traj = true;
+  return MDS_OK;
+}
+
+int mds_set_geometric_gains(mds_handle* h, const mds_geometric_gains* g) {
+  if (!h || !g) return fail(MDS_EINVAL, "mds_set_geometric_gains: null argument");
+  if (!(g->max_tilt_angle > 0) || !(g->max_tilt_angle < M_PI / 2)) return fail(MDS_EINVAL, "mds_set_geometric_gains: max_tilt_angle");
+  h->gains = *g;
+  fill_consts(h->cfg, h->gains, h->cf);
+  fill_consts(h->cfg, h->gains, h->cd);
+  return MDS_OK;
+}
+
+static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, hipStream_t st) {
+  const dim3 grid = grid_for(h->n, kBlock);
+#define MDS_LAUNCH_GEO(HAS_OBS, HAS_ACT)                                                                            \
+  MDS_DISPATCH(h, (k_step_geometric<T, S, HAS_OBS, HAS_ACT><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t, (S*)h->state, \
+                                                                                     (const T*)h->lem, (T*)h->last_rpm, \
+                                                                                     (S*)obs, (S*)act)))
+  if (obs && act) MDS_LAUNCH_GEO(true, true);
+  else if (obs) MDS_LAUNCH_GEO(true, false);
+  else if (act) MDS_LAUNCH_GEO(false, true);
+  else MDS_LAUNCH_GEO(false, false);
+#undef MDS_LAUNCH_GEO
+  return MDS_OK;
+}
+
+int mds_step_geometric(mds_handle* h, double t, void* obs, void* act, void* stream) {
+  if (!h) return fail(MDS_EINVAL, "mds_step_geometric: null handle");
+  if (!h->has_traj) return fail(MDS_ESTATE, "mds_step_geometric: call mds_set_lemniscate first");
+  if (!aligned16(obs) || !aligned16(act)) return fail(MDS_EALIGN, "mds_step_geometric: obs_dev/action_dev");
+  launch_step_geometric(h, t, obs, act, (hipStream_t)stream);
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs, int obs_every_step, void* stream) {
+  if (!h || n_steps < 0) return fail(MDS_EINVAL, "mds_rollout_geometric");
+  if (!h->has_traj) return fail(MDS_ESTATE, "mds_rollout_geometric: call mds_set_lemniscate first");
+  if (!aligned16(obs)) return fail(MDS_EALIGN, "mds_rollout_geometric: obs_dev");
+  const double dt = 1.0 / h->cfg.ctrl_freq;
+  for (int k = 0; k < n_steps; ++k) {
+    // t accumulates exactly like the reference loop (t += env.CTRL_TIMESTEP, EnvGeometric.py:473)
+    launch_step_geometric(h, t0, (obs_every_step || k == n_steps - 1) ? obs : nullptr, nullptr, (hipStream_t)stream);
+    t0 += dt;
+  }
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_lemniscate_eval(mds_handle* h, double t, void* des, void* stream) {
+  if (!h || !des) return fail(MDS_EINVAL, "mds_lemniscate_eval: null argument");
+  if (!h->has_traj) return fail(MDS_ESTATE, "mds_lemniscate_eval: call mds_set_lemniscate first");
+  MDS_DISPATCH(h, (k_lemniscate_eval<T, S><<<grid_for(h->n, 256), 256, 0, (hipStream_t)stream>>>(h->n, h->ld, t, (const T*)h->lem, (S*)des)));
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_geometric_compute(mds_handle* h, const void* obs, const void* des, void* rpm, void* aux, void* stream) {
+  if (!h || !obs || !des || !rpm) return fail(MDS_EINVAL, "mds_geometric_compute: null argument");
+  if (!aligned16(rpm)) return fail(MDS_EALIGN, "mds_geometric_compute: rpm_dev");
+  MDS_DISPATCH(h, (k_geometric_compute<T, S><<<grid_for(h->n, 256), 256, 0, (hipStream_t)stream>>>(C, h->n, (const S*)obs, (const S*)des,
+                                                                                                     (S*)rpm, (S*)aux)));
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_input_to_action(mds_handle* h, const void* u, void* rpm, void* stream) {
+  if (!h || !u || !rpm) return fail(MDS_EINVAL, "mds_input_to_action: null argument");
+  if (!aligned16(u) || !aligned16(rpm)) return fail(MDS_EALIGN, "mds_input_to_action");
+  MDS_DISPATCH(h, (k_input_to_action<T, S><<<grid_for(h->n, 256), 256, 0, (hipStream_t)stream>>>(C, h->n, (const S*)u, (S*)rpm)));
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_action_to_input(mds_handle* h, const void* rpm, int cap_rpm, void* u, void* stream) {
+  if (!h || !u || !rpm) return fail(MDS_EINVAL, "mds_action_to_input: null argument");
+  if (!aligned16(u) || !aligned16(rpm)) return fail(MDS_EALIGN, "mds_action_to_input");
+  MDS_DISPATCH(h, (k_action_to_input<T, S><<<grid_for(h->n, 256), 256, 0, (hipStream_t)stream>>>(C, h->n, cap_rpm, (const S*)rpm, (S*)u)));
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_quadrotor_dynamics(int dtype, int count, const void* state, const void* u, double m, const double J[3], double g,
+                           void* out, void* stream) {
+  if (count < 0 || !state || !u || !out || !J) return fail(MDS_EINVAL, "mds_quadrotor_dynamics: bad argument");
+  if (count == 0) return MDS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid = grid_for(count, 256);
+  if (dtype == MDS_F32)
+    k_quadrotor_dynamics<float, float><<<grid, 256, 0, st>>>(count, (const float*)state, (const float*)u, (float)m, (float)J[0],
+                                                              (float)J[1], (float)J[2], (float)g, (float*)out);
+  else if (dtype == MDS_F64)
+    k_quadrotor_dynamics<double, double><<<grid, 256, 0, st>>>(count, (const double*)state, (const double*)u, m, J[0], J[1], J[2], g,
+                                                                (double*)out);
+  else if (dtype == MDS_F16)
+    k_quadrotor_dynamics<float, half_t><<<grid, 256, 0, st>>>(count, (const half_t*)state, (const half_t*)u, (float)m, (float)J[0],
+                                                               (float)J[1], (float)J[2], (float)g, (half_t*)out);
+  else
+    return fail(MDS_EINVAL, "mds_quadrotor_dynamics: dtype");
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+}  // extern "C"

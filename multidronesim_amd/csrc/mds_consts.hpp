@@ -1,0 +1,47 @@
+// Host-side set-up of the per-launch constant block (computed in double, rounded once).
+// Shared by the C-ABI (mds_api.hip) and the test-only host emulation (tests/emul).
+#pragma once
+#include <math.h>
+
+#include "../../include/mds.h"
+#include "mds_math.hpp"
+
+namespace mds {
+
+template <typename T> inline void fill_consts(const mds_config& cfg, const mds_geometric_gains& g, Consts<T>& c) {
+  c.kf = (T)cfg.KF;
+  c.km = (T)cfg.KM;
+  c.arm = (T)cfg.L;
+  c.mass = (T)cfg.M;
+  c.inv_mass = (T)(1.0 / cfg.M);
+  c.gravity = (T)(cfg.G * cfg.M);
+  c.max_rpm = (T)sqrt(cfg.thrust2weight * cfg.G * cfg.M / (4.0 * cfg.KF));
+  c.hover_rpm = (T)sqrt(cfg.G * cfg.M / (4.0 * cfg.KF));
+  c.thrust_corr = (T)(4.0 * (double)c.kf * (double)c.hover_rpm * (double)c.hover_rpm - (double)c.gravity);
+  for (int k = 0; k < 3; ++k) {
+    c.J[k] = (T)cfg.J[k];
+    c.invJ[k] = (T)(1.0 / cfg.J[k]);
+    c.drag[k] = (T)cfg.drag_coeff[k];
+    c.kp[k] = (T)g.Kp[k];
+    c.kv[k] = (T)g.Kv[k];
+    c.kR[k] = (T)g.KR[k];
+    c.kw[k] = (T)g.Kw[k];
+  }
+  c.dt = (T)(1.0 / cfg.pyb_freq);
+  c.substeps = cfg.pyb_freq / cfg.ctrl_freq;
+  c.cf2x = cfg.drone_model == MDS_CF2X;
+  c.use_drag = cfg.physics == MDS_PHYSICS_DYN_DRAG;
+  c.rk4 = cfg.integrator == MDS_INTEGRATOR_RK4;
+  c.g_ctrl = (T)g.g;
+  c.cos_max_tilt = (T)cos(g.max_tilt_angle);
+  c.tan_max_tilt = (T)tan(g.max_tilt_angle);
+  const double max_rpm = sqrt(cfg.thrust2weight * cfg.G * cfg.M / (4.0 * cfg.KF));
+  c.min_motor_thrust = (T)(9440.3 * 9440.3 * cfg.KF);   // utils/model_conversions.py:99
+  c.max_motor_thrust = (T)(4.0 * cfg.KF * max_rpm * max_rpm);
+  c.inv_2L = (T)(1.0 / (2.0 * cfg.L));
+  c.inv_4r = (T)(cfg.KF / (4.0 * cfg.KM));
+  c.inv_kf = (T)(1.0 / cfg.KF);
+}
+
+
+}  // namespace mds

@@ -1,0 +1,339 @@
+// HIP kernels (gfx950 / CDNA4, wave64) of the batched multi-drone step.
+//
+// Data layout in HBM (DESIGN.md "Data layout"):
+//   state   : struct-of-arrays, 13 planes of `ld` elements each (ld = n rounded up to 256),
+//             plane p holds component p of every drone -> lane i of a wave reads element
+//             base+i of each plane: 13 fully coalesced 256-byte (fp32) wave loads.
+//   origin  : 3 planes (compute type) -- local-frame origin per drone.
+//   lem     : 7 planes (compute type) -- Lemniscate parameters per drone.
+//   action  : caller's [n,4] array-of-structs: one 16-byte load per lane, contiguous.
+//   obs     : caller's [n,20] array-of-structs.  A wave's 64 drones own one contiguous
+//             5 KiB span of it; the 20 floats of each lane are staged through LDS and the
+//             span is written with 16-byte-per-lane, fully coalesced stores.
+// One drone per lane, 256 lanes per workgroup; no MFMA (no contraction wider than 4x4).
+#include <hip/hip_runtime.h>
+
+#include "mds_math.hpp"
+
+namespace mds {
+
+typedef _Float16 half_t;
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+
+template <typename S, typename T> __device__ __forceinline__ T ldp(const S* __restrict__ p, size_t i) { return (T)p[i]; }
+template <typename S, typename T> __device__ __forceinline__ void stp(S* __restrict__ p, size_t i, T v) { p[i] = (S)v; }
+
+// 4 consecutive storage elements (one drone's action / rpm / u row)
+template <typename S, typename T> __device__ __forceinline__ void load4(const S* __restrict__ p, T out[4]) {
+  struct alignas(4 * sizeof(S)) V {
+    S v[4];
+  };
+  const V x = *reinterpret_cast<const V*>(p);
+  for (int k = 0; k < 4; ++k) out[k] = (T)x.v[k];
+}
+template <typename S, typename T> __device__ __forceinline__ void store4(S* __restrict__ p, const T in[4]) {
+  struct alignas(4 * sizeof(S)) V {
+    S v[4];
+  };
+  V x;
+  for (int k = 0; k < 4; ++k) x.v[k] = (S)in[k];
+  *reinterpret_cast<V*>(p) = x;
+}
+
+template <typename S, typename T> __device__ __forceinline__ void load_state(const S* __restrict__ st, size_t ld, size_t i, State<T>& s) {
+  s.p = {ldp<S, T>(st + 0 * ld, i), ldp<S, T>(st + 1 * ld, i), ldp<S, T>(st + 2 * ld, i)};
+  s.q[0] = ldp<S, T>(st + 3 * ld, i);
+  s.q[1] = ldp<S, T>(st + 4 * ld, i);
+  s.q[2] = ldp<S, T>(st + 5 * ld, i);
+  s.q[3] = ldp<S, T>(st + 6 * ld, i);
+  s.v = {ldp<S, T>(st + 7 * ld, i), ldp<S, T>(st + 8 * ld, i), ldp<S, T>(st + 9 * ld, i)};
+  s.w = {ldp<S, T>(st + 10 * ld, i), ldp<S, T>(st + 11 * ld, i), ldp<S, T>(st + 12 * ld, i)};
+}
+template <typename S, typename T> __device__ __forceinline__ void store_state(S* __restrict__ st, size_t ld, size_t i, const State<T>& s) {
+  stp<S, T>(st + 0 * ld, i, s.p.x); stp<S, T>(st + 1 * ld, i, s.p.y); stp<S, T>(st + 2 * ld, i, s.p.z);
+  stp<S, T>(st + 3 * ld, i, s.q[0]); stp<S, T>(st + 4 * ld, i, s.q[1]); stp<S, T>(st + 5 * ld, i, s.q[2]);
+  stp<S, T>(st + 6 * ld, i, s.q[3]);
+  stp<S, T>(st + 7 * ld, i, s.v.x); stp<S, T>(st + 8 * ld, i, s.v.y); stp<S, T>(st + 9 * ld, i, s.v.z);
+  stp<S, T>(st + 10 * ld, i, s.w.x); stp<S, T>(st + 11 * ld, i, s.w.y); stp<S, T>(st + 12 * ld, i, s.w.z);
+}
+
+// Observation packing: each lane owns one 20-element row; the wave's rows form one
+// contiguous span of the caller's [n,20] array.  Rows go to LDS (ds_write_b128, conflict
+// free at the 80-byte fp32 row stride), then lane l stores 16-byte chunk (it*64 + l).
+constexpr int kObsDim = 20;
+
+template <typename S, typename T>
+__device__ __forceinline__ void write_obs_rows(unsigned char* __restrict__ lds_block, S* __restrict__ obs, int n, int i,
+                                               bool valid, const T o[kObsDim]) {
+  constexpr int kRowBytes = kObsDim * (int)sizeof(S);           // 80 / 160 / 40
+  constexpr int kUnit = (kRowBytes % 16 == 0) ? 16 : 8;          // widest aligned LDS store per row
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  unsigned char* lds_wave = lds_block + wave * (kWave * kRowBytes);
+  if (valid) {
+    alignas(16) S row[kObsDim];
+    for (int k = 0; k < kObsDim; ++k) row[k] = (S)o[k];
+    unsigned char* dst = lds_wave + lane * kRowBytes;
+    if (kUnit == 16) {
+      for (int k = 0; k < kRowBytes / 16; ++k) reinterpret_cast<uint4*>(dst)[k] = reinterpret_cast<const uint4*>(row)[k];
+    } else {
+      for (int k = 0; k < kRowBytes / 8; ++k) reinterpret_cast<uint2*>(dst)[k] = reinterpret_cast<const uint2*>(row)[k];
+    }
+  }
+  __syncthreads();
+  const int wave_base = i - lane;                                // first drone of this wave
+  const int rows = min(kWave, n - wave_base);                    // <= 0 for fully invalid waves
+  if (rows > 0) {
+    const int bytes = rows * kRowBytes;                          // multiple of 8; of 16 unless half with odd rows
+    unsigned char* gdst = reinterpret_cast<unsigned char*>(obs) + (size_t)wave_base * kRowBytes;
+    constexpr int kIters = (kWave * kRowBytes + kWave * 16 - 1) / (kWave * 16);
+    for (int it = 0; it < kIters; ++it) {
+      const int off = (it * kWave + lane) * 16;
+      if (off + 16 <= bytes) {
+        *reinterpret_cast<uint4*>(gdst + off) = *reinterpret_cast<const uint4*>(lds_wave + off);
+      } else if (off + 8 <= bytes) {                             // 8-byte tail (fp16 rows, odd row count)
+        *reinterpret_cast<uint2*>(gdst + off) = *reinterpret_cast<const uint2*>(lds_wave + off);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// [UPSTREAM] BaseAviary.step for every drone (a1-a4)
+// ------------------------------------------------------------------------------------
+template <typename T, typename S, bool HAS_OBS>
+__global__ __launch_bounds__(kBlock) void k_step(const Consts<T> c, const int n, const size_t ld, S* __restrict__ state,
+                                                 const T* __restrict__ origin, T* __restrict__ last_rpm,
+                                                 const S* __restrict__ action, S* __restrict__ obs) {
+  __shared__ __align__(16) unsigned char lds[HAS_OBS ? (kBlock * kObsDim * sizeof(S)) : 16];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = i < n;
+  T o[kObsDim];
+  if (valid) {
+    State<T> s;
+    load_state<S, T>(state, ld, i, s);
+    T act[4], prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4];
+    load4<S, T>(action + (size_t)i * 4, act);
+    if (c.use_drag)
+      for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
+    aviary_step(c, s, act, prev, clipped);
+    store_state<S, T>(state, ld, i, s);
+    if (c.use_drag)
+      for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
+    if (HAS_OBS) {
+      const V3<T> org = {origin[i], origin[ld + i], origin[2 * ld + i]};
+      pack_obs(s, org, clipped, o);
+    }
+  }
+  if (HAS_OBS) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
+}
+
+// ------------------------------------------------------------------------------------
+// fused trajectory + geometric controller + mixer + physics step (a10, a7-a9, a1-a4)
+// ------------------------------------------------------------------------------------
+template <typename T, typename S, bool HAS_OBS, bool HAS_ACT>
+__global__ __launch_bounds__(kBlock) void k_step_geometric(const Consts<T> c, const int n, const size_t ld, const double t,
+                                                           S* __restrict__ state, const T* __restrict__ lem,
+                                                           T* __restrict__ last_rpm, S* __restrict__ obs,
+                                                           S* __restrict__ action_out) {
+  __shared__ __align__(16) unsigned char lds[HAS_OBS ? (kBlock * kObsDim * sizeof(S)) : 16];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = i < n;
+  T o[kObsDim];
+  if (valid) {
+    State<T> s;
+    load_state<S, T>(state, ld, i, s);
+    LemniscateParams<T> P;
+    P.a = lem[0 * ld + i];
+    P.omega = lem[1 * ld + i];
+    P.cx = lem[2 * ld + i];
+    P.cy = lem[3 * ld + i];
+    P.cz = lem[4 * ld + i];
+    P.yaw_rate = lem[5 * ld + i];
+    P.phase_shift = lem[6 * ld + i];
+    T prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4], act[4];
+    if (c.use_drag)
+      for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
+    {
+      const Desired<T> des = lemniscate_local(P, t);
+      const M3<T> R = quat_to_rot(s.q);
+      const V3<T> ang_v = mul(R, s.w);
+      T u[4];
+      geometric_control<T>(c, s.p - des.p, R, s.v, ang_v, des, u, nullptr);
+      input_to_action(c, u, act);
+    }
+    aviary_step(c, s, act, prev, clipped);
+    store_state<S, T>(state, ld, i, s);
+    if (c.use_drag)
+      for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
+    if (HAS_ACT) store4<S, T>(action_out + (size_t)i * 4, act);
+    if (HAS_OBS) pack_obs(s, V3<T>{P.cx, P.cy, P.cz}, clipped, o);
+  }
+  if (HAS_OBS) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
+}
+
+// [UPSTREAM] _computeObs from the current state
+template <typename T, typename S>
+__global__ __launch_bounds__(kBlock) void k_get_obs(const int n, const size_t ld, const S* __restrict__ state,
+                                                    const T* __restrict__ origin, const T* __restrict__ last_rpm,
+                                                    S* __restrict__ obs) {
+  __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = i < n;
+  T o[kObsDim];
+  if (valid) {
+    State<T> s;
+    load_state<S, T>(state, ld, i, s);
+    const T rpm[4] = {last_rpm[i], last_rpm[ld + i], last_rpm[2 * ld + i], last_rpm[3 * ld + i]};
+    pack_obs(s, V3<T>{origin[i], origin[ld + i], origin[2 * ld + i]}, rpm, o);
+  }
+  write_obs_rows<S, T>(lds, obs, n, i, valid, o);
+}
+
+// ------------------------------------------------------------------------------------
+// set-up kernels (double in, storage out; not on the hot path)
+// ------------------------------------------------------------------------------------
+template <typename T, typename S>
+__global__ void k_reset(const int n, const size_t ld, const double* __restrict__ xyz, const double* __restrict__ rpy,
+                        const T* __restrict__ origin, S* __restrict__ state, T* __restrict__ last_rpm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double q[4];
+  quat_from_euler<double>(rpy[3 * i], rpy[3 * i + 1], rpy[3 * i + 2], q);
+  for (int k = 0; k < 3; ++k) state[k * ld + i] = (S)(xyz[3 * i + k] - (double)origin[k * ld + i]);
+  for (int k = 0; k < 4; ++k) state[(3 + k) * ld + i] = (S)q[k];
+  for (int k = 7; k < 13; ++k) state[k * ld + i] = (S)0;
+  for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = T(0);
+}
+
+template <typename T, typename S>
+__global__ void k_set_origin(const int n, const size_t ld, const double* __restrict__ new_origin, T* __restrict__ origin,
+                             S* __restrict__ state) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = 0; k < 3; ++k) {
+    const double world = (double)state[k * ld + i] + (double)origin[k * ld + i];
+    const T no = (T)new_origin[3 * i + k];
+    origin[k * ld + i] = no;
+    state[k * ld + i] = (S)(world - (double)no);
+  }
+}
+
+template <typename T, typename S>
+__global__ void k_get_state(const int n, const size_t ld, const S* __restrict__ state, const T* __restrict__ origin,
+                            double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = 0; k < 13; ++k) {
+    double v = (double)state[k * ld + i];
+    if (k < 3) v += (double)origin[k * ld + i];
+    out[13 * (size_t)i + k] = v;
+  }
+}
+
+template <typename T, typename S>
+__global__ void k_set_state(const int n, const size_t ld, const double* __restrict__ in, const T* __restrict__ origin,
+                            S* __restrict__ state) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = 0; k < 13; ++k) {
+    double v = in[13 * (size_t)i + k];
+    if (k < 3) v -= (double)origin[k * ld + i];
+    state[k * ld + i] = (S)v;
+  }
+}
+
+template <typename T>
+__global__ void k_set_planes(const int n, const size_t ld, const int dim, const double* __restrict__ in, T* __restrict__ planes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = 0; k < dim; ++k) planes[k * ld + i] = (T)in[(size_t)dim * i + k];
+}
+
+// ------------------------------------------------------------------------------------
+// stand-alone operators (array-of-structs in/out; parity surface, not the fused path)
+// ------------------------------------------------------------------------------------
+template <typename T, typename S>
+__global__ void k_lemniscate_eval(const int n, const size_t ld, const double t, const T* __restrict__ lem, S* __restrict__ des) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  LemniscateParams<T> P = {lem[i], lem[ld + i], lem[2 * ld + i], lem[3 * ld + i], lem[4 * ld + i], lem[5 * ld + i],
+                           lem[6 * ld + i]};
+  const Desired<T> d = lemniscate_local(P, t);
+  S* o = des + (size_t)i * 11;
+  o[0] = (S)(d.p.x + P.cx); o[1] = (S)(d.p.y + P.cy); o[2] = (S)(d.p.z + P.cz);
+  o[3] = (S)d.v.x; o[4] = (S)d.v.y; o[5] = (S)d.v.z;
+  o[6] = (S)d.a.x; o[7] = (S)d.a.y; o[8] = (S)d.a.z;
+  o[9] = (S)d.yaw; o[10] = (S)d.yaw_rate;
+}
+
+template <typename T, typename S>
+__global__ void k_geometric_compute(const Consts<T> c, const int n, const S* __restrict__ obs, const S* __restrict__ des,
+                                    S* __restrict__ rpm, S* __restrict__ aux) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const S* o = obs + (size_t)i * 20;
+  const S* d = des + (size_t)i * 11;
+  // utils/model_conversions.py:105-114 obs_to_geo_model
+  const T q[4] = {(T)o[3], (T)o[4], (T)o[5], (T)o[6]};
+  const M3<T> R = quat_to_rot(q);
+  const V3<T> p = {(T)o[0], (T)o[1], (T)o[2]}, v = {(T)o[10], (T)o[11], (T)o[12]}, w = {(T)o[13], (T)o[14], (T)o[15]};
+  Desired<T> D;
+  D.p = {(T)d[0], (T)d[1], (T)d[2]};
+  D.v = {(T)d[3], (T)d[4], (T)d[5]};
+  D.a = {(T)d[6], (T)d[7], (T)d[8]};
+  D.yaw = (T)d[9];
+  D.yaw_rate = (T)d[10];
+  // the stand-alone operator takes an arbitrary yaw: reduce it for the fp32 sincos
+  D.yaw = reduced_phase<T>(0.0, T(0), D.yaw);
+  T u[4], act[4];
+  GeoAux<T> A;
+  geometric_control<T>(c, p - D.p, R, v, w, D, u, &A);
+  input_to_action(c, u, act);
+  store4<S, T>(rpm + (size_t)i * 4, act);
+  if (aux) {
+    S* a = aux + (size_t)i * 13;
+    a[0] = (S)A.force;
+    a[1] = (S)A.w_des.x; a[2] = (S)A.w_des.y; a[3] = (S)A.w_des.z;
+    a[4] = (S)A.b1d.x; a[5] = (S)A.b2d.x; a[6] = (S)A.b3d.x;     // R_des row-major, columns b1d b2d b3d
+    a[7] = (S)A.b1d.y; a[8] = (S)A.b2d.y; a[9] = (S)A.b3d.y;
+    a[10] = (S)A.b1d.z; a[11] = (S)A.b2d.z; a[12] = (S)A.b3d.z;
+  }
+}
+
+template <typename T, typename S>
+__global__ void k_input_to_action(const Consts<T> c, const int n, const S* __restrict__ u, S* __restrict__ rpm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T ui[4], r[4];
+  load4<S, T>(u + (size_t)i * 4, ui);
+  input_to_action(c, ui, r);
+  store4<S, T>(rpm + (size_t)i * 4, r);
+}
+
+template <typename T, typename S>
+__global__ void k_action_to_input(const Consts<T> c, const int n, const int cap, const S* __restrict__ rpm, S* __restrict__ u) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T r[4], ui[4];
+  load4<S, T>(rpm + (size_t)i * 4, r);
+  action_to_input(c, r, cap, ui);
+  store4<S, T>(u + (size_t)i * 4, ui);
+}
+
+template <typename T, typename S>
+__global__ void k_quadrotor_dynamics(const int n, const S* __restrict__ state, const S* __restrict__ u, const T m, const T J0,
+                                     const T J1, const T J2, const T g, S* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T s[18], ui[4], o[12];
+  for (int k = 0; k < 18; ++k) s[k] = (T)state[(size_t)i * 18 + k];
+  for (int k = 0; k < 4; ++k) ui[k] = (T)u[(size_t)i * 4 + k];
+  const T J[3] = {J0, J1, J2};
+  quadrotor_dynamics<T>(s, ui, m, J, g, o);
+  for (int k = 0; k < 12; ++k) out[(size_t)i * 12 + k] = (S)o[k];
+}
+
+}  // namespace mds

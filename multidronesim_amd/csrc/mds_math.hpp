@@ -1,0 +1,515 @@
+// Per-drone arithmetic of the batched multi-drone step, templated on the compute type T
+// (float for the fp32 / fp16-storage paths, double for the f64 verification path).
+//
+// Every function here runs inside the HIP kernels of mds_kernels.hip (one drone per
+// lane).  The same header also compiles with plain g++ so that tests/emul can run the
+// fp32 arithmetic on the CPU for precision studies and sanitizer runs -- that build is
+// test tooling only and is never loaded by the multidronesim_amd package.
+//
+// Reference lines restated (paths relative to the reference checkout):
+//   [UPSTREAM] gym_pybullet_drones BaseAviary._dynamics/_integrateQ/_drag and
+//   pybullet getEulerFromQuaternion/getMatrixFromQuaternion  -- spec in SURVEY.md 3.4
+//   trajectories/Lemniscate.py:32-63
+//   utils/model_conversions.py:69-114
+//   control/geometric.py:59-115
+//   model/dynamics.py:83-106
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MDS_HD __host__ __device__ __forceinline__
+#else
+#define MDS_HD inline
+#endif
+
+namespace mds {
+
+// ------------------------------------------------------------------------------------
+// scalar helpers
+// ------------------------------------------------------------------------------------
+MDS_HD float m_sqrt(float x) { return sqrtf(x); }
+MDS_HD double m_sqrt(double x) { return sqrt(x); }
+MDS_HD float m_fma(float a, float b, float c) { return fmaf(a, b, c); }
+MDS_HD double m_fma(double a, double b, double c) { return fma(a, b, c); }
+MDS_HD float m_abs(float x) { return fabsf(x); }
+MDS_HD double m_abs(double x) { return fabs(x); }
+MDS_HD float m_atan2(float y, float x) { return atan2f(y, x); }
+MDS_HD double m_atan2(double y, double x) { return atan2(y, x); }
+MDS_HD float m_asin(float x) { return asinf(x); }
+MDS_HD double m_asin(double x) { return asin(x); }
+template <typename T> MDS_HD T m_min(T a, T b) { return a < b ? a : b; }
+template <typename T> MDS_HD T m_max(T a, T b) { return a > b ? a : b; }
+template <typename T> MDS_HD T m_clamp(T x, T lo, T hi) { return m_min(m_max(x, lo), hi); }
+
+MDS_HD void m_sincos(double x, double* s, double* c) {
+  *s = sin(x);
+  *c = cos(x);
+}
+
+// sin/cos of an argument ALREADY reduced to about [-pi, pi] (callers reduce phases in
+// double): one more Cody-Waite step to [-pi/4, pi/4] and two short minimax polynomials.
+// Max error < 1.5 ulp on the reduced range; ~25 VALU ops instead of ocml's generic path.
+MDS_HD void m_sincos(float x, float* s, float* c) {
+  const float k = rintf(x * 0.636619772367581343f);  // x * 2/pi
+  // r = x - k*pi/2 with pi/2 split in three parts (exact for |k| <= 4)
+  float r = fmaf(k, -1.57079601287841796875f, x);
+  r = fmaf(k, -3.1391647326017846353352069854736328125e-7f, r);
+  r = fmaf(k, -5.390302529957764765544e-15f, r);
+  const float r2 = r * r;
+  // sin(r) ~ r + r^3 * P(r^2), cos(r) ~ 1 - r^2/2 + r^4 * Q(r^2)
+  float ps = fmaf(r2, 2.6083159809786593541503e-06f, -1.981069071916863322258e-04f);
+  ps = fmaf(ps, r2, 8.333078585565090179443e-03f);
+  ps = fmaf(ps, r2, -1.666665971279144287109e-01f);
+  const float sr = fmaf(ps * r2, r, r);
+  float pc = fmaf(r2, 2.443315711809948e-05f, -1.388731625493765e-03f);
+  pc = fmaf(pc, r2, 4.166664568298827e-02f);
+  const float cr = fmaf(pc * r2, r2, fmaf(r2, -0.5f, 1.0f));
+  const int q = (int)k & 3;
+  const float ss = (q & 1) ? cr : sr;
+  const float cc = (q & 1) ? sr : cr;
+  *s = (q & 2) ? -ss : ss;
+  *c = ((q + 1) & 2) ? -cc : cc;
+}
+
+// phase = a*t + b reduced to [-pi, pi], formed in double so that a 30 s horizon does not
+// cost the fp32 path 1e-6 rad of phase (t is passed as double through the C-ABI).
+template <typename T> MDS_HD T reduced_phase(double t, T a, T b) {
+  const double ph = fma(t, (double)a, (double)b);
+  const double k = rint(ph * 0.15915494309189533577);  // 1/(2 pi)
+  return (T)fma(k, -6.283185307179586476925, ph);
+}
+template <> MDS_HD double reduced_phase<double>(double t, double a, double b) { return t * a + b; }
+
+template <typename T> struct V3 {
+  T x, y, z;
+};
+template <typename T> MDS_HD V3<T> v3(T x, T y, T z) { return V3<T>{x, y, z}; }
+template <typename T> MDS_HD V3<T> operator+(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T> MDS_HD V3<T> operator-(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename T> MDS_HD V3<T> operator*(T s, V3<T> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <typename T> MDS_HD V3<T> hadamard(V3<T> a, V3<T> b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+template <typename T> MDS_HD T dot(V3<T> a, V3<T> b) { return m_fma(a.x, b.x, m_fma(a.y, b.y, a.z * b.z)); }
+template <typename T> MDS_HD V3<T> cross(V3<T> a, V3<T> b) {
+  return {m_fma(a.y, b.z, -(a.z * b.y)), m_fma(a.z, b.x, -(a.x * b.z)), m_fma(a.x, b.y, -(a.y * b.x))};
+}
+template <typename T> MDS_HD T norm(V3<T> a) { return m_sqrt(dot(a, a)); }
+
+// row-major 3x3
+template <typename T> struct M3 {
+  T m[9];
+};
+template <typename T> MDS_HD V3<T> mul(const M3<T>& R, V3<T> v) {
+  return {m_fma(R.m[0], v.x, m_fma(R.m[1], v.y, R.m[2] * v.z)), m_fma(R.m[3], v.x, m_fma(R.m[4], v.y, R.m[5] * v.z)),
+          m_fma(R.m[6], v.x, m_fma(R.m[7], v.y, R.m[8] * v.z))};
+}
+template <typename T> MDS_HD V3<T> mulT(const M3<T>& R, V3<T> v) {
+  return {m_fma(R.m[0], v.x, m_fma(R.m[3], v.y, R.m[6] * v.z)), m_fma(R.m[1], v.x, m_fma(R.m[4], v.y, R.m[7] * v.z)),
+          m_fma(R.m[2], v.x, m_fma(R.m[5], v.y, R.m[8] * v.z))};
+}
+template <typename T> MDS_HD V3<T> col(const M3<T>& R, int j) { return {R.m[j], R.m[3 + j], R.m[6 + j]}; }
+
+// ------------------------------------------------------------------------------------
+// constants handed to every kernel by value (host fills them in double, see mds_api)
+// ------------------------------------------------------------------------------------
+template <typename T> struct Consts {
+  // [UPSTREAM] BaseAviary.__init__ / urdf
+  T kf, km, arm, mass, inv_mass, gravity /* M*G */, max_rpm;
+  T hover_rpm;    // sqrt(MG / 4KF) rounded to T
+  T thrust_corr;  // 4*KF*hover_rpm^2 - M*G (rounding of hover_rpm, computed in double)
+  T J[3], invJ[3], drag[3];
+  T dt;           // PYB_TIMESTEP
+  int substeps;   // PYB_FREQ / CTRL_FREQ
+  int cf2x;       // 1: X frame torques, 0: + frame (cf2p)
+  int use_drag;   // physics == DYN_DRAG
+  int rk4;        // integrator
+  // control/geometric.py:14-23 and utils/model_conversions.py:85-103
+  T kp[3], kv[3], kR[3], kw[3];
+  T g_ctrl;                       // 9.81 (sic, env.G is 9.8)
+  T cos_max_tilt, tan_max_tilt;   // 40 deg
+  T min_motor_thrust;             // 9440.3^2 * KF
+  T max_motor_thrust;             // env.MAX_THRUST used per motor (sic)
+  T inv_2L, inv_4r;               // closed-form inverse of the "+" mixer, r = KM/KF
+  T inv_kf;
+};
+
+template <typename T> struct State {
+  V3<T> p;       // world position
+  T q[4];        // xyzw
+  V3<T> v;       // world velocity
+  V3<T> w;       // body rates (upstream rpy_rates)
+};
+
+// [UPSTREAM] p.getMatrixFromQuaternion (btMatrix3x3::setRotation, s = 2/|q|^2).  Scale
+// invariant, so it also equals scipy Rotation.from_quat(q).as_matrix() used by
+// model_conversions.py:110.
+template <typename T> MDS_HD M3<T> quat_to_rot(const T q[4]) {
+  const T x = q[0], y = q[1], z = q[2], w = q[3];
+  const T d = m_fma(x, x, m_fma(y, y, m_fma(z, z, w * w)));
+  const T s = T(2) / d;
+  const T xs = x * s, ys = y * s, zs = z * s;
+  const T wx = w * xs, wy = w * ys, wz = w * zs;
+  const T xx = x * xs, xy = x * ys, xz = x * zs;
+  const T yy = y * ys, yz = y * zs, zz = z * zs;
+  M3<T> R;
+  R.m[0] = T(1) - (yy + zz);
+  R.m[1] = xy - wz;
+  R.m[2] = xz + wy;
+  R.m[3] = xy + wz;
+  R.m[4] = T(1) - (xx + zz);
+  R.m[5] = yz - wx;
+  R.m[6] = xz - wy;
+  R.m[7] = yz + wx;
+  R.m[8] = T(1) - (xx + yy);
+  return R;
+}
+
+// [UPSTREAM] p.getQuaternionFromEuler (btQuaternion::setEulerZYX)
+template <typename T> MDS_HD void quat_from_euler(T roll, T pitch, T yaw, T q[4]) {
+  T sr, cr, sp, cp, sy, cy;
+  m_sincos(roll * T(0.5), &sr, &cr);
+  m_sincos(pitch * T(0.5), &sp, &cp);
+  m_sincos(yaw * T(0.5), &sy, &cy);
+  q[0] = sr * cp * cy - cr * sp * sy;
+  q[1] = cr * sp * cy + sr * cp * sy;
+  q[2] = cr * cp * sy - sr * sp * cy;
+  q[3] = cr * cp * cy + sr * sp * sy;
+}
+
+// [UPSTREAM] p.getEulerFromQuaternion incl. the +-0.99999 gimbal branches
+template <typename T> MDS_HD V3<T> euler_from_quat(const T q[4]) {
+  const T x = q[0], y = q[1], z = q[2], w = q[3];
+  const T sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
+  const T sarg = T(-2) * (x * z - w * y);
+  V3<T> rpy;
+  if (sarg <= T(-0.99999)) {
+    rpy = {T(0), T(-1.57079632679489661923), T(2) * m_atan2(x, -y)};
+  } else if (sarg >= T(0.99999)) {
+    rpy = {T(0), T(1.57079632679489661923), T(2) * m_atan2(-x, y)};
+  } else {
+    rpy.x = m_atan2(T(2) * (y * z + w * x), squ - sqx - sqy + sqz);
+    rpy.y = m_asin(sarg);
+    rpy.z = m_atan2(T(2) * (x * y + w * z), squ + sqx - sqy - sqz);
+  }
+  return rpy;
+}
+
+// [UPSTREAM] _dynamics: thrust (body z) and body torques from 4 clipped RPM.
+// Same quantities, conditioned for fp32: differences of squares are formed as
+// (a-b)(a+b) (a-b is exact for nearby RPM), and the thrust is returned as its EXCESS over
+// the weight, T - M*G = KF*sum(rpm_i^2 - hover^2) + corr, so that near hover neither the
+// torques nor the net vertical force lose digits to cancellation.
+template <typename T> MDS_HD T dsq(T a, T b) { return (a - b) * (a + b); }
+template <typename T> MDS_HD void rotor_wrench(const Consts<T>& c, const T rpm[4], T* thrust_excess, V3<T>* tau) {
+  const T h = c.hover_rpm;
+  *thrust_excess = m_fma(c.kf, (dsq(rpm[0], h) + dsq(rpm[1], h)) + (dsq(rpm[2], h) + dsq(rpm[3], h)), c.thrust_corr);
+  tau->z = c.km * (dsq(rpm[1], rpm[0]) + dsq(rpm[3], rpm[2]));       // -z0 + z1 - z2 + z3
+  if (c.cf2x) {
+    const T l = c.arm * T(0.70710678118654752440) * c.kf;
+    tau->x = l * (dsq(rpm[0], rpm[2]) + dsq(rpm[1], rpm[3]));        // (f0 + f1 - f2 - f3) L/sqrt2
+    tau->y = l * (dsq(rpm[1], rpm[0]) + dsq(rpm[2], rpm[3]));        // (-f0 + f1 + f2 - f3) L/sqrt2
+  } else {
+    const T l = c.arm * c.kf;
+    tau->x = l * dsq(rpm[1], rpm[3]);                                 // (f1 - f3) L
+    tau->y = l * dsq(rpm[2], rpm[0]);                                 // (-f0 + f2) L
+  }
+}
+
+// linear + angular acceleration of the rigid body (shared by Euler and RK4).
+// force_world = R [0,0,T] - [0,0,MG] with T = MG + excess:  f_z = (R33 - 1) T + excess.
+template <typename T>
+MDS_HD void body_accel(const Consts<T>& c, const T q[4], V3<T> vel, V3<T> w, T thrust_excess, V3<T> tau, const T drag_s,
+                       V3<T>* acc, V3<T>* wdot) {
+  const T x = q[0], y = q[1], z = q[2], ww = q[3];
+  const T s = T(2) / m_fma(x, x, m_fma(y, y, m_fma(z, z, ww * ww)));
+  const T thrust = c.gravity + thrust_excess;
+  const T r02 = s * m_fma(x, z, ww * y), r12 = s * m_fma(y, z, -(ww * x)), r22m1 = -s * m_fma(x, x, y * y);
+  V3<T> f = {r02 * thrust, r12 * thrust, m_fma(r22m1, thrust, thrust_excess)};
+  if (c.use_drag) {  // [UPSTREAM] _drag: world force -c (.) sum(2 pi rpm_prev/60) (.) v_world
+    f.x = m_fma(-c.drag[0] * drag_s, vel.x, f.x);
+    f.y = m_fma(-c.drag[1] * drag_s, vel.y, f.y);
+    f.z = m_fma(-c.drag[2] * drag_s, vel.z, f.z);
+  }
+  *acc = c.inv_mass * f;
+  const V3<T> Jw = {c.J[0] * w.x, c.J[1] * w.y, c.J[2] * w.z};
+  const V3<T> t = tau - cross(w, Jw);
+  *wdot = {t.x * c.invJ[0], t.y * c.invJ[1], t.z * c.invJ[2]};
+}
+
+// [UPSTREAM] _integrateQ (exact exponential for a constant body rate); identity for
+// |omega| <= 1e-8 (np.isclose default atol).  Re-normalised: Bullet stores unit quats.
+template <typename T> MDS_HD void integrate_q(T q[4], V3<T> w, T dt) {
+  const T wn = norm(w);
+  if (wn <= T(1e-8)) return;
+  T st, ct;
+  m_sincos(wn * dt * T(0.5), &st, &ct);
+  const T k = st / wn;
+  const T x = q[0], y = q[1], z = q[2], ww = q[3];
+  const T p = w.x, qq = w.y, r = w.z;
+  T nx = m_fma(ct, x, k * (r * y - qq * z + p * ww));
+  T ny = m_fma(ct, y, k * (-r * x + p * z + qq * ww));
+  T nz = m_fma(ct, z, k * (qq * x - p * y + r * ww));
+  T nw = m_fma(ct, ww, k * (-p * x - qq * y - r * z));
+  const T inv = T(1) / m_sqrt(m_fma(nx, nx, m_fma(ny, ny, m_fma(nz, nz, nw * nw))));
+  q[0] = nx * inv;
+  q[1] = ny * inv;
+  q[2] = nz * inv;
+  q[3] = nw * inv;
+}
+
+// [UPSTREAM] _dynamics, Physics.DYN: explicit Euler on (v, omega); p with NEW v, q with NEW omega
+template <typename T> MDS_HD void step_euler(const Consts<T>& c, State<T>& s, const T rpm[4], T drag_s) {
+  T thrust;
+  V3<T> tau, acc, wdot;
+  rotor_wrench(c, rpm, &thrust, &tau);
+  body_accel(c, s.q, s.v, s.w, thrust, tau, drag_s, &acc, &wdot);
+  s.v = {m_fma(c.dt, acc.x, s.v.x), m_fma(c.dt, acc.y, s.v.y), m_fma(c.dt, acc.z, s.v.z)};
+  s.w = {m_fma(c.dt, wdot.x, s.w.x), m_fma(c.dt, wdot.y, s.w.y), m_fma(c.dt, wdot.z, s.w.z)};
+  s.p = {m_fma(c.dt, s.v.x, s.p.x), m_fma(c.dt, s.v.y, s.p.y), m_fma(c.dt, s.v.z, s.p.z)};
+  integrate_q(s.q, s.w, c.dt);
+}
+
+// classical RK4 on the 13-state (north_star integrator; qdot = 1/2 Lambda(omega) q)
+template <typename T> struct Deriv {
+  V3<T> dp;
+  T dq[4];
+  V3<T> dv, dw;
+};
+template <typename T> MDS_HD Deriv<T> deriv13(const Consts<T>& c, const State<T>& s, T thrust, V3<T> tau, T drag_s) {
+  Deriv<T> d;
+  body_accel(c, s.q, s.v, s.w, thrust, tau, drag_s, &d.dv, &d.dw);
+  d.dp = s.v;
+  const T x = s.q[0], y = s.q[1], z = s.q[2], w = s.q[3], p = s.w.x, q = s.w.y, r = s.w.z;
+  d.dq[0] = T(0.5) * (r * y - q * z + p * w);
+  d.dq[1] = T(0.5) * (-r * x + p * z + q * w);
+  d.dq[2] = T(0.5) * (q * x - p * y + r * w);
+  d.dq[3] = T(0.5) * (-p * x - q * y - r * z);
+  return d;
+}
+template <typename T> MDS_HD State<T> axpy13(const State<T>& s, T h, const Deriv<T>& d) {
+  State<T> o;
+  o.p = s.p + h * d.dp;
+  for (int i = 0; i < 4; ++i) o.q[i] = m_fma(h, d.dq[i], s.q[i]);
+  o.v = s.v + h * d.dv;
+  o.w = s.w + h * d.dw;
+  return o;
+}
+template <typename T> MDS_HD void step_rk4(const Consts<T>& c, State<T>& s, const T rpm[4], T drag_s) {
+  T thrust;
+  V3<T> tau;
+  rotor_wrench(c, rpm, &thrust, &tau);
+  const Deriv<T> k1 = deriv13(c, s, thrust, tau, drag_s);
+  const Deriv<T> k2 = deriv13(c, axpy13(s, T(0.5) * c.dt, k1), thrust, tau, drag_s);
+  const Deriv<T> k3 = deriv13(c, axpy13(s, T(0.5) * c.dt, k2), thrust, tau, drag_s);
+  const Deriv<T> k4 = deriv13(c, axpy13(s, c.dt, k3), thrust, tau, drag_s);
+  const T h6 = c.dt / T(6);
+  s.p = s.p + h6 * ((k1.dp + k4.dp) + T(2) * (k2.dp + k3.dp));
+  s.v = s.v + h6 * ((k1.dv + k4.dv) + T(2) * (k2.dv + k3.dv));
+  s.w = s.w + h6 * ((k1.dw + k4.dw) + T(2) * (k2.dw + k3.dw));
+  T n2 = T(0);
+  for (int i = 0; i < 4; ++i) {
+    s.q[i] = m_fma(h6, (k1.dq[i] + k4.dq[i]) + T(2) * (k2.dq[i] + k3.dq[i]), s.q[i]);
+    n2 = m_fma(s.q[i], s.q[i], n2);
+  }
+  const T inv = T(1) / m_sqrt(n2);
+  for (int i = 0; i < 4; ++i) s.q[i] *= inv;
+}
+
+// [UPSTREAM] BaseAviary.step inner loop for one drone: clip, substeps, last_clipped_action.
+// rpm_prev: previous control step's clipped action (only read when use_drag).
+template <typename T> MDS_HD void aviary_step(const Consts<T>& c, State<T>& s, const T action[4], T rpm_prev[4], T clipped[4]) {
+  for (int i = 0; i < 4; ++i) clipped[i] = m_clamp(action[i], T(0), c.max_rpm);
+  for (int k = 0; k < c.substeps; ++k) {
+    T drag_s = T(0);
+    if (c.use_drag) drag_s = T(0.10471975511965977462) * ((rpm_prev[0] + rpm_prev[1]) + (rpm_prev[2] + rpm_prev[3]));
+    if (c.rk4) step_rk4(c, s, clipped, drag_s);
+    else step_euler(c, s, clipped, drag_s);
+    for (int i = 0; i < 4; ++i) rpm_prev[i] = clipped[i];
+  }
+}
+
+// [UPSTREAM] _getDroneStateVector: pos3 | quat4 xyzw | rpy3 | vel3 | ang_v3 (world) | last_clipped_action4.
+// ang_v = R(q) w: upstream hands Bullet R(q_before) w, identical because Exp(w dt) w = w.
+template <typename T> MDS_HD void pack_obs(const State<T>& s, V3<T> origin, const T rpm[4], T o[20]) {
+  const M3<T> R = quat_to_rot(s.q);
+  const V3<T> av = mul(R, s.w);
+  const V3<T> rpy = euler_from_quat(s.q);
+  o[0] = s.p.x + origin.x; o[1] = s.p.y + origin.y; o[2] = s.p.z + origin.z;
+  o[3] = s.q[0]; o[4] = s.q[1]; o[5] = s.q[2]; o[6] = s.q[3];
+  o[7] = rpy.x; o[8] = rpy.y; o[9] = rpy.z;
+  o[10] = s.v.x; o[11] = s.v.y; o[12] = s.v.z;
+  o[13] = av.x; o[14] = av.y; o[15] = av.z;
+  o[16] = rpm[0]; o[17] = rpm[1]; o[18] = rpm[2]; o[19] = rpm[3];
+}
+
+// ------------------------------------------------------------------------------------
+// trajectories/Lemniscate.py:32-63.  `centre` is NOT added here: the caller works in the
+// drone's local frame (origin = trajectory centre) -- see DESIGN.md "local frame".
+// ------------------------------------------------------------------------------------
+template <typename T> struct Desired {
+  V3<T> p, v, a;
+  T yaw, yaw_rate;
+};
+template <typename T> struct LemniscateParams {
+  T a, omega, cx, cy, cz, yaw_rate, phase_shift;
+};
+template <typename T> MDS_HD Desired<T> lemniscate_local(const LemniscateParams<T>& P, double t) {
+  Desired<T> d;
+  const T th = reduced_phase<T>(t, P.omega, P.phase_shift);
+  T s, c;
+  m_sincos(th, &s, &c);
+  const T s2 = s * s, c2 = c * c;
+  const T den = T(1) + s2;
+  const T inv = T(1) / den;
+  const T inv2 = inv * inv;
+  const T aw = P.a * P.omega;
+  d.p = {P.a * s * c * inv, P.a * c * inv, T(0)};
+  d.v = {-aw * (s2 * s2 + s2 + (s2 - T(1)) * c2) * inv2, -aw * s * (s2 + T(2) * c2 + T(1)) * inv2, T(0)};
+  // sin 2th, cos 2th, cos 4th by double angle (the reference calls sin/cos on 2th, 4th)
+  const T sin2 = T(2) * s * c, cos2 = c2 - s2, cos4 = T(1) - T(2) * sin2 * sin2;
+  const T e = cos2 - T(3);
+  const T inv3 = T(1) / (e * e * e);
+  const T aw2 = aw * P.omega;
+  d.a = {T(4) * aw2 * sin2 * (T(3) * cos2 + T(7)) * inv3, aw2 * c * (T(44) * cos2 + cos4 - T(21)) * inv3, T(0)};
+  const T ph = reduced_phase<T>(t, P.yaw_rate, T(0));
+  T sy, cy;
+  m_sincos(ph, &sy, &cy);
+  d.yaw = T(3.14159265358979323846) * sy;
+  d.yaw_rate = T(3.14159265358979323846) * P.yaw_rate * cy;
+  return d;
+}
+
+// ------------------------------------------------------------------------------------
+// utils/model_conversions.py:69-103 (CF2P "+" mixer)
+// ------------------------------------------------------------------------------------
+template <typename T> MDS_HD void input_to_action(const Consts<T>& c, const T u_in[4], T rpm[4]) {
+  const T u0 = m_max(u_in[0], T(0));
+  const T a = T(0.25) * u0, b1 = u_in[1] * c.inv_2L, b2 = u_in[2] * c.inv_2L, d = u_in[3] * c.inv_4r;
+  T th[4] = {a - b2 - d, a + b1 + d, a + b2 - d, a - b1 + d};
+  for (int i = 0; i < 4; ++i) {
+    th[i] = m_clamp(th[i], c.min_motor_thrust, c.max_motor_thrust);
+    rpm[i] = m_sqrt(th[i] * c.inv_kf);
+  }
+}
+template <typename T> MDS_HD void action_to_input(const Consts<T>& c, const T action[4], int cap_rpm, T u[4]) {
+  T f[4];
+  for (int i = 0; i < 4; ++i) {
+    const T r = cap_rpm ? m_clamp(action[i], T(0), c.max_rpm) : action[i];
+    f[i] = c.kf * r * r;
+  }
+  const T r = c.km * c.inv_kf;
+  u[0] = (f[0] + f[1]) + (f[2] + f[3]);
+  u[1] = c.arm * (f[1] - f[3]);
+  u[2] = c.arm * (f[2] - f[0]);
+  u[3] = r * ((f[1] - f[0]) + (f[3] - f[2]));
+}
+
+// ------------------------------------------------------------------------------------
+// control/geometric.py:59-115 with its quirks (g = 9.81; obs[13:16] (world ang_v) used as
+// the body rate; R_des.transpose(0,1) is a no-op so w_des_hat = R_des @ R_dot_des;
+// f_des_dot uses Kp on the body-frame velocity error).
+//   p_rel = p - p_des (formed by the caller so that the local frame cancels exactly)
+// ------------------------------------------------------------------------------------
+template <typename T> struct GeoAux {  // return_omegas=True outputs (:106-108)
+  T force;
+  V3<T> w_des;
+  V3<T> b1d, b2d, b3d;  // columns of R_des
+};
+template <typename T>
+MDS_HD void geometric_control(const Consts<T>& c, V3<T> p_rel, const M3<T>& R, V3<T> v_world, V3<T> w,
+                              const Desired<T>& des, T u[4], GeoAux<T>* aux) {
+  const V3<T> Kp = {c.kp[0], c.kp[1], c.kp[2]}, Kv = {c.kv[0], c.kv[1], c.kv[2]};
+  const V3<T> v_b = mulT(R, v_world);                                   // :70
+  const V3<T> RTvd = mulT(R, des.v);
+  const V3<T> ev = v_b - RTvd;
+  // f_des_body/m = R^T(g e3 - Kp ep + a_d) - Kv ev - w x R^T v_d      (:73-74)
+  V3<T> tw = des.a - hadamard(Kp, p_rel);
+  tw.z += c.g_ctrl;
+  const V3<T> fb_m = mulT(R, tw) - hadamard(Kv, ev) - cross(w, RTvd);
+  V3<T> f_w = mul(R, c.mass * fb_m);                                    // :75
+  T fn = norm(f_w);
+  if (f_w.z < c.cos_max_tilt * fn) {                                    // tilt > 40 deg  (:79-80)
+    const T xy = m_sqrt(m_fma(f_w.x, f_w.x, f_w.y * f_w.y));
+    const T scale = f_w.z * c.tan_max_tilt / xy;                        // :81-83
+    f_w.x *= scale;
+    f_w.y *= scale;
+    fn = norm(f_w);
+  }
+  const T fbz = dot(col(R, 2), f_w);                                    // (R^T f_w).z  (:85)
+  const T inv_fn = T(1) / fn;
+  T sy, cy;
+  m_sincos(des.yaw, &sy, &cy);
+  const V3<T> b1c = {cy, sy, T(0)};                                     // :88
+  const V3<T> b3d = inv_fn * f_w;
+  const V3<T> c1 = cross(b3d, b1c);
+  const T n1 = norm(c1);
+  const V3<T> b2d = (T(1) / n1) * c1;
+  const V3<T> c2 = cross(b2d, b3d);
+  const V3<T> b1d = (T(1) / norm(c2)) * c2;                             // :91
+  const V3<T> b1c_dot = {-sy * des.yaw_rate, cy * des.yaw_rate, T(0)};  // :95
+  const V3<T> f_dot = (c.mass * inv_fn) * mul(R, hadamard(Kp, ev));     // :96
+  const V3<T> b3d_dot = cross(cross(b3d, f_dot), b3d);                  // :97
+  const V3<T> inner = (T(1) / n1) * (cross(b1c_dot, b3d) + cross(b1c, b3d_dot));  // |b1c x b3d| = |b3d x b1c|
+  const V3<T> b2d_dot = cross(cross(b2d, inner), b2d);                  // :98-99
+  const V3<T> b1d_dot = cross(b3d_dot, b2d) + cross(b3d, b2d_dot);      // :100
+  // W = R_des @ R_dot_des (no-op transpose, :102); w_des = (W21, W02, W10) (:103)
+  const V3<T> w_des = {m_fma(b1d.z, b2d_dot.x, m_fma(b2d.z, b2d_dot.y, b3d.z * b2d_dot.z)),
+                       m_fma(b1d.x, b3d_dot.x, m_fma(b2d.x, b3d_dot.y, b3d.x * b3d_dot.z)),
+                       m_fma(b1d.y, b1d_dot.x, m_fma(b2d.y, b1d_dot.y, b3d.y * b1d_dot.z))};
+  if (aux) {
+    aux->force = fbz;                                                   // f_w^T (R e3)  (:107)
+    aux->w_des = w_des;
+    aux->b1d = b1d;
+    aux->b2d = b2d;
+    aux->b3d = b3d;
+  }
+  // e_R = 1/2 KR vee(R_des^T R - R^T R_des), vee(M) = (-M12, M02, -M01)  (:109, :36-44)
+  const V3<T> r0 = col(R, 0), r1 = col(R, 1), r2 = col(R, 2);
+  const T E12 = dot(b2d, r2) - dot(b3d, r1);
+  const T E02 = dot(b1d, r2) - dot(b3d, r0);
+  const T E01 = dot(b1d, r1) - dot(b2d, r0);
+  const V3<T> eR = {T(-0.5) * c.kR[0] * E12, T(0.5) * c.kR[1] * E02, T(-0.5) * c.kR[2] * E01};
+  const V3<T> Rdw = {m_fma(b1d.x, w_des.x, m_fma(b2d.x, w_des.y, b3d.x * w_des.z)),
+                     m_fma(b1d.y, w_des.x, m_fma(b2d.y, w_des.y, b3d.y * w_des.z)),
+                     m_fma(b1d.z, w_des.x, m_fma(b2d.z, w_des.y, b3d.z * w_des.z))};
+  const V3<T> ew = w - mulT(R, Rdw);
+  const V3<T> Jw = {c.J[0] * w.x, c.J[1] * w.y, c.J[2] * w.z};
+  const V3<T> wxJw = cross(w, Jw);
+  u[0] = m_max(T(0), fbz);                                              // :114
+  u[1] = c.J[0] * (-eR.x - c.kw[0] * ew.x) - wxJw.x;                    // :110-111
+  u[2] = c.J[1] * (-eR.y - c.kw[1] * ew.y) - wxJw.y;
+  u[3] = c.J[2] * (-eR.z - c.kw[2] * ew.z) - wxJw.z;
+}
+
+// One fused control step of simulations/EnvGeometric.py:434-469 for one drone:
+// trajs[j](t) -> ctrl.compute(obs[j]) -> env.step(action).  State is in the local frame
+// whose origin is the trajectory centre.
+template <typename T>
+MDS_HD void fused_geometric_step(const Consts<T>& c, const LemniscateParams<T>& P, double t, State<T>& s, T rpm_prev[4],
+                                 T clipped[4]) {
+  const Desired<T> des = lemniscate_local(P, t);
+  const M3<T> R = quat_to_rot(s.q);
+  const V3<T> ang_v = mul(R, s.w);  // obs[13:16]
+  T u[4], action[4];
+  geometric_control<T>(c, s.p - des.p, R, s.v, ang_v, des, u, nullptr);
+  input_to_action(c, u, action);
+  aviary_step(c, s, action, rpm_prev, clipped);
+}
+
+// model/dynamics.py:83-106: (state18, u4) -> 12 floats (x_dot = v, "R_dot" = w, v_dot, w_dot)
+template <typename T> MDS_HD void quadrotor_dynamics(const T s[18], const T u[4], T m, const T J[3], T g, T out[12]) {
+  out[0] = s[12]; out[1] = s[13]; out[2] = s[14];
+  out[3] = s[15]; out[4] = s[16]; out[5] = s[17];
+  const T a = u[0] / m;
+  out[6] = s[5] * a;   // R[:,2] = s[3+2], s[3+5], s[3+8]
+  out[7] = s[8] * a;
+  out[8] = s[11] * a - g;
+  const V3<T> w = {s[15], s[16], s[17]};
+  const V3<T> Jw = {J[0] * w.x, J[1] * w.y, J[2] * w.z};
+  const V3<T> cx = cross(w, Jw);
+  out[9] = (u[1] - cx.x) / J[0];
+  out[10] = (u[2] - cx.y) / J[1];
+  out[11] = (u[3] - cx.z) / J[2];
+}
+
+}  // namespace mds

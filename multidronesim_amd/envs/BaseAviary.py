@@ -1,0 +1,301 @@
+"""Batched replacement of [UPSTREAM] gym_pybullet_drones.envs.BaseAviary.
+
+The reference drives this class through ``CtrlAviary(...)`` (PIDEnv.py:106-116,
+simulations/EnvGeometric.py:89-100), ``env.step(action)`` (EnvGeometric.py:469),
+``env.render()`` (:475), ``env.close()`` (:481) and the attribute census of SURVEY.md
+section 3.4.  Here every drone of every env is stepped by one HIP kernel launch
+(``mds_step`` / ``mds_step_geometric`` in include/mds.h); Bullet is not involved.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from .. import _capi as capi
+from .._device import DTYPE_BY_NAME, TORCH_DTYPE, require_gpu, stream_ptr, to_device
+from ..utils.enums import DroneModel, Physics
+
+__all__ = ["BaseAviary", "DroneModel", "Physics"]
+
+_PHYSICS_MAP = {Physics.DYN: capi.MDS_PHYSICS_DYN, Physics.PYB: capi.MDS_PHYSICS_DYN,
+                Physics.PYB_DRAG: capi.MDS_PHYSICS_DYN_DRAG}
+_MODEL_MAP = {DroneModel.CF2X: capi.MDS_CF2X, DroneModel.CF2P: capi.MDS_CF2P}
+
+
+class BaseAviary:
+    """Gym-style multi-drone env, batched over ``num_envs`` independent copies.
+
+    Shapes follow the reference when ``num_envs == 1`` and NumPy goes in: ``step(action[D,4])
+    -> obs[D,20]``.  With a torch tensor in (any ``num_envs``) everything stays on the GPU:
+    ``step(action[E,D,4]) -> obs[E,D,20]``.  obs layout ([UPSTREAM] _getDroneStateVector):
+    pos3 | quat4 xyzw | rpy3 | vel3 | ang_v3 (world) | last clipped RPM4.
+
+    ``Physics.PYB`` (the reference's default, PIDEnv.py:19) is served by the explicit
+    ``Physics.DYN`` rigid-body model -- there is no Bullet here; ``PYB_DRAG`` adds upstream's
+    ``_drag`` term.  Ground effect / downwash variants are not part of this hot path.
+    """
+
+    def __init__(self, drone_model: DroneModel = DroneModel.CF2X, num_drones: int = 1, neighbourhood_radius: float = np.inf,
+                 initial_xyzs=None, initial_rpys=None, physics: Physics = Physics.PYB, pyb_freq: int = 240,
+                 ctrl_freq: int = 240, gui=False, record=False, obstacles=False, user_debug_gui=True,
+                 output_folder="results", *, num_envs: int = 1, dtype="float32", integrator: str = "euler",
+                 device: int | None = None):
+        lib = capi.load_library()
+        if isinstance(drone_model, str):
+            drone_model = DroneModel(drone_model)
+        if isinstance(physics, str):
+            physics = Physics(physics)
+        if drone_model not in _MODEL_MAP:
+            raise NotImplementedError(f"drone model {drone_model} (only CF2X / CF2P urdf constants are built in)")
+        if physics not in _PHYSICS_MAP:
+            raise NotImplementedError(f"physics {physics}: ground effect / downwash are outside this hot path")
+        if pyb_freq % ctrl_freq != 0:
+            raise ValueError("pyb_freq is not divisible by env_freq.")  # [UPSTREAM] BaseAviary.__init__
+        if device is None:
+            import os
+            device = int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() and torch.cuda.device_count() > 1 else 0
+        self.device = require_gpu(device)
+        self._lib = lib
+        self.DRONE_MODEL, self.PHYSICS = drone_model, physics
+        self.NUM_DRONES, self.NUM_ENVS = int(num_drones), int(num_envs)
+        self.NEIGHBOURHOOD_RADIUS = neighbourhood_radius
+        self.PYB_FREQ, self.CTRL_FREQ = int(pyb_freq), int(ctrl_freq)
+        self.PYB_STEPS_PER_CTRL = self.PYB_FREQ // self.CTRL_FREQ
+        self.CTRL_TIMESTEP, self.PYB_TIMESTEP = 1.0 / self.CTRL_FREQ, 1.0 / self.PYB_FREQ
+        self.GUI, self.RECORD, self.OBSTACLES, self.USER_DEBUG = gui, record, obstacles, user_debug_gui
+        self.OUTPUT_FOLDER = output_folder
+        self._dtype_code = DTYPE_BY_NAME[dtype]
+        self.dtype = TORCH_DTYPE[self._dtype_code]
+
+        cfg = capi.MdsConfig()
+        capi.check(lib.mds_default_config(_MODEL_MAP[drone_model], C.byref(cfg)), "mds_default_config")
+        cfg.num_envs, cfg.num_drones = self.NUM_ENVS, self.NUM_DRONES
+        cfg.dtype = self._dtype_code
+        cfg.physics = _PHYSICS_MAP[physics]
+        cfg.integrator = {"euler": capi.MDS_INTEGRATOR_EULER, "rk4": capi.MDS_INTEGRATOR_RK4}[integrator]
+        cfg.pyb_freq, cfg.ctrl_freq = self.PYB_FREQ, self.CTRL_FREQ
+        cfg.device = self.device.index
+        self._cfg = cfg
+        # urdf constants ([UPSTREAM] _parseURDFParameters) + derived attributes the reference reads off env
+        self.M, self.L, self.KF, self.KM = cfg.M, cfg.L, cfg.KF, cfg.KM
+        self.THRUST2WEIGHT_RATIO = cfg.thrust2weight
+        self.J = np.diag([cfg.J[0], cfg.J[1], cfg.J[2]])
+        self.J_INV = np.linalg.inv(self.J)
+        self.G = cfg.G
+        self.DRAG_COEFF = np.array([cfg.drag_coeff[0], cfg.drag_coeff[1], cfg.drag_coeff[2]])
+        h = C.c_void_p()
+        capi.check(lib.mds_create(C.byref(cfg), C.byref(h)), "mds_create")
+        self._h = h
+        d = (C.c_double * 8)()
+        capi.check(lib.mds_get_derived(self._h, d), "mds_get_derived")
+        (self.GRAVITY, self.HOVER_RPM, self.MAX_RPM, self.MAX_THRUST, self.MAX_XY_TORQUE, self.MAX_Z_TORQUE) = list(d)[:6]
+        self.n = self.NUM_ENVS * self.NUM_DRONES
+        self.DRONE_IDS = np.arange(1, self.NUM_DRONES + 1)
+        self.CLIENT = -1
+        # initial poses ([UPSTREAM] defaults: a line of drones 4L apart, just above the floor)
+        if initial_xyzs is None:
+            initial_xyzs = np.vstack([np.array([x * 4 * self.L for x in range(self.NUM_DRONES)]),
+                                      np.array([y * 4 * self.L for y in range(self.NUM_DRONES)]),
+                                      np.ones(self.NUM_DRONES) * 0.1125]).T
+        if initial_rpys is None:
+            initial_rpys = np.zeros((self.NUM_DRONES, 3))
+        self.INIT_XYZS = self._broadcast_init(initial_xyzs)
+        self.INIT_RPYS = self._broadcast_init(initial_rpys)
+        self._obs = torch.zeros((self.NUM_ENVS, self.NUM_DRONES, capi.OBS_DIM), dtype=self.dtype, device=self.device)
+        self._act = torch.zeros((self.NUM_ENVS, self.NUM_DRONES, capi.ACT_DIM), dtype=self.dtype, device=self.device)
+        self._has_traj = False
+        self.step_counter = 0
+        self.RESET_TIME = time.time()
+        self._housekeeping()
+
+    # ------------------------------------------------------------------ helpers
+    def _broadcast_init(self, a):
+        a = np.asarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a, dtype=np.float64)
+        if a.shape == (self.NUM_DRONES, 3):
+            a = np.broadcast_to(a, (self.NUM_ENVS, self.NUM_DRONES, 3))
+        if a.shape != (self.NUM_ENVS, self.NUM_DRONES, 3):
+            raise ValueError(f"initial_xyzs/initial_rpys must be ({self.NUM_DRONES},3) or "
+                             f"({self.NUM_ENVS},{self.NUM_DRONES},3), got {a.shape}")
+        return np.ascontiguousarray(a)
+
+    def _stream(self):
+        return C.c_void_p(stream_ptr(self.device))
+
+    def _require_open(self):
+        if self._h is None:
+            raise capi.MdsError(capi.MDS_OK - 5, "BaseAviary", "environment is closed")
+
+    def _housekeeping(self):
+        """[UPSTREAM] _housekeeping: poses from INIT_XYZS / INIT_RPYS, zero velocity and action."""
+        self._require_open()
+        xyz = self.INIT_XYZS.reshape(-1, 3)
+        rpy = self.INIT_RPYS.reshape(-1, 3)
+        capi.check(self._lib.mds_reset(self._h, capi.as_double_ptr(xyz), capi.as_double_ptr(rpy), self._stream()), "mds_reset")
+        self.step_counter = 0
+
+    def _out(self, obs: torch.Tensor, numpy_out: bool):
+        if not numpy_out:
+            return obs
+        o = obs.detach().to("cpu", torch.float64).numpy()
+        return o[0] if self.NUM_ENVS == 1 else o
+
+    # ------------------------------------------------------------------ gym API
+    def reset(self, seed: int = None, options: dict = None):
+        """gymnasium ``reset() -> (obs, info)``.  (The reference never calls it -- SURVEY.md 3.3.)"""
+        self._housekeeping()
+        obs = self._computeObs()
+        return self._out(obs, True) if not getattr(self, "_tensor_mode", False) else obs, self._computeInfo()
+
+    def step(self, action):
+        """[UPSTREAM] BaseAviary.step: clip RPM, PYB_FREQ//CTRL_FREQ physics substeps, 20-float obs.
+        Returns ``(obs, reward, terminated, truncated, info)`` exactly like CtrlAviary."""
+        self._require_open()
+        numpy_in = not isinstance(action, torch.Tensor)
+        self._tensor_mode = not numpy_in
+        act = to_device(action, self.device, self.dtype)
+        if act.numel() != self.n * capi.ACT_DIM:
+            raise ValueError(f"action must hold {self.NUM_ENVS}x{self.NUM_DRONES}x4 RPMs, got shape {tuple(act.shape)}")
+        capi.check(self._lib.mds_step(self._h, C.c_void_p(act.data_ptr()), C.c_void_p(self._obs.data_ptr()), self._stream()),
+                   "mds_step")
+        self.step_counter += self.PYB_STEPS_PER_CTRL
+        return (self._out(self._obs, numpy_in), self._computeReward(), self._computeTerminated(),
+                self._computeTruncated(), self._computeInfo())
+
+    def render(self, mode="human", close=False):
+        """[UPSTREAM] BaseAviary.render: text dump of every drone of env 0 (EnvGeometric.py:475)."""
+        o = self._computeObs().detach().to("cpu", torch.float64).numpy()[0]
+        print("\n[INFO] BaseAviary.render() ——— it {:04d}".format(self.step_counter),
+              "——— wall-clock time {:.1f}s,".format(time.time() - self.RESET_TIME),
+              "simulation time {:.1f}s@{:d}Hz ({:.2f}x)".format(self.step_counter * self.PYB_TIMESTEP, self.PYB_FREQ,
+                                                               (self.step_counter * self.PYB_TIMESTEP) / max(time.time() - self.RESET_TIME, 1e-9)))
+        for i in range(self.NUM_DRONES):
+            print("[INFO] BaseAviary.render() ——— drone {:d}".format(i),
+                  "——— x {:+06.2f}, y {:+06.2f}, z {:+06.2f}".format(o[i, 0], o[i, 1], o[i, 2]),
+                  "——— velocity {:+06.2f}, {:+06.2f}, {:+06.2f}".format(o[i, 10], o[i, 11], o[i, 12]),
+                  "——— roll {:+06.2f}, pitch {:+06.2f}, yaw {:+06.2f}".format(*(o[i, 7:10] * 180 / np.pi)),
+                  "——— angular velocity {:+06.4f}, {:+06.4f}, {:+06.4f} ——— ".format(o[i, 13], o[i, 14], o[i, 15]))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            self._lib.mds_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def getPyBulletClient(self):
+        return self.CLIENT
+
+    def getDroneIds(self):
+        return self.DRONE_IDS
+
+    def _showDroneLocalAxes(self, nth_drone):
+        pass  # Bullet GUI helper; nothing to draw here
+
+    # ------------------------------------------------------------------ obs / state
+    def _computeObs(self) -> torch.Tensor:
+        self._require_open()
+        capi.check(self._lib.mds_get_obs(self._h, C.c_void_p(self._obs.data_ptr()), self._stream()), "mds_get_obs")
+        return self._obs
+
+    def _getDroneStateVector(self, nth_drone, env: int = 0):
+        return self._obs[env, nth_drone].detach().to("cpu", torch.float64).numpy()
+
+    def get_state(self) -> np.ndarray:
+        """World-frame 13-float state [E, D, 13] (pos3 | quat4 xyzw | vel3 | body rates3), float64 copy."""
+        self._require_open()
+        out = np.zeros((self.n, capi.STATE_DIM))
+        capi.check(self._lib.mds_get_state(self._h, capi.as_double_ptr(out), self._stream()), "mds_get_state")
+        return out.reshape(self.NUM_ENVS, self.NUM_DRONES, capi.STATE_DIM)
+
+    def set_state(self, state):
+        self._require_open()
+        s = np.ascontiguousarray(np.asarray(state, dtype=np.float64).reshape(self.n, capi.STATE_DIM))
+        capi.check(self._lib.mds_set_state(self._h, capi.as_double_ptr(s), self._stream()), "mds_set_state")
+
+    def _kin(self, lo, hi):
+        s = self.get_state()
+        return s[0, :, lo:hi] if self.NUM_ENVS == 1 else s[:, :, lo:hi]
+
+    pos = property(lambda self: self._kin(0, 3))
+    quat = property(lambda self: self._kin(3, 7))
+    vel = property(lambda self: self._kin(7, 10))
+    rpy_rates = property(lambda self: self._kin(10, 13))
+
+    @property
+    def rpy(self):
+        o = self._computeObs().detach().to("cpu", torch.float64).numpy()[..., 7:10]
+        return o[0] if self.NUM_ENVS == 1 else o
+
+    @property
+    def ang_v(self):
+        o = self._computeObs().detach().to("cpu", torch.float64).numpy()[..., 13:16]
+        return o[0] if self.NUM_ENVS == 1 else o
+
+    # ------------------------------------------------------------------ fused on-GPU control loop
+    def set_trajectories(self, trajs):
+        """Attach one Lemniscate per drone (list of D, list of E*D, or an [E,D,7]/[D,7] parameter
+        array: a, omega, centre3, yaw_rate, phase_shift) for ``step_geometric``."""
+        self._require_open()
+        if isinstance(trajs, (list, tuple)):
+            P = np.array([t.params() for t in trajs], dtype=np.float64)
+        else:
+            P = np.asarray(trajs, dtype=np.float64)
+        if P.shape == (self.NUM_DRONES, capi.LEM_DIM):
+            P = np.broadcast_to(P, (self.NUM_ENVS, self.NUM_DRONES, capi.LEM_DIM))
+        P = np.ascontiguousarray(P.reshape(self.n, capi.LEM_DIM))
+        capi.check(self._lib.mds_set_lemniscate(self._h, capi.as_double_ptr(P), self._stream()), "mds_set_lemniscate")
+        self._has_traj = True
+
+    def set_geometric_gains(self, Kp=None, Kv=None, KR=None, Kw=None, g=None, max_tilt_angle=None):
+        gains = capi.MdsGeometricGains()
+        capi.check(self._lib.mds_default_geometric_gains(C.byref(gains)), "mds_default_geometric_gains")
+        for name, val in (("Kp", Kp), ("Kv", Kv), ("KR", KR), ("Kw", Kw)):
+            if val is not None:
+                v = np.broadcast_to(np.asarray(val, dtype=np.float64), (3,))
+                setattr(gains, name, (C.c_double * 3)(*v))
+        if g is not None:
+            gains.g = float(g)
+        if max_tilt_angle is not None:
+            gains.max_tilt_angle = float(max_tilt_angle)
+        capi.check(self._lib.mds_set_geometric_gains(self._h, C.byref(gains)), "mds_set_geometric_gains")
+
+    def step_geometric(self, t: float, return_action: bool = False):
+        """One fused control step of simulations/EnvGeometric.py:434-469 for every drone:
+        trajectory sample -> GeometricControl.compute -> input_to_action -> env.step."""
+        self._require_open()
+        act_ptr = C.c_void_p(self._act.data_ptr()) if return_action else C.c_void_p(None)
+        capi.check(self._lib.mds_step_geometric(self._h, C.c_double(t), C.c_void_p(self._obs.data_ptr()), act_ptr,
+                                                self._stream()), "mds_step_geometric")
+        self.step_counter += self.PYB_STEPS_PER_CTRL
+        return (self._obs, self._act) if return_action else self._obs
+
+    def rollout_geometric(self, t0: float, n_steps: int, want_obs: bool = True, obs_every_step: bool = False):
+        """``n_steps`` fused control steps enqueued from C; returns the last observation.
+        ``obs_every_step`` materialises the [E,D,20] observation on every step (as env.step does)."""
+        self._require_open()
+        obs_ptr = C.c_void_p(self._obs.data_ptr()) if want_obs else C.c_void_p(None)
+        capi.check(self._lib.mds_rollout_geometric(self._h, C.c_double(t0), C.c_int(n_steps), obs_ptr,
+                                                   C.c_int(1 if obs_every_step else 0), self._stream()),
+                   "mds_rollout_geometric")
+        self.step_counter += n_steps * self.PYB_STEPS_PER_CTRL
+        return self._obs if want_obs else None
+
+    # ------------------------------------------------------------------ gym hooks (CtrlAviary fills them)
+    def _computeReward(self):
+        raise NotImplementedError
+
+    def _computeTerminated(self):
+        raise NotImplementedError
+
+    def _computeTruncated(self):
+        raise NotImplementedError
+
+    def _computeInfo(self):
+        raise NotImplementedError

@@ -1,0 +1,104 @@
+"""TEST TOOLING ONLY: ctypes driver for the g++ build of the device arithmetic
+(tests/emul/mds_emul.cpp).  Used by CPU tests to study fp32 precision against the oracle
+before spending GPU time; the product never loads this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from multidronesim_amd._capi import MdsConfig, MdsGeometricGains, MDS_CF2P
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libmds_emul.so")
+SRC = os.path.join(HERE, "mds_emul.cpp")
+_PD = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    deps = [SRC] + [os.path.join(HERE, "..", "..", "multidronesim_amd", "csrc", f) for f in ("mds_math.hpp", "mds_consts.hpp")]
+    if force or not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-mfma", "-ffp-contract=fast", "-o", SO, SRC])
+    return SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        for sfx in ("f32", "f64"):
+            getattr(_lib, f"emul_create_{sfx}").restype = C.c_void_p
+    return _lib
+
+
+def dp(a):
+    return a.ctypes.data_as(_PD)
+
+
+class Emul:
+    def __init__(self, dtype="f32", num_envs=1, num_drones=1, pyb_freq=100, ctrl_freq=100, physics=0, integrator=0,
+                 model=MDS_CF2P):
+        L = lib()
+        self.sfx = dtype
+        self.cfg = MdsConfig()
+        self.gains = MdsGeometricGains()
+        L.emul_default_config(model, C.byref(self.cfg), C.byref(self.gains))
+        self.cfg.num_envs, self.cfg.num_drones = num_envs, num_drones
+        self.cfg.pyb_freq, self.cfg.ctrl_freq = pyb_freq, ctrl_freq
+        self.cfg.physics, self.cfg.integrator = physics, integrator
+        self.n = num_envs * num_drones
+        self.h = C.c_void_p(getattr(L, f"emul_create_{dtype}")(C.byref(self.cfg), C.byref(self.gains)))
+
+    def _f(self, name):
+        return getattr(lib(), f"{name}_{self.sfx}")
+
+    def set_state(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        self._f("emul_set_state")(self.h, dp(s))
+
+    def get_state(self):
+        out = np.zeros((self.n, 13))
+        self._f("emul_get_state")(self.h, dp(out))
+        return out
+
+    def set_lemniscate(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        self._f("emul_set_lem")(self.h, dp(p))
+
+    def step(self, action):
+        a = np.ascontiguousarray(action, dtype=np.float64)
+        obs = np.zeros((self.n, 20))
+        self._f("emul_step")(self.h, dp(a), dp(obs))
+        return obs
+
+    def step_geometric(self, t):
+        obs = np.zeros((self.n, 20))
+        act = np.zeros((self.n, 4))
+        self._f("emul_step_geo")(self.h, C.c_double(t), dp(obs), dp(act))
+        return obs, act
+
+    def geometric_compute(self, obs, des):
+        obs = np.ascontiguousarray(obs, dtype=np.float64)
+        des = np.ascontiguousarray(des, dtype=np.float64)
+        n = obs.shape[0]
+        rpm = np.zeros((n, 4))
+        aux = np.zeros((n, 13))
+        self._f("emul_geo_compute")(self.h, C.c_int(n), dp(obs), dp(des), dp(rpm), dp(aux))
+        return rpm, aux
+
+    def lemniscate(self, t):
+        des = np.zeros((self.n, 11))
+        self._f("emul_lem")(self.h, C.c_double(t), dp(des))
+        return des
+
+
+def sincos_f32(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    s = np.zeros_like(x)
+    c = np.zeros_like(x)
+    PF = C.POINTER(C.c_float)
+    lib().emul_sincos_f32(C.c_int(x.size), x.ctypes.data_as(PF), s.ctypes.data_as(PF), c.ctypes.data_as(PF))
+    return s, c

@@ -1,0 +1,167 @@
+// TEST TOOLING ONLY.  Compiles the device arithmetic of multidronesim_amd/csrc/mds_math.hpp
+// with g++ so the fp32 / f64 per-drone math can be exercised on the CPU (precision studies
+// against the oracle, UBSan/ASan runs).  Never loaded by the multidronesim_amd package;
+// the product path is the HIP library only.
+#include <string.h>
+
+#include "../../multidronesim_amd/csrc/mds_consts.hpp"
+
+using namespace mds;
+
+template <typename T> static void load_state(const double* st, State<T>& s, const double* org) {
+  s.p = {(T)(st[0] - org[0]), (T)(st[1] - org[1]), (T)(st[2] - org[2])};
+  for (int k = 0; k < 4; ++k) s.q[k] = (T)st[3 + k];
+  s.v = {(T)st[7], (T)st[8], (T)st[9]};
+  s.w = {(T)st[10], (T)st[11], (T)st[12]};
+}
+
+// Persistent emulated handle: state kept in T (like the device SoA), I/O in double.
+template <typename T> struct Emul {
+  Consts<T> c;
+  int n;
+  State<T>* s;
+  T (*prev)[4];
+  LemniscateParams<T>* P;
+  double (*org)[3];
+};
+
+template <typename T> static void* emul_create(const mds_config* cfg, const mds_geometric_gains* g) {
+  Emul<T>* e = new Emul<T>();
+  fill_consts(*cfg, *g, e->c);
+  e->n = cfg->num_envs * cfg->num_drones;
+  e->s = new State<T>[e->n];
+  e->prev = new T[e->n][4];
+  e->P = new LemniscateParams<T>[e->n];
+  e->org = new double[e->n][3];
+  memset(e->prev, 0, sizeof(T) * 4 * e->n);
+  memset(e->org, 0, sizeof(double) * 3 * e->n);
+  return e;
+}
+
+template <typename T> static void emul_set_state(void* h, const double* st) {
+  Emul<T>* e = (Emul<T>*)h;
+  for (int i = 0; i < e->n; ++i) load_state<T>(st + 13 * i, e->s[i], e->org[i]);
+}
+template <typename T> static void emul_get_state(void* h, double* st) {
+  Emul<T>* e = (Emul<T>*)h;
+  for (int i = 0; i < e->n; ++i) {
+    const State<T>& s = e->s[i];
+    double* o = st + 13 * i;
+    o[0] = (double)s.p.x + e->org[i][0]; o[1] = (double)s.p.y + e->org[i][1]; o[2] = (double)s.p.z + e->org[i][2];
+    for (int k = 0; k < 4; ++k) o[3 + k] = s.q[k];
+    o[7] = s.v.x; o[8] = s.v.y; o[9] = s.v.z; o[10] = s.w.x; o[11] = s.w.y; o[12] = s.w.z;
+  }
+}
+template <typename T> static void emul_set_lem(void* h, const double* p) {
+  Emul<T>* e = (Emul<T>*)h;
+  double* st = new double[13 * (size_t)e->n];
+  emul_get_state<T>(h, st);
+  for (int i = 0; i < e->n; ++i) {
+    const double* q = p + 7 * i;
+    e->P[i] = {(T)q[0], (T)q[1], (T)q[2], (T)q[3], (T)q[4], (T)q[5], (T)q[6]};
+    for (int k = 0; k < 3; ++k) e->org[i][k] = (double)(T)q[2 + k];
+  }
+  emul_set_state<T>(h, st);
+  delete[] st;
+}
+template <typename T> static void emul_step(void* h, const double* action, double* obs) {
+  Emul<T>* e = (Emul<T>*)h;
+  for (int i = 0; i < e->n; ++i) {
+    T act[4], clipped[4], o[20];
+    for (int k = 0; k < 4; ++k) act[k] = (T)action[4 * i + k];
+    aviary_step(e->c, e->s[i], act, e->prev[i], clipped);
+    if (obs) {
+      pack_obs(e->s[i], V3<T>{(T)e->org[i][0], (T)e->org[i][1], (T)e->org[i][2]}, clipped, o);
+      for (int k = 0; k < 20; ++k) obs[20 * i + k] = o[k];
+    }
+  }
+}
+template <typename T> static void emul_step_geo(void* h, double t, double* obs, double* act_out) {
+  Emul<T>* e = (Emul<T>*)h;
+  for (int i = 0; i < e->n; ++i) {
+    T clipped[4], act[4], o[20], u[4];
+    State<T>& s = e->s[i];
+    const Desired<T> des = lemniscate_local(e->P[i], t);
+    const M3<T> R = quat_to_rot(s.q);
+    const V3<T> ang_v = mul(R, s.w);
+    geometric_control<T>(e->c, s.p - des.p, R, s.v, ang_v, des, u, nullptr);
+    input_to_action(e->c, u, act);
+    aviary_step(e->c, s, act, e->prev[i], clipped);
+    if (act_out)
+      for (int k = 0; k < 4; ++k) act_out[4 * i + k] = act[k];
+    if (obs) {
+      pack_obs(s, V3<T>{e->P[i].cx, e->P[i].cy, e->P[i].cz}, clipped, o);
+      for (int k = 0; k < 20; ++k) obs[20 * i + k] = o[k];
+    }
+  }
+}
+template <typename T> static void emul_geo_compute(void* h, int n, const double* obs, const double* des, double* rpm, double* aux) {
+  Emul<T>* e = (Emul<T>*)h;
+  for (int i = 0; i < n; ++i) {
+    const double* o = obs + 20 * i;
+    const double* d = des + 11 * i;
+    const T q[4] = {(T)o[3], (T)o[4], (T)o[5], (T)o[6]};
+    const M3<T> R = quat_to_rot(q);
+    Desired<T> D;
+    D.p = {(T)d[0], (T)d[1], (T)d[2]};
+    D.v = {(T)d[3], (T)d[4], (T)d[5]};
+    D.a = {(T)d[6], (T)d[7], (T)d[8]};
+    D.yaw = reduced_phase<T>(0.0, T(0), (T)d[9]);
+    D.yaw_rate = (T)d[10];
+    T u[4], act[4];
+    GeoAux<T> A;
+    geometric_control<T>(e->c, V3<T>{(T)o[0], (T)o[1], (T)o[2]} - D.p, R, V3<T>{(T)o[10], (T)o[11], (T)o[12]},
+                         V3<T>{(T)o[13], (T)o[14], (T)o[15]}, D, u, &A);
+    input_to_action(e->c, u, act);
+    for (int k = 0; k < 4; ++k) rpm[4 * i + k] = act[k];
+    if (aux) {
+      double* a = aux + 13 * i;
+      a[0] = A.force; a[1] = A.w_des.x; a[2] = A.w_des.y; a[3] = A.w_des.z;
+      a[4] = A.b1d.x; a[5] = A.b2d.x; a[6] = A.b3d.x; a[7] = A.b1d.y; a[8] = A.b2d.y; a[9] = A.b3d.y;
+      a[10] = A.b1d.z; a[11] = A.b2d.z; a[12] = A.b3d.z;
+    }
+  }
+}
+template <typename T> static void emul_lem(void* h, double t, double* des) {
+  Emul<T>* e = (Emul<T>*)h;
+  for (int i = 0; i < e->n; ++i) {
+    const Desired<T> d = lemniscate_local(e->P[i], t);
+    double* o = des + 11 * i;
+    o[0] = (double)d.p.x + (double)e->P[i].cx; o[1] = (double)d.p.y + (double)e->P[i].cy; o[2] = (double)d.p.z + (double)e->P[i].cz;
+    o[3] = d.v.x; o[4] = d.v.y; o[5] = d.v.z; o[6] = d.a.x; o[7] = d.a.y; o[8] = d.a.z; o[9] = d.yaw; o[10] = d.yaw_rate;
+  }
+}
+
+extern "C" {
+void* emul_create_f32(const mds_config* c, const mds_geometric_gains* g) { return emul_create<float>(c, g); }
+void* emul_create_f64(const mds_config* c, const mds_geometric_gains* g) { return emul_create<double>(c, g); }
+void emul_set_state_f32(void* h, const double* s) { emul_set_state<float>(h, s); }
+void emul_set_state_f64(void* h, const double* s) { emul_set_state<double>(h, s); }
+void emul_get_state_f32(void* h, double* s) { emul_get_state<float>(h, s); }
+void emul_get_state_f64(void* h, double* s) { emul_get_state<double>(h, s); }
+void emul_set_lem_f32(void* h, const double* p) { emul_set_lem<float>(h, p); }
+void emul_set_lem_f64(void* h, const double* p) { emul_set_lem<double>(h, p); }
+void emul_step_f32(void* h, const double* a, double* o) { emul_step<float>(h, a, o); }
+void emul_step_f64(void* h, const double* a, double* o) { emul_step<double>(h, a, o); }
+void emul_step_geo_f32(void* h, double t, double* o, double* a) { emul_step_geo<float>(h, t, o, a); }
+void emul_step_geo_f64(void* h, double t, double* o, double* a) { emul_step_geo<double>(h, t, o, a); }
+void emul_geo_compute_f32(void* h, int n, const double* o, const double* d, double* r, double* a) { emul_geo_compute<float>(h, n, o, d, r, a); }
+void emul_geo_compute_f64(void* h, int n, const double* o, const double* d, double* r, double* a) { emul_geo_compute<double>(h, n, o, d, r, a); }
+void emul_lem_f32(void* h, double t, double* d) { emul_lem<float>(h, t, d); }
+void emul_lem_f64(void* h, double t, double* d) { emul_lem<double>(h, t, d); }
+void emul_sincos_f32(int n, const float* x, float* s, float* c) {
+  for (int i = 0; i < n; ++i) m_sincos(x[i], s + i, c + i);
+}
+void emul_default_config(int model, mds_config* cfg, mds_geometric_gains* g) {
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->num_envs = 1; cfg->num_drones = 1; cfg->dtype = MDS_F32; cfg->drone_model = model;
+  cfg->pyb_freq = 100; cfg->ctrl_freq = 100;
+  cfg->M = 0.027; cfg->L = 0.0397; cfg->KF = 3.16e-10; cfg->KM = 7.94e-12;
+  if (model == MDS_CF2P) { cfg->J[0] = 2.3951e-5; cfg->J[1] = 2.3951e-5; cfg->J[2] = 3.2347e-5; }
+  else { cfg->J[0] = 1.4e-5; cfg->J[1] = 1.4e-5; cfg->J[2] = 2.17e-5; }
+  cfg->G = 9.8; cfg->thrust2weight = 2.25;
+  cfg->drag_coeff[0] = 9.1785e-7; cfg->drag_coeff[1] = 9.1785e-7; cfg->drag_coeff[2] = 10.311e-7;
+  for (int k = 0; k < 3; ++k) { g->Kp[k] = 2.25; g->Kv[k] = 3.5; g->KR[k] = 125.0; g->Kw[k] = 10.0; }
+  g->g = 9.81; g->max_tilt_angle = 40.0 * M_PI / 180.0;
+}
+}

@@ -1,0 +1,71 @@
+"""Shared input generators for the parity tests (same seeded inputs for oracle and HIP)."""
+import numpy as np
+
+from oracle import np_oracle as O
+
+
+def c2_setup(E, D, seed=0, offset=5.0, phase="c2", omega=1.5, z0=0.5, yaw_rate=0.0):
+    """SURVEY.md 8d generator: drones on an r=1 circle around a per-env centre U(-offset,offset)^2,
+    one Lemniscate per drone.  phase "c2": -(pi/4)(d-1) (EnvGeometric.py:540); "c3": 2 pi d/(D+.25)
+    (CBFTestOrd3.py:450)."""
+    rng = np.random.default_rng(seed)
+    cen = np.zeros((E, D, 3))
+    cen[..., :2] = rng.uniform(-offset, offset, size=(E, 1, 2))
+    cen[..., 2] = 0.5
+    ang = 2 * np.pi * np.arange(D) / D
+    xyz = cen.copy()
+    xyz[..., 0] += np.sin(ang)
+    xyz[..., 1] += np.cos(ang)
+    xyz[..., 2] = z0
+    P = np.zeros((E, D, 7))
+    P[..., 0] = 1.0
+    P[..., 1] = omega
+    P[..., 2:5] = cen
+    P[..., 5] = yaw_rate
+    P[..., 6] = -(np.pi / 4) * (np.arange(D) - 1) if phase == "c2" else 2 * np.pi * np.arange(D) / (D + 0.25)
+    return xyz, np.zeros((E, D, 3)), P
+
+
+def oracle_closed_loop(xyz, rpy, P, steps, pyb_freq=100, ctrl_freq=100, physics="dyn", integrator="euler",
+                       consts=O.CF2P, record_every=None):
+    """Reference loop shape (simulations/EnvGeometric.py:431-473) on the oracle."""
+    n = xyz.reshape(-1, 3).shape[0]
+    Pf = P.reshape(-1, 7)
+    ora = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), consts, pyb_freq, ctrl_freq, physics, integrator)
+    obs = ora.step(np.zeros((n, 4)))
+    t = 0.0
+    out = [obs]
+    for k in range(steps):
+        pos, vel, acc, yaw, yd = O.lemniscate(t, Pf[:, 0], Pf[:, 1], Pf[:, 2:5], Pf[:, 5], Pf[:, 6])
+        rpm = O.geometric_compute(obs, pos, vel, acc, yaw, yd, consts)
+        obs = ora.step(rpm)
+        t += ora.CTRL_TIMESTEP
+        if record_every and (k + 1) % record_every == 0:
+            out.append(obs)
+    return obs, out
+
+
+def open_loop_rpm(k, dt, ph, hover=O.CF2P.HOVER_RPM):
+    """Deterministic near-hover RPM sequence: 3 % collective wobble + zero-mean differential
+    terms, so an uncontrolled drone stays within a few metres over 1000 steps."""
+    n = ph.shape[0]
+    t = k * dt
+    coll = 0.03 * np.sin(2 * np.pi * 1.3 * t + ph[:, 0:1])
+    dx = 0.01 * np.cos(2 * np.pi * 5.0 * t) * ph[:, 1]
+    dy = 0.01 * np.cos(2 * np.pi * 4.0 * t) * ph[:, 2]
+    dz = 0.02 * np.cos(2 * np.pi * 3.0 * t) * ph[:, 3:4]
+    s = np.ones((n, 4)) * (1 + coll)
+    s[:, 1] += dx
+    s[:, 3] -= dx
+    s[:, 2] += dy
+    s[:, 0] -= dy
+    s += dz * np.array([-1, 1, -1, 1])
+    return (hover * s).astype(np.float32).astype(np.float64)   # fp32-representable: identical inputs for both sides
+
+
+def open_loop_setup(n, seed=1, tilt=0.02):
+    rng = np.random.default_rng(seed)
+    xyz = rng.uniform(-1, 1, size=(n, 3)) + np.array([0, 0, 1.0])
+    rpy = rng.uniform(-tilt, tilt, size=(n, 3))
+    ph = np.concatenate([rng.uniform(0, 2 * np.pi, size=(n, 1)), rng.uniform(-1, 1, size=(n, 3))], axis=1)
+    return xyz, rpy, ph

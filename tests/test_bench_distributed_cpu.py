@@ -1,0 +1,38 @@
+"""N>1 path of bench.py on CPU: 2 ranks over gloo exercise the rendezvous, the barriers and the
+max-over-ranks timing reduction (the data path itself has no collective: env shards are
+independent)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_gloo_dry_run():
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout          # only rank 0 prints
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2
+    assert rec["elapsed"] >= 0.02               # the slower rank (sleeps 20 ms) defines the time
+
+
+def test_each_rank_gets_different_envs_and_same_shape():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.make_inputs(16, 8, "c3", 1000)
+    b = bench.make_inputs(16, 8, "c3", 1001)
+    assert a[0].shape == b[0].shape == (16, 8, 3) and a[2].shape == (16, 8, 7)
+    assert not np.allclose(a[0], b[0])
+    # per-env centre offsets in U(-5,5)^2, phase rule of CBFTestOrd3.py:450
+    assert np.abs(a[2][..., 2:4]).max() <= 5.0
+    np.testing.assert_allclose(a[2][0, :, 6], 2 * np.pi * np.arange(8) / 8.25)
+    c = bench.make_inputs(4, 4, "c2", 0)
+    np.testing.assert_allclose(c[2][0, :, 6], -(np.pi / 4) * (np.arange(4) - 1))

@@ -1,0 +1,141 @@
+"""CPU-side checks of the C-ABI boundary: libmds.so loads, exports every symbol that
+include/mds.h declares, validates arguments before touching the device, and fails LOUDLY
+(never silently falls back) where no GPU exists."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import multidronesim_amd
+from multidronesim_amd import _capi as capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(capi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return capi.load_library()
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "mds.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mds_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = header_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"libmds.so does not export {n}"
+    assert sorted(capi.PROTOTYPES) == names, "ctypes prototypes and include/mds.h disagree"
+
+
+def test_version_and_strerror(lib):
+    assert lib.mds_version() == 100
+    assert lib.mds_strerror(0) == b"ok"
+    assert b"aligned" in lib.mds_strerror(-4)
+    assert lib.mds_strerror(-99) == b"unknown status"
+
+
+def test_default_config_matches_urdf_constants(lib):
+    cfg = capi.MdsConfig()
+    assert lib.mds_default_config(capi.MDS_CF2P, C.byref(cfg)) == 0
+    assert (cfg.M, cfg.L, cfg.KF, cfg.KM, cfg.G, cfg.thrust2weight) == (0.027, 0.0397, 3.16e-10, 7.94e-12, 9.8, 2.25)
+    assert list(cfg.J) == [2.3951e-5, 2.3951e-5, 3.2347e-5]
+    assert lib.mds_default_config(capi.MDS_CF2X, C.byref(cfg)) == 0
+    assert list(cfg.J) == [1.4e-5, 1.4e-5, 2.17e-5]
+    assert lib.mds_default_config(7, C.byref(cfg)) == capi.MDS_OK - 1
+    g = capi.MdsGeometricGains()
+    assert lib.mds_default_geometric_gains(C.byref(g)) == 0
+    assert list(g.Kp) == [2.25] * 3 and list(g.Kv) == [3.5] * 3 and list(g.KR) == [125.0] * 3 and list(g.Kw) == [10.0] * 3
+    assert g.g == 9.81 and g.max_tilt_angle == pytest.approx(40 * np.pi / 180)
+
+
+def test_struct_layout_matches_header(lib):
+    # 10 int32 + (4 + 3 + 2 + 3) doubles ; 12 + 2 doubles
+    assert C.sizeof(capi.MdsConfig) == 10 * 4 + 12 * 8
+    assert C.sizeof(capi.MdsGeometricGains) == 14 * 8
+
+
+@pytest.mark.parametrize("mut", [dict(num_envs=0), dict(num_drones=-1), dict(dtype=9), dict(physics=5), dict(integrator=2),
+                                 dict(drone_model=3), dict(pyb_freq=240, ctrl_freq=100), dict(ctrl_freq=0), dict(M=0.0),
+                                 dict(KF=-1.0)])
+def test_create_rejects_bad_config_before_touching_the_device(lib, mut):
+    cfg = capi.MdsConfig()
+    lib.mds_default_config(capi.MDS_CF2P, C.byref(cfg))
+    for k, v in mut.items():
+        setattr(cfg, k, v)
+    h = C.c_void_p()
+    assert lib.mds_create(C.byref(cfg), C.byref(h)) == -1
+    assert not h.value
+    assert lib.mds_last_error() != b""
+    assert lib.mds_create(None, C.byref(h)) == -1
+
+
+def test_null_handle_calls_return_einval(lib):
+    assert lib.mds_step(None, None, None, None) == -1
+    assert lib.mds_step_geometric(None, 0.0, None, None, None) == -1
+    assert lib.mds_get_obs(None, None, None) == -1
+    assert lib.mds_destroy(None) == 0
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from multidronesim_amd.envs.CtrlAviary import CtrlAviary
+    with pytest.raises(multidronesim_amd.MdsError):
+        CtrlAviary(num_drones=2)
+    from multidronesim_amd.trajectories.Lemniscate import Lemniscate
+    with pytest.raises(multidronesim_amd.MdsError):
+        Lemniscate()(0.0)
+
+
+def test_missing_library_is_an_error(tmp_path):
+    with pytest.raises(multidronesim_amd.MdsError):
+        capi.load_library(str(tmp_path / "libmds.so"))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "multidronesim_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "np_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+                assert "tests.emul" not in txt and "libmds_emul" not in txt, f
+
+
+def test_reference_api_names_present():
+    """Names the reference imports / calls exist with the same spelling."""
+    from multidronesim_amd.envs.BaseAviary import DroneModel, Physics
+    from multidronesim_amd.envs.CtrlAviary import CtrlAviary
+    from multidronesim_amd.control.geometric import GeometricControl
+    from multidronesim_amd.control.base_controller import BaseController
+    from multidronesim_amd.trajectories.Lemniscate import Lemniscate, TrajectoryBase
+    from multidronesim_amd.utils.utils import sync, str2bool
+    from multidronesim_amd.utils.model_conversions import input_to_action, action_to_input
+    from multidronesim_amd.PIDEnv import MultiDroneEnv
+    from multidronesim_amd.model.dynamics import QuadrotorDynamics
+    assert DroneModel("cf2p") is DroneModel.CF2P and Physics("pyb") is Physics.PYB
+    for m in ("step", "reset", "render", "close", "getPyBulletClient", "getDroneIds", "_showDroneLocalAxes"):
+        assert callable(getattr(CtrlAviary, m))
+    for m in ("set_desired_trajectory", "compute"):
+        assert callable(getattr(GeometricControl, m)) and callable(getattr(BaseController, m))
+    for m in ("threaded_sim", "run_sim", "sim_step", "stop_sim", "stop", "build_args"):
+        assert callable(getattr(MultiDroneEnv, m))
+    assert str2bool("yes") is True and str2bool("0") is False
+    t = Lemniscate(a=2, omega=0.5, center=np.array([1, 2, 3]), yaw_rate=0.1, phase_shift=0.3)
+    np.testing.assert_allclose(t.params(), [2, 0.5, 1, 2, 3, 0.1, 0.3])
+    assert Lemniscate(omega=2.0, revolutions=3).get_total_time() == pytest.approx(3 * np.pi)
+    m = MultiDroneEnv(num_drones=3, gui=False)
+    assert m.INIT_XYZS.shape == (3, 3) and m.TARGET_POSITIONS[1, 2] == 1.0
+    q = QuadrotorDynamics(100)
+    with pytest.raises(ValueError):
+        q.step(np.zeros(4))

@@ -1,0 +1,72 @@
+"""CPU tests of the DEVICE arithmetic (multidronesim_amd/csrc/mds_math.hpp compiled with g++,
+tests/emul): the same templates the HIP kernels instantiate, checked against the golden
+vectors and the oracle.  This pins the restatement before any GPU time is spent; the GPU
+parity tests proper are in test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from tests import helpers as H
+from tests.emul import emul as E
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_fp32_sincos_accuracy():
+    x = np.linspace(-3.3, 3.3, 200001).astype(np.float32)
+    s, c = E.sincos_f32(x)
+    assert np.abs(s.astype(np.float64) - np.sin(x.astype(np.float64))).max() < 1.5e-7
+    assert np.abs(c.astype(np.float64) - np.cos(x.astype(np.float64))).max() < 1.5e-7
+
+
+@pytest.mark.parametrize("dt,tol_rpm_rel,tol_aux", [("f64", 1e-13, 1e-13), ("f32", 1e-6, 2e-6)])
+def test_geometric_golden(dt, tol_rpm_rel, tol_aux):
+    d = np.load(os.path.join(G, "geometric_compute.npz"))
+    rpm, aux = E.Emul(dt).geometric_compute(d["obs"], d["des"])
+    assert np.abs(rpm / d["rpm"] - 1).max() < tol_rpm_rel
+    assert np.abs(aux[:, 0] - d["force"]).max() < tol_aux
+    assert np.abs(aux[:, 1:4] - d["w_des"]).max() < tol_aux * 5
+    assert np.abs(aux[:, 4:].reshape(-1, 3, 3) - d["R_des"]).max() < tol_aux
+
+
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-12), ("f32", 1e-5)])
+def test_lemniscate_golden(dt, tol):
+    g = np.load(os.path.join(G, "lemniscate.npz"))
+    e = E.Emul(dt, num_envs=3)
+    e.set_lemniscate(g["params"])
+    for i, t in enumerate(g["ts"]):
+        assert np.abs(e.lemniscate(t) - g["out"][:, i]).max() < tol
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(integrator=1), dict(physics=1), dict(pyb_freq=240, ctrl_freq=48)])
+def test_open_loop_f64_matches_oracle(kw):
+    n = 32
+    xyz, rpy, ph = H.open_loop_setup(n)
+    pf, cf = kw.get("pyb_freq", 240), kw.get("ctrl_freq", 240)
+    ora = O.AviaryOracle(xyz, rpy, pyb_freq=pf, ctrl_freq=cf, integrator="rk4" if kw.get("integrator") else "euler",
+                         physics="dyn_drag" if kw.get("physics") else "dyn")
+    em = E.Emul("f64", num_envs=n, pyb_freq=pf, ctrl_freq=cf, integrator=kw.get("integrator", 0), physics=kw.get("physics", 0))
+    em.set_state(np.concatenate([ora.pos, ora.quat, ora.vel, ora.rates], axis=1))
+    for k in range(300):
+        a = H.open_loop_rpm(k, ora.CTRL_TIMESTEP, ph)
+        obs, eobs = ora.step(a), em.step(a)
+    np.testing.assert_allclose(eobs, obs, atol=1e-10, rtol=1e-12)
+
+
+def test_closed_loop_f32_within_1e5_over_1000_steps():
+    xyz, rpy, P = H.c2_setup(16, 4)
+    obs, _ = H.oracle_closed_loop(xyz, rpy, P, 1000)
+    em = E.Emul("f32", num_envs=16, num_drones=4)
+    n = 64
+    ora0 = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), pyb_freq=100, ctrl_freq=100)
+    em.set_state(np.concatenate([ora0.pos, ora0.quat, ora0.vel, ora0.rates], axis=1))
+    em.set_lemniscate(P.reshape(-1, 7))
+    em.step(np.zeros((n, 4)))
+    t = 0.0
+    for k in range(1000):
+        eobs, _ = em.step_geometric(t)
+        t += 0.01
+    assert np.abs(eobs[:, :16] - obs[:, :16]).max() < 1e-5      # north_star tolerance, fp32 state
+    assert np.abs(eobs[:, 16:] / obs[:, 16:] - 1).max() < 2e-6  # RPM echo: relative

@@ -1,0 +1,368 @@
+"""GPU parity tests: the HIP path (through the C-ABI of include/mds.h, via the ctypes layer)
+against the float64 oracle on the same seeded inputs, and against the golden vectors minted
+from the reference.  Tolerances: north_star's 1e-5 absolute per state for fp32 state; the f64
+dtype must agree to ~1e-10 (same algorithm, same precision)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def mds():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device: -m gpu tests need a real MI355X (there is no CPU fallback)")
+    import multidronesim_amd
+    multidronesim_amd.load_library()
+    from multidronesim_amd.envs.CtrlAviary import CtrlAviary, DroneModel, Physics
+    import types
+    return types.SimpleNamespace(CtrlAviary=CtrlAviary, DroneModel=DroneModel, Physics=Physics, torch=torch)
+
+
+def make_env(mds, E, D, xyz, rpy, dtype="float32", pyb=100, ctrl=100, physics=None, integrator="euler", model=None):
+    return mds.CtrlAviary(drone_model=model or mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy,
+                          physics=physics or mds.Physics.DYN, pyb_freq=pyb, ctrl_freq=ctrl, num_envs=E, dtype=dtype,
+                          integrator=integrator)
+
+
+def np_obs(t):
+    return t.detach().double().cpu().numpy().reshape(-1, 20)
+
+
+# ---------------------------------------------------------------------------------------------
+# a1-a4: physics step
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kw", [dict(), dict(integrator="rk4"), dict(physics="drag"), dict(pyb=240, ctrl=48),
+                                dict(model="cf2x")])
+def test_step_f64_matches_oracle_1000_steps(mds, kw):
+    n = 96
+    xyz, rpy, ph = H.open_loop_setup(n)
+    pyb, ctrl = kw.get("pyb", 240), kw.get("ctrl", 240)
+    steps = 1000 if pyb == ctrl else 200
+    consts = O.CF2X if kw.get("model") == "cf2x" else O.CF2P
+    ora = O.AviaryOracle(xyz, rpy, consts, pyb, ctrl, "dyn_drag" if kw.get("physics") else "dyn", kw.get("integrator", "euler"))
+    env = make_env(mds, n, 1, xyz[:, None, :], rpy[:, None, :], "float64", pyb, ctrl,
+                   mds.Physics.PYB_DRAG if kw.get("physics") else mds.Physics.DYN, kw.get("integrator", "euler"),
+                   mds.DroneModel.CF2X if kw.get("model") == "cf2x" else None)
+    np.testing.assert_allclose(np_obs(env._computeObs()), ora.obs(), atol=1e-14)
+    for k in range(steps):
+        a = H.open_loop_rpm(k, ora.CTRL_TIMESTEP, ph)
+        obs = ora.step(a)
+        gobs, r, term, trunc, info = env.step(mds.torch.as_tensor(a.reshape(n, 1, 4)))
+    np.testing.assert_allclose(np_obs(gobs), obs, atol=1e-9, rtol=1e-12)
+    assert (r, term, trunc, info) == (-1, False, False, {"answer": 42})
+    np.testing.assert_allclose(env.get_state().reshape(n, 13),
+                               np.concatenate([ora.pos, ora.quat, ora.vel, ora.rates], axis=1), atol=1e-9)
+    env.close()
+
+
+def test_step_f32_open_loop(mds):
+    """fp32 state, uncontrolled near-hover flight at 240 Hz.  Open loop the quadrotor is a chain
+    of integrators, so fp32 rounding grows ~t^2.5: <= 1e-5 holds for 500 steps and 3e-5 at 1000
+    (measured ~1.3e-5); the closed-loop configs below hold 1e-5 over the full 1000."""
+    n = 256
+    xyz, rpy, ph = H.open_loop_setup(n)
+    ora = O.AviaryOracle(xyz, rpy, pyb_freq=240, ctrl_freq=240)
+    env = make_env(mds, n, 1, xyz[:, None, :], rpy[:, None, :], "float32", 240, 240)
+    s0 = env.get_state().reshape(n, 13)      # start both from the fp32-rounded initial state
+    ora.pos, ora.quat, ora.vel, ora.rates = s0[:, 0:3].copy(), s0[:, 3:7].copy(), s0[:, 7:10].copy(), s0[:, 10:13].copy()
+    for k in range(1000):
+        a = H.open_loop_rpm(k, ora.CTRL_TIMESTEP, ph)
+        obs = ora.step(a)
+        gobs, *_ = env.step(mds.torch.as_tensor(a.reshape(n, 1, 4), dtype=mds.torch.float32))
+        if k == 499:
+            assert np.abs(np_obs(gobs)[:, :16] - obs[:, :16]).max() < 1e-5
+    err = np.abs(np_obs(gobs)[:, :16] - obs[:, :16]).max()
+    assert err < 3e-5, err
+    np.testing.assert_allclose(np_obs(gobs)[:, 16:], obs[:, 16:], rtol=1e-7)
+    env.close()
+
+
+def test_step_clips_action_and_reference_shapes(mds):
+    """E=1 with NumPy in -> reference shapes: obs [D,20]; RPM clipped to [0, MAX_RPM] lands in obs[16:20]."""
+    D = 3
+    xyz = np.array([[0, 0, 1.0], [1, 0, 1.0], [0, 1, 1.0]])
+    env = make_env(mds, 1, D, xyz, np.zeros((D, 3)), "float64", 240, 240)
+    a = np.array([[-5.0, 1e6, 100.0, 200.0]] * D)
+    obs, *_ = env.step(a)
+    assert isinstance(obs, np.ndarray) and obs.shape == (D, 20)
+    np.testing.assert_allclose(obs[:, 16:20], [[0.0, O.CF2P.MAX_RPM, 100.0, 200.0]] * D, rtol=1e-15)
+    ora = O.AviaryOracle(xyz, np.zeros((D, 3)), pyb_freq=240, ctrl_freq=240)
+    np.testing.assert_allclose(obs, ora.step(a), atol=1e-12)
+    for name in ("M", "G", "L", "KF", "KM", "MAX_RPM", "MAX_THRUST", "HOVER_RPM", "MAX_XY_TORQUE", "MAX_Z_TORQUE", "GRAVITY"):
+        np.testing.assert_allclose(getattr(env, name), getattr(O.CF2P, name), rtol=1e-14)
+    assert env.CTRL_TIMESTEP == 1 / 240 and env.J.shape == (3, 3)
+    o2, info = env.reset()
+    np.testing.assert_allclose(o2[:, 0:3], xyz)
+    np.testing.assert_allclose(o2[:, 16:20], 0)
+    assert env.pos.shape == (D, 3) and env.getDroneIds().shape == (D,)
+    env.render()
+    env.close()
+    with pytest.raises(ValueError):
+        make_env(mds, 1, 1, np.zeros((1, 3)), np.zeros((1, 3)), pyb=240, ctrl=100)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 255, 257, 1000])
+def test_ragged_sizes(mds, n):
+    """n not a multiple of the wave (64) / workgroup (256): tail lanes and the LDS obs staging."""
+    xyz, rpy, ph = H.open_loop_setup(n, seed=n)
+    ora = O.AviaryOracle(xyz, rpy, pyb_freq=240, ctrl_freq=240)
+    env = make_env(mds, n, 1, xyz[:, None, :], rpy[:, None, :], "float64", 240, 240)
+    guard = mds.torch.full((n + 8, 20), 777.0, dtype=mds.torch.float64, device=env.device)   # canary after the obs rows
+    env._obs = guard[:n].reshape(n, 1, 20)
+    for k in range(5):
+        a = H.open_loop_rpm(k, ora.CTRL_TIMESTEP, ph)
+        obs = ora.step(a)
+        gobs, *_ = env.step(mds.torch.as_tensor(a.reshape(n, 1, 4)))
+    np.testing.assert_allclose(np_obs(gobs), obs, atol=1e-12)
+    assert (guard[n:] == 777.0).all()
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# golden vectors through the C-ABI (a5, a7-a10)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,tol_rel,tol_aux", [("float64", 1e-12, 1e-12), ("float32", 2e-6, 4e-6)])
+def test_geometric_compute_golden(mds, dtype, tol_rel, tol_aux):
+    from multidronesim_amd.control.geometric import GeometricControl
+    d = np.load(os.path.join(G, "geometric_compute.npz"))
+    n = d["obs"].shape[0]
+    env = make_env(mds, n, 1, np.zeros((n, 1, 3)), np.zeros((n, 1, 3)), dtype)
+    ctrl = GeometricControl(env)
+    rpm, force, w_des, R_des = ctrl.compute_batched(d["obs"].reshape(n, 1, 20), d["des"].reshape(n, 1, 11), return_omegas=True)
+    rpm = rpm.double().cpu().numpy().reshape(n, 4)
+    assert np.abs(rpm / d["rpm"] - 1).max() < tol_rel
+    assert np.abs(force.double().cpu().numpy().reshape(n) - d["force"]).max() < tol_aux
+    assert np.abs(w_des.double().cpu().numpy().reshape(n, 3) - d["w_des"]).max() < 5 * tol_aux
+    assert np.abs(R_des.double().cpu().numpy().reshape(n, 3, 3) - d["R_des"]).max() < tol_aux
+    rpm_only = ctrl.compute_batched(d["obs"].reshape(n, 1, 20), d["des"].reshape(n, 1, 11)).double().cpu().numpy()
+    np.testing.assert_array_equal(rpm_only.reshape(n, 4), rpm)
+    env.close()
+
+
+def test_reference_signatures_single_drone(mds):
+    """GeometricControl(env).compute(obs) and Lemniscate(...)(t) with the reference's call shapes,
+    on the SURVEY.md 8c spot values (incl. the no-op-transpose quirk)."""
+    from multidronesim_amd.control.geometric import GeometricControl
+    from multidronesim_amd.trajectories.Lemniscate import Lemniscate
+    d = np.load(os.path.join(G, "geometric_compute.npz"))
+    env = make_env(mds, 1, 2, np.zeros((2, 3)), np.zeros((2, 3)), "float64")
+    traj = Lemniscate(center=np.array([0, 0, .5]), omega=1.5, yaw_rate=0.3)
+    pos, vel, acc, yaw, om = traj(0.37)
+    np.testing.assert_allclose(pos, [0.3505205637, 0.6651959776, 0.5], atol=1e-9)
+    np.testing.assert_allclose(vel, [0.1534443003, -1.3181327684, 0], atol=1e-9)
+    np.testing.assert_allclose(acc, [-4.0263528439, 0.2337315706, 0], atol=1e-9)
+    np.testing.assert_allclose([yaw, om], [0.3480011356, 0.9366776206], atol=1e-9)
+    assert traj.get_total_time() == pytest.approx(2 * np.pi / 1.5)
+    ctrl = GeometricControl(env)
+    ctrl.set_desired_trajectory(0, pos, vel, acc, yaw, om)
+    rpm = ctrl.compute(d["spot_obs"])
+    np.testing.assert_allclose(rpm, [14426.96568, 14788.12966, 11884.78050, 16030.20029], atol=1e-4)
+    force, w_des, R_des = ctrl.compute(d["spot_obs"], return_omegas=True)
+    np.testing.assert_allclose(w_des, [0.5956908439, -0.0106877434, 0.7451911107], atol=1e-9)
+    assert R_des.shape == (3, 3)
+    env.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-12), ("float32", 1e-5)])
+def test_lemniscate_eval_golden(mds, dtype, tol):
+    g = np.load(os.path.join(G, "lemniscate.npz"))
+    env = make_env(mds, 1, 3, np.zeros((3, 3)), np.zeros((3, 3)), dtype)
+    env.set_trajectories(g["params"])
+    des = mds.torch.zeros((3, 11), dtype=env.dtype, device=env.device)
+    from multidronesim_amd._device import stream_ptr
+    for i, t in enumerate(g["ts"]):
+        rc = env._lib.mds_lemniscate_eval(env._h, C.c_double(float(t)), C.c_void_p(des.data_ptr()), C.c_void_p(stream_ptr(env.device)))
+        assert rc == 0
+        assert np.abs(des.double().cpu().numpy() - g["out"][:, i]).max() < tol
+    env.close()
+
+
+@pytest.mark.parametrize("dtype,rtol", [("float64", 1e-12), ("float32", 1e-6)])
+def test_mixer_golden(mds, dtype, rtol):
+    from multidronesim_amd.utils.model_conversions import action_to_input, input_to_action
+    d = np.load(os.path.join(G, "mixer.npz"))
+    n = d["u"].shape[0]
+    env = make_env(mds, n, 1, np.zeros((n, 1, 3)), np.zeros((n, 1, 3)), dtype)
+    np.testing.assert_allclose(input_to_action(env, d["u"]), d["rpm"], rtol=rtol)
+    np.testing.assert_allclose(action_to_input(env, d["act"]), d["u_back"], rtol=rtol * 20, atol=1e-9 if dtype == "float32" else 1e-18)
+    np.testing.assert_allclose(action_to_input(env, d["act"], cap_rpm=False), d["u_back_nocap"], rtol=rtol * 20,
+                               atol=1e-9 if dtype == "float32" else 1e-18)
+    np.testing.assert_allclose(input_to_action(env, d["u"][0]), d["rpm"][0], rtol=rtol)   # (4,) reference shape
+    env.close()
+
+
+def test_quadrotor_dynamics_golden(mds):
+    from multidronesim_amd.model.dynamics import QuadrotorDynamics
+    d = np.load(os.path.join(G, "dynamics_deriv.npz"))
+    q = QuadrotorDynamics(sim_freq=100)
+    np.testing.assert_allclose(q.dynamics(0.0, d["state"], d["u"]), d["out_hb"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(q.dynamics(0.0, d["state"][0], d["u"][0]), d["out_hb"][0], rtol=1e-12, atol=1e-12)
+
+    class EnvLike:
+        M, G, KF, PYB_FREQ = float(d["env_m"]), float(d["env_g"]), 3.16e-10, 100
+        J = np.diag([2.3951e-5, 2.3951e-5, 3.2347e-5])
+    q.load_env_params(EnvLike)     # stale Hummingbird J quirk
+    np.testing.assert_allclose(q.dynamics(0.0, d["state"], d["u_env"]), d["out_env"], rtol=1e-12, atol=1e-12)
+    f32 = q.dynamics(0.0, mds.torch.as_tensor(d["state"], dtype=mds.torch.float32), mds.torch.as_tensor(d["u_env"], dtype=mds.torch.float32))
+    np.testing.assert_allclose(f32.double().cpu().numpy(), d["out_env"], rtol=2e-5, atol=2e-5)
+    with pytest.raises(ValueError):
+        q.step(d["u"][0])
+
+
+# ---------------------------------------------------------------------------------------------
+# fused trajectory + controller + step: BASELINE configs C2 / C3 at oracle-sized batches
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("E,D,phase,dtype,tol", [(64, 4, "c2", "float32", 1e-5), (32, 8, "c3", "float32", 1e-5),
+                                                 (16, 4, "c2", "float64", 1e-9)])
+def test_fused_geometric_1000_steps(mds, E, D, phase, dtype, tol):
+    xyz, rpy, P = H.c2_setup(E, D, phase=phase)
+    obs, hist = H.oracle_closed_loop(xyz, rpy, P, 1000, record_every=250)
+    env = make_env(mds, E, D, xyz, rpy, dtype)
+    env.set_trajectories(P)
+    env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))        # EnvGeometric.py:431
+    t, k_hist = 0.0, 1
+    for k in range(1000):
+        gobs = env.step_geometric(t)
+        t += env.CTRL_TIMESTEP
+        if (k + 1) % 250 == 0:
+            g = np_obs(gobs)
+            assert np.abs(g[:, :16] - hist[k_hist][:, :16]).max() < tol, (k, np.abs(g[:, :16] - hist[k_hist][:, :16]).max())
+            assert np.abs(g[:, 16:] / hist[k_hist][:, 16:] - 1).max() < max(tol, 2e-6)
+            k_hist += 1
+    env.close()
+
+
+def test_fused_matches_unfused_operator_chain(mds):
+    """step_geometric == lemniscate_eval -> geometric_compute -> step, operator by operator."""
+    from multidronesim_amd.control.geometric import GeometricControl
+    from multidronesim_amd._device import stream_ptr
+    E, D = 8, 4
+    xyz, rpy, P = H.c2_setup(E, D, yaw_rate=0.2)
+    a = make_env(mds, E, D, xyz, rpy, "float64")
+    b = make_env(mds, E, D, xyz, rpy, "float64")
+    a.set_trajectories(P)
+    b.set_trajectories(P)
+    ctrl = GeometricControl(b)
+    des = mds.torch.zeros((E, D, 11), dtype=b.dtype, device=b.device)
+    oa, *_ = a.step(mds.torch.zeros((E, D, 4), dtype=a.dtype))
+    ob, *_ = b.step(mds.torch.zeros((E, D, 4), dtype=b.dtype))
+    t = 0.0
+    for k in range(50):
+        oa, act_a = a.step_geometric(t, return_action=True)
+        assert b._lib.mds_lemniscate_eval(b._h, C.c_double(t), C.c_void_p(des.data_ptr()), C.c_void_p(stream_ptr(b.device))) == 0
+        rpm = ctrl.compute_batched(ob, des)
+        np.testing.assert_allclose(act_a.cpu().numpy(), rpm.cpu().numpy(), rtol=1e-9)
+        ob, *_ = b.step(rpm)
+        t += a.CTRL_TIMESTEP
+    np.testing.assert_allclose(oa.cpu().numpy(), ob.cpu().numpy(), atol=1e-9)
+    a.close()
+    b.close()
+
+
+def test_rollout_equals_stepwise_and_substeps_drag_rk4(mds):
+    E, D = 8, 4
+    xyz, rpy, P = H.c2_setup(E, D)
+    for kw in (dict(), dict(pyb=200, ctrl=100), dict(physics="drag"), dict(integrator="rk4")):
+        phys = mds.Physics.PYB_DRAG if kw.get("physics") else mds.Physics.DYN
+        envs = [make_env(mds, E, D, xyz, rpy, "float64", kw.get("pyb", 100), kw.get("ctrl", 100), phys, kw.get("integrator", "euler"))
+                for _ in range(2)]
+        for e in envs:
+            e.set_trajectories(P)
+            e.step(mds.torch.zeros((E, D, 4), dtype=e.dtype))
+        t = 0.0
+        for k in range(40):
+            o1 = envs[0].step_geometric(t)
+            t += 0.01
+        o2 = envs[1].rollout_geometric(0.0, 40)
+        np.testing.assert_allclose(o1.cpu().numpy(), o2.cpu().numpy(), atol=1e-13)
+        obs, _ = H.oracle_closed_loop(xyz, rpy, P, 40, kw.get("pyb", 100), kw.get("ctrl", 100),
+                                      "dyn_drag" if kw.get("physics") else "dyn", kw.get("integrator", "euler"))
+        np.testing.assert_allclose(np_obs(o1), obs, atol=1e-9, rtol=1e-11)
+        for e in envs:
+            e.close()
+
+
+def test_fp16_storage_is_stable_and_close(mds):
+    """fp16 state storage / fp32 arithmetic (config 5) is a throughput configuration: 2^-11
+    relative storage rounding.  Gate: stays finite, unit quaternion, tracks the oracle to 5e-2
+    over 100 closed-loop steps."""
+    E, D = 16, 2
+    xyz, rpy, P = H.c2_setup(E, D, offset=0.0)
+    obs, _ = H.oracle_closed_loop(xyz, rpy, P, 100)
+    env = make_env(mds, E, D, xyz, rpy, "float16")
+    env.set_trajectories(P)
+    env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+    t = 0.0
+    for k in range(100):
+        gobs = env.step_geometric(t)
+        t += 0.01
+    g = np_obs(gobs)
+    assert np.isfinite(g).all()
+    assert np.abs(np.linalg.norm(g[:, 3:7], axis=1) - 1).max() < 2e-3
+    assert np.abs(g[:, :3] - obs[:, :3]).max() < 5e-2
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# full BASELINE size (C3: 65 536 x 8) through size-independent properties
+# ---------------------------------------------------------------------------------------------
+def test_c3_full_size_properties(mds):
+    E, D = 65536, 8
+    xyz, rpy, P = H.c2_setup(E, D, phase="c3")
+    # (1) replicate invariance: envs 0..255 are copied into envs 1024..1279 -> bitwise equal outputs
+    xyz[1024:1280], P[1024:1280] = xyz[0:256], P[0:256]
+    env = make_env(mds, E, D, xyz, rpy, "float32")
+    env.set_trajectories(P)
+    env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+    steps = 200
+    obs = env.rollout_geometric(0.0, steps).clone()
+    assert mds.torch.equal(obs[0:256], obs[1024:1280])
+    # (2) a small batch holding only envs 0..63 gives bitwise the same rows (no cross-drone coupling)
+    small = make_env(mds, 64, D, xyz[:64], rpy[:64], "float32")
+    small.set_trajectories(P[:64])
+    small.step(mds.torch.zeros((64, D, 4), dtype=small.dtype))
+    so = small.rollout_geometric(0.0, steps)
+    assert mds.torch.equal(so, obs[:64])
+    # (3) invariants on every row: finite, unit quaternion, RPM inside the clip range
+    assert mds.torch.isfinite(obs).all()
+    assert (obs[..., 3:7].norm(dim=-1) - 1).abs().max().item() < 1e-5
+    assert obs[..., 16:].min().item() >= 9440.3 * (1 - 1e-6) and obs[..., 16:].max().item() <= O.CF2P.MAX_RPM * (1 + 1e-6)
+    # (4) a strided sample of 512 envs against the oracle
+    idx = np.arange(0, E, E // 512)
+    oobs, _ = H.oracle_closed_loop(xyz[idx], rpy[idx], P[idx], steps)
+    g = obs[idx].double().cpu().numpy().reshape(-1, 20)
+    assert np.abs(g[:, :16] - oobs[:, :16]).max() < 1e-5
+    env.close()
+    small.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# error behaviour of the C-ABI (no throw, status codes)
+# ---------------------------------------------------------------------------------------------
+def test_capi_error_codes(mds):
+    from multidronesim_amd import _capi as capi
+    from multidronesim_amd import MdsError
+    lib = capi.load_library()
+    env = make_env(mds, 2, 2, np.zeros((2, 3)), np.zeros((2, 3)))
+    with pytest.raises(MdsError) as ei:
+        env.step_geometric(0.0)                     # no trajectory attached
+    assert ei.value.status == -5
+    buf = mds.torch.zeros(4 * 20 + 4, dtype=mds.torch.float32, device=env.device)
+    act = mds.torch.zeros((4, 4), dtype=mds.torch.float32, device=env.device)
+    assert lib.mds_step(env._h, C.c_void_p(act.data_ptr()), C.c_void_p(buf.data_ptr() + 4), None) == -4   # misaligned obs
+    assert lib.mds_step(env._h, None, None, None) == -1
+    assert lib.mds_step(env._h, C.c_void_p(act.data_ptr()), None, None) == 0                               # obs optional
+    with pytest.raises(ValueError):
+        env.step(np.zeros((3, 4)))
+    env.close()
+    with pytest.raises(MdsError):
+        env.step(np.zeros((2, 4)))
