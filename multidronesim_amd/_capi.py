@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmds.so")
+# MDS_LIB_PATH selects another build of the same library (kernel-tuning experiments)
+LIB_PATH = os.environ.get("MDS_LIB_PATH") or os.path.join(_HERE, "libmds.so")
 
 MDS_OK = 0
 MDS_F32, MDS_F64, MDS_F16 = 0, 1, 2

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -49,6 +50,9 @@ struct mds_handle {
   void* lem;           // T [7][ld]
   double* scratch;     // double [n*20] device staging for host<->device set-up calls
   bool has_traj;
+  int num_cus;             // multiProcessorCount of the device
+  int geo_blocks_per_cu;   // persistent-grid width of k_step_geometric (MDS_GEO_BLOCKS_PER_CU overrides)
+  int geo_use_dma;         // fp32/Euler: MDS_GEO_DMA=1 selects the persistent LDS-DMA staged kernel (default: register-staged)
   Consts<float> cf;
   Consts<double> cd;
 };
@@ -143,6 +147,16 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   h->n = cfg->num_envs * cfg->num_drones;
   h->ld = ((size_t)h->n + 255) / 256 * 256;
   h->has_traj = false;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess) cus = 0;
+    h->num_cus = cus > 0 ? cus : 256;
+    const char* env = getenv("MDS_GEO_BLOCKS_PER_CU");
+    const int v = env ? atoi(env) : 0;
+    h->geo_blocks_per_cu = (v >= 1 && v <= 64) ? v : 3;
+    const char* dma = getenv("MDS_GEO_DMA");
+    h->geo_use_dma = dma ? atoi(dma) != 0 : 0;   // measured on MI355X at C3: register-staged 21.1 us vs LDS-DMA 22.8 us
+  }
   fill_consts(h->cfg, h->gains, h->cf);
   fill_consts(h->cfg, h->gains, h->cd);
   const size_t es = elem_size(cfg->dtype), cs = comp_size(cfg->dtype);
@@ -261,13 +275,21 @@ int mds_step(mds_handle* h, const void* action, void* obs, void* stream) {
   if (!aligned16(action) || !aligned16(obs)) return fail(MDS_EALIGN, "mds_step: action_dev/obs_dev");
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid = grid_for(h->n, kBlock);
-  if (obs) {
-    MDS_DISPATCH(h, (k_step<T, S, true><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, (S*)h->state, (const T*)h->origin, (T*)h->last_rpm,
-                                                                  (const S*)action, (S*)obs)));
-  } else {
-    MDS_DISPATCH(h, (k_step<T, S, false><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, (S*)h->state, (const T*)h->origin, (T*)h->last_rpm,
-                                                                   (const S*)action, (S*)nullptr)));
-  }
+#define MDS_LAUNCH_STEP(HAS_OBS, RK4, DRAG)                                                                          \
+  MDS_DISPATCH(h, (k_step<T, S, HAS_OBS, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, (S*)h->state, (const T*)h->origin, \
+                                                                             (T*)h->last_rpm, (const S*)action, (S*)obs)))
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
+#define MDS_STEP_OBS(HAS_OBS)                           \
+  do {                                                  \
+    if (rk4 && drag) MDS_LAUNCH_STEP(HAS_OBS, true, true);   \
+    else if (rk4) MDS_LAUNCH_STEP(HAS_OBS, true, false);     \
+    else if (drag) MDS_LAUNCH_STEP(HAS_OBS, false, true);    \
+    else MDS_LAUNCH_STEP(HAS_OBS, false, false);             \
+  } while (0)
+  if (obs) MDS_STEP_OBS(true);
+  else MDS_STEP_OBS(false);
+#undef MDS_STEP_OBS
+#undef MDS_LAUNCH_STEP
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }
@@ -302,15 +324,47 @@ int mds_set_geometric_gains(mds_handle* h, const mds_geometric_gains* g) {
 }
 
 static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, hipStream_t st) {
-  const dim3 grid = grid_for(h->n, kBlock);
-#define MDS_LAUNCH_GEO(HAS_OBS, HAS_ACT)                                                                            \
-  MDS_DISPATCH(h, (k_step_geometric<T, S, HAS_OBS, HAS_ACT><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t, (S*)h->state, \
-                                                                                     (const T*)h->lem, (T*)h->last_rpm, \
-                                                                                     (S*)obs, (S*)act)))
+  const unsigned nbatch = (unsigned)((h->n + kBlock - 1) / kBlock);
+#define MDS_LAUNCH_GEO2(HAS_OBS, HAS_ACT, RK4, DRAG)                                                                           \
+  MDS_DISPATCH(h, (k_step_geometric<T, S, HAS_OBS, HAS_ACT, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t, (S*)h->state, \
+                                                                                                (const T*)h->lem, (T*)h->last_rpm, \
+                                                                                                (S*)obs, (S*)act)))
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
+  if (h->cfg.dtype == MDS_F32 && !rk4 && h->geo_use_dma) {   // fp32 / Euler hot path: LDS-DMA staged persistent kernel
+    const Consts<float>& C = h->cf;
+    // persistent grid: at most geo_blocks_per_cu workgroups per CU, each striding over batches
+    const unsigned cap = (unsigned)(h->num_cus * h->geo_blocks_per_cu);
+    const dim3 grid(nbatch < cap ? nbatch : cap);
+#define MDS_LAUNCH_DMA(HAS_OBS, HAS_ACT, DRAG)                                                                         \
+  k_step_geometric_f32_dma<HAS_OBS, HAS_ACT, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t, (float*)h->state,        \
+                                                                            (const float*)h->lem, (float*)h->last_rpm, \
+                                                                            (float*)obs, (float*)act)
+#define MDS_LAUNCH_DMA2(HAS_OBS, HAS_ACT)            \
+  do {                                               \
+    if (drag) MDS_LAUNCH_DMA(HAS_OBS, HAS_ACT, true); \
+    else MDS_LAUNCH_DMA(HAS_OBS, HAS_ACT, false);     \
+  } while (0)
+    if (obs && act) MDS_LAUNCH_DMA2(true, true);
+    else if (obs) MDS_LAUNCH_DMA2(true, false);
+    else if (act) MDS_LAUNCH_DMA2(false, true);
+    else MDS_LAUNCH_DMA2(false, false);
+#undef MDS_LAUNCH_DMA2
+#undef MDS_LAUNCH_DMA
+    return MDS_OK;
+  }
+  const dim3 grid(nbatch);
+#define MDS_LAUNCH_GEO(HAS_OBS, HAS_ACT)                         \
+  do {                                                           \
+    if (rk4 && drag) MDS_LAUNCH_GEO2(HAS_OBS, HAS_ACT, true, true);   \
+    else if (rk4) MDS_LAUNCH_GEO2(HAS_OBS, HAS_ACT, true, false);     \
+    else if (drag) MDS_LAUNCH_GEO2(HAS_OBS, HAS_ACT, false, true);    \
+    else MDS_LAUNCH_GEO2(HAS_OBS, HAS_ACT, false, false);             \
+  } while (0)
   if (obs && act) MDS_LAUNCH_GEO(true, true);
   else if (obs) MDS_LAUNCH_GEO(true, false);
   else if (act) MDS_LAUNCH_GEO(false, true);
   else MDS_LAUNCH_GEO(false, false);
+#undef MDS_LAUNCH_GEO2
 #undef MDS_LAUNCH_GEO
   return MDS_OK;
 }

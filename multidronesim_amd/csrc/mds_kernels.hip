@@ -21,6 +21,14 @@ typedef _Float16 half_t;
 
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
+// minimum waves per SIMD requested from the register allocator for the two hot kernels
+// (2nd __launch_bounds__ argument; tuned on MI355X, see DESIGN.md "Occupancy")
+#ifndef MDS_GEO_MIN_WAVES
+#define MDS_GEO_MIN_WAVES 4
+#endif
+#ifndef MDS_STEP_MIN_WAVES
+#define MDS_STEP_MIN_WAVES 4
+#endif
 
 template <typename S, typename T> __device__ __forceinline__ T ldp(const S* __restrict__ p, size_t i) { return (T)p[i]; }
 template <typename S, typename T> __device__ __forceinline__ void stp(S* __restrict__ p, size_t i, T v) { p[i] = (S)v; }
@@ -82,7 +90,11 @@ __device__ __forceinline__ void write_obs_rows(unsigned char* __restrict__ lds_b
       for (int k = 0; k < kRowBytes / 8; ++k) reinterpret_cast<uint2*>(dst)[k] = reinterpret_cast<const uint2*>(row)[k];
     }
   }
-  __syncthreads();
+  // each wave stages and drains its own LDS slice: the LDS unit executes one wave's
+  // instructions in order, so a wave-scope fence (no s_barrier) orders write -> read
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int wave_base = i - lane;                                // first drone of this wave
   const int rows = min(kWave, n - wave_base);                    // <= 0 for fully invalid waves
   if (rows > 0) {
@@ -98,13 +110,16 @@ __device__ __forceinline__ void write_obs_rows(unsigned char* __restrict__ lds_b
       }
     }
   }
+  // the slice is reused by the wave's next batch (persistent kernels): reads before the next writes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 }
 
 // ------------------------------------------------------------------------------------
 // [UPSTREAM] BaseAviary.step for every drone (a1-a4)
 // ------------------------------------------------------------------------------------
-template <typename T, typename S, bool HAS_OBS>
-__global__ __launch_bounds__(kBlock) void k_step(const Consts<T> c, const int n, const size_t ld, S* __restrict__ state,
+template <typename T, typename S, bool HAS_OBS, bool RK4, bool DRAG>
+__global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && !RK4) ? MDS_STEP_MIN_WAVES : 1) void k_step(const Consts<T> c, const int n, const size_t ld, S* __restrict__ state,
                                                  const T* __restrict__ origin, T* __restrict__ last_rpm,
                                                  const S* __restrict__ action, S* __restrict__ obs) {
   __shared__ __align__(16) unsigned char lds[HAS_OBS ? (kBlock * kObsDim * sizeof(S)) : 16];
@@ -116,11 +131,11 @@ __global__ __launch_bounds__(kBlock) void k_step(const Consts<T> c, const int n,
     load_state<S, T>(state, ld, i, s);
     T act[4], prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4];
     load4<S, T>(action + (size_t)i * 4, act);
-    if (c.use_drag)
+    if (DRAG)
       for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
-    aviary_step(c, s, act, prev, clipped);
+    aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
     store_state<S, T>(state, ld, i, s);
-    if (c.use_drag)
+    if (DRAG)
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
     if (HAS_OBS) {
       const V3<T> org = {origin[i], origin[ld + i], origin[2 * ld + i]};
@@ -133,29 +148,39 @@ __global__ __launch_bounds__(kBlock) void k_step(const Consts<T> c, const int n,
 // ------------------------------------------------------------------------------------
 // fused trajectory + geometric controller + mixer + physics step (a10, a7-a9, a1-a4)
 // ------------------------------------------------------------------------------------
-template <typename T, typename S, bool HAS_OBS, bool HAS_ACT>
-__global__ __launch_bounds__(kBlock) void k_step_geometric(const Consts<T> c, const int n, const size_t ld, const double t,
-                                                           S* __restrict__ state, const T* __restrict__ lem,
-                                                           T* __restrict__ last_rpm, S* __restrict__ obs,
-                                                           S* __restrict__ action_out) {
-  __shared__ __align__(16) unsigned char lds[HAS_OBS ? (kBlock * kObsDim * sizeof(S)) : 16];
-  const int i = blockIdx.x * kBlock + threadIdx.x;
+template <typename T> struct GeoIn {
+  State<T> s;
+  LemniscateParams<T> P;
+};
+template <typename T, typename S>
+__device__ __forceinline__ void load_geo_in(const S* __restrict__ state, const T* __restrict__ lem, size_t ld, size_t i, GeoIn<T>& in) {
+  load_state<S, T>(state, ld, i, in.s);
+  in.P.a = lem[0 * ld + i];
+  in.P.omega = lem[1 * ld + i];
+  in.P.cx = lem[2 * ld + i];
+  in.P.cy = lem[3 * ld + i];
+  in.P.cz = lem[4 * ld + i];
+  in.P.yaw_rate = lem[5 * ld + i];
+  in.P.phase_shift = lem[6 * ld + i];
+}
+
+// One batch row of the fused kernel: controller + physics on registers already loaded.
+template <typename T, typename S, bool HAS_OBS, bool HAS_ACT, bool RK4, bool DRAG>
+__device__ __forceinline__ void geo_process(const Consts<T>& c, const int n, const size_t ld, const double t, const int i,
+                                            GeoIn<T>& in, S* __restrict__ state, T* __restrict__ last_rpm,
+                                            S* __restrict__ obs, S* __restrict__ action_out, unsigned char* lds) {
   const bool valid = i < n;
   T o[kObsDim];
   if (valid) {
-    State<T> s;
-    load_state<S, T>(state, ld, i, s);
-    LemniscateParams<T> P;
-    P.a = lem[0 * ld + i];
-    P.omega = lem[1 * ld + i];
-    P.cx = lem[2 * ld + i];
-    P.cy = lem[3 * ld + i];
-    P.cz = lem[4 * ld + i];
-    P.yaw_rate = lem[5 * ld + i];
-    P.phase_shift = lem[6 * ld + i];
+    State<T>& s = in.s;
+    const LemniscateParams<T>& P = in.P;
     T prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4], act[4];
-    if (c.use_drag)
+    if (DRAG)
       for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
+#if defined(MDS_TUNE_NOCOMPUTE)   // timing-only build: memory traffic of the kernel without its arithmetic
+    for (int k = 0; k < 4; ++k) act[k] = clipped[k] = P.a + P.omega + P.yaw_rate + P.phase_shift + T(k);
+    s.p.x += T(1);
+#else
     {
       const Desired<T> des = lemniscate_local(P, t);
       const M3<T> R = quat_to_rot(s.q);
@@ -164,14 +189,120 @@ __global__ __launch_bounds__(kBlock) void k_step_geometric(const Consts<T> c, co
       geometric_control<T>(c, s.p - des.p, R, s.v, ang_v, des, u, nullptr);
       input_to_action(c, u, act);
     }
-    aviary_step(c, s, act, prev, clipped);
-    store_state<S, T>(state, ld, i, s);
-    if (c.use_drag)
+    aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
+#endif
+    if (DRAG)
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
     if (HAS_ACT) store4<S, T>(action_out + (size_t)i * 4, act);
+#if defined(MDS_TUNE_NOCOMPUTE)
+    if (HAS_OBS) {
+      o[0] = s.p.x + P.cx; o[1] = s.p.y + P.cy; o[2] = s.p.z + P.cz; o[3] = s.q[0]; o[4] = s.q[1]; o[5] = s.q[2]; o[6] = s.q[3];
+      o[7] = s.q[0]; o[8] = s.q[1]; o[9] = s.q[2]; o[10] = s.v.x; o[11] = s.v.y; o[12] = s.v.z; o[13] = s.w.x; o[14] = s.w.y; o[15] = s.w.z;
+      for (int k = 0; k < 4; ++k) o[16 + k] = clipped[k];
+    }
+#else
     if (HAS_OBS) pack_obs(s, V3<T>{P.cx, P.cy, P.cz}, clipped, o);
+#endif
   }
+  // observation rows go out first (their LDS round trip must not sit behind the state stores)
   if (HAS_OBS) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
+  if (valid) store_state<S, T>(state, ld, i, in.s);
+}
+
+// Generic form (f64 verification dtype, fp16 storage, RK4): one batch of 256 drones per
+// workgroup, inputs loaded straight into registers.  The fp32/Euler hot path uses
+// k_step_geometric_f32_dma below.
+#ifndef MDS_GEOSIMPLE_MIN_WAVES
+#define MDS_GEOSIMPLE_MIN_WAVES 1
+#endif
+template <typename T, typename S, bool HAS_OBS, bool HAS_ACT, bool RK4, bool DRAG>
+__global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && !RK4) ? MDS_GEOSIMPLE_MIN_WAVES : 1) void k_step_geometric(const Consts<T> c, const int n, const size_t ld, const double t,
+                                                           S* __restrict__ state, const T* __restrict__ lem,
+                                                           T* __restrict__ last_rpm, S* __restrict__ obs,
+                                                           S* __restrict__ action_out) {
+  __shared__ __align__(16) unsigned char lds[HAS_OBS ? (kBlock * kObsDim * sizeof(S)) : 16];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  GeoIn<T> in;
+  if (i < n) load_geo_in<T, S>(state, lem, ld, i, in);
+  geo_process<T, S, HAS_OBS, HAS_ACT, RK4, DRAG>(c, n, ld, t, i, in, state, last_rpm, obs, action_out, lds);
+}
+
+// ------------------------------------------------------------------------------------
+// fp32 hot path of the fused step: persistent waves + LDS-DMA input staging.
+//
+// Every wave owns a 5 KiB LDS slice holding the 20 input words (13 state + 7 trajectory) of
+// its 64 drones, one 256-byte row per SoA plane, filled by `global_load_lds_dword` (the load
+// writes LDS directly: no destination VGPRs are held while it is in flight).  Per batch:
+//   wait for the slice -> 20 ds_read_b32 into registers -> start the DMA of the wave's NEXT
+//   batch into the same slice -> ~1.1 k VALU instructions of controller + physics ->
+//   13 coalesced state stores + the observation rows through a second LDS slice.
+// so the next batch's 5 KiB per wave stream in under the arithmetic.  The grid is sized to
+// the chip (blocks_per_cu x CUs); workgroups stride over batches; waves never s_barrier.
+// The compiler does not track LDS-DMA completion: the s_waitcnt below are explicit.
+// ------------------------------------------------------------------------------------
+constexpr int kGeoPlanes = 20;
+
+__device__ __forceinline__ void geo_dma_issue(const float* __restrict__ state, const float* __restrict__ lem, const size_t ld,
+                                              const size_t i, float (*slice)[kWave]) {
+#pragma unroll
+  for (int p = 0; p < 13; ++p) __builtin_amdgcn_global_load_lds(state + p * ld + i, &slice[p][0], 4, 0, 0);
+#pragma unroll
+  for (int p = 0; p < 7; ++p) __builtin_amdgcn_global_load_lds(lem + p * ld + i, &slice[13 + p][0], 4, 0, 0);
+}
+
+template <bool HAS_OBS, bool HAS_ACT, bool DRAG>
+__global__ __launch_bounds__(kBlock, MDS_GEO_MIN_WAVES) void k_step_geometric_f32_dma(
+    const Consts<float> c, const int n, const size_t ld, const double t, float* __restrict__ state,
+    const float* __restrict__ lem, float* __restrict__ last_rpm, float* __restrict__ obs, float* __restrict__ action_out) {
+  __shared__ __align__(16) float in_buf[kBlock / kWave][kGeoPlanes][kWave];
+  __shared__ __align__(16) unsigned char obs_buf[HAS_OBS ? (kBlock * kObsDim * sizeof(float)) : 16];
+  const int nbatch = (n + kBlock - 1) / kBlock;
+  int batch = blockIdx.x;
+  if (batch >= nbatch) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  float(*slice)[kWave] = in_buf[wave];
+  // LDS byte address of this lane's column of the slice (low 32 bits of the flat LDS address)
+  const unsigned slice_addr = (unsigned)(size_t)&slice[0][lane];
+  geo_dma_issue(state, lem, ld, (size_t)batch * kBlock + threadIdx.x, slice);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // first batch: nothing younger than its DMA rows yet
+  while (true) {
+    const int i = batch * kBlock + threadIdx.x;
+    // The slice is read with explicit ds_read_b32 (the compiler would put a full vmcnt(0)
+    // in front of any LDS read it can see while LDS-DMA is pending); the wait for them is
+    // explicit too and carries the 20 registers so that no use can be scheduled above it.
+    float r[kGeoPlanes];
+#pragma unroll
+    for (int p = 0; p < kGeoPlanes; ++p) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r[p]) : "v"(slice_addr), "n"(p * kWave * 4));
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]),
+                   "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]), "+v"(r[16]), "+v"(r[17]), "+v"(r[18]),
+                   "+v"(r[19])
+                 :
+                 : "memory");                           // slice fully read before the next DMA may overwrite it
+    GeoIn<float> in;
+    in.s.p = {r[0], r[1], r[2]};
+    in.s.q[0] = r[3]; in.s.q[1] = r[4]; in.s.q[2] = r[5]; in.s.q[3] = r[6];
+    in.s.v = {r[7], r[8], r[9]};
+    in.s.w = {r[10], r[11], r[12]};
+    in.P = {r[13], r[14], r[15], r[16], r[17], r[18], r[19]};
+    const int next = batch + gridDim.x;
+    if (next < nbatch) geo_dma_issue(state, lem, ld, (size_t)next * kBlock + threadIdx.x, slice);
+    geo_process<float, float, HAS_OBS, HAS_ACT, false, DRAG>(c, n, ld, t, i, in, state, last_rpm, obs, action_out, obs_buf);
+    if (next >= nbatch) break;
+    batch = next;
+    // The next batch's 20 DMA rows must have landed.  vmcnt retires in issue order and the only
+    // vector-memory instructions issued after them are this batch's stores (13 state dwords +
+    // 5 obs dwordx4 [+1 action]): waiting for "all but those" leaves the stores in flight under
+    // the next batch's arithmetic.  A wave reaches this point only after a FULL batch (the one
+    // partial batch is the last), so every one of those stores was issued.
+    // tests/test_isa_contract.py checks the counts against the generated ISA.
+    if (DRAG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (HAS_OBS && HAS_ACT) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+    else if (HAS_OBS) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if (HAS_ACT) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+  }
 }
 
 // [UPSTREAM] _computeObs from the current state

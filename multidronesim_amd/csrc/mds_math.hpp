@@ -28,14 +28,48 @@ namespace mds {
 // ------------------------------------------------------------------------------------
 // scalar helpers
 // ------------------------------------------------------------------------------------
+// fp32 reciprocal / square root / reciprocal square root: on the device the 1-ulp hardware
+// instructions (v_rcp_f32, v_sqrt_f32, v_rsq_f32) -- the IEEE-exact expansions hipcc emits for
+// `/` and sqrtf cost 12 / 18 VALU ops each and the fused kernel needs ~30 of them per drone.
+// All operands here are far from the denormal range.  double keeps exact IEEE operations.
+#if defined(__HIP_DEVICE_COMPILE__)
+MDS_HD float m_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+MDS_HD float m_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+MDS_HD float m_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+#else
+MDS_HD float m_rcp(float x) { return 1.0f / x; }
 MDS_HD float m_sqrt(float x) { return sqrtf(x); }
+MDS_HD float m_rsqrt(float x) { return 1.0f / sqrtf(x); }
+#endif
+MDS_HD double m_rcp(double x) { return 1.0 / x; }
 MDS_HD double m_sqrt(double x) { return sqrt(x); }
+MDS_HD double m_rsqrt(double x) { return 1.0 / sqrt(x); }
 MDS_HD float m_fma(float a, float b, float c) { return fmaf(a, b, c); }
 MDS_HD double m_fma(double a, double b, double c) { return fma(a, b, c); }
 MDS_HD float m_abs(float x) { return fabsf(x); }
 MDS_HD double m_abs(double x) { return fabs(x); }
-MDS_HD float m_atan2(float y, float x) { return atan2f(y, x); }
 MDS_HD double m_atan2(double y, double x) { return atan2(y, x); }
+// fp32 atan2: octant reduction to a = min/max in [0,1], one near-minimax odd polynomial of
+// degree 17 (max error 1e-7 rad incl. fp32 evaluation), ~25 VALU ops vs ocml's ~45.
+MDS_HD float m_atan2(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float a = mx > 0.0f ? mn * m_rcp(mx) : 0.0f;
+  const float z = a * a;
+  float p = 2.4567161705e-03f;
+  p = fmaf(p, z, -1.4401325081e-02f);
+  p = fmaf(p, z, 3.9781171302e-02f);
+  p = fmaf(p, z, -7.2348530072e-02f);
+  p = fmaf(p, z, 1.0498944039e-01f);
+  p = fmaf(p, z, -1.4161228666e-01f);
+  p = fmaf(p, z, 1.9985906696e-01f);
+  p = fmaf(p, z, -3.3332597024e-01f);
+  p = fmaf(p, z, 9.9999988638e-01f);
+  float r = p * a;
+  r = ay > ax ? 1.57079632679489661923f - r : r;
+  r = x < 0.0f ? 3.14159265358979323846f - r : r;
+  return copysignf(r, y);
+}
 MDS_HD float m_asin(float x) { return asinf(x); }
 MDS_HD double m_asin(double x) { return asin(x); }
 template <typename T> MDS_HD T m_min(T a, T b) { return a < b ? a : b; }
@@ -146,7 +180,7 @@ template <typename T> struct State {
 template <typename T> MDS_HD M3<T> quat_to_rot(const T q[4]) {
   const T x = q[0], y = q[1], z = q[2], w = q[3];
   const T d = m_fma(x, x, m_fma(y, y, m_fma(z, z, w * w)));
-  const T s = T(2) / d;
+  const T s = T(2) * m_rcp(d);
   const T xs = x * s, ys = y * s, zs = z * s;
   const T wx = w * xs, wy = w * ys, wz = w * zs;
   const T xx = x * xs, xy = x * ys, xz = x * zs;
@@ -162,6 +196,16 @@ template <typename T> MDS_HD M3<T> quat_to_rot(const T q[4]) {
   R.m[7] = yz + wx;
   R.m[8] = T(1) - (xx + yy);
   return R;
+}
+
+// R(q) v for a (near-)unit quaternion without forming R: v + 2 q_w (q_v x v) + 2 q_v x (q_v x v),
+// scaled by 1/|q|^2 like quat_to_rot.
+template <typename T> MDS_HD V3<T> quat_rotate(const T q[4], V3<T> v) {
+  const V3<T> qv = {q[0], q[1], q[2]};
+  const T s = T(2) * m_rcp(m_fma(q[0], q[0], m_fma(q[1], q[1], m_fma(q[2], q[2], q[3] * q[3]))));
+  const V3<T> t = s * cross(qv, v);
+  const V3<T> u = cross(qv, t);
+  return {m_fma(q[3], t.x, v.x) + u.x, m_fma(q[3], t.y, v.y) + u.y, m_fma(q[3], t.z, v.z) + u.z};
 }
 
 // [UPSTREAM] p.getQuaternionFromEuler (btQuaternion::setEulerZYX)
@@ -217,15 +261,15 @@ template <typename T> MDS_HD void rotor_wrench(const Consts<T>& c, const T rpm[4
 
 // linear + angular acceleration of the rigid body (shared by Euler and RK4).
 // force_world = R [0,0,T] - [0,0,MG] with T = MG + excess:  f_z = (R33 - 1) T + excess.
-template <typename T>
+template <typename T, bool DRAG>
 MDS_HD void body_accel(const Consts<T>& c, const T q[4], V3<T> vel, V3<T> w, T thrust_excess, V3<T> tau, const T drag_s,
                        V3<T>* acc, V3<T>* wdot) {
   const T x = q[0], y = q[1], z = q[2], ww = q[3];
-  const T s = T(2) / m_fma(x, x, m_fma(y, y, m_fma(z, z, ww * ww)));
+  const T s = T(2) * m_rcp(m_fma(x, x, m_fma(y, y, m_fma(z, z, ww * ww))));
   const T thrust = c.gravity + thrust_excess;
   const T r02 = s * m_fma(x, z, ww * y), r12 = s * m_fma(y, z, -(ww * x)), r22m1 = -s * m_fma(x, x, y * y);
   V3<T> f = {r02 * thrust, r12 * thrust, m_fma(r22m1, thrust, thrust_excess)};
-  if (c.use_drag) {  // [UPSTREAM] _drag: world force -c (.) sum(2 pi rpm_prev/60) (.) v_world
+  if (DRAG) {  // [UPSTREAM] _drag: world force -c (.) sum(2 pi rpm_prev/60) (.) v_world
     f.x = m_fma(-c.drag[0] * drag_s, vel.x, f.x);
     f.y = m_fma(-c.drag[1] * drag_s, vel.y, f.y);
     f.z = m_fma(-c.drag[2] * drag_s, vel.z, f.z);
@@ -239,18 +283,20 @@ MDS_HD void body_accel(const Consts<T>& c, const T q[4], V3<T> vel, V3<T> w, T t
 // [UPSTREAM] _integrateQ (exact exponential for a constant body rate); identity for
 // |omega| <= 1e-8 (np.isclose default atol).  Re-normalised: Bullet stores unit quats.
 template <typename T> MDS_HD void integrate_q(T q[4], V3<T> w, T dt) {
-  const T wn = norm(w);
-  if (wn <= T(1e-8)) return;
+  const T w2 = dot(w, w);
+  if (w2 <= T(1e-16)) return;                 // |omega| <= 1e-8
+  const T inv_wn = m_rsqrt(w2);
+  const T wn = w2 * inv_wn;
   T st, ct;
   m_sincos(wn * dt * T(0.5), &st, &ct);
-  const T k = st / wn;
+  const T k = st * inv_wn;
   const T x = q[0], y = q[1], z = q[2], ww = q[3];
   const T p = w.x, qq = w.y, r = w.z;
   T nx = m_fma(ct, x, k * (r * y - qq * z + p * ww));
   T ny = m_fma(ct, y, k * (-r * x + p * z + qq * ww));
   T nz = m_fma(ct, z, k * (qq * x - p * y + r * ww));
   T nw = m_fma(ct, ww, k * (-p * x - qq * y - r * z));
-  const T inv = T(1) / m_sqrt(m_fma(nx, nx, m_fma(ny, ny, m_fma(nz, nz, nw * nw))));
+  const T inv = m_rsqrt(m_fma(nx, nx, m_fma(ny, ny, m_fma(nz, nz, nw * nw))));
   q[0] = nx * inv;
   q[1] = ny * inv;
   q[2] = nz * inv;
@@ -258,11 +304,11 @@ template <typename T> MDS_HD void integrate_q(T q[4], V3<T> w, T dt) {
 }
 
 // [UPSTREAM] _dynamics, Physics.DYN: explicit Euler on (v, omega); p with NEW v, q with NEW omega
-template <typename T> MDS_HD void step_euler(const Consts<T>& c, State<T>& s, const T rpm[4], T drag_s) {
+template <typename T, bool DRAG> MDS_HD void step_euler(const Consts<T>& c, State<T>& s, const T rpm[4], T drag_s) {
   T thrust;
   V3<T> tau, acc, wdot;
   rotor_wrench(c, rpm, &thrust, &tau);
-  body_accel(c, s.q, s.v, s.w, thrust, tau, drag_s, &acc, &wdot);
+  body_accel<T, DRAG>(c, s.q, s.v, s.w, thrust, tau, drag_s, &acc, &wdot);
   s.v = {m_fma(c.dt, acc.x, s.v.x), m_fma(c.dt, acc.y, s.v.y), m_fma(c.dt, acc.z, s.v.z)};
   s.w = {m_fma(c.dt, wdot.x, s.w.x), m_fma(c.dt, wdot.y, s.w.y), m_fma(c.dt, wdot.z, s.w.z)};
   s.p = {m_fma(c.dt, s.v.x, s.p.x), m_fma(c.dt, s.v.y, s.p.y), m_fma(c.dt, s.v.z, s.p.z)};
@@ -275,9 +321,9 @@ template <typename T> struct Deriv {
   T dq[4];
   V3<T> dv, dw;
 };
-template <typename T> MDS_HD Deriv<T> deriv13(const Consts<T>& c, const State<T>& s, T thrust, V3<T> tau, T drag_s) {
+template <typename T, bool DRAG> MDS_HD Deriv<T> deriv13(const Consts<T>& c, const State<T>& s, T thrust, V3<T> tau, T drag_s) {
   Deriv<T> d;
-  body_accel(c, s.q, s.v, s.w, thrust, tau, drag_s, &d.dv, &d.dw);
+  body_accel<T, DRAG>(c, s.q, s.v, s.w, thrust, tau, drag_s, &d.dv, &d.dw);
   d.dp = s.v;
   const T x = s.q[0], y = s.q[1], z = s.q[2], w = s.q[3], p = s.w.x, q = s.w.y, r = s.w.z;
   d.dq[0] = T(0.5) * (r * y - q * z + p * w);
@@ -294,14 +340,14 @@ template <typename T> MDS_HD State<T> axpy13(const State<T>& s, T h, const Deriv
   o.w = s.w + h * d.dw;
   return o;
 }
-template <typename T> MDS_HD void step_rk4(const Consts<T>& c, State<T>& s, const T rpm[4], T drag_s) {
+template <typename T, bool DRAG> MDS_HD void step_rk4(const Consts<T>& c, State<T>& s, const T rpm[4], T drag_s) {
   T thrust;
   V3<T> tau;
   rotor_wrench(c, rpm, &thrust, &tau);
-  const Deriv<T> k1 = deriv13(c, s, thrust, tau, drag_s);
-  const Deriv<T> k2 = deriv13(c, axpy13(s, T(0.5) * c.dt, k1), thrust, tau, drag_s);
-  const Deriv<T> k3 = deriv13(c, axpy13(s, T(0.5) * c.dt, k2), thrust, tau, drag_s);
-  const Deriv<T> k4 = deriv13(c, axpy13(s, c.dt, k3), thrust, tau, drag_s);
+  const Deriv<T> k1 = deriv13<T, DRAG>(c, s, thrust, tau, drag_s);
+  const Deriv<T> k2 = deriv13<T, DRAG>(c, axpy13(s, T(0.5) * c.dt, k1), thrust, tau, drag_s);
+  const Deriv<T> k3 = deriv13<T, DRAG>(c, axpy13(s, T(0.5) * c.dt, k2), thrust, tau, drag_s);
+  const Deriv<T> k4 = deriv13<T, DRAG>(c, axpy13(s, c.dt, k3), thrust, tau, drag_s);
   const T h6 = c.dt / T(6);
   s.p = s.p + h6 * ((k1.dp + k4.dp) + T(2) * (k2.dp + k3.dp));
   s.v = s.v + h6 * ((k1.dv + k4.dv) + T(2) * (k2.dv + k3.dv));
@@ -311,28 +357,30 @@ template <typename T> MDS_HD void step_rk4(const Consts<T>& c, State<T>& s, cons
     s.q[i] = m_fma(h6, (k1.dq[i] + k4.dq[i]) + T(2) * (k2.dq[i] + k3.dq[i]), s.q[i]);
     n2 = m_fma(s.q[i], s.q[i], n2);
   }
-  const T inv = T(1) / m_sqrt(n2);
+  const T inv = m_rsqrt(n2);
   for (int i = 0; i < 4; ++i) s.q[i] *= inv;
 }
 
 // [UPSTREAM] BaseAviary.step inner loop for one drone: clip, substeps, last_clipped_action.
 // rpm_prev: previous control step's clipped action (only read when use_drag).
-template <typename T> MDS_HD void aviary_step(const Consts<T>& c, State<T>& s, const T action[4], T rpm_prev[4], T clipped[4]) {
+// RK4 / DRAG are compile-time so that the Euler/DYN kernels carry no RK4 register pressure.
+template <typename T, bool RK4, bool DRAG>
+MDS_HD void aviary_step(const Consts<T>& c, State<T>& s, const T action[4], T rpm_prev[4], T clipped[4]) {
   for (int i = 0; i < 4; ++i) clipped[i] = m_clamp(action[i], T(0), c.max_rpm);
   for (int k = 0; k < c.substeps; ++k) {
     T drag_s = T(0);
-    if (c.use_drag) drag_s = T(0.10471975511965977462) * ((rpm_prev[0] + rpm_prev[1]) + (rpm_prev[2] + rpm_prev[3]));
-    if (c.rk4) step_rk4(c, s, clipped, drag_s);
-    else step_euler(c, s, clipped, drag_s);
-    for (int i = 0; i < 4; ++i) rpm_prev[i] = clipped[i];
+    if (DRAG) drag_s = T(0.10471975511965977462) * ((rpm_prev[0] + rpm_prev[1]) + (rpm_prev[2] + rpm_prev[3]));
+    if (RK4) step_rk4<T, DRAG>(c, s, clipped, drag_s);
+    else step_euler<T, DRAG>(c, s, clipped, drag_s);
+    if (DRAG)
+      for (int i = 0; i < 4; ++i) rpm_prev[i] = clipped[i];
   }
 }
 
 // [UPSTREAM] _getDroneStateVector: pos3 | quat4 xyzw | rpy3 | vel3 | ang_v3 (world) | last_clipped_action4.
 // ang_v = R(q) w: upstream hands Bullet R(q_before) w, identical because Exp(w dt) w = w.
 template <typename T> MDS_HD void pack_obs(const State<T>& s, V3<T> origin, const T rpm[4], T o[20]) {
-  const M3<T> R = quat_to_rot(s.q);
-  const V3<T> av = mul(R, s.w);
+  const V3<T> av = quat_rotate(s.q, s.w);
   const V3<T> rpy = euler_from_quat(s.q);
   o[0] = s.p.x + origin.x; o[1] = s.p.y + origin.y; o[2] = s.p.z + origin.z;
   o[3] = s.q[0]; o[4] = s.q[1]; o[5] = s.q[2]; o[6] = s.q[3];
@@ -360,7 +408,7 @@ template <typename T> MDS_HD Desired<T> lemniscate_local(const LemniscateParams<
   m_sincos(th, &s, &c);
   const T s2 = s * s, c2 = c * c;
   const T den = T(1) + s2;
-  const T inv = T(1) / den;
+  const T inv = m_rcp(den);
   const T inv2 = inv * inv;
   const T aw = P.a * P.omega;
   d.p = {P.a * s * c * inv, P.a * c * inv, T(0)};
@@ -368,7 +416,7 @@ template <typename T> MDS_HD Desired<T> lemniscate_local(const LemniscateParams<
   // sin 2th, cos 2th, cos 4th by double angle (the reference calls sin/cos on 2th, 4th)
   const T sin2 = T(2) * s * c, cos2 = c2 - s2, cos4 = T(1) - T(2) * sin2 * sin2;
   const T e = cos2 - T(3);
-  const T inv3 = T(1) / (e * e * e);
+  const T inv3 = m_rcp(e * e * e);
   const T aw2 = aw * P.omega;
   d.a = {T(4) * aw2 * sin2 * (T(3) * cos2 + T(7)) * inv3, aw2 * c * (T(44) * cos2 + cos4 - T(21)) * inv3, T(0)};
   const T ph = reduced_phase<T>(t, P.yaw_rate, T(0));
@@ -427,29 +475,29 @@ MDS_HD void geometric_control(const Consts<T>& c, V3<T> p_rel, const M3<T>& R, V
   tw.z += c.g_ctrl;
   const V3<T> fb_m = mulT(R, tw) - hadamard(Kv, ev) - cross(w, RTvd);
   V3<T> f_w = mul(R, c.mass * fb_m);                                    // :75
-  T fn = norm(f_w);
-  if (f_w.z < c.cos_max_tilt * fn) {                                    // tilt > 40 deg  (:79-80)
-    const T xy = m_sqrt(m_fma(f_w.x, f_w.x, f_w.y * f_w.y));
-    const T scale = f_w.z * c.tan_max_tilt / xy;                        // :81-83
+  T f2 = dot(f_w, f_w);
+  T inv_fn = m_rsqrt(f2);
+  if (f_w.z * inv_fn < c.cos_max_tilt) {                                // tilt > 40 deg  (:79-80)
+    const T scale = f_w.z * c.tan_max_tilt * m_rsqrt(m_fma(f_w.x, f_w.x, f_w.y * f_w.y));   // :81-83
     f_w.x *= scale;
     f_w.y *= scale;
-    fn = norm(f_w);
+    f2 = dot(f_w, f_w);
+    inv_fn = m_rsqrt(f2);
   }
   const T fbz = dot(col(R, 2), f_w);                                    // (R^T f_w).z  (:85)
-  const T inv_fn = T(1) / fn;
   T sy, cy;
   m_sincos(des.yaw, &sy, &cy);
   const V3<T> b1c = {cy, sy, T(0)};                                     // :88
   const V3<T> b3d = inv_fn * f_w;
   const V3<T> c1 = cross(b3d, b1c);
-  const T n1 = norm(c1);
-  const V3<T> b2d = (T(1) / n1) * c1;
+  const T inv_n1 = m_rsqrt(dot(c1, c1));
+  const V3<T> b2d = inv_n1 * c1;
   const V3<T> c2 = cross(b2d, b3d);
-  const V3<T> b1d = (T(1) / norm(c2)) * c2;                             // :91
+  const V3<T> b1d = m_rsqrt(dot(c2, c2)) * c2;                          // :91
   const V3<T> b1c_dot = {-sy * des.yaw_rate, cy * des.yaw_rate, T(0)};  // :95
   const V3<T> f_dot = (c.mass * inv_fn) * mul(R, hadamard(Kp, ev));     // :96
   const V3<T> b3d_dot = cross(cross(b3d, f_dot), b3d);                  // :97
-  const V3<T> inner = (T(1) / n1) * (cross(b1c_dot, b3d) + cross(b1c, b3d_dot));  // |b1c x b3d| = |b3d x b1c|
+  const V3<T> inner = inv_n1 * (cross(b1c_dot, b3d) + cross(b1c, b3d_dot));       // |b1c x b3d| = |b3d x b1c|
   const V3<T> b2d_dot = cross(cross(b2d, inner), b2d);                  // :98-99
   const V3<T> b1d_dot = cross(b3d_dot, b2d) + cross(b3d, b2d_dot);      // :100
   // W = R_des @ R_dot_des (no-op transpose, :102); w_des = (W21, W02, W10) (:103)
@@ -479,21 +527,6 @@ MDS_HD void geometric_control(const Consts<T>& c, V3<T> p_rel, const M3<T>& R, V
   u[1] = c.J[0] * (-eR.x - c.kw[0] * ew.x) - wxJw.x;                    // :110-111
   u[2] = c.J[1] * (-eR.y - c.kw[1] * ew.y) - wxJw.y;
   u[3] = c.J[2] * (-eR.z - c.kw[2] * ew.z) - wxJw.z;
-}
-
-// One fused control step of simulations/EnvGeometric.py:434-469 for one drone:
-// trajs[j](t) -> ctrl.compute(obs[j]) -> env.step(action).  State is in the local frame
-// whose origin is the trajectory centre.
-template <typename T>
-MDS_HD void fused_geometric_step(const Consts<T>& c, const LemniscateParams<T>& P, double t, State<T>& s, T rpm_prev[4],
-                                 T clipped[4]) {
-  const Desired<T> des = lemniscate_local(P, t);
-  const M3<T> R = quat_to_rot(s.q);
-  const V3<T> ang_v = mul(R, s.w);  // obs[13:16]
-  T u[4], action[4];
-  geometric_control<T>(c, s.p - des.p, R, s.v, ang_v, des, u, nullptr);
-  input_to_action(c, u, action);
-  aviary_step(c, s, action, rpm_prev, clipped);
 }
 
 // model/dynamics.py:83-106: (state18, u4) -> 12 floats (x_dot = v, "R_dot" = w, v_dot, w_dot)

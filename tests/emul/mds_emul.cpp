@@ -15,6 +15,13 @@ template <typename T> static void load_state(const double* st, State<T>& s, cons
   s.w = {(T)st[10], (T)st[11], (T)st[12]};
 }
 
+template <typename T> static void emul_aviary_step(const Consts<T>& c, State<T>& s, const T act[4], T prev[4], T clipped[4]) {
+  if (c.rk4 && c.use_drag) aviary_step<T, true, true>(c, s, act, prev, clipped);
+  else if (c.rk4) aviary_step<T, true, false>(c, s, act, prev, clipped);
+  else if (c.use_drag) aviary_step<T, false, true>(c, s, act, prev, clipped);
+  else aviary_step<T, false, false>(c, s, act, prev, clipped);
+}
+
 // Persistent emulated handle: state kept in T (like the device SoA), I/O in double.
 template <typename T> struct Emul {
   Consts<T> c;
@@ -69,7 +76,7 @@ template <typename T> static void emul_step(void* h, const double* action, doubl
   for (int i = 0; i < e->n; ++i) {
     T act[4], clipped[4], o[20];
     for (int k = 0; k < 4; ++k) act[k] = (T)action[4 * i + k];
-    aviary_step(e->c, e->s[i], act, e->prev[i], clipped);
+    emul_aviary_step(e->c, e->s[i], act, e->prev[i], clipped);
     if (obs) {
       pack_obs(e->s[i], V3<T>{(T)e->org[i][0], (T)e->org[i][1], (T)e->org[i][2]}, clipped, o);
       for (int k = 0; k < 20; ++k) obs[20 * i + k] = o[k];
@@ -86,7 +93,7 @@ template <typename T> static void emul_step_geo(void* h, double t, double* obs, 
     const V3<T> ang_v = mul(R, s.w);
     geometric_control<T>(e->c, s.p - des.p, R, s.v, ang_v, des, u, nullptr);
     input_to_action(e->c, u, act);
-    aviary_step(e->c, s, act, e->prev[i], clipped);
+    emul_aviary_step(e->c, s, act, e->prev[i], clipped);
     if (act_out)
       for (int k = 0; k < 4; ++k) act_out[4 * i + k] = act[k];
     if (obs) {
