@@ -197,10 +197,19 @@ def main(argv=None):
                    "physics": "DYN (explicit Euler)", "parallelism": f"env-shard x{world}, no collective",
                    "launch": "python" if args.python_loop else "C rollout loop"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "kernel": "k_step_geometric<float,float,true,false>", "kernel_us": kernel_us,
+                     "traffic": None, "kernel": "k_step_geometric<float,float,true,false,false,false>", "kernel_us": kernel_us,
                      "bytes_per_launch": BYTES_PER_DRONE_STEP * n_local},
         "device_ms_per_step_max_rank": dev_ms_max / args.steps, "state_sane": ok,
     }
+    # HBM traffic from the PMC counters cannot be read inside this process; the committed summary of the
+    # separate rocprofv3 --pmc passes (profiles/, same kernel and workload) is reported when it matches.
+    pmc = os.path.join(ROOT, "profiles", "r01b_pmc_traffic_c3.json")
+    if args.workload == "c3" and args.dtype == "float32" and os.path.exists(pmc):
+        try:
+            line["roofline"]["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch"]
+            line["roofline"]["traffic_source"] = "profiles/r01b_pmc_traffic_c3.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
+        except Exception:
+            pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(D, phase, args.cpu_budget)
     elif rank == 0:
