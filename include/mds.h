@@ -166,6 +166,41 @@ int mds_action_to_input(mds_handle* h, const void* rpm_dev /*[n,4]*/, int cap_rp
 int mds_quadrotor_dynamics(int dtype, int count, const void* state_dev, const void* u_dev, double m, const double J[3],
                            double g, void* out_dev, void* stream);
 
+/* ---- ECBF safety filter (cbf/cbf.py, cbf/qptracker.py) ------------------------------------ */
+
+/* DroneCBF.__init__ (cbf/cbf.py:545-580) after its own derivations: Kcbf = place_poles gains
+ * (ascending), umax = [MAX_THRUST | Ymax, omega_max3], Fmin = -M*G, Fmax = MAX_THRUST.
+ * order 2 = LinearizedOmegaModel (xdim 9), order 3 = LinearizedYankOmegaModel (xdim 10). */
+typedef struct mds_cbf_params {
+  int32_t order;     /* 2 or 3 */
+  int32_t n_obs;     /* static sphere obstacles (x_obs_list / obs_r_list), <= 16 */
+  int32_t max_iter;  /* QP iteration cap per env; 0 = default (64 * rows) */
+  int32_t reserved;
+  double Kcbf[3];
+  double umax[4];
+  double safety_radius, zscale;
+  double Fmin, Fmax;
+  double tol;        /* convergence: largest remaining move of a thrust variable; 0 = default */
+} mds_cbf_params;
+
+/* obstacles_host: double [n_obs,4] = centre xyz, radius (NULL when n_obs == 0).  num_drones <= 32. */
+int mds_cbf_configure(mds_handle* h, const mds_cbf_params* p, const double* obstacles_host);
+
+/* rows of G u <= h per env: D(D-1)/2 + 8D (+2D for order 3) + D*n_obs (cbf/cbf.py:337-367) */
+int mds_cbf_num_rows(const mds_handle* h);
+
+/* CBF._build_ineq_const (cbf/cbf.py:308-367) for every env, dense, in the reference's row order:
+ * x_dev, xdes_dev [n, xdim] (linear-model states, xdim = 9 | 10) -> G_dev [E, m, 4D], h_dev [E, m]. */
+int mds_cbf_rows(mds_handle* h, const void* x_dev, const void* xdes_dev, void* G_dev, void* h_dev, void* stream);
+
+/* DroneQPTracker.compute_control (cbf/qptracker.py:22-34) for every env:
+ * obs_dev [n,20], xdes_dev [n,xdim], u_nominal_dev [n,4] (thrust already offset by -M*G,
+ * simulations/CBFTest.py:339) -> u_safe_dev [n,4]; status_dev [E] int32: 0 = QP solved,
+ * 1 = no solution within the cap -> that env's u_safe is u_nominal unchanged
+ * (qptracker.py:30-34).  Order 2 only (order 3 returns MDS_EUNSUPPORTED). */
+int mds_cbf_filter(mds_handle* h, const void* obs_dev, const void* xdes_dev, const void* u_nominal_dev, void* u_safe_dev,
+                   int32_t* status_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,12 @@ class MdsGeometricGains(C.Structure):
                 ("g", C.c_double), ("max_tilt_angle", C.c_double)]
 
 
+class MdsCbfParams(C.Structure):
+    _fields_ = [("order", C.c_int32), ("n_obs", C.c_int32), ("max_iter", C.c_int32), ("reserved", C.c_int32),
+                ("Kcbf", C.c_double * 3), ("umax", C.c_double * 4), ("safety_radius", C.c_double), ("zscale", C.c_double),
+                ("Fmin", C.c_double), ("Fmax", C.c_double), ("tol", C.c_double)]
+
+
 class MdsError(RuntimeError):
     def __init__(self, status, where, detail):
         super().__init__(f"{where}: {detail} (mds_status {status})")
@@ -65,6 +71,10 @@ PROTOTYPES = {
     "mds_input_to_action": (C.c_int, [_P, _P, _P, _P]),
     "mds_action_to_input": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "mds_quadrotor_dynamics": (C.c_int, [C.c_int, C.c_int, _P, _P, C.c_double, _PD, C.c_double, _P, _P]),
+    "mds_cbf_configure": (C.c_int, [_P, C.POINTER(MdsCbfParams), _PD]),
+    "mds_cbf_num_rows": (C.c_int, [_P]),
+    "mds_cbf_rows": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "mds_cbf_filter": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

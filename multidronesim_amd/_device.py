@@ -26,4 +26,7 @@ def stream_ptr(device: torch.device) -> int:
 def to_device(x, device, dtype) -> torch.Tensor:
     if isinstance(x, torch.Tensor):
         return x.to(device=device, dtype=dtype).contiguous()
-    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(device)
+    a = np.asarray(x)
+    if not (a.flags.c_contiguous and a.flags.writeable):
+        a = np.array(a, order="C")          # broadcast views etc.: torch wants a writable buffer
+    return torch.as_tensor(a, dtype=dtype).to(device)

@@ -11,6 +11,7 @@
 #include "../../include/mds.h"
 #include "mds_consts.hpp"
 #include "mds_kernels.hip"
+#include "mds_cbf_kernels.hip"
 
 using namespace mds;
 
@@ -55,6 +56,13 @@ struct mds_handle {
   int geo_use_dma;         // fp32/Euler: MDS_GEO_DMA=1 selects the persistent LDS-DMA staged kernel (default: register-staged)
   Consts<float> cf;
   Consts<double> cd;
+  // ECBF filter
+  bool has_cbf;
+  mds_cbf_params cbf;
+  CbfParams<float> cbf_f;
+  CbfParams<double> cbf_d;
+  int* pair_ij;        // device [D(D-1)/2]
+  void* obstacles;     // device T [n_obs,4]
 };
 
 // dispatch on the handle dtype: F32 -> <float,float>, F64 -> <double,double>, F16 -> <float,half_t>
@@ -70,6 +78,22 @@ struct mds_handle {
   } while (0)
 
 static inline dim3 grid_for(int n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+template <typename T> static void fill_cbf(const mds_handle* h, const mds_cbf_params& p, CbfParams<T>& o) {
+  o.order = p.order;
+  o.n_obs = p.n_obs;
+  o.num_drones = h->cfg.num_drones;
+  for (int k = 0; k < 3; ++k) o.k[k] = (T)p.Kcbf[k];
+  for (int k = 0; k < 4; ++k) o.umax[k] = (T)p.umax[k];
+  o.Ds_pair = (T)(2.0 * p.safety_radius);
+  o.safety_radius = (T)p.safety_radius;
+  o.zscale = (T)p.zscale;
+  o.inv_c4 = (T)(1.0 / (p.zscale * p.zscale * p.zscale * p.zscale));
+  o.inv_m = (T)(1.0 / h->cfg.M);
+  o.g = (T)h->cfg.G;
+  o.Fmin = (T)p.Fmin;
+  o.Fmax = (T)p.Fmax;
+}
 
 extern "C" {
 
@@ -162,6 +186,9 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   const size_t es = elem_size(cfg->dtype), cs = comp_size(cfg->dtype);
   h->state = h->origin = h->last_rpm = h->lem = nullptr;
   h->scratch = nullptr;
+  h->has_cbf = false;
+  h->pair_ij = nullptr;
+  h->obstacles = nullptr;
   hipError_t e = hipMalloc(&h->state, 13 * h->ld * es);
   if (e == hipSuccess) e = hipMalloc(&h->origin, 3 * h->ld * cs);
   if (e == hipSuccess) e = hipMalloc(&h->last_rpm, 4 * h->ld * cs);
@@ -195,6 +222,8 @@ int mds_destroy(mds_handle* h) {
   if (h->last_rpm) (void)hipFree(h->last_rpm);
   if (h->lem) (void)hipFree(h->lem);
   if (h->scratch) (void)hipFree(h->scratch);
+  if (h->pair_ij) (void)hipFree(h->pair_ij);
+  if (h->obstacles) (void)hipFree(h->obstacles);
   delete h;
   return MDS_OK;
 }
@@ -442,6 +471,92 @@ int mds_quadrotor_dynamics(int dtype, int count, const void* state, const void* 
                                                                (float)J[1], (float)J[2], (float)g, (half_t*)out);
   else
     return fail(MDS_EINVAL, "mds_quadrotor_dynamics: dtype");
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_cbf_configure(mds_handle* h, const mds_cbf_params* p, const double* obstacles) {
+  if (!h || !p) return fail(MDS_EINVAL, "mds_cbf_configure: null argument");
+  if (p->order != 2 && p->order != 3) return fail(MDS_EINVAL, "mds_cbf_configure: order must be 2 or 3");
+  if (p->n_obs < 0 || p->n_obs > kCbfMaxObs) return fail(MDS_EINVAL, "mds_cbf_configure: n_obs out of range");
+  if (p->n_obs > 0 && !obstacles) return fail(MDS_EINVAL, "mds_cbf_configure: obstacles_host is NULL");
+  if (h->cfg.num_drones > kCbfMaxD) return fail(MDS_EUNSUPPORTED, "mds_cbf_configure: more than 32 drones per env");
+  if (h->cfg.dtype == MDS_F16) return fail(MDS_EUNSUPPORTED, "mds_cbf_configure: fp16 storage");
+  if (!(p->zscale > 0) || !(p->safety_radius > 0)) return fail(MDS_EINVAL, "mds_cbf_configure: zscale / safety_radius");
+  const int D = h->cfg.num_drones, npairs = D * (D - 1) / 2;
+  if (!h->pair_ij && npairs > 0) {
+    int* host = new (std::nothrow) int[npairs];
+    if (!host) return fail(MDS_ENOMEM, "mds_cbf_configure: host allocation");
+    int r = 0;
+    for (int i = 0; i < D - 1; ++i)
+      for (int j = i + 1; j < D; ++j) host[r++] = i | (j << 8);
+    hipError_t e = hipMalloc((void**)&h->pair_ij, sizeof(int) * npairs);
+    if (e == hipSuccess) e = hipMemcpy(h->pair_ij, host, sizeof(int) * npairs, hipMemcpyHostToDevice);
+    delete[] host;
+    if (e != hipSuccess) return fail_hip(e, "mds_cbf_configure: pair table");
+  }
+  if (!h->obstacles) MDS_HIP(hipMalloc(&h->obstacles, sizeof(double) * 4 * kCbfMaxObs));
+  if (p->n_obs > 0) {
+    if (h->cfg.dtype == MDS_F64) {
+      MDS_HIP(hipMemcpy(h->obstacles, obstacles, sizeof(double) * 4 * p->n_obs, hipMemcpyHostToDevice));
+    } else {
+      float tmp[4 * kCbfMaxObs];
+      for (int k = 0; k < 4 * p->n_obs; ++k) tmp[k] = (float)obstacles[k];
+      MDS_HIP(hipMemcpy(h->obstacles, tmp, sizeof(float) * 4 * p->n_obs, hipMemcpyHostToDevice));
+    }
+  }
+  h->cbf = *p;
+  fill_cbf(h, *p, h->cbf_f);
+  fill_cbf(h, *p, h->cbf_d);
+  h->has_cbf = true;
+  return MDS_OK;
+}
+
+int mds_cbf_num_rows(const mds_handle* h) {
+  if (!h || !h->has_cbf) return fail(MDS_ESTATE, "mds_cbf_num_rows: call mds_cbf_configure first");
+  return cbf_num_rows(h->cfg.num_drones, h->cbf.order, h->cbf.n_obs);
+}
+
+int mds_cbf_rows(mds_handle* h, const void* x, const void* xdes, void* G, void* hv, void* stream) {
+  if (!h || !x || !xdes || !G || !hv) return fail(MDS_EINVAL, "mds_cbf_rows: null argument");
+  if (!h->has_cbf) return fail(MDS_ESTATE, "mds_cbf_rows: call mds_cbf_configure first");
+  hipStream_t st = (hipStream_t)stream;
+  const int E = h->cfg.num_envs;
+  if (h->cfg.dtype == MDS_F64)
+    k_cbf_rows<double, double><<<E, 256, 0, st>>>(h->cbf_d, E, h->pair_ij, (const double*)h->obstacles, (const double*)x,
+                                                  (const double*)xdes, (double*)G, (double*)hv);
+  else
+    k_cbf_rows<float, float><<<E, 256, 0, st>>>(h->cbf_f, E, h->pair_ij, (const float*)h->obstacles, (const float*)x,
+                                                (const float*)xdes, (float*)G, (float*)hv);
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void* unom, void* usafe, int32_t* status,
+                   void* stream) {
+  if (!h || !obs || !xdes || !unom || !usafe || !status) return fail(MDS_EINVAL, "mds_cbf_filter: null argument");
+  if (!h->has_cbf) return fail(MDS_ESTATE, "mds_cbf_filter: call mds_cbf_configure first");
+  if (h->cbf.order != 2) return fail(MDS_EUNSUPPORTED, "mds_cbf_filter: only the order-2 (omega) model is built");
+  hipStream_t st = (hipStream_t)stream;
+  const int E = h->cfg.num_envs, D = h->cfg.num_drones;
+  const int m = D * (D - 1) / 2 + D * h->cbf.n_obs + 2 * D;          // thrust sub-problem rows
+  const int R = (m + 63) / 64;
+  const int max_iter = h->cbf.max_iter > 0 ? h->cbf.max_iter : 64 * m;
+  const dim3 grid((unsigned)((E + 3) / 4));
+#define MDS_CBF_LAUNCH(T, CP, RR, TOL)                                                                                  \
+  k_cbf_filter_o2<T, T, RR><<<grid, 256, 0, st>>>(CP, E, h->pair_ij, (const T*)h->obstacles, (const T*)obs, (const T*)xdes, \
+                                                  (const T*)unom, (T*)usafe, (int*)status, max_iter, (T)((TOL) * (TOL)))
+#define MDS_CBF_DISPATCH(T, CP, TOL)                    \
+  do {                                                  \
+    if (R <= 4) MDS_CBF_LAUNCH(T, CP, 4, TOL);          \
+    else if (R <= 8) MDS_CBF_LAUNCH(T, CP, 8, TOL);     \
+    else MDS_CBF_LAUNCH(T, CP, 17, TOL);                \
+  } while (0)
+  if (R > 17) return fail(MDS_EUNSUPPORTED, "mds_cbf_filter: too many rows per env");
+  if (h->cfg.dtype == MDS_F64) MDS_CBF_DISPATCH(double, h->cbf_d, h->cbf.tol > 0 ? h->cbf.tol : 1e-12);
+  else MDS_CBF_DISPATCH(float, h->cbf_f, h->cbf.tol > 0 ? h->cbf.tol : 1e-6);
+#undef MDS_CBF_DISPATCH
+#undef MDS_CBF_LAUNCH
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }

@@ -1,0 +1,93 @@
+// Exponential-CBF rows of cbf/cbf.py in closed form, templated on the compute type.
+//
+// The reference builds, per pair, dense 2*xdim matrices and a (2*xdim)^3 tensor
+// (cbf/cbf.py:194-283).  For the two hover linearisations it is used with
+// (model/linear_omega.py:46-53, model/linear_yank_omega.py:45-51) the result collapses to
+// 3-vector algebra; tests/golden/cbf_rows_o{2,3}.npz, minted from the
+// reference's own construction, pin this restatement (incl. its quirks: the hard-coded
+// slots 6,7,8 in custom_hdots for order 3, :158-169, and the force-box rows written to the
+// omega_z column, :446-464).
+#pragma once
+#include "mds_math.hpp"
+
+namespace mds {
+
+template <typename T> struct CbfParams {
+  int order;      // 2: state [r,p,y,vx,vy,vz,x,y,z], inputs [F-mg, wx,wy,wz]; 3: [r,p,y,F,vx,vy,vz,x,y,z], [Y,wx,wy,wz]
+  int n_obs;
+  int num_drones;
+  T k[3];         // Kcbf, ascending (cbf/cbf.py:119-124)
+  T umax[4];      // cbf/cbf.py:566-572
+  T Ds_pair;      // 2 * safety_radius (:291)
+  T safety_radius;
+  T zscale, inv_c4;
+  T inv_m, g;     // env.M, env.G (9.8) through the linear models
+  T Fmin, Fmax;   // order 3 force box (:564-565)
+};
+
+// One ECBF row between agent i (state xi, desired xdi) and agent / obstacle j.
+//   h_row = Kcbf . hdots + L_f^r h,   Lg[4] with G[4i:4i+4] = -Lg, G[4j:4j+4] = +Lg.
+// e = pos_i - pos_j from the ACTUAL states; d = (xi - xdi) - (xj - xdj) (error states);
+// for an obstacle the caller passes dj = 0 (cbf/cbf.py:380-392).
+template <typename T>
+MDS_HD void cbf_pair_row(const CbfParams<T>& P, const T* xi, const T* xdi, const T* xj, const T* xdj, bool obstacle, T Ds,
+                         T* h_row, T Lg[4]) {
+  const int xd = P.order == 2 ? 9 : 10;
+  const T ex = xi[xd - 3] - xj[xd - 3], ey = xi[xd - 2] - xj[xd - 2], ez = xi[xd - 1] - xj[xd - 1];
+  T d[10];
+  for (int k = 0; k < xd; ++k) d[k] = (xi[k] - xdi[k]) - (obstacle ? T(0) : (xj[k] - xdj[k]));
+  const T s = m_fma(ex, ex, ey * ey);
+  const T ezc = ez / P.zscale;
+  const T ezc2 = ezc * ezc;
+  const T Ds2 = Ds * Ds;
+  const T h = m_fma(s, s, m_fma(ezc2, ezc2, -(Ds2 * Ds2)));
+  const T gx = T(4) * ex * s, gy = T(4) * ey * s, gz = T(4) * ez * ez * ez * P.inv_c4;
+  const T Hxx = T(12) * ex * ex + T(4) * ey * ey, Hxy = T(8) * ex * ey, Hyy = T(4) * ex * ex + T(12) * ey * ey,
+          Hzz = T(12) * ez * ez * P.inv_c4;
+  if (P.order == 2) {
+    const T dr = d[0], dp = d[1], dvx = d[3], dvy = d[4], dvz = d[5];
+    const T dax = P.g * dp, day = -P.g * dr;
+    const T hdot = m_fma(gx, dvx, m_fma(gy, dvy, gz * dvz));
+    const T quad = Hxx * dvx * dvx + T(2) * Hxy * dvx * dvy + Hyy * dvy * dvy + Hzz * dvz * dvz;
+    const T Lf2 = m_fma(gx, dax, gy * day) + quad;
+    *h_row = m_fma(P.k[0], h, m_fma(P.k[1], hdot, Lf2));
+    Lg[0] = gz * P.inv_m;
+    Lg[1] = T(0);
+    Lg[2] = T(0);
+    Lg[3] = T(0);
+  } else {
+    const T dr = d[0], dp = d[1], dF = d[3], dvx = d[4], dvy = d[5], dvz = d[6];
+    const T dax = P.g * dp, day = -P.g * dr, daz = dF * P.inv_m;
+    const T hdot = m_fma(gx, dvx, m_fma(gy, dvy, gz * dvz));
+    // custom_hdots i == 2 with slots 6,7,8 = (vz, x, y) of the 10-state (quirk kept)
+    const T w0 = dF * P.inv_m, w1 = dvx, w2 = dvy;
+    const T hddot_ref = P.g * (gy * dp - gz * dr) + (Hxx * w0 * w0 + T(2) * Hxy * w0 * w1 + Hyy * w1 * w1 + Hzz * w2 * w2);
+    const T Hdv_da = Hxx * dvx * dax + Hxy * (dvx * day + dvy * dax) + Hyy * dvy * day + Hzz * dvz * daz;
+    const T T3 = T(24) * ex * dvx * dvx * dvx + T(24) * ey * dvx * dvx * dvy + T(24) * ex * dvx * dvy * dvy +
+                 T(24) * ey * dvy * dvy * dvy + (T(24) * ez * P.inv_c4) * dvz * dvz * dvz;
+    const T Lf3 = T(3) * Hdv_da + T3;
+    *h_row = P.k[0] * h + P.k[1] * hdot + P.k[2] * hddot_ref + Lf3;
+    Lg[0] = gz * P.inv_m;
+    Lg[1] = -P.g * gy;
+    Lg[2] = P.g * gx;
+    Lg[3] = T(0);
+  }
+}
+
+// utils/model_conversions.py:20-58 obs_to_lin_model(obs, dim = 9 | 10) for one drone
+template <typename T> MDS_HD void obs_to_lin(const T* obs20, int order, T kf, T* x) {
+  x[0] = obs20[7]; x[1] = obs20[8]; x[2] = obs20[9];
+  int o = 3;
+  if (order == 3) {  // calc_z_thrust (:137-143)
+    x[3] = kf * (obs20[16] * obs20[16] + obs20[17] * obs20[17] + obs20[18] * obs20[18] + obs20[19] * obs20[19]);
+    o = 4;
+  }
+  x[o] = obs20[10]; x[o + 1] = obs20[11]; x[o + 2] = obs20[12];
+  x[o + 3] = obs20[0]; x[o + 4] = obs20[1]; x[o + 5] = obs20[2];
+}
+
+// row bookkeeping of CBF._build_ineq_const (cbf/cbf.py:308-367)
+MDS_HD int cbf_num_pairs(int D) { return D * (D - 1) / 2; }
+MDS_HD int cbf_num_rows(int D, int order, int n_obs) { return cbf_num_pairs(D) + 8 * D + (order == 3 ? 2 * D : 0) + D * n_obs; }
+
+}  // namespace mds
