@@ -174,7 +174,7 @@ int mds_quadrotor_dynamics(int dtype, int count, const void* state_dev, const vo
 typedef struct mds_cbf_params {
   int32_t order;     /* 2 or 3 */
   int32_t n_obs;     /* static sphere obstacles (x_obs_list / obs_r_list), <= 16 */
-  int32_t max_iter;  /* QP iteration cap per env; 0 = default (64 * rows) */
+  int32_t max_iter;  /* QP iteration cap per env; 0 = default */
   int32_t reserved;
   double Kcbf[3];
   double umax[4];

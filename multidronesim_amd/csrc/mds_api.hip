@@ -522,12 +522,16 @@ int mds_cbf_rows(mds_handle* h, const void* x, const void* xdes, void* G, void* 
   if (!h->has_cbf) return fail(MDS_ESTATE, "mds_cbf_rows: call mds_cbf_configure first");
   hipStream_t st = (hipStream_t)stream;
   const int E = h->cfg.num_envs;
-  if (h->cfg.dtype == MDS_F64)
-    k_cbf_rows<double, double><<<E, 256, 0, st>>>(h->cbf_d, E, h->pair_ij, (const double*)h->obstacles, (const double*)x,
-                                                  (const double*)xdes, (double*)G, (double*)hv);
-  else
-    k_cbf_rows<float, float><<<E, 256, 0, st>>>(h->cbf_f, E, h->pair_ij, (const float*)h->obstacles, (const float*)x,
-                                                (const float*)xdes, (float*)G, (float*)hv);
+#define MDS_ROWS(T, CP, ORD)                                                                                            \
+  k_cbf_rows<T, T, ORD><<<E, 256, 0, st>>>(CP, E, h->pair_ij, (const T*)h->obstacles, (const T*)x, (const T*)xdes, (T*)G, (T*)hv)
+  if (h->cfg.dtype == MDS_F64) {
+    if (h->cbf.order == 2) MDS_ROWS(double, h->cbf_d, 2);
+    else MDS_ROWS(double, h->cbf_d, 3);
+  } else {
+    if (h->cbf.order == 2) MDS_ROWS(float, h->cbf_f, 2);
+    else MDS_ROWS(float, h->cbf_f, 3);
+  }
+#undef MDS_ROWS
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }
@@ -543,9 +547,19 @@ int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void*
   const int R = (m + 63) / 64;
   const int max_iter = h->cbf.max_iter > 0 ? h->cbf.max_iter : 64 * m;
   const dim3 grid((unsigned)((E + 3) / 4));
-#define MDS_CBF_LAUNCH(T, CP, RR, TOL)                                                                                  \
-  k_cbf_filter_o2<T, T, RR><<<grid, 256, 0, st>>>(CP, E, h->pair_ij, (const T*)h->obstacles, (const T*)obs, (const T*)xdes, \
-                                                  (const T*)unom, (T*)usafe, (int*)status, max_iter, (T)((TOL) * (TOL)))
+  const char* solver = getenv("MDS_CBF_SOLVER");          // "hildreth" selects the coordinate-ascent kernel (A/B)
+  const bool hildreth = solver && solver[0] == 'h';
+#define MDS_CBF_LAUNCH(T, CP, RR, TOL)                                                                                      \
+  do {                                                                                                                      \
+    if (hildreth)                                                                                                           \
+      k_cbf_filter_o2<T, T, RR><<<grid, 256, 0, st>>>(CP, E, h->pair_ij, (const T*)h->obstacles, (const T*)obs,              \
+                                                      (const T*)xdes, (const T*)unom, (T*)usafe, (int*)status, max_iter,    \
+                                                      (T)((TOL) * (TOL)));                                                  \
+    else                                                                                                                    \
+      k_cbf_filter_o2_gi<T, T, RR><<<grid, 256, 0, st>>>(CP, E, h->pair_ij, (const T*)h->obstacles, (const T*)obs,           \
+                                                         (const T*)xdes, (const T*)unom, (T*)usafe, (int*)status, max_iter, \
+                                                         (T)((TOL) * (TOL)));                                               \
+  } while (0)
 #define MDS_CBF_DISPATCH(T, CP, TOL)                    \
   do {                                                  \
     if (R <= 4) MDS_CBF_LAUNCH(T, CP, 4, TOL);          \

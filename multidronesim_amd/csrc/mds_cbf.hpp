@@ -29,12 +29,15 @@ template <typename T> struct CbfParams {
 //   h_row = Kcbf . hdots + L_f^r h,   Lg[4] with G[4i:4i+4] = -Lg, G[4j:4j+4] = +Lg.
 // e = pos_i - pos_j from the ACTUAL states; d = (xi - xdi) - (xj - xdj) (error states);
 // for an obstacle the caller passes dj = 0 (cbf/cbf.py:380-392).
-template <typename T>
+template <typename T, int ORDER>
 MDS_HD void cbf_pair_row(const CbfParams<T>& P, const T* xi, const T* xdi, const T* xj, const T* xdj, bool obstacle, T Ds,
                          T* h_row, T Lg[4]) {
-  const int xd = P.order == 2 ? 9 : 10;
+  constexpr int xd = ORDER == 2 ? 9 : 10;
   const T ex = xi[xd - 3] - xj[xd - 3], ey = xi[xd - 2] - xj[xd - 2], ez = xi[xd - 1] - xj[xd - 1];
-  T d[10];
+  T d[xd];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
   for (int k = 0; k < xd; ++k) d[k] = (xi[k] - xdi[k]) - (obstacle ? T(0) : (xj[k] - xdj[k]));
   const T s = m_fma(ex, ex, ey * ey);
   const T ezc = ez / P.zscale;
@@ -44,7 +47,7 @@ MDS_HD void cbf_pair_row(const CbfParams<T>& P, const T* xi, const T* xdi, const
   const T gx = T(4) * ex * s, gy = T(4) * ey * s, gz = T(4) * ez * ez * ez * P.inv_c4;
   const T Hxx = T(12) * ex * ex + T(4) * ey * ey, Hxy = T(8) * ex * ey, Hyy = T(4) * ex * ex + T(12) * ey * ey,
           Hzz = T(12) * ez * ez * P.inv_c4;
-  if (P.order == 2) {
+  if (ORDER == 2) {
     const T dr = d[0], dp = d[1], dvx = d[3], dvy = d[4], dvz = d[5];
     const T dax = P.g * dp, day = -P.g * dr;
     const T hdot = m_fma(gx, dvx, m_fma(gy, dvy, gz * dvz));
@@ -56,7 +59,8 @@ MDS_HD void cbf_pair_row(const CbfParams<T>& P, const T* xi, const T* xdi, const
     Lg[2] = T(0);
     Lg[3] = T(0);
   } else {
-    const T dr = d[0], dp = d[1], dF = d[3], dvx = d[4], dvy = d[5], dvz = d[6];
+    constexpr int o3 = ORDER == 2 ? 0 : 1;   // keeps the order-3 slots in range when instantiated for order 2
+    const T dr = d[0], dp = d[1], dF = d[3], dvx = d[3 + o3], dvy = d[4 + o3], dvz = d[5 + o3];
     const T dax = P.g * dp, day = -P.g * dr, daz = dF * P.inv_m;
     const T hdot = m_fma(gx, dvx, m_fma(gy, dvy, gz * dvz));
     // custom_hdots i == 2 with slots 6,7,8 = (vz, x, y) of the 10-state (quirk kept)

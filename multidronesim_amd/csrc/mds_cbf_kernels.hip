@@ -18,14 +18,15 @@ struct CbfTables {
 // Dense G, h exactly as CBF._build_ineq_const returns them (parity surface; one workgroup
 // per env).  Row order: pairs | +I(4D) | -I(4D) | [order 3: 2 force rows per agent] | obstacles.
 // ------------------------------------------------------------------------------------
-template <typename T, typename S>
+template <typename T, typename S, int ORDER>
 __global__ __launch_bounds__(256) void k_cbf_rows(const CbfParams<T> P, const int E, const int* __restrict__ pair_ij,
                                                   const T* __restrict__ obstacles, const S* __restrict__ x,
                                                   const S* __restrict__ xdes, S* __restrict__ G, S* __restrict__ h) {
   __shared__ T sx[kCbfMaxD][10], sxd[kCbfMaxD][10];
   const int env = blockIdx.x;
-  const int D = P.num_drones, xd = P.order == 2 ? 9 : 10;
-  const int npairs = cbf_num_pairs(D), m = cbf_num_rows(D, P.order, P.n_obs), ncol = 4 * D;
+  constexpr int xd = ORDER == 2 ? 9 : 10;
+  const int D = P.num_drones;
+  const int npairs = cbf_num_pairs(D), m = cbf_num_rows(D, ORDER, P.n_obs), ncol = 4 * D;
   for (int k = threadIdx.x; k < D * xd; k += blockDim.x) {
     sx[k / xd][k % xd] = (T)x[(size_t)env * D * xd + k];
     sxd[k / xd][k % xd] = (T)xdes[(size_t)env * D * xd + k];
@@ -34,12 +35,12 @@ __global__ __launch_bounds__(256) void k_cbf_rows(const CbfParams<T> P, const in
   S* he = h + (size_t)env * m;
   for (int k = threadIdx.x; k < m * ncol; k += blockDim.x) Ge[k] = (S)0;
   __syncthreads();
-  const int box0 = npairs, force0 = npairs + 8 * D, obs0 = force0 + (P.order == 3 ? 2 * D : 0);
+  const int box0 = npairs, force0 = npairs + 8 * D, obs0 = force0 + (ORDER == 3 ? 2 * D : 0);
   for (int r = threadIdx.x; r < m; r += blockDim.x) {
     T hr, Lg[4];
     if (r < npairs) {
       const int ij = pair_ij[r], i = ij & 255, j = ij >> 8;
-      cbf_pair_row(P, sx[i], sxd[i], sx[j], sxd[j], false, P.Ds_pair, &hr, Lg);
+      cbf_pair_row<T, ORDER>(P, sx[i], sxd[i], sx[j], sxd[j], false, P.Ds_pair, &hr, Lg);
       for (int k = 0; k < 4; ++k) {
         Ge[(size_t)r * ncol + 4 * i + k] = (S)(-Lg[k]);
         Ge[(size_t)r * ncol + 4 * j + k] = (S)Lg[k];
@@ -55,12 +56,13 @@ __global__ __launch_bounds__(256) void k_cbf_rows(const CbfParams<T> P, const in
       he[r] = (S)((q & 1) ? P.k[2] * (sx[i][3] - P.Fmin) : P.k[2] * (P.Fmax - sx[i][3]));
     } else {                                 // custom_build_obstacles_const (:369-398)
       const int q = r - obs0, i = q / P.n_obs, o = q % P.n_obs;
-      T xo[10];
-      for (int k = 0; k < 10; ++k) xo[k] = T(0);
+      T xo[xd];
+#pragma unroll
+      for (int k = 0; k < xd - 3; ++k) xo[k] = T(0);
       xo[xd - 3] = obstacles[4 * o];
       xo[xd - 2] = obstacles[4 * o + 1];
       xo[xd - 1] = obstacles[4 * o + 2];
-      cbf_pair_row(P, sx[i], sxd[i], xo, xo, true, P.safety_radius + obstacles[4 * o + 3], &hr, Lg);
+      cbf_pair_row<T, ORDER>(P, sx[i], sxd[i], xo, xo, true, P.safety_radius + obstacles[4 * o + 3], &hr, Lg);
       for (int k = 0; k < 4; ++k) Ge[(size_t)r * ncol + 4 * i + k] = (S)(-Lg[k]);
       he[r] = (S)hr;
     }
@@ -79,8 +81,11 @@ __global__ __launch_bounds__(256) void k_cbf_rows(const CbfParams<T> P, const in
 // lives in LDS.  Hildreth's dual coordinate ascent with Gauss-Southwell selection: every
 // iteration all lanes evaluate their rows, a wave-wide arg-max picks the row whose multiplier
 // update moves F the most, the owner applies it.  Converges to the unique minimiser when the
-// rows are feasible; otherwise the iteration cap trips and the env falls back to u_hat with
-// status 1 (the reference falls back when cvxopt raises, qptracker.py:30-34).
+// rows are feasible.  Infeasibility is certified by weak duality: every update raises the dual
+// value by score/2, and for a feasible problem the dual never exceeds the primal optimum, which
+// the thrust box bounds by 1/2 sum_i (|F_hat_i| + umax_0)^2 -- once the accumulated dual value
+// passes that bound the rows are infeasible and the env falls back to u_hat with status 1 (the
+// reference falls back when cvxopt raises, qptracker.py:30-34).  The iteration cap is a backstop.
 // ------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ void wave_argmax(T& score, int& row) {
 #pragma unroll
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void k_cbf_filter_o2(const CbfParams<T> P, con
       ii[k] = ij & 255;
       jj[k] = ij >> 8;
       T hr, Lg[4];
-      cbf_pair_row(P, sx[wave][ii[k]], sxd[wave][ii[k]], sx[wave][jj[k]], sxd[wave][jj[k]], false, P.Ds_pair, &hr, Lg);
+      cbf_pair_row<T, 2>(P, sx[wave][ii[k]], sxd[wave][ii[k]], sx[wave][jj[k]], sxd[wave][jj[k]], false, P.Ds_pair, &hr, Lg);
       ci[k] = -Lg[0];
       cj[k] = Lg[0];
       b[k] = hr;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void k_cbf_filter_o2(const CbfParams<T> P, con
       const int q = r - npairs, i = q / P.n_obs, o = q % P.n_obs;
       T xo[9] = {T(0), T(0), T(0), T(0), T(0), T(0), obstacles[4 * o], obstacles[4 * o + 1], obstacles[4 * o + 2]};
       T hr, Lg[4];
-      cbf_pair_row(P, sx[wave][i], sxd[wave][i], xo, xo, true, P.safety_radius + obstacles[4 * o + 3], &hr, Lg);
+      cbf_pair_row<T, 2>(P, sx[wave][i], sxd[wave][i], xo, xo, true, P.safety_radius + obstacles[4 * o + 3], &hr, Lg);
       ii[k] = jj[k] = i;
       ci[k] = -Lg[0];
       b[k] = hr;
@@ -156,6 +161,14 @@ __global__ __launch_bounds__(256) void k_cbf_filter_o2(const CbfParams<T> P, con
   }
   bool converged = false;
   const bool any_bad = __any(bad);
+  // weak-duality bound on the optimum (wave-uniform): sum over drones of (|F_hat| + umax_0)^2
+  T bound = T(0);
+  for (int d = 0; d < D; ++d) {
+    const T w = m_abs(su[wave][d]) + P.umax[0];
+    bound = m_fma(w, w, bound);
+  }
+  bound *= T(1.0001);
+  T dual2 = T(0);                                          // 2 x accumulated dual value
   int it = 0;
   for (; it < max_iter && !any_bad; ++it) {
     T best = T(0), best_dl = T(0);
@@ -178,6 +191,8 @@ __global__ __launch_bounds__(256) void k_cbf_filter_o2(const CbfParams<T> P, con
       converged = true;
       break;
     }
+    dual2 += wbest;
+    if (dual2 > bound) break;                              // certified infeasible
     if (wrow == lane + 64 * best_k && best == wbest) {     // the owner applies its update
 #pragma unroll
       for (int k = 0; k < R; ++k)
@@ -198,6 +213,279 @@ __global__ __launch_bounds__(256) void k_cbf_filter_o2(const CbfParams<T> P, con
     for (int k = 0; k < 4; ++k) u[k] = (T)unom[(base + d) * 4 + k];
     if (converged) {
       u[0] = su[wave][d];
+      for (int k = 1; k < 4; ++k) u[k] = m_clamp(u[k], -P.umax[k], P.umax[k]);
+    }
+    for (int k = 0; k < 4; ++k) usafe[(base + d) * 4 + k] = (S)u[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Exact solver for the same thrust sub-problem: Goldfarb-Idnani dual active set with H = I,
+// one wavefront per env.  The active normals N (n x q, q <= n = drones per env) are kept as a
+// thin QR (Q: n x q orthonormal columns, R: q x q upper triangular) in the wave's LDS slice;
+// adding a row appends a Gram-Schmidt column, dropping one re-triangularises with Givens
+// rotations.  Rows are normalised to unit length so every threshold is a distance.  The number
+// of iterations is of the order of the number of active rows (Hildreth's coordinate ascent
+// needs 10^2..10^4 on crowded scenes); the result is the exact minimiser, the same the oracle's
+// qp_project computes.
+// ------------------------------------------------------------------------------------
+#define MDS_WAVE_SYNC()                                   \
+  do {                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+template <typename T> __device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = m_max(v, __shfl_xor(v, off));
+  return v;
+}
+template <typename T> __device__ __forceinline__ void wave_argmin(T& val, int& idx) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const T ov = __shfl_xor(val, off);
+    const int oi = __shfl_xor(idx, off);
+    const bool take = (ov < val) || (ov == val && oi < idx);
+    val = take ? ov : val;
+    idx = take ? oi : idx;
+  }
+}
+template <typename T, int R> __device__ __forceinline__ T pick(const T (&a)[R], int k) {
+  T v = a[0];
+#pragma unroll
+  for (int q = 1; q < R; ++q) v = (q == k) ? a[q] : v;
+  return v;
+}
+template <typename T> struct GiEps;
+template <> struct GiEps<float> {
+  static constexpr float z = 1e-9f, r = 1e-6f, inf = 3.0e38f;
+};
+template <> struct GiEps<double> {
+  static constexpr double z = 1e-20, r = 1e-12, inf = 1.0e300;
+};
+
+constexpr int kQS = kCbfMaxD + 1;   // padded LDS row stride (conflict-free column walks)
+
+template <typename T, typename S, int R>
+__global__ __launch_bounds__(256) void k_cbf_filter_o2_gi(const CbfParams<T> P, const int E, const int* __restrict__ pair_ij,
+                                                          const T* __restrict__ obstacles, const S* __restrict__ obs,
+                                                          const S* __restrict__ xdes, const S* __restrict__ unom,
+                                                          S* __restrict__ usafe, int* __restrict__ status, const int max_iter,
+                                                          const T tol2) {
+  __shared__ T sx[4][kCbfMaxD][9], sxd[4][kCbfMaxD][9];
+  __shared__ T su_[4][kCbfMaxD], sd_[4][kCbfMaxD], slam_[4][kCbfMaxD];
+  __shared__ T sQ_[4][kCbfMaxD][kQS], sR_[4][kCbfMaxD][kQS];
+  __shared__ int sact_[4][kCbfMaxD];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int env = blockIdx.x * 4 + wave;
+  if (env >= E) return;                                    // wave-uniform
+  T* su = su_[wave];
+  T* sd = sd_[wave];
+  T* slam = slam_[wave];
+  T(*sQ)[kQS] = sQ_[wave];
+  T(*sR)[kQS] = sR_[wave];
+  int* sact = sact_[wave];
+  const int D = P.num_drones, n = D;
+  const size_t base = (size_t)env * D;
+  for (int d = lane; d < D; d += 64) {
+    T o[20];
+    for (int k = 0; k < 20; ++k) o[k] = (T)obs[(base + d) * 20 + k];
+    obs_to_lin<T>(o, 2, T(0), sx[wave][d]);
+    for (int k = 0; k < 9; ++k) sxd[wave][d][k] = (T)xdes[(base + d) * 9 + k];
+    su[d] = (T)unom[(base + d) * 4];
+  }
+  MDS_WAVE_SYNC();
+
+  const int npairs = cbf_num_pairs(D), nobs_rows = D * P.n_obs, m = npairs + nobs_rows + 2 * D;
+  // unit-norm rows: ci u_i + cj u_j <= b
+  T ci[R], cj[R], b[R];
+  int ii[R], jj[R];
+  bool valid[R], act[R];
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int r = lane + 64 * k;
+    ci[k] = cj[k] = b[k] = T(0);
+    ii[k] = jj[k] = 0;
+    valid[k] = false;
+    act[k] = false;
+    if (r < npairs) {
+      const int ij = pair_ij[r];
+      ii[k] = ij & 255;
+      jj[k] = ij >> 8;
+      T hr, Lg[4];
+      cbf_pair_row<T, 2>(P, sx[wave][ii[k]], sxd[wave][ii[k]], sx[wave][jj[k]], sxd[wave][jj[k]], false, P.Ds_pair, &hr, Lg);
+      ci[k] = -Lg[0];
+      cj[k] = Lg[0];
+      b[k] = hr;
+    } else if (r < npairs + nobs_rows) {
+      const int q = r - npairs, i = q / P.n_obs, o = q % P.n_obs;
+      T xo[9] = {T(0), T(0), T(0), T(0), T(0), T(0), obstacles[4 * o], obstacles[4 * o + 1], obstacles[4 * o + 2]};
+      T hr, Lg[4];
+      cbf_pair_row<T, 2>(P, sx[wave][i], sxd[wave][i], xo, xo, true, P.safety_radius + obstacles[4 * o + 3], &hr, Lg);
+      ii[k] = jj[k] = i;
+      ci[k] = -Lg[0];
+      b[k] = hr;
+    } else if (r < m) {
+      const int q = r - npairs - nobs_rows;
+      ii[k] = jj[k] = q % D;
+      ci[k] = q < D ? T(1) : T(-1);
+      b[k] = P.umax[0];
+    }
+    if (r < m) {
+      const T n2 = m_fma(ci[k], ci[k], cj[k] * cj[k]);
+      if (n2 > T(0)) {
+        const T inv = T(1) / m_sqrt(n2);
+        ci[k] *= inv;
+        cj[k] *= inv;
+        b[k] *= inv;
+        valid[k] = true;
+      } else if (b[k] < T(0)) {
+        bad = true;                                        // 0 * u <= h with h < 0
+      }
+    }
+  }
+  bool converged = false;
+  bool infeasible = __any(bad);
+  int q = 0, it = 0;
+  while (!infeasible && it < max_iter) {
+    // ---- most violated row outside the active set (distance^2 to its half-space) ----
+    T best = T(0);
+    int best_k = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const T res = m_fma(ci[k], su[ii[k]], m_fma(cj[k], su[jj[k]], -b[k]));
+      const T sc = (valid[k] && !act[k] && res > T(0)) ? res * res : T(0);
+      if (sc > best) {
+        best = sc;
+        best_k = k;
+      }
+    }
+    T wbest = best;
+    int wrow = lane + 64 * best_k;
+    wave_argmax(wbest, wrow);
+    if (!(wbest > tol2)) {
+      converged = true;
+      break;
+    }
+    const int owner = wrow & 63, kk = wrow >> 6;
+    const T wci = __shfl(pick<T, R>(ci, kk), owner), wcj = __shfl(pick<T, R>(cj, kk), owner), wb = __shfl(pick<T, R>(b, kk), owner);
+    const int wii = __shfl(pick<int, R>(ii, kk), owner), wjj = __shfl(pick<int, R>(jj, kk), owner);
+    const bool two = wjj != wii;
+    T lam_new = T(0);
+    // ---- bring that row into the active set, dropping blocking rows on the way ----
+    while (true) {
+      if (++it > max_iter) {
+        infeasible = true;
+        break;
+      }
+      const T res = m_fma(wci, su[wii], m_fma(two ? wcj : T(0), su[wjj], -wb));
+      T dc = T(0);
+      if (lane < q) dc = m_fma(wci, sQ[wii][lane], two ? wcj * sQ[wjj][lane] : T(0));   // d = Q^T a
+      if (lane < n) sd[lane] = dc;
+      MDS_WAVE_SYNC();
+      T zv = T(0);                                                                       // z = a - Q d
+      if (lane < n) {
+        zv = (lane == wii ? wci : T(0)) + ((two && lane == wjj) ? wcj : T(0));
+        for (int c = 0; c < q; ++c) zv = m_fma(-sQ[lane][c], sd[c], zv);
+      }
+      const T zz = wave_sum(zv * zv);
+      T rc = dc;                                                                         // r = R^-1 d
+      for (int k = q - 1; k >= 0; --k) {
+        const T rk = __shfl(rc, k) / sR[k][k];
+        if (lane == k) rc = rk;
+        else if (lane < k) rc = m_fma(-sR[lane][k], rk, rc);
+      }
+      const T rmax = wave_max(lane < q ? m_abs(rc) : T(0));
+      T t1 = GiEps<T>::inf;
+      int drop = lane;
+      if (lane < q && rc > GiEps<T>::r * rmax && rc > T(0)) t1 = m_max(slam[lane], T(0)) / rc;
+      wave_argmin(t1, drop);
+      const bool has_z = zz > GiEps<T>::z;
+      const T t2 = has_z ? res / zz : GiEps<T>::inf;
+      const T t = m_min(t1, t2);
+      if (!(t < GiEps<T>::inf)) {
+        infeasible = true;                                                               // no step possible: rows inconsistent
+        break;
+      }
+      const bool full = has_z && t2 <= t1;
+      MDS_WAVE_SYNC();
+      if (has_z && lane < n) su[lane] = m_fma(-t, zv, su[lane]);
+      if (lane < q) slam[lane] = m_fma(-t, rc, slam[lane]);
+      lam_new += t;
+      MDS_WAVE_SYNC();
+      if (full) {                                                                        // add: N <- [N a]
+        const T nz = m_sqrt(zz);
+        if (lane < n) sQ[lane][q] = zv / nz;
+        if (lane < q) sR[lane][q] = dc;
+        if (lane == 0) {
+          sR[q][q] = nz;
+          slam[q] = lam_new;
+          sact[q] = wrow;
+        }
+        if (lane == owner) {
+#pragma unroll
+          for (int k = 0; k < R; ++k)
+            if (k == kk) act[k] = true;
+        }
+        ++q;
+        MDS_WAVE_SYNC();
+        break;
+      }
+      // ---- drop active column `drop` (its multiplier reached zero) ----
+      const int drow = sact[drop];
+      if (lane == (drow & 63)) {
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+          if (k == (drow >> 6)) act[k] = false;
+      }
+      T lnext = T(0);
+      int anext = 0;
+      if (lane >= drop && lane < q - 1) {
+        lnext = slam[lane + 1];
+        anext = sact[lane + 1];
+      }
+      MDS_WAVE_SYNC();
+      if (lane >= drop && lane < q - 1) {
+        slam[lane] = lnext;
+        sact[lane] = anext;
+      }
+      if (lane < q)                                                                      // each lane shifts its own row of R
+        for (int k = drop; k < q - 1; ++k) sR[lane][k] = sR[lane][k + 1];
+      MDS_WAVE_SYNC();
+      for (int l = drop; l < q - 1; ++l) {                                               // Givens on rows l, l+1
+        const T a = sR[l][l], bb = sR[l + 1][l];
+        const T rr = m_sqrt(m_fma(a, a, bb * bb));
+        const T cs = rr > T(0) ? a / rr : T(1), sn = rr > T(0) ? bb / rr : T(0);
+        MDS_WAVE_SYNC();
+        if (lane >= l && lane < q - 1) {
+          const T x = sR[l][lane], y = sR[l + 1][lane];
+          sR[l][lane] = m_fma(cs, x, sn * y);
+          sR[l + 1][lane] = m_fma(-sn, x, cs * y);
+        }
+        if (lane < n) {
+          const T x = sQ[lane][l], y = sQ[lane][l + 1];
+          sQ[lane][l] = m_fma(cs, x, sn * y);
+          sQ[lane][l + 1] = m_fma(-sn, x, cs * y);
+        }
+        MDS_WAVE_SYNC();
+      }
+      --q;
+    }
+  }
+  if (lane == 0) status[env] = converged ? 0 : 1;
+  MDS_WAVE_SYNC();
+  for (int d = lane; d < D; d += 64) {
+    T u[4];
+    for (int k = 0; k < 4; ++k) u[k] = (T)unom[(base + d) * 4 + k];
+    if (converged) {
+      u[0] = su[d];
       for (int k = 1; k < 4; ++k) u[k] = m_clamp(u[k], -P.umax[k], P.umax[k]);
     }
     for (int k = 0; k < 4; ++k) usafe[(base + d) * 4 + k] = (S)u[k];
