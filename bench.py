@@ -30,7 +30,9 @@ WORKLOADS = {
     # name: (envs per GPU, drones per env, phase rule, description)
     "c3": (65536, 8, "c3", "C3: 65536 envs x 8 drones per GPU, Lemniscate tracking, fused traj+geometric+DYN step, obs every step"),
     "c2": (4096, 4, "c2", "C2: 4096 envs x 4 drones per GPU, geometric controller free flight, fused step, obs every step"),
+    "c4": (16384, 16, "c3", "C4: 16384 envs x 16 drones per GPU, geometric nominal -> order-2 ECBF QP (4 sphere obstacles) -> ThrustOmega -> DYN step"),
 }
+BYTES_PER_DRONE_STEP_C4 = 132 + 148 + 260   # three launches: nominal (R 80, W 52) + filter (R 132, W 16) + low-level step (R 104, W 156)
 BYTES_PER_DRONE_STEP = 212          # R state 52 + R traj params 28 + W state 52 + W obs 80
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -152,12 +154,33 @@ def main(argv=None):
     xyz, rpy, P = make_inputs(E, D, phase, 1000 + rank)          # every rank owns different envs
     env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN,
                      pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=args.dtype, device=local_rank)
+    tracker = None
+    if args.workload == "c4":
+        # trajectories / start heights stacked 0.3 m apart: with the omega linearisation the barrier acts through e_z only
+        P[..., 4] = 0.5 + 0.3 * np.arange(D)
+        xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+        env.close()
+        env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN,
+                         pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=args.dtype, device=local_rank)
+        from multidronesim_amd.cbf.cbf import DroneCBF
+        from multidronesim_amd.cbf.qptracker import DroneQPTracker
+        from multidronesim_amd.model.linear_omega import LinearizedOmegaModel
+        cbf = DroneCBF(env, [LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2,
+                       cbf_poles=np.array([-2.2, -2.4]))                                    # CBFTest.py:419
+        tracker = DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+        c4_obs = [np.array([[sx * 0.5, sy * 0.5, 0.5], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
+        c4_r = [0.1] * 4
     env.set_trajectories(P)
     env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=device))     # EnvGeometric.py:431
     dt = env.CTRL_TIMESTEP
 
     def run(t0, k):
-        if args.python_loop:
+        if tracker is not None:
+            t = t0
+            for _ in range(k):
+                env.step_cbf_geometric(t, tracker, c4_obs, c4_r)
+                t += dt
+        elif args.python_loop:
             t = t0
             for _ in range(k):
                 env.step_geometric(t)
@@ -187,7 +210,8 @@ def main(argv=None):
     total_units = n_local * world * args.steps
     value = total_units / elapsed
     kernel_us = dev_ms * 1e3 / args.steps                   # average launch-to-launch duration on the stream (HIP events)
-    achieved = BYTES_PER_DRONE_STEP * n_local / (kernel_us * 1e-6) / 1e9
+    bytes_per = BYTES_PER_DRONE_STEP_C4 if args.workload == "c4" else BYTES_PER_DRONE_STEP
+    achieved = bytes_per * n_local / (kernel_us * 1e-6) / 1e9
     line = {
         "metric": "drone-steps/sec (whole node) at N_envs x N_drones; achieved HBM GB/s vs roofline",
         "value": value, "unit": "drone-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,7 +222,7 @@ def main(argv=None):
                    "launch": "python" if args.python_loop else "C rollout loop"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": None, "kernel": "k_step_geometric<float,float,true,false,false,false>", "kernel_us": kernel_us,
-                     "bytes_per_launch": BYTES_PER_DRONE_STEP * n_local},
+                     "bytes_per_launch": bytes_per * n_local},
         "device_ms_per_step_max_rank": dev_ms_max / args.steps, "state_sane": ok,
     }
     # HBM traffic from the PMC counters cannot be read inside this process; the committed summary of the
@@ -210,7 +234,11 @@ def main(argv=None):
             line["roofline"]["traffic_source"] = "profiles/r01b_pmc_traffic_c3.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
         except Exception:
             pass
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if args.workload == "c4":
+        st = env._cbf_status
+        line["roofline"]["kernel"] = "k_cbf_nominal + k_cbf_filter_o2_gi + k_lowlevel_step (3 launches per step; QP is latency/ALU bound)"
+        line["cbf_fallback_frac_last_step"] = float((st != 0).float().mean().item())
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "c4":
         line["cpu_baseline"] = cpu_baseline(D, phase, args.cpu_budget)
     elif rank == 0:
         line["cpu_baseline"] = None

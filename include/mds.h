@@ -201,6 +201,27 @@ int mds_cbf_rows(mds_handle* h, const void* x_dev, const void* xdes_dev, void* G
 int mds_cbf_filter(mds_handle* h, const void* obs_dev, const void* xdes_dev, const void* u_nominal_dev, void* u_safe_dev,
                    int32_t* status_dev, void* stream);
 
+/* ---- low-level body-rate controller (control/low_level/thrust_omega_ctrl.py) ---------------- */
+
+/* ThrustOmegaController.reset(): zero last_omega and the integral of every drone (mds_reset does
+ * this too). */
+int mds_lowlevel_reset(mds_handle* h, void* stream);
+
+/* LQROmegaController.compute_low_level(u, obs) (control/lqr/lqr_omega_controller.py:77-88) ->
+ * ThrustOmegaController.computeControlFromInput (thrust_omega_ctrl.py:81-132) for every drone:
+ * u_dev [n,4] = (thrust N, target body rates), obs_dev [n,20] (its world-frame rate is rotated to
+ * the body frame) -> rpm_dev [n,4].  Stateful (PID memory lives in the handle). */
+int mds_thrust_omega_compute(mds_handle* h, const void* u_dev, const void* obs_dev, void* rpm_dev, void* stream);
+/* same with the current BODY rates given directly: rates_dev [n,3] (computeControlFromInput's own signature) */
+int mds_thrust_omega_from_rates(mds_handle* h, const void* u_dev, const void* rates_dev, void* rpm_dev, void* stream);
+
+/* One CBF-filtered control step of simulations/CBFTest.py:303-350 for every env (order 2):
+ * nominal (force - M G, w_des) from the geometric controller on the handle's trajectories ->
+ * ECBF QP -> + M G -> ThrustOmega low level -> env.step.  obs_dev [n,20] holds the CURRENT
+ * observation on entry (as returned by the previous step) and the next one on return;
+ * status_dev [E] as mds_cbf_filter; action_dev [n,4] (RPM) optional. */
+int mds_step_cbf_geometric(mds_handle* h, double t, void* obs_dev, int32_t* status_dev, void* action_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

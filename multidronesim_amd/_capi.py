@@ -75,6 +75,10 @@ PROTOTYPES = {
     "mds_cbf_num_rows": (C.c_int, [_P]),
     "mds_cbf_rows": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "mds_cbf_filter": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "mds_lowlevel_reset": (C.c_int, [_P, _P]),
+    "mds_thrust_omega_compute": (C.c_int, [_P, _P, _P, _P, _P]),
+    "mds_thrust_omega_from_rates": (C.c_int, [_P, _P, _P, _P, _P]),
+    "mds_step_cbf_geometric": (C.c_int, [_P, C.c_double, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -63,6 +63,10 @@ struct mds_handle {
   CbfParams<double> cbf_d;
   int* pair_ij;        // device [D(D-1)/2]
   void* obstacles;     // device T [n_obs,4]
+  void* cbf_unom;      // S [n,4]  scratch of mds_step_cbf_geometric
+  void* cbf_xdes;      // S [n,9]
+  void* cbf_usafe;     // S [n,4]
+  void* ll;            // T [6][ld]: ThrustOmega last_omega3 | integral3
 };
 
 // dispatch on the handle dtype: F32 -> <float,float>, F64 -> <double,double>, F16 -> <float,half_t>
@@ -189,11 +193,14 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   h->has_cbf = false;
   h->pair_ij = nullptr;
   h->obstacles = nullptr;
+  h->cbf_unom = h->cbf_xdes = h->cbf_usafe = h->ll = nullptr;
   hipError_t e = hipMalloc(&h->state, 13 * h->ld * es);
   if (e == hipSuccess) e = hipMalloc(&h->origin, 3 * h->ld * cs);
   if (e == hipSuccess) e = hipMalloc(&h->last_rpm, 4 * h->ld * cs);
   if (e == hipSuccess) e = hipMalloc(&h->lem, 7 * h->ld * cs);
   if (e == hipSuccess) e = hipMalloc((void**)&h->scratch, (size_t)h->n * 20 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&h->ll, 6 * h->ld * cs);
+  if (e == hipSuccess) e = hipMemset(h->ll, 0, 6 * h->ld * cs);
   if (e == hipSuccess) e = hipMemset(h->state, 0, 13 * h->ld * es);
   if (e == hipSuccess) e = hipMemset(h->origin, 0, 3 * h->ld * cs);
   if (e == hipSuccess) e = hipMemset(h->last_rpm, 0, 4 * h->ld * cs);
@@ -224,6 +231,10 @@ int mds_destroy(mds_handle* h) {
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->pair_ij) (void)hipFree(h->pair_ij);
   if (h->obstacles) (void)hipFree(h->obstacles);
+  if (h->cbf_unom) (void)hipFree(h->cbf_unom);
+  if (h->cbf_xdes) (void)hipFree(h->cbf_xdes);
+  if (h->cbf_usafe) (void)hipFree(h->cbf_usafe);
+  if (h->ll) (void)hipFree(h->ll);
   delete h;
   return MDS_OK;
 }
@@ -253,6 +264,7 @@ int mds_reset(mds_handle* h, const double* xyz, const double* rpy, void* stream)
   MDS_DISPATCH(h, (k_reset<T, S><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, h->ld, h->scratch, h->scratch + (size_t)3 * h->n,
                                                                         (const T*)h->origin, (S*)h->state, (T*)h->last_rpm)));
   MDS_HIP(hipGetLastError());
+  MDS_HIP(hipMemsetAsync(h->ll, 0, 6 * h->ld * comp_size(h->cfg.dtype), st));
   MDS_HIP(hipStreamSynchronize(st));   // host buffers may be reused by the caller
   return MDS_OK;
 }
@@ -555,10 +567,14 @@ int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void*
       k_cbf_filter_o2<T, T, RR><<<grid, 256, 0, st>>>(CP, E, h->pair_ij, (const T*)h->obstacles, (const T*)obs,              \
                                                       (const T*)xdes, (const T*)unom, (T*)usafe, (int*)status, max_iter,    \
                                                       (T)((TOL) * (TOL)));                                                  \
+    else if (D <= 16)                                                                                                       \
+      k_cbf_filter_o2_gi<T, T, RR, 16><<<grid, 256, 0, st>>>(CP, E, h->pair_ij, (const T*)h->obstacles, (const T*)obs,       \
+                                                             (const T*)xdes, (const T*)unom, (T*)usafe, (int*)status,       \
+                                                             max_iter, (T)((TOL) * (TOL)));                                 \
     else                                                                                                                    \
-      k_cbf_filter_o2_gi<T, T, RR><<<grid, 256, 0, st>>>(CP, E, h->pair_ij, (const T*)h->obstacles, (const T*)obs,           \
-                                                         (const T*)xdes, (const T*)unom, (T*)usafe, (int*)status, max_iter, \
-                                                         (T)((TOL) * (TOL)));                                               \
+      k_cbf_filter_o2_gi<T, T, RR, 32><<<grid, 256, 0, st>>>(CP, E, h->pair_ij, (const T*)h->obstacles, (const T*)obs,       \
+                                                             (const T*)xdes, (const T*)unom, (T*)usafe, (int*)status,       \
+                                                             max_iter, (T)((TOL) * (TOL)));                                 \
   } while (0)
 #define MDS_CBF_DISPATCH(T, CP, TOL)                    \
   do {                                                  \
@@ -571,6 +587,67 @@ int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void*
   else MDS_CBF_DISPATCH(float, h->cbf_f, h->cbf.tol > 0 ? h->cbf.tol : 1e-6);
 #undef MDS_CBF_DISPATCH
 #undef MDS_CBF_LAUNCH
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_lowlevel_reset(mds_handle* h, void* stream) {
+  if (!h) return fail(MDS_EINVAL, "mds_lowlevel_reset: null handle");
+  MDS_HIP(hipMemsetAsync(h->ll, 0, 6 * h->ld * comp_size(h->cfg.dtype), (hipStream_t)stream));
+  return MDS_OK;
+}
+
+static int launch_thrust_omega(mds_handle* h, const void* u, const void* src, int rates_given, void* rpm, hipStream_t st) {
+  MDS_DISPATCH(h, (k_thrust_omega<T, S><<<grid_for(h->n, 256), 256, 0, st>>>(C, h->n, h->ld, (T)(1.0 / h->cfg.ctrl_freq), rates_given,
+                                                                             (T*)h->ll, (const S*)u, (const S*)src, (S*)rpm)));
+  return MDS_OK;
+}
+
+int mds_thrust_omega_compute(mds_handle* h, const void* u, const void* obs, void* rpm, void* stream) {
+  if (!h || !u || !obs || !rpm) return fail(MDS_EINVAL, "mds_thrust_omega_compute: null argument");
+  if (!aligned16(u) || !aligned16(rpm)) return fail(MDS_EALIGN, "mds_thrust_omega_compute");
+  launch_thrust_omega(h, u, obs, 0, rpm, (hipStream_t)stream);
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_thrust_omega_from_rates(mds_handle* h, const void* u, const void* rates, void* rpm, void* stream) {
+  if (!h || !u || !rates || !rpm) return fail(MDS_EINVAL, "mds_thrust_omega_from_rates: null argument");
+  if (!aligned16(u) || !aligned16(rpm)) return fail(MDS_EALIGN, "mds_thrust_omega_from_rates");
+  launch_thrust_omega(h, u, rates, 1, rpm, (hipStream_t)stream);
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_step_cbf_geometric(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream) {
+  if (!h || !obs || !status) return fail(MDS_EINVAL, "mds_step_cbf_geometric: null argument");
+  if (!h->has_traj) return fail(MDS_ESTATE, "mds_step_cbf_geometric: call mds_set_lemniscate first");
+  if (!h->has_cbf) return fail(MDS_ESTATE, "mds_step_cbf_geometric: call mds_cbf_configure first");
+  if (h->cbf.order != 2) return fail(MDS_EUNSUPPORTED, "mds_step_cbf_geometric: order 2 only");
+  if (!aligned16(obs) || !aligned16(action)) return fail(MDS_EALIGN, "mds_step_cbf_geometric: obs_dev/action_dev");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t es = elem_size(h->cfg.dtype);
+  if (!h->cbf_unom) {
+    MDS_HIP(hipMalloc(&h->cbf_unom, (size_t)h->n * 4 * es));
+    MDS_HIP(hipMalloc(&h->cbf_xdes, (size_t)h->n * 9 * es));
+    MDS_HIP(hipMalloc(&h->cbf_usafe, (size_t)h->n * 4 * es));
+  }
+  const dim3 grid = grid_for(h->n, kBlock);
+  MDS_DISPATCH(h, (k_cbf_nominal<T, S><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t, (const S*)h->state, (const T*)h->lem,
+                                                                (S*)h->cbf_unom, (S*)h->cbf_xdes)));
+  int rc = mds_cbf_filter(h, obs, h->cbf_xdes, h->cbf_unom, h->cbf_usafe, status, stream);
+  if (rc != MDS_OK) return rc;
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
+#define MDS_LL(RK4, DRAG)                                                                                                      \
+  MDS_DISPATCH(h, (k_lowlevel_step<T, S, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, (T)(1.0 / h->cfg.ctrl_freq),      \
+                                                                             (T)(h->cfg.M * h->cfg.G), (S*)h->state,           \
+                                                                             (const T*)h->origin, (T*)h->last_rpm, (T*)h->ll, \
+                                                                             (const S*)h->cbf_usafe, (S*)obs, (S*)action)))
+  if (rk4 && drag) MDS_LL(true, true);
+  else if (rk4) MDS_LL(true, false);
+  else if (drag) MDS_LL(false, true);
+  else MDS_LL(false, false);
+#undef MDS_LL
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }

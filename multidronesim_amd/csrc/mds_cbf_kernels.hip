@@ -270,18 +270,19 @@ template <> struct GiEps<double> {
   static constexpr double z = 1e-20, r = 1e-12, inf = 1.0e300;
 };
 
-constexpr int kQS = kCbfMaxD + 1;   // padded LDS row stride (conflict-free column walks)
-
-template <typename T, typename S, int R>
+// NMAX = compile-time bound on drones per env (LDS footprint of Q, R scales with NMAX^2)
+template <typename T, typename S, int R, int NMAX>
 __global__ __launch_bounds__(256) void k_cbf_filter_o2_gi(const CbfParams<T> P, const int E, const int* __restrict__ pair_ij,
                                                           const T* __restrict__ obstacles, const S* __restrict__ obs,
                                                           const S* __restrict__ xdes, const S* __restrict__ unom,
                                                           S* __restrict__ usafe, int* __restrict__ status, const int max_iter,
                                                           const T tol2) {
-  __shared__ T sx[4][kCbfMaxD][9], sxd[4][kCbfMaxD][9];
-  __shared__ T su_[4][kCbfMaxD], sd_[4][kCbfMaxD], slam_[4][kCbfMaxD];
-  __shared__ T sQ_[4][kCbfMaxD][kQS], sR_[4][kCbfMaxD][kQS];
-  __shared__ int sact_[4][kCbfMaxD];
+  constexpr int kQS = NMAX + 1;     // padded LDS row stride (conflict-free column walks)
+  __shared__ T sx[4][NMAX][9], sxd[4][NMAX][9];
+  __shared__ T su_[4][NMAX], sd_[4][NMAX], slam_[4][NMAX];
+  __shared__ T sQ_[4][NMAX][kQS], sR_[4][NMAX][kQS];
+  __shared__ int sact_[4][NMAX];
+  __shared__ __align__(16) S sraw[4][NMAX * 20];            // the env's observation rows, loaded coalesced
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int env = blockIdx.x * 4 + wave;
   if (env >= E) return;                                    // wave-uniform
@@ -293,11 +294,16 @@ __global__ __launch_bounds__(256) void k_cbf_filter_o2_gi(const CbfParams<T> P, 
   int* sact = sact_[wave];
   const int D = P.num_drones, n = D;
   const size_t base = (size_t)env * D;
-  for (int d = lane; d < D; d += 64) {
-    T o[20];
-    for (int k = 0; k < 20; ++k) o[k] = (T)obs[(base + d) * 20 + k];
-    obs_to_lin<T>(o, 2, T(0), sx[wave][d]);
-    for (int k = 0; k < 9; ++k) sxd[wave][d][k] = (T)xdes[(base + d) * 9 + k];
+  // an env's D x 20 observation block, its D x 9 xdes block and D x 4 nominal block are contiguous
+  for (int k = lane; k < D * 20; k += 64) sraw[wave][k] = obs[base * 20 + k];
+  for (int k = lane; k < D * 9; k += 64) sxd[wave][k / 9][k % 9] = (T)xdes[base * 9 + k];
+  MDS_WAVE_SYNC();
+  for (int d = lane; d < D; d += 64) {       // obs_to_lin_model(obs, dim=9): [rpy, vel, pos] (model_conversions.py:36-48)
+    const S* o = &sraw[wave][d * 20];
+    T* x = sx[wave][d];
+    x[0] = (T)o[7]; x[1] = (T)o[8]; x[2] = (T)o[9];
+    x[3] = (T)o[10]; x[4] = (T)o[11]; x[5] = (T)o[12];
+    x[6] = (T)o[0]; x[7] = (T)o[1]; x[8] = (T)o[2];
     su[d] = (T)unom[(base + d) * 4];
   }
   MDS_WAVE_SYNC();

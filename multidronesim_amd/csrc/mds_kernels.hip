@@ -305,6 +305,99 @@ __global__ __launch_bounds__(kBlock, MDS_GEO_MIN_WAVES) void k_step_geometric_f3
   }
 }
 
+// ------------------------------------------------------------------------------------
+// CBF-filtered control step (simulations/CBFTest.py:303-350) = three launches:
+//   k_cbf_nominal    per drone : trajs[j](t), GeometricControl.compute(return_omegas) ->
+//                                u_hat = (force - M G, w_des), xdes = [0,0,yaw, vel, pos]   (:339-343)
+//   k_cbf_filter_o2* per env   : DroneQPTracker.compute_control                             (:345)
+//   k_lowlevel_step  per drone : u_safe[0] += M G (:346), ThrustOmegaController (:348),
+//                                env.step(action) (:350)
+// ------------------------------------------------------------------------------------
+template <typename T, typename S>
+__global__ __launch_bounds__(kBlock) void k_cbf_nominal(const Consts<T> c, const int n, const size_t ld, const double t,
+                                                        const S* __restrict__ state, const T* __restrict__ lem,
+                                                        S* __restrict__ unom, S* __restrict__ xdes) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  GeoIn<T> in;
+  load_geo_in<T, S>(state, lem, ld, i, in);
+  const Desired<T> des = lemniscate_local(in.P, t);
+  const M3<T> R = quat_to_rot(in.s.q);
+  const V3<T> ang_v = mul(R, in.s.w);
+  T u[4];
+  GeoAux<T> A;
+  geometric_control<T>(c, in.s.p - des.p, R, in.s.v, ang_v, des, u, &A);
+  const T un[4] = {A.force - c.gravity, A.w_des.x, A.w_des.y, A.w_des.z};
+  store4<S, T>(unom + (size_t)i * 4, un);
+  S* xd = xdes + (size_t)i * 9;
+  xd[0] = (S)0; xd[1] = (S)0; xd[2] = (S)des.yaw;
+  xd[3] = (S)des.v.x; xd[4] = (S)des.v.y; xd[5] = (S)des.v.z;
+  xd[6] = (S)(des.p.x + in.P.cx); xd[7] = (S)(des.p.y + in.P.cy); xd[8] = (S)(des.p.z + in.P.cz);
+}
+
+template <typename T, typename S, bool RK4, bool DRAG>
+__global__ __launch_bounds__(kBlock) void k_lowlevel_step(const Consts<T> c, const int n, const size_t ld, const T ctrl_dt,
+                                                          const T thrust_offset, S* __restrict__ state,
+                                                          const T* __restrict__ origin, T* __restrict__ last_rpm,
+                                                          T* __restrict__ ll, const S* __restrict__ u_in, S* __restrict__ obs,
+                                                          S* __restrict__ action_out) {
+  __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = i < n;
+  T o[kObsDim];
+  State<T> s;
+  if (valid) {
+    load_state<S, T>(state, ld, i, s);
+    T u[4];
+    load4<S, T>(u_in + (size_t)i * 4, u);
+    u[0] += thrust_offset;
+    LowLevelState<T> L;
+    L.last_omega = {ll[0 * ld + i], ll[1 * ld + i], ll[2 * ld + i]};
+    L.integral = {ll[3 * ld + i], ll[4 * ld + i], ll[5 * ld + i]};
+    T act[4], prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4];
+    // compute_low_level rotates obs[13:16] (= R w) back with R^T: the body rate is the state's w
+    thrust_omega_control(c, ctrl_dt, u, s.w, L, act);
+    ll[0 * ld + i] = L.last_omega.x; ll[1 * ld + i] = L.last_omega.y; ll[2 * ld + i] = L.last_omega.z;
+    ll[3 * ld + i] = L.integral.x; ll[4 * ld + i] = L.integral.y; ll[5 * ld + i] = L.integral.z;
+    if (DRAG)
+      for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
+    aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
+    if (DRAG)
+      for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
+    if (action_out) store4<S, T>(action_out + (size_t)i * 4, act);
+    pack_obs(s, V3<T>{origin[i], origin[ld + i], origin[2 * ld + i]}, clipped, o);
+  }
+  write_obs_rows<S, T>(lds, obs, n, i, valid, o);
+  if (valid) store_state<S, T>(state, ld, i, s);
+}
+
+// ThrustOmegaController.computeControlFromInput through LQROmegaController.compute_low_level
+// (lqr_omega_controller.py:77-88): u [n,4] = (thrust, w_target), obs [n,20] -> rpm [n,4]; stateful.
+template <typename T, typename S>
+__global__ void k_thrust_omega(const Consts<T> c, const int n, const size_t ld, const T ctrl_dt, const int body_rates_given,
+                               T* __restrict__ ll, const S* __restrict__ u_in, const S* __restrict__ obs_or_rates,
+                               S* __restrict__ rpm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T u[4], act[4];
+  load4<S, T>(u_in + (size_t)i * 4, u);
+  V3<T> cur;
+  if (body_rates_given) {
+    cur = {(T)obs_or_rates[(size_t)i * 3], (T)obs_or_rates[(size_t)i * 3 + 1], (T)obs_or_rates[(size_t)i * 3 + 2]};
+  } else {
+    const S* o = obs_or_rates + (size_t)i * 20;
+    const T q[4] = {(T)o[3], (T)o[4], (T)o[5], (T)o[6]};
+    cur = mulT(quat_to_rot(q), V3<T>{(T)o[13], (T)o[14], (T)o[15]});
+  }
+  LowLevelState<T> L;
+  L.last_omega = {ll[0 * ld + i], ll[1 * ld + i], ll[2 * ld + i]};
+  L.integral = {ll[3 * ld + i], ll[4 * ld + i], ll[5 * ld + i]};
+  thrust_omega_control(c, ctrl_dt, u, cur, L, act);
+  ll[0 * ld + i] = L.last_omega.x; ll[1 * ld + i] = L.last_omega.y; ll[2 * ld + i] = L.last_omega.z;
+  ll[3 * ld + i] = L.integral.x; ll[4 * ld + i] = L.integral.y; ll[5 * ld + i] = L.integral.z;
+  store4<S, T>(rpm + (size_t)i * 4, act);
+}
+
 // [UPSTREAM] _computeObs from the current state
 template <typename T, typename S>
 __global__ __launch_bounds__(kBlock) void k_get_obs(const int n, const size_t ld, const S* __restrict__ state,

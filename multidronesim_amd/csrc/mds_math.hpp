@@ -529,6 +529,45 @@ MDS_HD void geometric_control(const Consts<T>& c, V3<T> p_rel, const M3<T>& R, V
   u[3] = c.J[2] * (-eR.z - c.kw[2] * ew.z) - wxJw.z;
 }
 
+// ------------------------------------------------------------------------------------
+// control/low_level/thrust_omega_ctrl.py:81-132: body-rate PID -> PWM -> RPM
+// (constants :39-60: P 17500, I 10, D 0, PWM2RPM 0.2685 / 4070.3, PWM in [20000, 65535],
+// torque clip +-3200).  Stateful: last_omega and the (oddly signed, :117) integral.
+// ------------------------------------------------------------------------------------
+template <typename T> struct LowLevelState {
+  V3<T> last_omega, integral;
+};
+template <typename T>
+MDS_HD void thrust_omega_control(const Consts<T>& c, T ctrl_dt, const T u[4], V3<T> cur, LowLevelState<T>& s, T rpm[4]) {
+  const T kP = T(17500), kI = T(10), kD = T(0);
+  const T kScale = T(0.2685), kConst = T(4070.3), kMinPwm = T(20000), kMaxPwm = T(65535);
+  const T u0 = m_max(u[0], T(0));                                                       // :91
+  const T pwm_thrust = m_clamp((m_sqrt(u0 * c.inv_kf * T(0.25)) - kConst) / kScale, kMinPwm, kMaxPwm);   // :92-93
+  const T inv_dt = T(1) / ctrl_dt;
+  const V3<T> rate_e = {-(cur.x - s.last_omega.x) * inv_dt, -(cur.y - s.last_omega.y) * inv_dt, -(cur.z - s.last_omega.z) * inv_dt};
+  const V3<T> e = {u[1] - cur.x, u[2] - cur.y, u[3] - cur.z};                           // :112
+  s.last_omega = cur;
+  s.integral = {m_clamp(m_clamp(s.integral.x - e.x * ctrl_dt, T(-1500), T(1500)), T(-1), T(1)),   // :117-119
+                m_clamp(m_clamp(s.integral.y - e.y * ctrl_dt, T(-1500), T(1500)), T(-1), T(1)),
+                m_clamp(s.integral.z - e.z * ctrl_dt, T(-1500), T(1500))};
+  const T tx = m_clamp(kP * e.x + kI * s.integral.x + kD * rate_e.x, T(-3200), T(3200));  // :123-129
+  const T ty = m_clamp(kP * e.y + kI * s.integral.y + kD * rate_e.y, T(-3200), T(3200));
+  const T tz = m_clamp(kP * e.z + kI * s.integral.z + kD * rate_e.z, T(-3200), T(3200));
+  T pwm[4];
+  if (c.cf2x) {                                                                          // MIXER_MATRIX :46-59
+    pwm[0] = pwm_thrust + (T(-0.5) * tx + T(-0.5) * ty - tz);
+    pwm[1] = pwm_thrust + (T(-0.5) * tx + T(0.5) * ty + tz);
+    pwm[2] = pwm_thrust + (T(0.5) * tx + T(0.5) * ty - tz);
+    pwm[3] = pwm_thrust + (T(0.5) * tx + T(-0.5) * ty + tz);
+  } else {
+    pwm[0] = pwm_thrust + (-ty - tz);
+    pwm[1] = pwm_thrust + (tx + tz);
+    pwm[2] = pwm_thrust + (ty - tz);
+    pwm[3] = pwm_thrust + (-tx + tz);
+  }
+  for (int i = 0; i < 4; ++i) rpm[i] = m_fma(kScale, m_clamp(pwm[i], kMinPwm, kMaxPwm), kConst);   // :130-132
+}
+
 // model/dynamics.py:83-106: (state18, u4) -> 12 floats (x_dot = v, "R_dot" = w, v_dot, w_dot)
 template <typename T> MDS_HD void quadrotor_dynamics(const T s[18], const T u[4], T m, const T J[3], T g, T out[12]) {
   out[0] = s[12]; out[1] = s[13]; out[2] = s[14];

@@ -287,6 +287,21 @@ class BaseAviary:
         self.step_counter += n_steps * self.PYB_STEPS_PER_CTRL
         return self._obs if want_obs else None
 
+    def step_cbf_geometric(self, t: float, tracker, x_obs=None, obs_r_list=None, return_action: bool = False):
+        """One CBF-filtered control step of simulations/CBFTest.py:303-350 for every env: geometric
+        nominal (force - M G, w_des) -> ``tracker`` (DroneQPTracker) ECBF QP -> ThrustOmega low level
+        -> env.step.  Uses and updates the env's current observation; returns (obs, status[E])."""
+        self._require_open()
+        tracker.cbf.configure(x_obs, obs_r_list)
+        if getattr(self, "_cbf_status", None) is None:
+            self._cbf_status = torch.zeros((self.NUM_ENVS,), dtype=torch.int32, device=self.device)
+        act_ptr = C.c_void_p(self._act.data_ptr()) if return_action else C.c_void_p(None)
+        capi.check(self._lib.mds_step_cbf_geometric(self._h, C.c_double(t), C.c_void_p(self._obs.data_ptr()),
+                                                    C.c_void_p(self._cbf_status.data_ptr()), act_ptr, self._stream()),
+                   "mds_step_cbf_geometric")
+        self.step_counter += self.PYB_STEPS_PER_CTRL
+        return (self._obs, self._cbf_status, self._act) if return_action else (self._obs, self._cbf_status)
+
     # ------------------------------------------------------------------ gym hooks (CtrlAviary fills them)
     def _computeReward(self):
         raise NotImplementedError

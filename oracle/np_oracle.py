@@ -449,6 +449,54 @@ def geometric_compute(obs, p_des, v_des, a_des, yaw_des, yawrate_des, c: DroneCo
 
 
 # --------------------------------------------------------------------------------------
+# f-1: control/low_level/thrust_omega_ctrl.py:81-132 (body-rate PID -> PWM -> RPM) and
+# control/lqr/lqr_omega_controller.py:77-88 compute_low_level (world -> body rate)
+# --------------------------------------------------------------------------------------
+
+
+class ThrustOmegaOracle:
+    """ThrustOmegaController (stateful: last_omega, integral_omega_e), batched over drones.
+    Constants :39-60: P=17500, I=10, D=0, PWM2RPM 0.2685/4070.3, PWM in [20000, 65535],
+    torque clip +-3200, CF2P / CF2X mixer."""
+
+    P = np.array([17500., 17500., 17500.])
+    I = np.array([10., 10., 10.])
+    Dg = np.array([0., 0., 0.])
+    SCALE, CONST, MIN_PWM, MAX_PWM = 0.2685, 4070.3, 20000, 65535
+    MIX = {"cf2x": np.array([[-.5, -.5, -1], [-.5, .5, 1], [.5, .5, -1], [.5, -.5, 1]]),
+           "cf2p": np.array([[0, -1, -1], [+1, 0, 1], [0, 1, -1], [-1, 0, 1]], dtype=np.float64)}
+
+    def __init__(self, n, c: DroneConsts = CF2P):
+        self.c = c
+        self.last_omega = np.zeros((n, 3))
+        self.integral = np.zeros((n, 3))
+
+    def compute_from_input(self, u, dt, cur_omega_body):
+        """computeControlFromInput (:81-98) + omega_PID (:103-132): u = [thrust, wx, wy, wz]."""
+        u = np.array(u, dtype=np.float64)
+        cur = np.asarray(cur_omega_body, dtype=np.float64)
+        u0 = np.clip(u[..., 0], 0, None)
+        pwm_thrust = np.clip((np.sqrt(u0 / (self.c.KF * 4)) - self.CONST) / self.SCALE, self.MIN_PWM, self.MAX_PWM)
+        rate_e = -(cur - self.last_omega) / dt
+        e = u[..., 1:4] - cur
+        self.last_omega = cur.copy()
+        self.integral = self.integral - e * dt                       # sic: minus (:117)
+        self.integral = np.clip(self.integral, -1500., 1500.)
+        self.integral[..., 0:2] = np.clip(self.integral[..., 0:2], -1., 1.)
+        tq = np.clip(self.P * e + self.I * self.integral + self.Dg * rate_e, -3200, 3200)
+        pwm = pwm_thrust[..., None] + np.einsum("ij,...j->...i", self.MIX[self.c.MODEL], tq)
+        pwm = np.clip(pwm, self.MIN_PWM, self.MAX_PWM)
+        return self.SCALE * pwm + self.CONST
+
+    def compute_low_level(self, u, obs, dt):
+        """LQROmegaController.compute_low_level (lqr_omega_controller.py:77-88): obs[13:16] is the
+        world-frame rate, rotated into the body frame with R(obs quat)^T."""
+        obs = np.asarray(obs, dtype=np.float64)
+        R = quat_to_rotmat_scipy(obs[..., 3:7])
+        return self.compute_from_input(u, dt, matTvec(R, obs[..., 13:16]))
+
+
+# --------------------------------------------------------------------------------------
 # a5: model/dynamics.py:83-106
 # --------------------------------------------------------------------------------------
 

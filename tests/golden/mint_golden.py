@@ -289,6 +289,67 @@ def mint_cbf(ref):
         print("cbf order", order, "cases", idx, "Kcbf", Kcbf, "umax", umax, "last G", G.shape)
 
 
+def mint_thrust_omega():
+    """control/low_level/thrust_omega_ctrl.py subclasses [UPSTREAM] gym_pybullet_drones BaseControl,
+    which is not installed: the fixture is minted with a STUB base class that supplies only what the
+    file reads (DRONE_MODEL, KF, reset() -> control_counter).  Marked base-class stubbed."""
+    gpd = types.ModuleType("gym_pybullet_drones")
+    gpd.__path__ = []
+    ctl = types.ModuleType("gym_pybullet_drones.control")
+    ctl.__path__ = []
+    bc = types.ModuleType("gym_pybullet_drones.control.BaseControl")
+    ut = types.ModuleType("gym_pybullet_drones.utils")
+    ut.__path__ = []
+    en = types.ModuleType("gym_pybullet_drones.utils.enums")
+    from enum import Enum
+
+    class DroneModel(Enum):
+        CF2X = "cf2x"
+        CF2P = "cf2p"
+        RACE = "racer"
+
+    class BaseControl:   # stub of [UPSTREAM] BaseControl: urdf constants + counter only
+        def __init__(self, drone_model, g=9.8):
+            self.DRONE_MODEL = drone_model
+            self.GRAVITY = g * 0.027
+            self.KF = 3.16e-10
+            self.KM = 7.94e-12
+            self.reset()
+
+        def reset(self):
+            self.control_counter = 0
+
+    en.DroneModel = DroneModel
+    bc.BaseControl = BaseControl
+    for name, mod in (("gym_pybullet_drones", gpd), ("gym_pybullet_drones.control", ctl),
+                      ("gym_pybullet_drones.control.BaseControl", bc), ("gym_pybullet_drones.utils", ut),
+                      ("gym_pybullet_drones.utils.enums", en)):
+        sys.modules[name] = mod
+    to = load("ref_thrust_omega", REF + "/control/low_level/thrust_omega_ctrl.py")
+    rng = np.random.default_rng(5)
+    out = {}
+    for model in ("cf2p", "cf2x"):
+        env = make_env()
+        env.DRONE_MODEL = DroneModel(model)
+        n, T = 24, 40
+        u = np.zeros((T, n, 4))
+        u[..., 0] = 0.2646 * (1 + 0.3 * rng.normal(size=(T, n)))
+        u[:, :4, 0] = rng.uniform(-0.05, 0.02, size=(T, 4))              # negative / tiny thrust -> MIN_PWM clip
+        u[..., 1:] = rng.normal(size=(T, n, 3)) * 1.5
+        u[:, 4:8, 1:] *= 20.0                                              # torque clip +-3200 and PWM clips
+        cur = rng.normal(size=(T, n, 3)) * 0.8
+        rpm = np.zeros((T, n, 4))
+        ctrls = [to.ThrustOmegaController(env) for _ in range(n)]
+        for t in range(T):
+            for i in range(n):
+                rpm[t, i] = ctrls[i].computeControlFromInput(u[t, i].copy(), 0.01, cur[t, i].copy())
+        out[f"{model}_u"], out[f"{model}_cur"], out[f"{model}_rpm"] = u, cur, rpm
+        out[f"{model}_integral"] = np.array([c.integral_omega_e for c in ctrls])
+    np.savez_compressed(OUT + "/thrust_omega.npz", dt=0.01, base_class="stubbed", **out, **META)
+    print("thrust_omega", rpm.shape, "clips: min", int((rpm <= 0.2685 * 20000 + 4070.3 + 1e-9).sum()),
+          "max", int((rpm >= 0.2685 * 65535 + 4070.3 - 1e-9).sum()))
+
+
 if __name__ == "__main__":
     ref = load_reference()
     mint_lemniscate(ref)
@@ -296,3 +357,4 @@ if __name__ == "__main__":
     mint_mixer(ref)
     mint_dynamics(ref)
     mint_cbf(ref)
+    mint_thrust_omega()

@@ -69,3 +69,36 @@ def open_loop_setup(n, seed=1, tilt=0.02):
     rpy = rng.uniform(-tilt, tilt, size=(n, 3))
     ph = np.concatenate([rng.uniform(0, 2 * np.pi, size=(n, 1)), rng.uniform(-1, 1, size=(n, 3))], axis=1)
     return xyz, rpy, ph
+
+
+def oracle_cbf_closed_loop(xyz, rpy, P, steps, Kcbf, umax, safety_radius, zscale, x_obs, obs_r, pyb_freq=100, ctrl_freq=100,
+                           consts=O.CF2P):
+    """simulations/CBFTest.py:303-350 on the oracle, per env: geometric nominal (return_omegas) ->
+    u_hat = (force - M G, w_des), xdes = [0,0,yaw, vel, pos] -> ECBF QP (fallback to nominal) ->
+    + M G -> ThrustOmega low level -> env.step.  Returns (obs [E,D,20], status history [steps,E])."""
+    E, D = xyz.shape[0], xyz.shape[1]
+    n = E * D
+    Pf = P.reshape(-1, 7)
+    ora = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), consts, pyb_freq, ctrl_freq)
+    ll = O.ThrustOmegaOracle(n, consts)
+    obs = ora.step(np.zeros((n, 4)))
+    t = 0.0
+    hist = []
+    for k in range(steps):
+        pos, vel, acc, yaw, yd = O.lemniscate(t, Pf[:, 0], Pf[:, 1], Pf[:, 2:5], Pf[:, 5], Pf[:, 6])
+        force, w_des, _ = O.geometric_compute(obs, pos, vel, acc, yaw, yd, consts, return_omegas=True)
+        unom = np.concatenate([(force - consts.M * consts.G)[:, None], w_des], axis=1)
+        xdes = np.concatenate([np.zeros((n, 2)), yaw[:, None], vel, pos], axis=1)
+        x = O.obs_to_lin_model(obs, 9)
+        usafe = np.zeros((n, 4))
+        st = np.zeros(E, dtype=int)
+        for e in range(E):
+            sl = slice(e * D, (e + 1) * D)
+            usafe[sl], st[e] = O.cbf_filter(x[sl], xdes[sl], unom[sl], 2, Kcbf, umax, safety_radius, zscale, consts,
+                                            np.array(x_obs) if x_obs is not None else None, obs_r)
+        hist.append(st)
+        usafe[:, 0] += consts.M * consts.G
+        rpm = ll.compute_low_level(usafe, obs, ora.CTRL_TIMESTEP)
+        obs = ora.step(rpm)
+        t += ora.CTRL_TIMESTEP
+    return obs.reshape(E, D, 20), np.array(hist)

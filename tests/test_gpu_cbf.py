@@ -164,3 +164,52 @@ def test_cbf_filter_infeasible_falls_back_and_reference_signature(mds):
     assert status == 0 and np.abs(u_ref[:, 0]).max() > 1e-3
     np.testing.assert_allclose(u, u_ref, atol=1e-8)
     env.close()
+
+
+@pytest.mark.parametrize("model", ["cf2p", "cf2x"])
+def test_thrust_omega_golden(mds, model):
+    """control/low_level/thrust_omega_ctrl.py through mds_thrust_omega_from_rates (stateful, 40 calls)."""
+    from multidronesim_amd.control.low_level.thrust_omega_ctrl import ThrustOmegaController
+    d = np.load(os.path.join(G, "thrust_omega.npz"))
+    u, cur, rpm = d[f"{model}_u"], d[f"{model}_cur"], d[f"{model}_rpm"]
+    n = u.shape[1]
+    for dtype, rtol in (("float64", 1e-12), ("float32", 2e-6)):
+        env = mds.CtrlAviary(drone_model=mds.DroneModel(model), num_drones=1, initial_xyzs=np.zeros((n, 1, 3)), initial_rpys=np.zeros((n, 1, 3)),
+                             physics=mds.Physics.DYN, pyb_freq=100, ctrl_freq=100, num_envs=n, dtype=dtype)
+        ctl = ThrustOmegaController(env)
+        for t in range(u.shape[0]):
+            got = ctl.compute_batched(u[t].reshape(n, 1, 4), cur[t].reshape(n, 1, 3)).double().cpu().numpy().reshape(n, 4)
+            np.testing.assert_allclose(got, rpm[t], rtol=rtol)
+        ctl.reset()
+        got = ctl.computeControlFromInput(u[0, 0], 0.01, cur[0, 0])          # reference signature, fresh state
+        np.testing.assert_allclose(got, rpm[0, 0], rtol=rtol)
+        env.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-8), ("float32", 2e-5)])
+def test_c4_closed_loop_matches_oracle(mds, dtype, tol):
+    """Config 4 pipeline (geometric nominal -> ECBF QP -> ThrustOmega -> step), 8 envs x 6 drones on
+    crossing Lemniscates with 4 sphere obstacles, 150 control steps, against the oracle loop."""
+    from tests import helpers as H2
+    E, D, steps = 8, 6, 150
+    xyz, rpy, P = H2.c2_setup(E, D, phase="c3", offset=0.0, omega=1.0)
+    xyz[..., 2] = 0.5 + 0.25 * np.arange(D)            # stacked start: barrier rows act through e_z
+    P[..., 4] = 0.5 + 0.12 * np.arange(D)              # trajectories 12 cm apart vertically: rows become active
+    x_obs = [np.array([[sx * 0.5, sy * 0.5, 0.5], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
+    obs_r = [0.1] * 4
+    env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                         pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype)
+    env.set_trajectories(P)
+    cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2)
+    trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+    oobs, ohist = H2.oracle_cbf_closed_loop(xyz, rpy, P, steps, cbf.Kcbf.reshape(-1), cbf.umax, 0.1, 1.0, x_obs, obs_r)
+    env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+    t, n_fallback_match = 0.0, 0
+    for k in range(steps):
+        gobs, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
+        np.testing.assert_array_equal(st.cpu().numpy(), ohist[k])
+        t += env.CTRL_TIMESTEP
+    g = gobs.double().cpu().numpy()
+    assert np.abs(g[..., :16] - oobs[..., :16]).max() < tol * 50      # PWM quantisation-free but clip-heavy loop: see DESIGN.md
+    assert np.isfinite(g).all()
+    env.close()

@@ -122,3 +122,18 @@ def test_place_poles_known_values():
     np.testing.assert_allclose(O.place_poles_chain([-2.2, -2.4]), [5.28, 4.6], rtol=1e-12)
     np.testing.assert_allclose(O.place_poles_chain([-3.0, -3.6, -5.6]), [60.48, 47.76, 12.2], rtol=1e-12)
     np.testing.assert_allclose(O.place_poles_chain([-2.2, -2.4, -2.6]), [13.728, 17.24, 7.2], rtol=1e-12)
+
+
+@pytest.mark.parametrize("model", ["cf2p", "cf2x"])
+def test_thrust_omega_matches_reference(model):
+    """control/low_level/thrust_omega_ctrl.py (fixture minted with a stubbed [UPSTREAM] BaseControl)."""
+    d = load("thrust_omega.npz")
+    assert str(d["base_class"]) == "stubbed"
+    u, cur, rpm = d[f"{model}_u"], d[f"{model}_cur"], d[f"{model}_rpm"]
+    ctl = O.ThrustOmegaOracle(u.shape[1], O.CF2P if model == "cf2p" else O.CF2X)
+    for t in range(u.shape[0]):
+        got = ctl.compute_from_input(u[t], float(d["dt"]), cur[t])
+        np.testing.assert_allclose(got, rpm[t], rtol=1e-13, atol=1e-9)
+    np.testing.assert_allclose(ctl.integral, d[f"{model}_integral"], atol=1e-14)
+    lo, hi = 0.2685 * 20000 + 4070.3, 0.2685 * 65535 + 4070.3
+    assert (np.abs(rpm - lo) < 1e-9).sum() > 10                      # MIN_PWM clip exercised (MAX_PWM is barely reachable: torque clip 3200)
