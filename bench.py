@@ -117,6 +117,9 @@ def main(argv=None):
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64", "float16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--fused-rollout", type=int, default=0, metavar="T",
+                    help="run the steps as launches of T control steps each (mds_rollout_geometric_fused: state in registers, "
+                         "every step's obs streamed to a [T,n,20] log) instead of one launch per step")
     ap.add_argument("--python-loop", action="store_true", help="issue each step from Python (env.step_geometric) instead of the C rollout loop")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU tests of the N>1 path")
     args = ap.parse_args(argv)
@@ -174,8 +177,19 @@ def main(argv=None):
     env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=device))     # EnvGeometric.py:431
     dt = env.CTRL_TIMESTEP
 
+    fused_T = args.fused_rollout
+    if fused_T:
+        if args.steps % fused_T or args.warmup % fused_T:
+            raise SystemExit("--steps and --warmup must be multiples of --fused-rollout")
+        log_buf = torch.empty((fused_T, E, D, 20), dtype=env.dtype, device=device)
+
     def run(t0, k):
-        if tracker is not None:
+        if fused_T:
+            t = t0
+            for _ in range(k // fused_T):
+                env.rollout_geometric_fused(t, fused_T, log=True, log_out=log_buf)
+                t += fused_T * dt
+        elif tracker is not None:
             t = t0
             for _ in range(k):
                 env.step_cbf_geometric(t, tracker, c4_obs, c4_r)
@@ -211,6 +225,8 @@ def main(argv=None):
     value = total_units / elapsed
     kernel_us = dev_ms * 1e3 / args.steps                   # average launch-to-launch duration on the stream (HIP events)
     bytes_per = BYTES_PER_DRONE_STEP_C4 if args.workload == "c4" else BYTES_PER_DRONE_STEP
+    if fused_T:
+        bytes_per = 80 + (132 + 80) / fused_T     # obs row per step + (state R/W, params, final obs) once per launch
     achieved = bytes_per * n_local / (kernel_us * 1e-6) / 1e9
     line = {
         "metric": "drone-steps/sec (whole node) at N_envs x N_drones; achieved HBM GB/s vs roofline",
@@ -234,6 +250,12 @@ def main(argv=None):
             line["roofline"]["traffic_source"] = "profiles/r01b_pmc_traffic_c3.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
         except Exception:
             pass
+    if fused_T:
+        line["roofline"]["kernel"] = f"k_rollout_geometric<float,float,false,false> ({fused_T} control steps per launch)"
+        line["roofline"]["kernel_us"] = kernel_us * fused_T
+        line["roofline"]["bytes_per_launch"] = bytes_per * n_local * fused_T
+        line["roofline"]["traffic"] = None
+        line["config"]["launch"] = f"fused rollout, {fused_T} steps per launch, obs log [T,n,20]"
     if args.workload == "c4":
         st = env._cbf_status
         line["roofline"]["kernel"] = "k_cbf_nominal + k_cbf_filter_o2_gi + k_lowlevel_step (3 launches per step; QP is latency/ALU bound)"

@@ -433,6 +433,28 @@ int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs, int 
   return MDS_OK;
 }
 
+int mds_rollout_geometric_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream) {
+  if (!h || n_steps < 0) return fail(MDS_EINVAL, "mds_rollout_geometric_fused");
+  if (!h->has_traj) return fail(MDS_ESTATE, "mds_rollout_geometric_fused: call mds_set_lemniscate first");
+  if (!aligned16(obs_log) || !aligned16(obs_last)) return fail(MDS_EALIGN, "mds_rollout_geometric_fused: obs buffers");
+  if (n_steps == 0) return MDS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid = grid_for(h->n, kBlock);
+  const double dt = 1.0 / h->cfg.ctrl_freq;
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
+#define MDS_ROLL(RK4, DRAG)                                                                                              \
+  MDS_DISPATCH(h, (k_rollout_geometric<T, S, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t0, dt, n_steps, (S*)h->state, \
+                                                                                 (const T*)h->lem, (T*)h->last_rpm,      \
+                                                                                 (S*)obs_log, (S*)obs_last)))
+  if (rk4 && drag) MDS_ROLL(true, true);
+  else if (rk4) MDS_ROLL(true, false);
+  else if (drag) MDS_ROLL(false, true);
+  else MDS_ROLL(false, false);
+#undef MDS_ROLL
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
 int mds_lemniscate_eval(mds_handle* h, double t, void* des, void* stream) {
   if (!h || !des) return fail(MDS_EINVAL, "mds_lemniscate_eval: null argument");
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_lemniscate_eval: call mds_set_lemniscate first");

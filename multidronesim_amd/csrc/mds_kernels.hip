@@ -242,6 +242,56 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && !RK4) ? MDS_GEOSIMPLE_MI
 }
 
 // ------------------------------------------------------------------------------------
+// Whole-rollout form of the same loop (simulations/EnvGeometric.py:434-473): n_steps control
+// steps in ONE launch.  State and trajectory parameters stay in registers between steps
+// (no per-step 52+28+52 bytes of state traffic), each step's observation rows are streamed
+// to obs_log[k] (the reference's `self.observations.append(obs)`, np.save'd as [T,D,20],
+// EnvGeometric.py:471,553) through the same per-wave LDS transposition.  t advances in
+// double exactly like the host loop (t += CTRL_TIMESTEP).
+// ------------------------------------------------------------------------------------
+template <typename T, typename S, bool RK4, bool DRAG>
+__global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c, const int n, const size_t ld, double t,
+                                                              const double ctrl_dt, const int n_steps, S* __restrict__ state,
+                                                              const T* __restrict__ lem, T* __restrict__ last_rpm,
+                                                              S* __restrict__ obs_log, S* __restrict__ obs_last) {
+  __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = i < n;
+  GeoIn<T> in;
+  T prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4] = {T(0), T(0), T(0), T(0)};
+  if (valid) {
+    load_geo_in<T, S>(state, lem, ld, i, in);
+    if (DRAG)
+      for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
+  }
+  for (int k = 0; k < n_steps; ++k) {
+    T o[kObsDim];
+    const bool want = obs_log != nullptr || (obs_last != nullptr && k == n_steps - 1);
+    if (valid) {
+      T act[4];
+      {
+        const Desired<T> des = lemniscate_local(in.P, t);
+        const M3<T> R = quat_to_rot(in.s.q);
+        const V3<T> ang_v = mul(R, in.s.w);
+        T u[4];
+        geometric_control<T>(c, in.s.p - des.p, R, in.s.v, ang_v, des, u, nullptr);
+        input_to_action(c, u, act);
+      }
+      aviary_step<T, RK4, DRAG>(c, in.s, act, prev, clipped);
+      if (want) pack_obs(in.s, V3<T>{in.P.cx, in.P.cy, in.P.cz}, clipped, o);
+    }
+    if (obs_log != nullptr) write_obs_rows<S, T>(lds, obs_log + (size_t)k * n * kObsDim, n, i, valid, o);
+    if (obs_last != nullptr && k == n_steps - 1) write_obs_rows<S, T>(lds, obs_last, n, i, valid, o);
+    t += ctrl_dt;
+  }
+  if (valid) {
+    store_state<S, T>(state, ld, i, in.s);
+    if (DRAG)
+      for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = prev[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // fp32 hot path of the fused step: persistent waves + LDS-DMA input staging.
 //
 // Every wave owns a 5 KiB LDS slice holding the 20 input words (13 state + 7 trajectory) of

@@ -294,6 +294,41 @@ def test_rollout_equals_stepwise_and_substeps_drag_rk4(mds):
             e.close()
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_fused_rollout_equals_stepwise_and_logs_every_step(mds, dtype):
+    """mds_rollout_geometric_fused (one launch, state in registers) == n calls of mds_step_geometric
+    (same templates; two kernels may differ in FMA contraction, so to rounding: 1e-5 / 1e-12; both also match the oracle), and its
+    [T,E,D,20] log holds every intermediate observation; ragged n (3 x 85 = 255)."""
+    atol = 1e-5 if dtype == "float32" else 1e-12
+    E, D, T = 85, 3, 60
+    xyz, rpy, P = H.c2_setup(E, D, phase="c3", yaw_rate=0.3)
+    a = make_env(mds, E, D, xyz, rpy, dtype)
+    b = make_env(mds, E, D, xyz, rpy, dtype)
+    for e in (a, b):
+        e.set_trajectories(P)
+        e.step(mds.torch.zeros((E, D, 4), dtype=e.dtype))
+    t, step_obs = 0.0, []
+    for k in range(T):
+        step_obs.append(a.step_geometric(t).clone())
+        t += a.CTRL_TIMESTEP
+    last, log = b.rollout_geometric_fused(0.0, T, log=True)
+    assert log.shape == (T, E, D, 20)
+    ref = mds.torch.stack(step_obs)
+    assert (log[..., :16] - ref[..., :16]).abs().max().item() < atol
+    assert ((log[..., 16:] - ref[..., 16:]).abs() / ref[..., 16:]).max().item() < atol
+    assert mds.torch.equal(last, log[-1])
+    np.testing.assert_allclose(a.get_state(), b.get_state(), atol=atol)
+    oobs, _ = H.oracle_closed_loop(xyz, rpy, P, T)
+    assert np.abs(np_obs(last)[:, :16] - oobs[:, :16]).max() < (1e-5 if dtype == "float32" else 1e-9)
+    last2, none = b.rollout_geometric_fused(T * b.CTRL_TIMESTEP, 5)          # no log, continues from the stored state
+    for k in range(5):
+        o = a.step_geometric(t)
+        t += a.CTRL_TIMESTEP
+    assert none is None and (last2[..., :16] - o[..., :16]).abs().max().item() < atol
+    a.close()
+    b.close()
+
+
 def test_fp16_storage_is_stable_and_close(mds):
     """fp16 state storage / fp32 arithmetic (config 5) is a throughput configuration: 2^-11
     relative storage rounding.  Gate: stays finite, unit quaternion, tracks the oracle to 5e-2
