@@ -260,6 +260,28 @@ def main(argv=None):
         st = env._cbf_status
         line["roofline"]["kernel"] = "k_cbf_nominal + k_cbf_filter_o2_gi + k_lowlevel_step (3 launches per step; QP is latency/ALU bound)"
         line["cbf_fallback_frac_last_step"] = float((st != 0).float().mean().item())
+    # secondary measurement (same workload, same run): the whole-rollout kernel, 50 control steps per launch with
+    # every step's observation streamed to a [50,n,20] log.  Reported beside the contract's per-step line.
+    if args.workload in ("c2", "c3") and not fused_T and not args.python_loop and args.steps >= 100:
+        T2 = 50
+        log2 = torch.empty((T2, E, D, 20), dtype=env.dtype, device=device)
+        env.rollout_geometric_fused(0.0, T2, log=True, log_out=log2)
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = max(1, min(args.steps, 1000) // T2)
+        e0.record(torch.cuda.current_stream(device))
+        for r_ in range(reps):
+            env.rollout_geometric_fused(r_ * T2 * dt, T2, log=True, log_out=log2)
+        e1.record(torch.cuda.current_stream(device))
+        torch.cuda.synchronize(device)
+        us = e0.elapsed_time(e1) * 1e3 / (reps * T2)
+        us = max_over_ranks(us, world, device)
+        b2 = 80 + 212 / T2
+        line["fused_rollout"] = {"steps_per_launch": T2, "us_per_step": us, "value": n_local * world / (us * 1e-6), "unit": "drone-steps/s",
+                                 "bytes_per_drone_step": b2, "achieved_GBps": b2 * n_local / (us * 1e-6) / 1e9,
+                                 "bound": "VALU (state in registers; only the obs log leaves the chip)",
+                                 "kernel": "k_rollout_geometric<float,float,false,false>"}
+        del log2
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "c4":
         line["cpu_baseline"] = cpu_baseline(D, phase, args.cpu_budget)
     elif rank == 0:

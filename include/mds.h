@@ -222,6 +222,15 @@ int mds_thrust_omega_compute(mds_handle* h, const void* u_dev, const void* obs_d
 /* same with the current BODY rates given directly: rates_dev [n,3] (computeControlFromInput's own signature) */
 int mds_thrust_omega_from_rates(mds_handle* h, const void* u_dev, const void* rates_dev, void* rpm_dev, void* stream);
 
+/* LQROmegaController (control/lqr/lqr_omega_controller.py): K [4,9] row-major is the gain its
+ * compute_gain_matrix() obtains from solve_continuous_are on the host (:53-57). */
+int mds_set_lqr_omega_gain(mds_handle* h, const double K[36]);
+/* LQROmegaController.compute(obs, skip_low_level=True) (:90-119): obs_dev [n,20], des_dev [n,11]
+ * (pos, vel, -, yaw, - of set_desired_trajectory) -> u_dev [n,4] = (F, wx, wy, wz) after cap_u. */
+int mds_lqr_omega_compute(mds_handle* h, const void* obs_dev, const void* des_dev, void* u_dev, void* stream);
+/* nominal controller of mds_step_cbf_geometric: 0 = GeometricControl(return_omegas), 1 = LQROmegaController */
+int mds_cbf_set_nominal(mds_handle* h, int which);
+
 /* One CBF-filtered control step of simulations/CBFTest.py:303-350 for every env (order 2):
  * nominal (force - M G, w_des) from the geometric controller on the handle's trajectories ->
  * ECBF QP -> + M G -> ThrustOmega low level -> env.step.  obs_dev [n,20] holds the CURRENT

@@ -79,6 +79,9 @@ PROTOTYPES = {
     "mds_lowlevel_reset": (C.c_int, [_P, _P]),
     "mds_thrust_omega_compute": (C.c_int, [_P, _P, _P, _P, _P]),
     "mds_thrust_omega_from_rates": (C.c_int, [_P, _P, _P, _P, _P]),
+    "mds_set_lqr_omega_gain": (C.c_int, [_P, _PD]),
+    "mds_lqr_omega_compute": (C.c_int, [_P, _P, _P, _P, _P]),
+    "mds_cbf_set_nominal": (C.c_int, [_P, C.c_int]),
     "mds_step_cbf_geometric": (C.c_int, [_P, C.c_double, _P, _P, _P, _P]),
 }
 

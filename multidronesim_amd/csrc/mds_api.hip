@@ -67,6 +67,10 @@ struct mds_handle {
   void* cbf_xdes;      // S [n,9]
   void* cbf_usafe;     // S [n,4]
   void* ll;            // T [6][ld]: ThrustOmega last_omega3 | integral3
+  bool has_lqr;
+  int cbf_nominal;     // 0 geometric, 1 lqr-omega
+  LqrGain<float> lqr_f;
+  LqrGain<double> lqr_d;
 };
 
 // dispatch on the handle dtype: F32 -> <float,float>, F64 -> <double,double>, F16 -> <float,half_t>
@@ -194,6 +198,8 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   h->pair_ij = nullptr;
   h->obstacles = nullptr;
   h->cbf_unom = h->cbf_xdes = h->cbf_usafe = h->ll = nullptr;
+  h->has_lqr = false;
+  h->cbf_nominal = 0;
   hipError_t e = hipMalloc(&h->state, 13 * h->ld * es);
   if (e == hipSuccess) e = hipMalloc(&h->origin, 3 * h->ld * cs);
   if (e == hipSuccess) e = hipMalloc(&h->last_rpm, 4 * h->ld * cs);
@@ -613,6 +619,39 @@ int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void*
   return MDS_OK;
 }
 
+int mds_set_lqr_omega_gain(mds_handle* h, const double K[36]) {
+  if (!h || !K) return fail(MDS_EINVAL, "mds_set_lqr_omega_gain: null argument");
+  for (int r = 0; r < 4; ++r)
+    for (int k = 0; k < 9; ++k) {
+      h->lqr_d.k[r][k] = K[9 * r + k];
+      h->lqr_f.k[r][k] = (float)K[9 * r + k];
+    }
+  h->has_lqr = true;
+  return MDS_OK;
+}
+
+int mds_lqr_omega_compute(mds_handle* h, const void* obs, const void* des, void* u, void* stream) {
+  if (!h || !obs || !des || !u) return fail(MDS_EINVAL, "mds_lqr_omega_compute: null argument");
+  if (!h->has_lqr) return fail(MDS_ESTATE, "mds_lqr_omega_compute: call mds_set_lqr_omega_gain first");
+  if (!aligned16(u)) return fail(MDS_EALIGN, "mds_lqr_omega_compute: u_dev");
+  hipStream_t st = (hipStream_t)stream;
+  if (h->cfg.dtype == MDS_F64)
+    k_lqr_omega_compute<double, double><<<grid_for(h->n, 256), 256, 0, st>>>(h->cd, h->lqr_d, h->n, (const double*)obs, (const double*)des, (double*)u);
+  else if (h->cfg.dtype == MDS_F32)
+    k_lqr_omega_compute<float, float><<<grid_for(h->n, 256), 256, 0, st>>>(h->cf, h->lqr_f, h->n, (const float*)obs, (const float*)des, (float*)u);
+  else
+    k_lqr_omega_compute<float, half_t><<<grid_for(h->n, 256), 256, 0, st>>>(h->cf, h->lqr_f, h->n, (const half_t*)obs, (const half_t*)des, (half_t*)u);
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_cbf_set_nominal(mds_handle* h, int which) {
+  if (!h || (which != 0 && which != 1)) return fail(MDS_EINVAL, "mds_cbf_set_nominal");
+  if (which == 1 && !h->has_lqr) return fail(MDS_ESTATE, "mds_cbf_set_nominal: call mds_set_lqr_omega_gain first");
+  h->cbf_nominal = which;
+  return MDS_OK;
+}
+
 int mds_lowlevel_reset(mds_handle* h, void* stream) {
   if (!h) return fail(MDS_EINVAL, "mds_lowlevel_reset: null handle");
   MDS_HIP(hipMemsetAsync(h->ll, 0, 6 * h->ld * comp_size(h->cfg.dtype), (hipStream_t)stream));
@@ -655,8 +694,17 @@ int mds_step_cbf_geometric(mds_handle* h, double t, void* obs, int32_t* status, 
     MDS_HIP(hipMalloc(&h->cbf_usafe, (size_t)h->n * 4 * es));
   }
   const dim3 grid = grid_for(h->n, kBlock);
-  MDS_DISPATCH(h, (k_cbf_nominal<T, S><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t, (const S*)h->state, (const T*)h->lem,
-                                                                (S*)h->cbf_unom, (S*)h->cbf_xdes)));
+  if (h->cbf_nominal == 1) {
+    if (h->cfg.dtype == MDS_F64)
+      k_cbf_nominal_lqr<double, double><<<grid, kBlock, 0, st>>>(h->cd, h->lqr_d, h->n, h->ld, t, (const double*)h->state,
+                                                                 (const double*)h->lem, (double*)h->cbf_unom, (double*)h->cbf_xdes);
+    else
+      k_cbf_nominal_lqr<float, float><<<grid, kBlock, 0, st>>>(h->cf, h->lqr_f, h->n, h->ld, t, (const float*)h->state,
+                                                               (const float*)h->lem, (float*)h->cbf_unom, (float*)h->cbf_xdes);
+  } else {
+    MDS_DISPATCH(h, (k_cbf_nominal<T, S><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t, (const S*)h->state, (const T*)h->lem,
+                                                                  (S*)h->cbf_unom, (S*)h->cbf_xdes)));
+  }
   int rc = mds_cbf_filter(h, obs, h->cbf_xdes, h->cbf_unom, h->cbf_usafe, status, stream);
   if (rc != MDS_OK) return rc;
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;

@@ -399,6 +399,43 @@ __global__ __launch_bounds__(kBlock) void k_cbf_nominal(const Consts<T> c, const
   xd[6] = (S)(des.p.x + in.P.cx); xd[7] = (S)(des.p.y + in.P.cy); xd[8] = (S)(des.p.z + in.P.cz);
 }
 
+// Same role with the LQR-omega nominal controller the reference's CBFTest actually instantiates
+// (simulations/CBFTest.py:290-293, control/lqr/lqr_omega_controller.py:90-119).
+template <typename T, typename S>
+__global__ __launch_bounds__(kBlock) void k_cbf_nominal_lqr(const Consts<T> c, const LqrGain<T> K, const int n, const size_t ld,
+                                                            const double t, const S* __restrict__ state,
+                                                            const T* __restrict__ lem, S* __restrict__ unom,
+                                                            S* __restrict__ xdes) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  GeoIn<T> in;
+  load_geo_in<T, S>(state, lem, ld, i, in);
+  const Desired<T> des = lemniscate_local(in.P, t);
+  const V3<T> rpy = euler_from_quat(in.s.q);
+  T u[4];
+  lqr_omega_control<T>(c, K, rpy, in.s.v, in.s.p, des.p, des.v, des.yaw, u);      // local frame: the centre cancels in p - p_des
+  const T un[4] = {u[0] - c.gravity, u[1], u[2], u[3]};                            // CBFTest.py:339
+  store4<S, T>(unom + (size_t)i * 4, un);
+  S* xd = xdes + (size_t)i * 9;
+  xd[0] = (S)0; xd[1] = (S)0; xd[2] = (S)des.yaw;
+  xd[3] = (S)des.v.x; xd[4] = (S)des.v.y; xd[5] = (S)des.v.z;
+  xd[6] = (S)(des.p.x + in.P.cx); xd[7] = (S)(des.p.y + in.P.cy); xd[8] = (S)(des.p.z + in.P.cz);
+}
+
+// LQROmegaController.compute(obs, skip_low_level=True): obs [n,20], des [n,11] -> u [n,4]
+template <typename T, typename S>
+__global__ void k_lqr_omega_compute(const Consts<T> c, const LqrGain<T> K, const int n, const S* __restrict__ obs,
+                                    const S* __restrict__ des, S* __restrict__ u_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const S* o = obs + (size_t)i * 20;
+  const S* d = des + (size_t)i * 11;
+  T u[4];
+  lqr_omega_control<T>(c, K, V3<T>{(T)o[7], (T)o[8], (T)o[9]}, V3<T>{(T)o[10], (T)o[11], (T)o[12]}, V3<T>{(T)o[0], (T)o[1], (T)o[2]},
+                       V3<T>{(T)d[0], (T)d[1], (T)d[2]}, V3<T>{(T)d[3], (T)d[4], (T)d[5]}, (T)d[9], u);
+  store4<S, T>(u_out + (size_t)i * 4, u);
+}
+
 template <typename T, typename S, bool RK4, bool DRAG>
 __global__ __launch_bounds__(kBlock) void k_lowlevel_step(const Consts<T> c, const int n, const size_t ld, const T ctrl_dt,
                                                           const T thrust_offset, S* __restrict__ state,

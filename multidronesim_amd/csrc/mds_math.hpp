@@ -46,6 +46,8 @@ MDS_HD double m_sqrt(double x) { return sqrt(x); }
 MDS_HD double m_rsqrt(double x) { return 1.0 / sqrt(x); }
 MDS_HD float m_fma(float a, float b, float c) { return fmaf(a, b, c); }
 MDS_HD double m_fma(double a, double b, double c) { return fma(a, b, c); }
+MDS_HD float m_rint(float x) { return rintf(x); }
+MDS_HD double m_rint(double x) { return rint(x); }
 MDS_HD float m_abs(float x) { return fabsf(x); }
 MDS_HD double m_abs(double x) { return fabs(x); }
 MDS_HD double m_atan2(double y, double x) { return atan2(y, x); }
@@ -419,9 +421,11 @@ template <typename T> MDS_HD Desired<T> lemniscate_local(const LemniscateParams<
   const T inv3 = m_rcp(e * e * e);
   const T aw2 = aw * P.omega;
   d.a = {T(4) * aw2 * sin2 * (T(3) * cos2 + T(7)) * inv3, aw2 * c * (T(44) * cos2 + cos4 - T(21)) * inv3, T(0)};
-  const T ph = reduced_phase<T>(t, P.yaw_rate, T(0));
-  T sy, cy;
-  m_sincos(ph, &sy, &cy);
+  T sy = T(0), cy = T(1);
+  if (P.yaw_rate != T(0)) {   // sin 0 = 0, cos 0 = 1 exactly: skipping is bitwise neutral, and wave-uniform in C2/C3
+    const T ph = reduced_phase<T>(t, P.yaw_rate, T(0));
+    m_sincos(ph, &sy, &cy);
+  }
   d.yaw = T(3.14159265358979323846) * sy;
   d.yaw_rate = T(3.14159265358979323846) * P.yaw_rate * cy;
   return d;
@@ -485,8 +489,8 @@ MDS_HD void geometric_control(const Consts<T>& c, V3<T> p_rel, const M3<T>& R, V
     inv_fn = m_rsqrt(f2);
   }
   const T fbz = dot(col(R, 2), f_w);                                    // (R^T f_w).z  (:85)
-  T sy, cy;
-  m_sincos(des.yaw, &sy, &cy);
+  T sy = T(0), cy = T(1);
+  if (des.yaw != T(0)) m_sincos(des.yaw, &sy, &cy);                     // exact at 0, skipped when the whole wave has yaw 0
   const V3<T> b1c = {cy, sy, T(0)};                                     // :88
   const V3<T> b3d = inv_fn * f_w;
   const V3<T> c1 = cross(b3d, b1c);
@@ -566,6 +570,36 @@ MDS_HD void thrust_omega_control(const Consts<T>& c, T ctrl_dt, const T u[4], V3
     pwm[3] = pwm_thrust + (-tx + tz);
   }
   for (int i = 0; i < 4; ++i) rpm[i] = m_fma(kScale, m_clamp(pwm[i], kMinPwm, kMaxPwm), kConst);   // :130-132
+}
+
+// ------------------------------------------------------------------------------------
+// control/lqr/lqr_omega_controller.py:90-119: u = -K e + [M G,0,0,0], cap_u.  x = [rpy, vel, pos]
+// (obs_to_lin_model dim 9).  R_eq^T R(rpy) = Rz(yaw - yaw_des) Ry Rx, so the 'xyz' euler error
+// is (roll, pitch, wrap(yaw - yaw_des)); position / velocity errors are rotated by Rz(yaw_des)^T.
+// ------------------------------------------------------------------------------------
+template <typename T> struct LqrGain {
+  T k[4][9];
+};
+template <typename T>
+MDS_HD void lqr_omega_control(const Consts<T>& c, const LqrGain<T>& K, V3<T> rpy, V3<T> vel, V3<T> pos, V3<T> pos_des, V3<T> vel_des,
+                              T yaw_des, T u[4]) {
+  T e[9];
+  e[0] = rpy.x;
+  e[1] = rpy.y;
+  const T dy = rpy.z - yaw_des;
+  e[2] = m_fma(T(-6.283185307179586476925), m_rint(dy * T(0.15915494309189533577)), dy);
+  T sy, cy;
+  m_sincos(reduced_phase<T>(0.0, T(0), yaw_des), &sy, &cy);
+  const V3<T> dv = vel - vel_des, dp = pos - pos_des;
+  e[3] = cy * dv.x + sy * dv.y; e[4] = -sy * dv.x + cy * dv.y; e[5] = dv.z;
+  e[6] = cy * dp.x + sy * dp.y; e[7] = -sy * dp.x + cy * dp.y; e[8] = dp.z;
+  for (int r = 0; r < 4; ++r) {
+    T acc = T(0);
+    for (int k = 0; k < 9; ++k) acc = m_fma(-K.k[r][k], e[k], acc);
+    u[r] = acc;
+  }
+  u[0] += c.gravity;                                                                      // :111
+  u[0] = m_clamp(u[0], T(4) * c.min_motor_thrust, c.max_motor_thrust);                    // cap_u :116-119
 }
 
 // model/dynamics.py:83-106: (state18, u4) -> 12 floats (x_dot = v, "R_dot" = w, v_dot, w_dot)

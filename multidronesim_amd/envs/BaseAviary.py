@@ -301,6 +301,11 @@ class BaseAviary:
         self.step_counter += n_steps * self.PYB_STEPS_PER_CTRL
         return self._obs, log_out
 
+    def set_cbf_nominal(self, which: str):
+        """Nominal controller of ``step_cbf_geometric``: "geometric" (GeometricControl return_omegas)
+        or "lqr_omega" (LQROmegaController, needs one constructed on this env first)."""
+        capi.check(self._lib.mds_cbf_set_nominal(self._h, {"geometric": 0, "lqr_omega": 1}[which]), "mds_cbf_set_nominal")
+
     def step_cbf_geometric(self, t: float, tracker, x_obs=None, obs_r_list=None, return_action: bool = False):
         """One CBF-filtered control step of simulations/CBFTest.py:303-350 for every env: geometric
         nominal (force - M G, w_des) -> ``tracker`` (DroneQPTracker) ECBF QP -> ThrustOmega low level

@@ -497,6 +497,54 @@ class ThrustOmegaOracle:
 
 
 # --------------------------------------------------------------------------------------
+# f-3: control/lqr/lqr_omega_controller.py:12-57 (gain), :90-119 (compute, cap_u)
+# --------------------------------------------------------------------------------------
+
+
+def linear_omega_AB(c: DroneConsts = CF2P):
+    """model/linear_omega.py:46-53."""
+    A = np.zeros((9, 9))
+    B = np.zeros((9, 4))
+    A[6:, 3:6] = np.eye(3)
+    A[3, 1] = c.G
+    A[4, 0] = -c.G
+    B[5, 0] = 1.0 / c.M
+    B[:3, 1:] = np.eye(3)
+    return A, B
+
+
+def lqr_omega_gain(c: DroneConsts = CF2P):
+    """LQROmegaController.__init__/compute_gain_matrix (:12-57): Bryson weights, continuous ARE."""
+    import scipy.linalg as la
+    R = np.diag([1 / c.MAX_THRUST ** 2, 1 / 0.1 ** 2, 1 / 0.1 ** 2, 1 / 0.1 ** 2])
+    Q = np.diag([1 / (np.pi / 20) ** 2] * 2 + [1 / (np.pi / 40) ** 2] + [1 / 0.15 ** 2] * 3 + [1 / 0.05 ** 2] * 3)
+    A, B = linear_omega_AB(c)
+    P = la.solve_continuous_are(A, B, Q, R, e=None, s=None, balanced=True)
+    return la.solve(R, B.T @ P)
+
+
+def lqr_omega_compute(obs, pos_des, vel_des, yaw_des, K, c: DroneConsts = CF2P):
+    """LQROmegaController.compute(obs, skip_low_level=True) (:90-119) -> u = [F, wx, wy, wz] after cap_u.
+    R_eq^T R(rpy) = Rz(yaw - yaw_des) Ry Rx, so its 'xyz' euler angles are (roll, pitch, wrap(yaw - yaw_des))."""
+    obs = np.asarray(obs, dtype=np.float64)
+    x = obs_to_lin_model(obs, 9, c)
+    yd = np.asarray(yaw_des, dtype=np.float64)
+    e = x.copy()
+    dy = x[..., 2] - yd
+    e[..., 2] = np.arctan2(np.sin(dy), np.cos(dy))
+    cy, sy = np.cos(yd), np.sin(yd)
+
+    def rot_eqT(v):     # R_eq^T v, R_eq = Rz(yaw_des)
+        return np.stack([cy * v[..., 0] + sy * v[..., 1], -sy * v[..., 0] + cy * v[..., 1], v[..., 2]], axis=-1)
+    e[..., 6:9] = rot_eqT(x[..., 6:9] - np.asarray(pos_des, dtype=np.float64))
+    e[..., 3:6] = rot_eqT(x[..., 3:6] - np.asarray(vel_des, dtype=np.float64))
+    u = -np.einsum("ij,...j->...i", K, e)
+    u[..., 0] += c.M * c.G
+    u[..., 0] = np.clip(u[..., 0], 4 * (9440.3 ** 2 * c.KF), c.MAX_THRUST)
+    return u
+
+
+# --------------------------------------------------------------------------------------
 # a5: model/dynamics.py:83-106
 # --------------------------------------------------------------------------------------
 

@@ -350,6 +350,43 @@ def mint_thrust_omega():
           "max", int((rpm >= 0.2685 * 65535 + 4070.3 - 1e-9).sum()))
 
 
+def mint_lqr_omega(ref):
+    """control/lqr/lqr_omega_controller.py: gain matrix and compute(obs, skip_low_level=True).  Its import of
+    control.low_level.thrust_omega_ctrl needs the stubbed [UPSTREAM] BaseControl registered by mint_thrust_omega()."""
+    m = types.ModuleType("model")
+    m.__path__ = [REF + "/model"]
+    sys.modules["model"] = m
+    sys.modules["model.linear_omega"] = ref["lin_o"]
+    sys.modules["utils.model_conversions"] = ref["mc"]
+    ll = types.ModuleType("control.low_level")
+    ll.__path__ = [REF + "/control/low_level"]
+    sys.modules["control.low_level"] = ll
+    load("control.low_level.thrust_omega_ctrl", REF + "/control/low_level/thrust_omega_ctrl.py")
+    lq = types.ModuleType("control.lqr")
+    lq.__path__ = [REF + "/control/lqr"]
+    sys.modules["control.lqr"] = lq
+    mod = load("control.lqr.lqr_omega_controller", REF + "/control/lqr/lqr_omega_controller.py")
+    env = make_env()
+    from enum import Enum
+    env.DRONE_MODEL = sys.modules["gym_pybullet_drones.utils.enums"].DroneModel("cf2p")
+    ctrl = mod.LQROmegaController(env, ref["lin_o"].LinearizedOmegaModel(env), None)
+    rng = np.random.default_rng(6)
+    n = 192
+    obs = random_obs(rng, n, np.array([0.3, -0.2, 0.8]), np.zeros(3), euler_max=0.5, pos_noise=0.4, vel_noise=0.4)
+    obs[:, 9] = rng.uniform(-3.1, 3.1, size=n)                      # yaw over the full circle (wrap of yaw - yaw_des)
+    pos_d = np.array([0.3, -0.2, 0.8]) + rng.normal(size=(n, 3)) * 0.2
+    vel_d = rng.normal(size=(n, 3)) * 0.3
+    yaw_d = rng.uniform(-3.1, 3.1, size=n)
+    pos_d[:16] += np.array([0, 0, 3.0])                              # thrust cap high
+    pos_d[16:32] -= np.array([0, 0, 3.0])                            # thrust cap low
+    u = np.zeros((n, 4))
+    for i in range(n):
+        ctrl.set_desired_trajectory(0, pos_d[i], vel_d[i], np.zeros(3), yaw_d[i], 0.0)
+        _, u[i] = ctrl.compute(obs[i].copy(), skip_low_level=True)
+    np.savez_compressed(OUT + "/lqr_omega.npz", K=ctrl.K, obs=obs, pos_d=pos_d, vel_d=vel_d, yaw_d=yaw_d, u=u, **META)
+    print("lqr_omega K", ctrl.K.shape, "u0 range", u[:, 0].min(), u[:, 0].max())
+
+
 if __name__ == "__main__":
     ref = load_reference()
     mint_lemniscate(ref)
@@ -358,3 +395,4 @@ if __name__ == "__main__":
     mint_dynamics(ref)
     mint_cbf(ref)
     mint_thrust_omega()
+    mint_lqr_omega(ref)

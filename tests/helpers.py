@@ -72,7 +72,7 @@ def open_loop_setup(n, seed=1, tilt=0.02):
 
 
 def oracle_cbf_closed_loop(xyz, rpy, P, steps, Kcbf, umax, safety_radius, zscale, x_obs, obs_r, pyb_freq=100, ctrl_freq=100,
-                           consts=O.CF2P):
+                           consts=O.CF2P, nominal="geometric"):
     """simulations/CBFTest.py:303-350 on the oracle, per env: geometric nominal (return_omegas) ->
     u_hat = (force - M G, w_des), xdes = [0,0,yaw, vel, pos] -> ECBF QP (fallback to nominal) ->
     + M G -> ThrustOmega low level -> env.step.  Returns (obs [E,D,20], status history [steps,E])."""
@@ -81,13 +81,18 @@ def oracle_cbf_closed_loop(xyz, rpy, P, steps, Kcbf, umax, safety_radius, zscale
     Pf = P.reshape(-1, 7)
     ora = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), consts, pyb_freq, ctrl_freq)
     ll = O.ThrustOmegaOracle(n, consts)
+    Klqr = O.lqr_omega_gain(consts) if nominal == "lqr_omega" else None
     obs = ora.step(np.zeros((n, 4)))
     t = 0.0
     hist = []
     for k in range(steps):
         pos, vel, acc, yaw, yd = O.lemniscate(t, Pf[:, 0], Pf[:, 1], Pf[:, 2:5], Pf[:, 5], Pf[:, 6])
-        force, w_des, _ = O.geometric_compute(obs, pos, vel, acc, yaw, yd, consts, return_omegas=True)
-        unom = np.concatenate([(force - consts.M * consts.G)[:, None], w_des], axis=1)
+        if nominal == "lqr_omega":       # simulations/CBFTest.py:290-293, :339
+            unom = O.lqr_omega_compute(obs, pos, vel, yaw, Klqr, consts)
+            unom[:, 0] -= consts.M * consts.G
+        else:
+            force, w_des, _ = O.geometric_compute(obs, pos, vel, acc, yaw, yd, consts, return_omegas=True)
+            unom = np.concatenate([(force - consts.M * consts.G)[:, None], w_des], axis=1)
         xdes = np.concatenate([np.zeros((n, 2)), yaw[:, None], vel, pos], axis=1)
         x = O.obs_to_lin_model(obs, 9)
         usafe = np.zeros((n, 4))

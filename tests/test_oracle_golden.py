@@ -137,3 +137,14 @@ def test_thrust_omega_matches_reference(model):
     np.testing.assert_allclose(ctl.integral, d[f"{model}_integral"], atol=1e-14)
     lo, hi = 0.2685 * 20000 + 4070.3, 0.2685 * 65535 + 4070.3
     assert (np.abs(rpm - lo) < 1e-9).sum() > 10                      # MIN_PWM clip exercised (MAX_PWM is barely reachable: torque clip 3200)
+
+
+def test_lqr_omega_matches_reference():
+    """control/lqr/lqr_omega_controller.py: ARE gain and compute(obs, skip_low_level=True) incl. cap_u."""
+    d = load("lqr_omega.npz")
+    K = O.lqr_omega_gain(O.CF2P)
+    np.testing.assert_allclose(K, d["K"], rtol=1e-8, atol=1e-10)
+    u = O.lqr_omega_compute(d["obs"], d["pos_d"], d["vel_d"], d["yaw_d"], d["K"])
+    np.testing.assert_allclose(u, d["u"], rtol=1e-10, atol=1e-10)
+    lo, hi = 4 * 9440.3 ** 2 * O.CF2P.KF, O.CF2P.MAX_THRUST
+    assert (np.abs(d["u"][:, 0] - lo) < 1e-12).sum() >= 8 and (np.abs(d["u"][:, 0] - hi) < 1e-12).sum() >= 8
