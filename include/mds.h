@@ -204,7 +204,8 @@ int mds_cbf_rows(mds_handle* h, const void* x_dev, const void* xdes_dev, void* G
  * obs_dev [n,20], xdes_dev [n,xdim], u_nominal_dev [n,4] (thrust already offset by -M*G,
  * simulations/CBFTest.py:339) -> u_safe_dev [n,4]; status_dev [E] int32: 0 = QP solved,
  * 1 = no solution within the cap -> that env's u_safe is u_nominal unchanged
- * (qptracker.py:30-34).  Order 2 only (order 3 returns MDS_EUNSUPPORTED). */
+ * (qptracker.py:30-34).  Order 2: D coupled thrust variables, omega box-clipped.  Order 3: 3D coupled
+ * (yank, wx, wy) variables (<= 63), omega_z clipped to its box / force-box interval. */
 int mds_cbf_filter(mds_handle* h, const void* obs_dev, const void* xdes_dev, const void* u_nominal_dev, void* u_safe_dev,
                    int32_t* status_dev, void* stream);
 

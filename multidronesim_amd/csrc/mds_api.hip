@@ -580,41 +580,62 @@ int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void*
                    void* stream) {
   if (!h || !obs || !xdes || !unom || !usafe || !status) return fail(MDS_EINVAL, "mds_cbf_filter: null argument");
   if (!h->has_cbf) return fail(MDS_ESTATE, "mds_cbf_filter: call mds_cbf_configure first");
-  if (h->cbf.order != 2) return fail(MDS_EUNSUPPORTED, "mds_cbf_filter: only the order-2 (omega) model is built");
   hipStream_t st = (hipStream_t)stream;
-  const int E = h->cfg.num_envs, D = h->cfg.num_drones;
-  const int m = D * (D - 1) / 2 + D * h->cbf.n_obs + 2 * D;          // thrust sub-problem rows
+  const int E = h->cfg.num_envs, D = h->cfg.num_drones, order = h->cbf.order;
+  const int nv = order == 2 ? 1 : 3, n = nv * D;
+  const int m = D * (D - 1) / 2 + D * h->cbf.n_obs + 2 * n;          // rows of the coupled sub-problem
   const int R = (m + 63) / 64;
   const int max_iter = h->cbf.max_iter > 0 ? h->cbf.max_iter : 64 * m;
-  const dim3 grid((unsigned)((E + 3) / 4));
-  const char* solver = getenv("MDS_CBF_SOLVER");          // "hildreth" selects the coordinate-ascent kernel (A/B)
-  const bool hildreth = solver && solver[0] == 'h';
-#define MDS_CBF_LAUNCH(T, CP, RR, TOL)                                                                                      \
-  do {                                                                                                                      \
-    if (hildreth)                                                                                                           \
-      k_cbf_filter_o2<T, T, RR><<<grid, 256, 0, st>>>(CP, E, h->pair_ij, (const T*)h->obstacles, (const T*)obs,              \
-                                                      (const T*)xdes, (const T*)unom, (T*)usafe, (int*)status, max_iter,    \
-                                                      (T)((TOL) * (TOL)));                                                  \
-    else if (D <= 16)                                                                                                       \
-      k_cbf_filter_o2_gi<T, T, RR, 16><<<grid, 256, 0, st>>>(CP, E, h->pair_ij, (const T*)h->obstacles, (const T*)obs,       \
-                                                             (const T*)xdes, (const T*)unom, (T*)usafe, (int*)status,       \
-                                                             max_iter, (T)((TOL) * (TOL)));                                 \
-    else                                                                                                                    \
-      k_cbf_filter_o2_gi<T, T, RR, 32><<<grid, 256, 0, st>>>(CP, E, h->pair_ij, (const T*)h->obstacles, (const T*)obs,       \
-                                                             (const T*)xdes, (const T*)unom, (T*)usafe, (int*)status,       \
-                                                             max_iter, (T)((TOL) * (TOL)));                                 \
-  } while (0)
-#define MDS_CBF_DISPATCH(T, CP, TOL)                    \
-  do {                                                  \
-    if (R <= 4) MDS_CBF_LAUNCH(T, CP, 4, TOL);          \
-    else if (R <= 8) MDS_CBF_LAUNCH(T, CP, 8, TOL);     \
-    else MDS_CBF_LAUNCH(T, CP, 17, TOL);                \
-  } while (0)
+  const dim3 grid((unsigned)((E + 3) / 4));                // Hildreth kernel: 4 envs per workgroup
+  const char* solver = getenv("MDS_CBF_SOLVER");          // "hildreth" selects the coordinate-ascent kernel (order 2, A/B)
+  const bool hildreth = solver && solver[0] == 'h' && order == 2;
+  if (n > 64) return fail(MDS_EUNSUPPORTED, "mds_cbf_filter: more than 64 coupled QP variables per env");
   if (R > 17) return fail(MDS_EUNSUPPORTED, "mds_cbf_filter: too many rows per env");
-  if (h->cfg.dtype == MDS_F64) MDS_CBF_DISPATCH(double, h->cbf_d, h->cbf.tol > 0 ? h->cbf.tol : 1e-12);
-  else MDS_CBF_DISPATCH(float, h->cbf_f, h->cbf.tol > 0 ? h->cbf.tol : 1e-6);
-#undef MDS_CBF_DISPATCH
-#undef MDS_CBF_LAUNCH
+  // WPB (envs per workgroup) shrinks with the LDS footprint of Q, R: 2 * NMAX * (NMAX+1) * sizeof(T) per env
+#define MDS_GI(T, CP, RR, NMAX, ORD, WPB, TOL)                                                                               \
+  k_cbf_filter_gi<T, T, RR, NMAX, ORD, WPB><<<dim3((unsigned)((E + WPB - 1) / WPB)), 64 * WPB, 0, st>>>(                      \
+      CP, E, (T)h->cfg.KF, h->pair_ij, (const T*)h->obstacles, (const T*)obs, (const T*)xdes, (const T*)unom, (T*)usafe,      \
+      (int*)status, max_iter, (T)((TOL) * (TOL)))
+#define MDS_GI_R(T, CP, NMAX, ORD, WPB, TOL)            \
+  do {                                                  \
+    if (R <= 4) MDS_GI(T, CP, 4, NMAX, ORD, WPB, TOL);  \
+    else if (R <= 8) MDS_GI(T, CP, 8, NMAX, ORD, WPB, TOL); \
+    else MDS_GI(T, CP, 17, NMAX, ORD, WPB, TOL);        \
+  } while (0)
+#define MDS_GI_ALL(T, CP, TOL)                                                        \
+  do {                                                                                \
+    if (order == 2) {                                                                 \
+      if (n <= 16) MDS_GI_R(T, CP, 16, 2, 4, TOL);                                    \
+      else MDS_GI_R(T, CP, 32, 2, 4, TOL);                                            \
+    } else {                                                                          \
+      if (n <= 24) MDS_GI_R(T, CP, 24, 3, 4, TOL);                                    \
+      else if (n <= 48) MDS_GI_R(T, CP, 48, 3, (sizeof(T) == 4 ? 2 : 1), TOL);        \
+      else MDS_GI_R(T, CP, 63, 3, 1, TOL);                                            \
+    }                                                                                 \
+  } while (0)
+#define MDS_HILD(T, CP, RR, TOL)                                                                                          \
+  k_cbf_filter_o2<T, T, RR><<<grid, 256, 0, st>>>(CP, E, h->pair_ij, (const T*)h->obstacles, (const T*)obs, (const T*)xdes, \
+                                                  (const T*)unom, (T*)usafe, (int*)status, max_iter, (T)((TOL) * (TOL)))
+#define MDS_HILD_R(T, CP, TOL)              \
+  do {                                      \
+    if (R <= 4) MDS_HILD(T, CP, 4, TOL);    \
+    else if (R <= 8) MDS_HILD(T, CP, 8, TOL); \
+    else MDS_HILD(T, CP, 17, TOL);          \
+  } while (0)
+  if (h->cfg.dtype == MDS_F64) {
+    const double tol = h->cbf.tol > 0 ? h->cbf.tol : 1e-12;
+    if (hildreth) MDS_HILD_R(double, h->cbf_d, tol);
+    else MDS_GI_ALL(double, h->cbf_d, tol);
+  } else {
+    const double tol = h->cbf.tol > 0 ? h->cbf.tol : 1e-6;
+    if (hildreth) MDS_HILD_R(float, h->cbf_f, tol);
+    else MDS_GI_ALL(float, h->cbf_f, tol);
+  }
+#undef MDS_HILD_R
+#undef MDS_HILD
+#undef MDS_GI_ALL
+#undef MDS_GI_R
+#undef MDS_GI
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }
@@ -684,7 +705,7 @@ int mds_step_cbf_geometric(mds_handle* h, double t, void* obs, int32_t* status, 
   if (!h || !obs || !status) return fail(MDS_EINVAL, "mds_step_cbf_geometric: null argument");
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_step_cbf_geometric: call mds_set_lemniscate first");
   if (!h->has_cbf) return fail(MDS_ESTATE, "mds_step_cbf_geometric: call mds_cbf_configure first");
-  if (h->cbf.order != 2) return fail(MDS_EUNSUPPORTED, "mds_step_cbf_geometric: order 2 only");
+  if (h->cbf.order != 2) return fail(MDS_EUNSUPPORTED, "mds_step_cbf_geometric: order 2 only (the order-3 loop needs the yank low-level controller)");
   if (!aligned16(obs) || !aligned16(action)) return fail(MDS_EALIGN, "mds_step_cbf_geometric: obs_dev/action_dev");
   hipStream_t st = (hipStream_t)stream;
   const size_t es = elem_size(h->cfg.dtype);

@@ -267,24 +267,29 @@ template <> struct GiEps<float> {
   static constexpr float z = 1e-9f, r = 1e-6f, inf = 3.0e38f;
 };
 template <> struct GiEps<double> {
-  static constexpr double z = 1e-20, r = 1e-12, inf = 1.0e300;
+  static constexpr double z = 1e-16, r = 1e-12, inf = 1.0e300;
 };
 
-// NMAX = compile-time bound on drones per env (LDS footprint of Q, R scales with NMAX^2)
-template <typename T, typename S, int R, int NMAX>
-__global__ __launch_bounds__(256) void k_cbf_filter_o2_gi(const CbfParams<T> P, const int E, const int* __restrict__ pair_ij,
-                                                          const T* __restrict__ obstacles, const S* __restrict__ obs,
-                                                          const S* __restrict__ xdes, const S* __restrict__ unom,
-                                                          S* __restrict__ usafe, int* __restrict__ status, const int max_iter,
-                                                          const T tol2) {
+// NV = QP variables per agent (order 2: thrust only -> 1; order 3: yank, wx, wy -> 3, wz is box-only),
+// NMAX = compile-time bound on the number of QP variables n = NV * D (LDS footprint of Q, R ~ NMAX^2).
+// WPB = wavefronts (= envs) per workgroup, chosen so that the LDS slices fit 160 KiB
+template <typename T, typename S, int R, int NMAX, int ORDER, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_cbf_filter_gi(const CbfParams<T> P, const int E, const T kf, const int* __restrict__ pair_ij,
+                                                       const T* __restrict__ obstacles, const S* __restrict__ obs,
+                                                       const S* __restrict__ xdes, const S* __restrict__ unom,
+                                                       S* __restrict__ usafe, int* __restrict__ status, const int max_iter,
+                                                       const T tol2) {
+  constexpr int NV = ORDER == 2 ? 1 : 3;
+  constexpr int XD = ORDER == 2 ? 9 : 10;
   constexpr int kQS = NMAX + 1;     // padded LDS row stride (conflict-free column walks)
-  __shared__ T sx[4][NMAX][9], sxd[4][NMAX][9];
-  __shared__ T su_[4][NMAX], sd_[4][NMAX], slam_[4][NMAX];
-  __shared__ T sQ_[4][NMAX][kQS], sR_[4][NMAX][kQS];
-  __shared__ int sact_[4][NMAX];
-  __shared__ __align__(16) S sraw[4][NMAX * 20];            // the env's observation rows, loaded coalesced
+  constexpr int DMAX = NMAX / NV;
+  __shared__ T sx[WPB][DMAX][XD], sxd[WPB][DMAX][XD];
+  __shared__ T su_[WPB][NMAX], sd_[WPB][NMAX], slam_[WPB][NMAX];
+  __shared__ T sQ_[WPB][NMAX][kQS], sR_[WPB][NMAX][kQS];
+  __shared__ int sact_[WPB][NMAX];
+  __shared__ __align__(16) S sraw[WPB][DMAX * 20];            // the env's observation rows, loaded coalesced
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int env = blockIdx.x * 4 + wave;
+  const int env = blockIdx.x * WPB + wave;
   if (env >= E) return;                                    // wave-uniform
   T* su = su_[wave];
   T* sd = sd_[wave];
@@ -292,70 +297,101 @@ __global__ __launch_bounds__(256) void k_cbf_filter_o2_gi(const CbfParams<T> P, 
   T(*sQ)[kQS] = sQ_[wave];
   T(*sR)[kQS] = sR_[wave];
   int* sact = sact_[wave];
-  const int D = P.num_drones, n = D;
+  const int D = P.num_drones, n = NV * D;
   const size_t base = (size_t)env * D;
-  // an env's D x 20 observation block, its D x 9 xdes block and D x 4 nominal block are contiguous
+  // an env's D x 20 observation block, its D x xdim xdes block and D x 4 nominal block are contiguous
   for (int k = lane; k < D * 20; k += 64) sraw[wave][k] = obs[base * 20 + k];
-  for (int k = lane; k < D * 9; k += 64) sxd[wave][k / 9][k % 9] = (T)xdes[base * 9 + k];
+  for (int k = lane; k < D * XD; k += 64) sxd[wave][k / XD][k % XD] = (T)xdes[base * XD + k];
   MDS_WAVE_SYNC();
-  for (int d = lane; d < D; d += 64) {       // obs_to_lin_model(obs, dim=9): [rpy, vel, pos] (model_conversions.py:36-48)
+  bool bad = false;
+  for (int d = lane; d < D; d += 64) {       // obs_to_lin_model(obs, dim = 9 | 10) (model_conversions.py:20-58)
     const S* o = &sraw[wave][d * 20];
     T* x = sx[wave][d];
     x[0] = (T)o[7]; x[1] = (T)o[8]; x[2] = (T)o[9];
-    x[3] = (T)o[10]; x[4] = (T)o[11]; x[5] = (T)o[12];
-    x[6] = (T)o[0]; x[7] = (T)o[1]; x[8] = (T)o[2];
-    su[d] = (T)unom[(base + d) * 4];
+    if (ORDER == 3) {
+      const T r0 = (T)o[16], r1 = (T)o[17], r2 = (T)o[18], r3 = (T)o[19];
+      x[3] = kf * (r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);                                  // calc_z_thrust (:137-143)
+    }
+    x[XD - 6] = (T)o[10]; x[XD - 5] = (T)o[11]; x[XD - 4] = (T)o[12];
+    x[XD - 3] = (T)o[0]; x[XD - 2] = (T)o[1]; x[XD - 1] = (T)o[2];
+    for (int k = 0; k < NV; ++k) su[NV * d + k] = (T)unom[(base + d) * 4 + k];
   }
   MDS_WAVE_SYNC();
 
-  const int npairs = cbf_num_pairs(D), nobs_rows = D * P.n_obs, m = npairs + nobs_rows + 2 * D;
-  // unit-norm rows: ci u_i + cj u_j <= b
-  T ci[R], cj[R], b[R];
-  int ii[R], jj[R];
+  const int npairs = cbf_num_pairs(D), nobs_rows = D * P.n_obs, m = npairs + nobs_rows + 2 * n;
+  // unit-norm rows:  sum_k ca[k] u[NV ia + k] + cb[k] u[NV ib + k] <= b
+  T ca[R][NV], cb[R][NV], b[R];
+  int ia[R], ib[R];
   bool valid[R], act[R];
-  bool bad = false;
 #pragma unroll
   for (int k = 0; k < R; ++k) {
     const int r = lane + 64 * k;
-    ci[k] = cj[k] = b[k] = T(0);
-    ii[k] = jj[k] = 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) ca[k][v] = cb[k][v] = T(0);
+    b[k] = T(0);
+    ia[k] = ib[k] = 0;
     valid[k] = false;
     act[k] = false;
     if (r < npairs) {
       const int ij = pair_ij[r];
-      ii[k] = ij & 255;
-      jj[k] = ij >> 8;
+      ia[k] = ij & 255;
+      ib[k] = ij >> 8;
       T hr, Lg[4];
-      cbf_pair_row<T, 2>(P, sx[wave][ii[k]], sxd[wave][ii[k]], sx[wave][jj[k]], sxd[wave][jj[k]], false, P.Ds_pair, &hr, Lg);
-      ci[k] = -Lg[0];
-      cj[k] = Lg[0];
+      cbf_pair_row<T, ORDER>(P, sx[wave][ia[k]], sxd[wave][ia[k]], sx[wave][ib[k]], sxd[wave][ib[k]], false, P.Ds_pair, &hr, Lg);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        ca[k][v] = -Lg[v];
+        cb[k][v] = Lg[v];
+      }
       b[k] = hr;
     } else if (r < npairs + nobs_rows) {
       const int q = r - npairs, i = q / P.n_obs, o = q % P.n_obs;
-      T xo[9] = {T(0), T(0), T(0), T(0), T(0), T(0), obstacles[4 * o], obstacles[4 * o + 1], obstacles[4 * o + 2]};
+      T xo[XD];
+#pragma unroll
+      for (int v = 0; v < XD - 3; ++v) xo[v] = T(0);
+      xo[XD - 3] = obstacles[4 * o];
+      xo[XD - 2] = obstacles[4 * o + 1];
+      xo[XD - 1] = obstacles[4 * o + 2];
       T hr, Lg[4];
-      cbf_pair_row<T, 2>(P, sx[wave][i], sxd[wave][i], xo, xo, true, P.safety_radius + obstacles[4 * o + 3], &hr, Lg);
-      ii[k] = jj[k] = i;
-      ci[k] = -Lg[0];
+      cbf_pair_row<T, ORDER>(P, sx[wave][i], sxd[wave][i], xo, xo, true, P.safety_radius + obstacles[4 * o + 3], &hr, Lg);
+      ia[k] = ib[k] = i;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) ca[k][v] = -Lg[v];
       b[k] = hr;
-    } else if (r < m) {
-      const int q = r - npairs - nobs_rows;
-      ii[k] = jj[k] = q % D;
-      ci[k] = q < D ? T(1) : T(-1);
-      b[k] = P.umax[0];
+    } else if (r < m) {                                    // +-u_var <= umax (cbf/cbf.py:400-412)
+      const int q = r - npairs - nobs_rows, var = q % n;
+      ia[k] = ib[k] = var / NV;
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        if (v == var % NV) ca[k][v] = q < n ? T(1) : T(-1);
+      b[k] = P.umax[var % NV];
     }
     if (r < m) {
-      const T n2 = m_fma(ci[k], ci[k], cj[k] * cj[k]);
+      T n2 = T(0);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) n2 = m_fma(ca[k][v], ca[k][v], m_fma(cb[k][v], cb[k][v], n2));
       if (n2 > T(0)) {
         const T inv = T(1) / m_sqrt(n2);
-        ci[k] *= inv;
-        cj[k] *= inv;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          ca[k][v] *= inv;
+          cb[k][v] *= inv;
+        }
         b[k] *= inv;
         valid[k] = true;
       } else if (b[k] < T(0)) {
         bad = true;                                        // 0 * u <= h with h < 0
       }
     }
+  }
+  // order 3: the omega_z input only has box rows, +-umax_3 and the force box written to its column
+  // (custom_force_bound_const, cbf/cbf.py:446-464, quirk kept): a 1-D interval per agent
+  T wz_lo = -P.umax[3], wz_hi = P.umax[3];
+  if (ORDER == 3 && lane < D) {
+    const T F = sx[wave][lane][3];
+    wz_hi = m_min(wz_hi, P.k[2] * (P.Fmax - F));
+    wz_lo = m_max(wz_lo, -(P.k[2] * (F - P.Fmin)));
+    if (wz_lo > wz_hi) bad = true;
   }
   bool converged = false;
   bool infeasible = __any(bad);
@@ -366,7 +402,9 @@ __global__ __launch_bounds__(256) void k_cbf_filter_o2_gi(const CbfParams<T> P, 
     int best_k = 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-      const T res = m_fma(ci[k], su[ii[k]], m_fma(cj[k], su[jj[k]], -b[k]));
+      T res = -b[k];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) res = m_fma(ca[k][v], su[NV * ia[k] + v], m_fma(cb[k][v], su[NV * ib[k] + v], res));
       const T sc = (valid[k] && !act[k] && res > T(0)) ? res * res : T(0);
       if (sc > best) {
         best = sc;
@@ -381,9 +419,21 @@ __global__ __launch_bounds__(256) void k_cbf_filter_o2_gi(const CbfParams<T> P, 
       break;
     }
     const int owner = wrow & 63, kk = wrow >> 6;
-    const T wci = __shfl(pick<T, R>(ci, kk), owner), wcj = __shfl(pick<T, R>(cj, kk), owner), wb = __shfl(pick<T, R>(b, kk), owner);
-    const int wii = __shfl(pick<int, R>(ii, kk), owner), wjj = __shfl(pick<int, R>(jj, kk), owner);
-    const bool two = wjj != wii;
+    T wca[NV], wcb[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      T tca = ca[0][v], tcb = cb[0][v];
+#pragma unroll
+      for (int k = 1; k < R; ++k) {
+        tca = (k == kk) ? ca[k][v] : tca;
+        tcb = (k == kk) ? cb[k][v] : tcb;
+      }
+      wca[v] = __shfl(tca, owner);
+      wcb[v] = __shfl(tcb, owner);
+    }
+    const T wb = __shfl(pick<T, R>(b, kk), owner);
+    const int wia = __shfl(pick<int, R>(ia, kk), owner), wib = __shfl(pick<int, R>(ib, kk), owner);
+    const bool two = wib != wia;
     T lam_new = T(0);
     // ---- bring that row into the active set, dropping blocking rows on the way ----
     while (true) {
@@ -391,14 +441,22 @@ __global__ __launch_bounds__(256) void k_cbf_filter_o2_gi(const CbfParams<T> P, 
         infeasible = true;
         break;
       }
-      const T res = m_fma(wci, su[wii], m_fma(two ? wcj : T(0), su[wjj], -wb));
+      T res = -wb;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) res = m_fma(wca[v], su[NV * wia + v], m_fma(two ? wcb[v] : T(0), su[NV * wib + v], res));
       T dc = T(0);
-      if (lane < q) dc = m_fma(wci, sQ[wii][lane], two ? wcj * sQ[wjj][lane] : T(0));   // d = Q^T a
+      if (lane < q) {                                                                    // d = Q^T a
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dc = m_fma(wca[v], sQ[NV * wia + v][lane], m_fma(two ? wcb[v] : T(0), sQ[NV * wib + v][lane], dc));
+      }
       if (lane < n) sd[lane] = dc;
       MDS_WAVE_SYNC();
       T zv = T(0);                                                                       // z = a - Q d
       if (lane < n) {
-        zv = (lane == wii ? wci : T(0)) + ((two && lane == wjj) ? wcj : T(0));
+        const int ag = lane / NV, vv = lane - ag * NV;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+          if (v == vv) zv = (ag == wia ? wca[v] : T(0)) + ((two && ag == wib) ? wcb[v] : T(0));
         for (int c = 0; c < q; ++c) zv = m_fma(-sQ[lane][c], sd[c], zv);
       }
       const T zz = wave_sum(zv * zv);
@@ -485,14 +543,32 @@ __global__ __launch_bounds__(256) void k_cbf_filter_o2_gi(const CbfParams<T> P, 
       --q;
     }
   }
+  if (converged) {
+    // final certificate: EVERY row (active ones included) holds at the returned point.  Guards the
+    // near-dependent / infeasible corner where a step along a numerically tiny z is taken.
+    T worst = T(0);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      T res = -b[k];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) res = m_fma(ca[k][v], su[NV * ia[k] + v], m_fma(cb[k][v], su[NV * ib[k] + v], res));
+      if (valid[k]) worst = m_max(worst, res);
+    }
+    worst = wave_max(worst);
+    if (worst * worst > T(100) * tol2) converged = false;
+  }
   if (lane == 0) status[env] = converged ? 0 : 1;
   MDS_WAVE_SYNC();
   for (int d = lane; d < D; d += 64) {
     T u[4];
     for (int k = 0; k < 4; ++k) u[k] = (T)unom[(base + d) * 4 + k];
     if (converged) {
-      u[0] = su[d];
-      for (int k = 1; k < 4; ++k) u[k] = m_clamp(u[k], -P.umax[k], P.umax[k]);
+      for (int k = 0; k < NV; ++k) u[k] = su[NV * d + k];
+      if (ORDER == 2) {
+        for (int k = 1; k < 4; ++k) u[k] = m_clamp(u[k], -P.umax[k], P.umax[k]);
+      } else {
+        u[3] = m_clamp(u[3], wz_lo, wz_hi);
+      }
     }
     for (int k = 0; k < 4; ++k) usafe[(base + d) * 4 + k] = (S)u[k];
   }

@@ -706,6 +706,14 @@ def qp_project(uhat, G, h, tol=1e-10, max_iter=None):
     G = np.asarray(G, dtype=np.float64)
     h = np.asarray(h, dtype=np.float64)
     m = G.shape[0]
+    # rows scaled to unit norm (same feasible set, same minimiser; multipliers are returned for the
+    # ORIGINAL rows): keeps the step-length logic well conditioned when |G_k| spans 1e-7..1e2
+    rn = np.sqrt((G * G).sum(axis=1))
+    if np.any((rn == 0) & (h < 0)):
+        return False, None, None                          # 0 * u <= h with h < 0
+    rs = np.where(rn > 0, rn, 1.0)
+    G = G / rs[:, None]
+    h = np.where(rn > 0, h / rs, np.inf)
     if max_iter is None:
         max_iter = 20 * (m + 10)
     u = uhat.copy()
@@ -713,12 +721,12 @@ def qp_project(uhat, G, h, tol=1e-10, max_iter=None):
     lam = np.zeros(0)
     for _ in range(max_iter):
         viol = G @ u - h
-        scale = np.maximum(1.0, np.abs(h))
+        scale = np.maximum(1.0, np.where(np.isfinite(h), np.abs(h), 1.0))
         k = int(np.argmax(viol / scale))
         if viol[k] <= tol * scale[k]:
             full = np.zeros(m)
             full[active] = lam
-            return True, u, full
+            return True, u, full / rs
         # add constraint k: move along z (primal) / r (dual) as in Goldfarb-Idnani with H = I
         gk = G[k]
         lam_k = 0.0

@@ -261,3 +261,67 @@ def test_c4_closed_loop_lqr_nominal_matches_oracle(mds):
         t += env.CTRL_TIMESTEP
     assert np.abs(gobs.double().cpu().numpy()[..., :16] - oobs[..., :16]).max() < 1e-6
     env.close()
+
+
+def c4_scene_o3(E, D, seed=0):
+    """Order-3 (yank-omega, xdim 10) version of the stacked scene: F from the RPM echo of the obs."""
+    obs, xdes9, unom, x_obs, obs_r = c4_scene(E, D, seed=seed, dz=0.75, vz=0.15)   # zscale 2: e_z counts half; stiffer poles
+    rng = np.random.default_rng(seed + 100)
+    obs[..., 16:20] = O.CF2P.HOVER_RPM * (1 + 0.05 * rng.normal(size=(E, D, 4)))
+    xdes = np.zeros((E, D, 10))
+    xdes[..., 0:3] = xdes9[..., 0:3]
+    xdes[..., 3] = O.CF2P.M * O.CF2P.G
+    xdes[..., 4:10] = xdes9[..., 3:9]
+    unom = np.concatenate([rng.normal(size=(E, D, 1)) * 0.2, rng.normal(size=(E, D, 3)) * 4.0], axis=-1)
+    x_obs3 = [np.array([xo[0], [0, 0, 0], [0, 0, 0]]) for xo in x_obs]
+    return obs, xdes, unom, x_obs3, obs_r
+
+
+@pytest.mark.parametrize("D,dtype,tol", [(16, "float64", 1e-7), (16, "float32", 1e-4), (4, "float64", 1e-7), (21, "float32", 1e-4)])
+def test_cbf_filter_order3_matches_oracle_qp(mds, D, dtype, tol):
+    """Order 3 (LinearizedYankOmegaModel, poles of CBFTestOrd3.py:452): 3D coupled variables per env."""
+    E = 24
+    obs, xdes, unom, x_obs, obs_r = c4_scene_o3(E, D, seed=D)
+    env = make_env(mds, E, D, dtype)
+    cbf = mds.DroneCBF(env, [mds.LinearizedYankOmegaModel(env) for _ in range(D)], safety_radius=0.125, zscale=2.0, order=3,
+                       cbf_poles=np.array([-3.0, -3.6, -5.6]))
+    trk = mds.DroneQPTracker(cbf, order=3, num_robots=D, xdim=10, env=env)
+    us, st = trk.compute_control_batched(obs, xdes, unom, x_obs, obs_r)
+    us, st = us.double().cpu().numpy(), st.cpu().numpy()
+    n_active = 0
+    for e in range(E):
+        x = O.obs_to_lin_model(obs[e], 10)
+        u_ref, status = O.cbf_filter(x, xdes[e], unom[e], 3, cbf.Kcbf.reshape(-1), cbf.umax, 0.125, 2.0, O.CF2P, np.array(x_obs), obs_r)
+        assert st[e] == status, (e, st[e], status)
+        if status == 0:
+            np.testing.assert_allclose(us[e], u_ref, atol=tol, rtol=0)
+            n_active += int(np.abs(u_ref[:, :3] - unom[e][:, :3]).max() > 1e-6)
+    assert n_active >= E // 3
+    env.close()
+
+
+@pytest.mark.parametrize("D,n_obs", [(1, 2), (32, 16), (32, 0)])
+def test_cbf_filter_size_limits(mds, D, n_obs):
+    """Edge sizes of the wave-per-env QP: a single drone (no pair rows), and the maxima D = 32, 16 obstacles
+    (1072 rows, 17 per lane)."""
+    E = 6
+    obs, xdes, unom, _, _ = c4_scene(E, D, seed=40 + D)
+    rng = np.random.default_rng(D)
+    x_obs = [np.array([[rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(0.2, 0.6)], [0, 0, 0]]) for _ in range(n_obs)]
+    obs_r = [0.08] * n_obs
+    env = make_env(mds, E, D, "float64")
+    cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2)
+    trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+    us, st = trk.compute_control_batched(obs, xdes, unom, x_obs if n_obs else None, obs_r if n_obs else None)
+    us, st = us.double().cpu().numpy(), st.cpu().numpy()
+    for e in range(E):
+        x = O.obs_to_lin_model(obs[e], 9)
+        u_ref, status = O.cbf_filter(x, xdes[e], unom[e], 2, cbf.Kcbf.reshape(-1), cbf.umax, 0.1, 1.0, O.CF2P,
+                                     np.array(x_obs) if n_obs else None, obs_r if n_obs else None)
+        assert st[e] == status
+        if status == 0:
+            np.testing.assert_allclose(us[e], u_ref, atol=1e-8)
+    env.close()
+    with pytest.raises(Exception):
+        big = make_env(mds, 1, 33, "float32")
+        mds.DroneCBF(big, [mds.LinearizedOmegaModel(big) for _ in range(33)], order=2).configure()
