@@ -51,9 +51,6 @@ struct mds_handle {
   void* lem;           // T [7][ld]
   double* scratch;     // double [n*20] device staging for host<->device set-up calls
   bool has_traj;
-  int num_cus;             // multiProcessorCount of the device
-  int geo_blocks_per_cu;   // persistent-grid width of k_step_geometric (MDS_GEO_BLOCKS_PER_CU overrides)
-  int geo_use_dma;         // fp32/Euler: MDS_GEO_DMA=1 selects the persistent LDS-DMA staged kernel (default: register-staged)
   Consts<float> cf;
   Consts<double> cd;
   // ECBF filter
@@ -179,16 +176,6 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   h->n = cfg->num_envs * cfg->num_drones;
   h->ld = ((size_t)h->n + 255) / 256 * 256;
   h->has_traj = false;
-  {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess) cus = 0;
-    h->num_cus = cus > 0 ? cus : 256;
-    const char* env = getenv("MDS_GEO_BLOCKS_PER_CU");
-    const int v = env ? atoi(env) : 0;
-    h->geo_blocks_per_cu = (v >= 1 && v <= 64) ? v : 3;
-    const char* dma = getenv("MDS_GEO_DMA");
-    h->geo_use_dma = dma ? atoi(dma) != 0 : 0;   // measured on MI355X at C3: register-staged 21.1 us vs LDS-DMA 22.8 us
-  }
   fill_consts(h->cfg, h->gains, h->cf);
   fill_consts(h->cfg, h->gains, h->cd);
   const size_t es = elem_size(cfg->dtype), cs = comp_size(cfg->dtype);
@@ -377,28 +364,6 @@ static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, 
                                                                                                 (const T*)h->lem, (T*)h->last_rpm, \
                                                                                                 (S*)obs, (S*)act)))
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
-  if (h->cfg.dtype == MDS_F32 && !rk4 && h->geo_use_dma) {   // fp32 / Euler hot path: LDS-DMA staged persistent kernel
-    const Consts<float>& C = h->cf;
-    // persistent grid: at most geo_blocks_per_cu workgroups per CU, each striding over batches
-    const unsigned cap = (unsigned)(h->num_cus * h->geo_blocks_per_cu);
-    const dim3 grid(nbatch < cap ? nbatch : cap);
-#define MDS_LAUNCH_DMA(HAS_OBS, HAS_ACT, DRAG)                                                                         \
-  k_step_geometric_f32_dma<HAS_OBS, HAS_ACT, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t, (float*)h->state,        \
-                                                                            (const float*)h->lem, (float*)h->last_rpm, \
-                                                                            (float*)obs, (float*)act)
-#define MDS_LAUNCH_DMA2(HAS_OBS, HAS_ACT)            \
-  do {                                               \
-    if (drag) MDS_LAUNCH_DMA(HAS_OBS, HAS_ACT, true); \
-    else MDS_LAUNCH_DMA(HAS_OBS, HAS_ACT, false);     \
-  } while (0)
-    if (obs && act) MDS_LAUNCH_DMA2(true, true);
-    else if (obs) MDS_LAUNCH_DMA2(true, false);
-    else if (act) MDS_LAUNCH_DMA2(false, true);
-    else MDS_LAUNCH_DMA2(false, false);
-#undef MDS_LAUNCH_DMA2
-#undef MDS_LAUNCH_DMA
-    return MDS_OK;
-  }
   const dim3 grid(nbatch);
 #define MDS_LAUNCH_GEO(HAS_OBS, HAS_ACT)                         \
   do {                                                           \

@@ -1,11 +1,13 @@
 // HIP kernels (gfx950 / CDNA4, wave64) of the batched multi-drone step.
 //
 // Data layout in HBM (DESIGN.md "Data layout"):
-//   state   : struct-of-arrays, 13 planes of `ld` elements each (ld = n rounded up to 256),
-//             plane p holds component p of every drone -> lane i of a wave reads element
-//             base+i of each plane: 13 fully coalesced 256-byte (fp32) wave loads.
+//   state   : packed struct-of-arrays.  The 13 components of drone i live in three 4-wide
+//             groups (pos3|qx, qy qz qw|vx, vy vz|wx wy: element 4*i of group g) plus one scalar
+//             plane (wz): lane i issues three 16-byte and one 4-byte access, every wave access
+//             is one contiguous 1 KiB / 256-byte transaction (ld = n rounded up to 256).
 //   origin  : 3 planes (compute type) -- local-frame origin per drone.
-//   lem     : 7 planes (compute type) -- Lemniscate parameters per drone.
+//   lem     : Lemniscate parameters, packed the same way: (a, omega, yaw_rate, phase) x4 |
+//             (cx, cy) x2 | cz.
 //   action  : caller's [n,4] array-of-structs: one 16-byte load per lane, contiguous.
 //   obs     : caller's [n,20] array-of-structs.  A wave's 64 drones own one contiguous
 //             5 KiB span of it; the 20 floats of each lane are staged through LDS and the
@@ -50,21 +52,39 @@ template <typename S, typename T> __device__ __forceinline__ void store4(S* __re
   *reinterpret_cast<V*>(p) = x;
 }
 
+// element index of state component k (0..12) of drone i in the packed layout
+__host__ __device__ __forceinline__ size_t sidx(int k, size_t i, size_t ld) {
+  return k < 12 ? (size_t)(k >> 2) * 4 * ld + 4 * i + (k & 3) : 12 * ld + i;
+}
+// element index of Lemniscate parameter k (a, omega, cx, cy, cz, yaw_rate, phase_shift) of drone i
+__host__ __device__ __forceinline__ size_t lidx(int k, size_t i, size_t ld) {
+  switch (k) {
+    case 0: return 4 * i;
+    case 1: return 4 * i + 1;
+    case 5: return 4 * i + 2;
+    case 6: return 4 * i + 3;
+    case 2: return 4 * ld + 2 * i;
+    case 3: return 4 * ld + 2 * i + 1;
+    default: return 6 * ld + i;
+  }
+}
+
 template <typename S, typename T> __device__ __forceinline__ void load_state(const S* __restrict__ st, size_t ld, size_t i, State<T>& s) {
-  s.p = {ldp<S, T>(st + 0 * ld, i), ldp<S, T>(st + 1 * ld, i), ldp<S, T>(st + 2 * ld, i)};
-  s.q[0] = ldp<S, T>(st + 3 * ld, i);
-  s.q[1] = ldp<S, T>(st + 4 * ld, i);
-  s.q[2] = ldp<S, T>(st + 5 * ld, i);
-  s.q[3] = ldp<S, T>(st + 6 * ld, i);
-  s.v = {ldp<S, T>(st + 7 * ld, i), ldp<S, T>(st + 8 * ld, i), ldp<S, T>(st + 9 * ld, i)};
-  s.w = {ldp<S, T>(st + 10 * ld, i), ldp<S, T>(st + 11 * ld, i), ldp<S, T>(st + 12 * ld, i)};
+  T a[4], b[4], c[4];
+  load4<S, T>(st + 4 * i, a);
+  load4<S, T>(st + 4 * ld + 4 * i, b);
+  load4<S, T>(st + 8 * ld + 4 * i, c);
+  s.p = {a[0], a[1], a[2]};
+  s.q[0] = a[3]; s.q[1] = b[0]; s.q[2] = b[1]; s.q[3] = b[2];
+  s.v = {b[3], c[0], c[1]};
+  s.w = {c[2], c[3], ldp<S, T>(st + 12 * ld, i)};
 }
 template <typename S, typename T> __device__ __forceinline__ void store_state(S* __restrict__ st, size_t ld, size_t i, const State<T>& s) {
-  stp<S, T>(st + 0 * ld, i, s.p.x); stp<S, T>(st + 1 * ld, i, s.p.y); stp<S, T>(st + 2 * ld, i, s.p.z);
-  stp<S, T>(st + 3 * ld, i, s.q[0]); stp<S, T>(st + 4 * ld, i, s.q[1]); stp<S, T>(st + 5 * ld, i, s.q[2]);
-  stp<S, T>(st + 6 * ld, i, s.q[3]);
-  stp<S, T>(st + 7 * ld, i, s.v.x); stp<S, T>(st + 8 * ld, i, s.v.y); stp<S, T>(st + 9 * ld, i, s.v.z);
-  stp<S, T>(st + 10 * ld, i, s.w.x); stp<S, T>(st + 11 * ld, i, s.w.y); stp<S, T>(st + 12 * ld, i, s.w.z);
+  const T a[4] = {s.p.x, s.p.y, s.p.z, s.q[0]}, b[4] = {s.q[1], s.q[2], s.q[3], s.v.x}, c[4] = {s.v.y, s.v.z, s.w.x, s.w.y};
+  store4<S, T>(st + 4 * i, a);
+  store4<S, T>(st + 4 * ld + 4 * i, b);
+  store4<S, T>(st + 8 * ld + 4 * i, c);
+  stp<S, T>(st + 12 * ld, i, s.w.z);
 }
 
 // Observation packing: each lane owns one 20-element row; the wave's rows form one
@@ -169,13 +189,19 @@ template <typename T> struct GeoIn {
 template <typename T, typename S>
 __device__ __forceinline__ void load_geo_in(const S* __restrict__ state, const T* __restrict__ lem, size_t ld, size_t i, GeoIn<T>& in) {
   load_state<S, T>(state, ld, i, in.s);
-  in.P.a = lem[0 * ld + i];
-  in.P.omega = lem[1 * ld + i];
-  in.P.cx = lem[2 * ld + i];
-  in.P.cy = lem[3 * ld + i];
-  in.P.cz = lem[4 * ld + i];
-  in.P.yaw_rate = lem[5 * ld + i];
-  in.P.phase_shift = lem[6 * ld + i];
+  T a[4];
+  load4<T, T>(lem + 4 * i, a);
+  struct alignas(2 * sizeof(T)) V2 {
+    T v[2];
+  };
+  const V2 c = *reinterpret_cast<const V2*>(lem + 4 * ld + 2 * i);
+  in.P.a = a[0];
+  in.P.omega = a[1];
+  in.P.yaw_rate = a[2];
+  in.P.phase_shift = a[3];
+  in.P.cx = c.v[0];
+  in.P.cy = c.v[1];
+  in.P.cz = lem[6 * ld + i];
 }
 
 // One batch row of the fused kernel: controller + physics on registers already loaded.
@@ -288,84 +314,6 @@ __global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c,
     store_state<S, T>(state, ld, i, in.s);
     if (DRAG)
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = prev[k];
-  }
-}
-
-// ------------------------------------------------------------------------------------
-// fp32 hot path of the fused step: persistent waves + LDS-DMA input staging.
-//
-// Every wave owns a 5 KiB LDS slice holding the 20 input words (13 state + 7 trajectory) of
-// its 64 drones, one 256-byte row per SoA plane, filled by `global_load_lds_dword` (the load
-// writes LDS directly: no destination VGPRs are held while it is in flight).  Per batch:
-//   wait for the slice -> 20 ds_read_b32 into registers -> start the DMA of the wave's NEXT
-//   batch into the same slice -> ~1.1 k VALU instructions of controller + physics ->
-//   13 coalesced state stores + the observation rows through a second LDS slice.
-// so the next batch's 5 KiB per wave stream in under the arithmetic.  The grid is sized to
-// the chip (blocks_per_cu x CUs); workgroups stride over batches; waves never s_barrier.
-// The compiler does not track LDS-DMA completion: the s_waitcnt below are explicit.
-// ------------------------------------------------------------------------------------
-constexpr int kGeoPlanes = 20;
-
-__device__ __forceinline__ void geo_dma_issue(const float* __restrict__ state, const float* __restrict__ lem, const size_t ld,
-                                              const size_t i, float (*slice)[kWave]) {
-#pragma unroll
-  for (int p = 0; p < 13; ++p) __builtin_amdgcn_global_load_lds(state + p * ld + i, &slice[p][0], 4, 0, 0);
-#pragma unroll
-  for (int p = 0; p < 7; ++p) __builtin_amdgcn_global_load_lds(lem + p * ld + i, &slice[13 + p][0], 4, 0, 0);
-}
-
-template <bool HAS_OBS, bool HAS_ACT, bool DRAG>
-__global__ __launch_bounds__(kBlock, MDS_GEO_MIN_WAVES) void k_step_geometric_f32_dma(
-    const Consts<float> c, const int n, const size_t ld, const double t, float* __restrict__ state,
-    const float* __restrict__ lem, float* __restrict__ last_rpm, float* __restrict__ obs, float* __restrict__ action_out) {
-  __shared__ __align__(16) float in_buf[kBlock / kWave][kGeoPlanes][kWave];
-  __shared__ __align__(16) unsigned char obs_buf[HAS_OBS ? (kBlock * kObsDim * sizeof(float)) : 16];
-  const int nbatch = (n + kBlock - 1) / kBlock;
-  int batch = blockIdx.x;
-  if (batch >= nbatch) return;
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  float(*slice)[kWave] = in_buf[wave];
-  // LDS byte address of this lane's column of the slice (low 32 bits of the flat LDS address)
-  const unsigned slice_addr = (unsigned)(size_t)&slice[0][lane];
-  geo_dma_issue(state, lem, ld, (size_t)batch * kBlock + threadIdx.x, slice);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // first batch: nothing younger than its DMA rows yet
-  while (true) {
-    const int i = batch * kBlock + threadIdx.x;
-    // The slice is read with explicit ds_read_b32 (the compiler would put a full vmcnt(0)
-    // in front of any LDS read it can see while LDS-DMA is pending); the wait for them is
-    // explicit too and carries the 20 registers so that no use can be scheduled above it.
-    float r[kGeoPlanes];
-#pragma unroll
-    for (int p = 0; p < kGeoPlanes; ++p) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r[p]) : "v"(slice_addr), "n"(p * kWave * 4));
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]),
-                   "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]), "+v"(r[16]), "+v"(r[17]), "+v"(r[18]),
-                   "+v"(r[19])
-                 :
-                 : "memory");                           // slice fully read before the next DMA may overwrite it
-    GeoIn<float> in;
-    in.s.p = {r[0], r[1], r[2]};
-    in.s.q[0] = r[3]; in.s.q[1] = r[4]; in.s.q[2] = r[5]; in.s.q[3] = r[6];
-    in.s.v = {r[7], r[8], r[9]};
-    in.s.w = {r[10], r[11], r[12]};
-    in.P = {r[13], r[14], r[15], r[16], r[17], r[18], r[19]};
-    const int next = batch + gridDim.x;
-    if (next < nbatch) geo_dma_issue(state, lem, ld, (size_t)next * kBlock + threadIdx.x, slice);
-    geo_process<float, float, HAS_OBS, HAS_ACT, false, DRAG>(c, n, ld, t, i, in, state, last_rpm, obs, action_out, obs_buf);
-    if (next >= nbatch) break;
-    batch = next;
-    // The next batch's 20 DMA rows must have landed.  vmcnt retires in issue order and the only
-    // vector-memory instructions issued after them are this batch's stores (13 state dwords +
-    // 5 obs dwordx4 [+1 action]): waiting for "all but those" leaves the stores in flight under
-    // the next batch's arithmetic.  A wave reaches this point only after a FULL batch (the one
-    // partial batch is the last), so every one of those stores was issued.
-    // tests/test_isa_contract.py checks the counts against the generated ISA.
-    if (DRAG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (HAS_OBS && HAS_ACT) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
-    else if (HAS_OBS) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-    else if (HAS_ACT) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
   }
 }
 
@@ -527,9 +475,9 @@ __global__ void k_reset(const int n, const size_t ld, const double* __restrict__
   if (i >= n) return;
   double q[4];
   quat_from_euler<double>(rpy[3 * i], rpy[3 * i + 1], rpy[3 * i + 2], q);
-  for (int k = 0; k < 3; ++k) state[k * ld + i] = (S)(xyz[3 * i + k] - (double)origin[k * ld + i]);
-  for (int k = 0; k < 4; ++k) state[(3 + k) * ld + i] = (S)q[k];
-  for (int k = 7; k < 13; ++k) state[k * ld + i] = (S)0;
+  for (int k = 0; k < 3; ++k) state[sidx(k, i, ld)] = (S)(xyz[3 * i + k] - (double)origin[k * ld + i]);
+  for (int k = 0; k < 4; ++k) state[sidx(3 + k, i, ld)] = (S)q[k];
+  for (int k = 7; k < 13; ++k) state[sidx(k, i, ld)] = (S)0;
   for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = T(0);
 }
 
@@ -539,10 +487,10 @@ __global__ void k_set_origin(const int n, const size_t ld, const double* __restr
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   for (int k = 0; k < 3; ++k) {
-    const double world = (double)state[k * ld + i] + (double)origin[k * ld + i];
+    const double world = (double)state[sidx(k, i, ld)] + (double)origin[k * ld + i];
     const T no = (T)new_origin[3 * i + k];
     origin[k * ld + i] = no;
-    state[k * ld + i] = (S)(world - (double)no);
+    state[sidx(k, i, ld)] = (S)(world - (double)no);
   }
 }
 
@@ -552,7 +500,7 @@ __global__ void k_get_state(const int n, const size_t ld, const S* __restrict__ 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   for (int k = 0; k < 13; ++k) {
-    double v = (double)state[k * ld + i];
+    double v = (double)state[sidx(k, i, ld)];
     if (k < 3) v += (double)origin[k * ld + i];
     out[13 * (size_t)i + k] = v;
   }
@@ -566,7 +514,7 @@ __global__ void k_set_state(const int n, const size_t ld, const double* __restri
   for (int k = 0; k < 13; ++k) {
     double v = in[13 * (size_t)i + k];
     if (k < 3) v -= (double)origin[k * ld + i];
-    state[k * ld + i] = (S)v;
+    state[sidx(k, i, ld)] = (S)v;
   }
 }
 
@@ -574,7 +522,7 @@ template <typename T>
 __global__ void k_set_planes(const int n, const size_t ld, const int dim, const double* __restrict__ in, T* __restrict__ planes) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  for (int k = 0; k < dim; ++k) planes[k * ld + i] = (T)in[(size_t)dim * i + k];
+  for (int k = 0; k < dim; ++k) planes[dim == 7 ? lidx(k, i, ld) : (size_t)k * ld + i] = (T)in[(size_t)dim * i + k];
 }
 
 // ------------------------------------------------------------------------------------
@@ -584,8 +532,8 @@ template <typename T, typename S>
 __global__ void k_lemniscate_eval(const int n, const size_t ld, const double t, const T* __restrict__ lem, S* __restrict__ des) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  LemniscateParams<T> P = {lem[i], lem[ld + i], lem[2 * ld + i], lem[3 * ld + i], lem[4 * ld + i], lem[5 * ld + i],
-                           lem[6 * ld + i]};
+  LemniscateParams<T> P = {lem[lidx(0, i, ld)], lem[lidx(1, i, ld)], lem[lidx(2, i, ld)], lem[lidx(3, i, ld)], lem[lidx(4, i, ld)],
+                           lem[lidx(5, i, ld)], lem[lidx(6, i, ld)]};
   const Desired<T> d = lemniscate_local(P, t);
   S* o = des + (size_t)i * 11;
   o[0] = (S)(d.p.x + P.cx); o[1] = (S)(d.p.y + P.cy); o[2] = (S)(d.p.z + P.cz);

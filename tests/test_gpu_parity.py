@@ -221,12 +221,9 @@ def test_quadrotor_dynamics_golden(mds):
 # ---------------------------------------------------------------------------------------------
 # fused trajectory + controller + step: BASELINE configs C2 / C3 at oracle-sized batches
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("E,D,phase,dtype,tol,dma", [(64, 4, "c2", "float32", 1e-5, "0"), (32, 8, "c3", "float32", 1e-5, "0"),
-                                                     (16, 4, "c2", "float64", 1e-9, "0"), (64, 4, "c2", "float32", 1e-5, "1"),
-                                                     (333, 3, "c3", "float32", 1e-5, "1")])
-def test_fused_geometric_1000_steps(mds, E, D, phase, dtype, tol, dma, monkeypatch):
-    monkeypatch.setenv("MDS_GEO_DMA", dma)
-    monkeypatch.setenv("MDS_GEO_BLOCKS_PER_CU", "1" if E == 333 else "3")
+@pytest.mark.parametrize("E,D,phase,dtype,tol", [(64, 4, "c2", "float32", 1e-5), (32, 8, "c3", "float32", 1e-5),
+                                                 (16, 4, "c2", "float64", 1e-9), (333, 3, "c3", "float32", 1e-5)])
+def test_fused_geometric_1000_steps(mds, E, D, phase, dtype, tol):
     xyz, rpy, P = H.c2_setup(E, D, phase=phase)
     obs, hist = H.oracle_closed_loop(xyz, rpy, P, 1000, record_every=250)
     env = make_env(mds, E, D, xyz, rpy, dtype)
@@ -353,12 +350,7 @@ def test_fp16_storage_is_stable_and_close(mds):
 # ---------------------------------------------------------------------------------------------
 # full BASELINE size (C3: 65 536 x 8) through size-independent properties
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dma", ["0", "1"])
-def test_c3_full_size_properties(mds, dma, monkeypatch):
-    """dma=1 runs the persistent LDS-DMA variant of the fused kernel (several batches per wave at
-    this size, so its hand-counted vmcnt hand-off is exercised); dma=0 the register-staged default."""
-    monkeypatch.setenv("MDS_GEO_DMA", dma)
-    monkeypatch.setenv("MDS_GEO_BLOCKS_PER_CU", "2")
+def test_c3_full_size_properties(mds):
     E, D = 65536, 8
     xyz, rpy, P = H.c2_setup(E, D, phase="c3")
     # (1) replicate invariance: envs 0..255 are copied into envs 1024..1279 -> bitwise equal outputs
