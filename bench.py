@@ -31,7 +31,9 @@ WORKLOADS = {
     "c3": (65536, 8, "c3", "C3: 65536 envs x 8 drones per GPU, Lemniscate tracking, fused traj+geometric+DYN step, obs every step"),
     "c2": (4096, 4, "c2", "C2: 4096 envs x 4 drones per GPU, geometric controller free flight, fused step, obs every step"),
     "c4": (16384, 16, "c3", "C4: 16384 envs x 16 drones per GPU, geometric nominal -> order-2 ECBF QP (4 sphere obstacles) -> ThrustOmega -> DYN step"),
+    "c5": (262144, 2, "c2", "C5: 262144 envs x 2 drones per GPU, fp16 state storage / fp32 math, env.step() with random RPM around hover, obs streamed to a rollout log"),
 }
+    # c5 is appended below (physics-only, fp16 storage)
 BYTES_PER_DRONE_STEP_C4 = 132 + 148 + 260   # three launches: nominal (R 80, W 52) + filter (R 132, W 16) + low-level step (R 104, W 156)
 BYTES_PER_DRONE_STEP = 212          # R state 52 + R traj params 28 + W state 52 + W obs 80
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
@@ -158,6 +160,18 @@ def main(argv=None):
     env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN,
                      pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=args.dtype, device=local_rank)
     tracker = None
+    c5 = args.workload == "c5"
+    if c5:
+        # physics-only path (mds_step): external random actions, obs of step k written into slot k % T of a rollout log
+        import ctypes as C
+        env.close()
+        env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN,
+                         pyb_freq=240, ctrl_freq=240, num_envs=E, dtype="float16" if args.dtype == "float32" else args.dtype, device=local_rank)
+        g = torch.Generator(device=device).manual_seed(1234 + rank)
+        c5_actions = [(env.HOVER_RPM * (1 + 0.05 * torch.randn((E, D, 4), device=device, generator=g))).clamp(0, env.MAX_RPM).to(env.dtype)
+                      for _ in range(8)]
+        c5_T = 16
+        c5_log = torch.empty((c5_T, E, D, 20), dtype=env.dtype, device=device)
     if args.workload == "c4":
         # trajectories / start heights stacked 0.3 m apart: with the omega linearisation the barrier acts through e_z only
         P[..., 4] = 0.5 + 0.3 * np.arange(D)
@@ -176,6 +190,7 @@ def main(argv=None):
     env.set_trajectories(P)
     env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=device))     # EnvGeometric.py:431
     dt = env.CTRL_TIMESTEP
+    c5_k = [0]
 
     fused_T = args.fused_rollout
     if fused_T:
@@ -184,7 +199,15 @@ def main(argv=None):
         log_buf = torch.empty((fused_T, E, D, 20), dtype=env.dtype, device=device)
 
     def run(t0, k):
-        if fused_T:
+        if c5:
+            st_ = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            for _ in range(k):
+                j = c5_k[0]
+                rc = env._lib.mds_step(env._h, C.c_void_p(c5_actions[j & 7].data_ptr()), C.c_void_p(c5_log[j % c5_T].data_ptr()), st_)
+                if rc != 0:
+                    raise RuntimeError(f"mds_step failed: {rc}")
+                c5_k[0] = j + 1
+        elif fused_T:
             t = t0
             for _ in range(k // fused_T):
                 env.rollout_geometric_fused(t, fused_T, log=True, log_out=log_buf)
@@ -218,13 +241,16 @@ def main(argv=None):
     elapsed = max_over_ranks(wall, world, device)
     dev_ms_max = max_over_ranks(dev_ms, world, device)
 
-    obs = env._obs
+    obs = c5_log[(c5_k[0] - 1) % c5_T] if c5 else env._obs
     ok = bool(torch.isfinite(obs).all().item()) and abs(float(obs[..., 3:7].norm(dim=-1).mean().item()) - 1.0) < 1e-3
     n_local = E * D
     total_units = n_local * world * args.steps
     value = total_units / elapsed
     kernel_us = dev_ms * 1e3 / args.steps                   # average launch-to-launch duration on the stream (HIP events)
     bytes_per = BYTES_PER_DRONE_STEP_C4 if args.workload == "c4" else BYTES_PER_DRONE_STEP
+    if c5:
+        es = {torch.float16: 2, torch.float32: 4, torch.float64: 8}[env.dtype]
+        bytes_per = 13 * es * 2 + 4 * es + 20 * es       # R state + W state + R action + W obs (origin read not counted)
     if fused_T:
         bytes_per = 80 + (132 + 80) / fused_T     # obs row per step + (state R/W, params, final obs) once per launch
     achieved = bytes_per * n_local / (kernel_us * 1e-6) / 1e9
@@ -256,6 +282,11 @@ def main(argv=None):
         line["roofline"]["bytes_per_launch"] = bytes_per * n_local * fused_T
         line["roofline"]["traffic"] = None
         line["config"]["launch"] = f"fused rollout, {fused_T} steps per launch, obs log [T,n,20]"
+    if c5:
+        line["roofline"]["kernel"] = "k_step<float,_Float16,true,false,false>"
+        line["roofline"]["traffic"] = None
+        line["dtype"] = {"float16": "f16-storage/f32-math", "float32": "f32", "float64": "f64"}[str(env.dtype).split(".")[-1]]
+        line["config"].update({"pyb_freq": 240, "ctrl_freq": 240, "launch": "python ctypes loop, obs -> rollout log slot"})
     if args.workload == "c4":
         st = env._cbf_status
         line["roofline"]["kernel"] = "k_cbf_nominal + k_cbf_filter_o2_gi + k_lowlevel_step (3 launches per step; QP is latency/ALU bound)"
@@ -282,7 +313,7 @@ def main(argv=None):
                                  "bound": "VALU (state in registers; only the obs log leaves the chip)",
                                  "kernel": "k_rollout_geometric<float,float,false,false>"}
         del log2
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "c4":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload not in ("c4", "c5"):
         line["cpu_baseline"] = cpu_baseline(D, phase, args.cpu_budget)
     elif rank == 0:
         line["cpu_baseline"] = None

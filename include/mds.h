@@ -125,6 +125,12 @@ int mds_get_obs(mds_handle* h, void* obs_dev, void* stream);
  * action_dev [n,4] RPM, obs_dev [n,20] (may be NULL: state only). */
 int mds_step(mds_handle* h, const void* action_dev, void* obs_dev, void* stream);
 
+/* Constant external force on every drone, world frame, Newton -- the reference's wind:
+ * p.applyExternalForce(DRONE_IDS[i], -1, [wind_force,0,0], WORLD_FRAME) every control step
+ * (simulations/EnvGeometric.py:34,463-467; wind_force = 2.5e-4).  Added to the rigid-body force in
+ * every physics substep.  Default zero. */
+int mds_set_wind(mds_handle* h, const double force_world[3]);
+
 /* trajectories/Lemniscate.py:14-30: one Lemniscate per drone, params_host double [n,7] =
  * (a, omega, centre_x, centre_y, centre_z, yaw_rate, phase_shift). */
 int mds_set_lemniscate(mds_handle* h, const double* params_host, void* stream);

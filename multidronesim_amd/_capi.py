@@ -62,6 +62,7 @@ PROTOTYPES = {
     "mds_set_origin": (C.c_int, [_P, _PD, _P]),
     "mds_get_obs": (C.c_int, [_P, _P, _P]),
     "mds_step": (C.c_int, [_P, _P, _P, _P]),
+    "mds_set_wind": (C.c_int, [_P, _PD]),
     "mds_set_lemniscate": (C.c_int, [_P, _PD, _P]),
     "mds_set_geometric_gains": (C.c_int, [_P, C.POINTER(MdsGeometricGains)]),
     "mds_step_geometric": (C.c_int, [_P, C.c_double, _P, _P, _P]),

@@ -43,6 +43,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 struct mds_handle {
   mds_config cfg;
   mds_geometric_gains gains;
+  double wind[3];
   int n;
   size_t ld;           // plane stride (elements)
   void* state;         // S [13][ld]
@@ -176,8 +177,9 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   h->n = cfg->num_envs * cfg->num_drones;
   h->ld = ((size_t)h->n + 255) / 256 * 256;
   h->has_traj = false;
-  fill_consts(h->cfg, h->gains, h->cf);
-  fill_consts(h->cfg, h->gains, h->cd);
+  h->wind[0] = h->wind[1] = h->wind[2] = 0.0;
+  fill_consts(h->cfg, h->gains, h->cf, h->wind);
+  fill_consts(h->cfg, h->gains, h->cd, h->wind);
   const size_t es = elem_size(cfg->dtype), cs = comp_size(cfg->dtype);
   h->state = h->origin = h->last_rpm = h->lem = nullptr;
   h->scratch = nullptr;
@@ -352,8 +354,16 @@ int mds_set_geometric_gains(mds_handle* h, const mds_geometric_gains* g) {
   if (!h || !g) return fail(MDS_EINVAL, "mds_set_geometric_gains: null argument");
   if (!(g->max_tilt_angle > 0) || !(g->max_tilt_angle < M_PI / 2)) return fail(MDS_EINVAL, "mds_set_geometric_gains: max_tilt_angle");
   h->gains = *g;
-  fill_consts(h->cfg, h->gains, h->cf);
-  fill_consts(h->cfg, h->gains, h->cd);
+  fill_consts(h->cfg, h->gains, h->cf, h->wind);
+  fill_consts(h->cfg, h->gains, h->cd, h->wind);
+  return MDS_OK;
+}
+
+int mds_set_wind(mds_handle* h, const double force_world[3]) {
+  if (!h || !force_world) return fail(MDS_EINVAL, "mds_set_wind: null argument");
+  for (int k = 0; k < 3; ++k) h->wind[k] = force_world[k];
+  fill_consts(h->cfg, h->gains, h->cf, h->wind);
+  fill_consts(h->cfg, h->gains, h->cd, h->wind);
   return MDS_OK;
 }
 

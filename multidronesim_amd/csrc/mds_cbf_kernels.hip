@@ -9,10 +9,8 @@ namespace mds {
 constexpr int kCbfMaxD = 32;      // drones per env supported by the wave-per-env kernels
 constexpr int kCbfMaxObs = 16;
 
-// (i, j) of pair row r in the reference's lexicographic order (cbf/cbf.py:342-346); built on the host
-struct CbfTables {
-  const int* pair_ij;   // [D(D-1)/2] packed i | j << 8
-};
+// pair_ij[r] = i | j << 8: (i, j) of pair row r in the reference's lexicographic order
+// (cbf/cbf.py:342-346); built on the host by mds_cbf_configure.
 
 // ------------------------------------------------------------------------------------
 // Dense G, h exactly as CBF._build_ineq_const returns them (parity surface; one workgroup

@@ -8,7 +8,8 @@
 
 namespace mds {
 
-template <typename T> inline void fill_consts(const mds_config& cfg, const mds_geometric_gains& g, Consts<T>& c) {
+template <typename T> inline void fill_consts(const mds_config& cfg, const mds_geometric_gains& g, Consts<T>& c, const double* wind = nullptr) {
+  for (int k = 0; k < 3; ++k) c.wind[k] = wind ? (T)wind[k] : T(0);
   c.kf = (T)cfg.KF;
   c.km = (T)cfg.KM;
   c.arm = (T)cfg.L;

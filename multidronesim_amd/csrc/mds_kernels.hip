@@ -21,13 +21,14 @@ namespace mds {
 
 typedef _Float16 half_t;
 
-constexpr int kBlock = 256;
-constexpr int kWave = 64;
-// minimum waves per SIMD requested from the register allocator for the two hot kernels
-// (2nd __launch_bounds__ argument; tuned on MI355X, see DESIGN.md "Occupancy")
-#ifndef MDS_GEO_MIN_WAVES
-#define MDS_GEO_MIN_WAVES 4
+#ifndef MDS_KBLOCK
+#define MDS_KBLOCK 256
 #endif
+constexpr int kBlock = MDS_KBLOCK;
+constexpr int kWave = 64;
+// minimum waves per SIMD requested from the register allocator for k_step (2nd __launch_bounds__
+// argument).  The fused kernel is left to the allocator: 78 VGPRs = 6 waves/SIMD without spills;
+// forcing 7 or 8 spills and measured 18 % slower.
 #ifndef MDS_STEP_MIN_WAVES
 #define MDS_STEP_MIN_WAVES 4
 #endif

@@ -154,6 +154,7 @@ template <typename T> struct Consts {
   T hover_rpm;    // sqrt(MG / 4KF) rounded to T
   T thrust_corr;  // 4*KF*hover_rpm^2 - M*G (rounding of hover_rpm, computed in double)
   T J[3], invJ[3], drag[3];
+  T wind[3];      // constant external world force on every drone (EnvGeometric.py:34,463-467), N
   T dt;           // PYB_TIMESTEP
   int substeps;   // PYB_FREQ / CTRL_FREQ
   int cf2x;       // 1: X frame torques, 0: + frame (cf2p)
@@ -270,7 +271,7 @@ MDS_HD void body_accel(const Consts<T>& c, const T q[4], V3<T> vel, V3<T> w, T t
   const T s = T(2) * m_rcp(m_fma(x, x, m_fma(y, y, m_fma(z, z, ww * ww))));
   const T thrust = c.gravity + thrust_excess;
   const T r02 = s * m_fma(x, z, ww * y), r12 = s * m_fma(y, z, -(ww * x)), r22m1 = -s * m_fma(x, x, y * y);
-  V3<T> f = {r02 * thrust, r12 * thrust, m_fma(r22m1, thrust, thrust_excess)};
+  V3<T> f = {m_fma(r02, thrust, c.wind[0]), m_fma(r12, thrust, c.wind[1]), m_fma(r22m1, thrust, thrust_excess) + c.wind[2]};
   if (DRAG) {  // [UPSTREAM] _drag: world force -c (.) sum(2 pi rpm_prev/60) (.) v_world
     f.x = m_fma(-c.drag[0] * drag_s, vel.x, f.x);
     f.y = m_fma(-c.drag[1] * drag_s, vel.y, f.y);

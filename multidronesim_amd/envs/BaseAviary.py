@@ -253,6 +253,12 @@ class BaseAviary:
         capi.check(self._lib.mds_set_lemniscate(self._h, capi.as_double_ptr(P), self._stream()), "mds_set_lemniscate")
         self._has_traj = True
 
+    def set_wind(self, force_world):
+        """Constant world-frame force [N] on every drone each physics substep -- the reference's
+        ``p.applyExternalForce(..., [wind_force, 0, 0], WORLD_FRAME)`` (EnvGeometric.py:463-467)."""
+        f = np.ascontiguousarray(np.asarray(force_world, dtype=np.float64).reshape(3))
+        capi.check(self._lib.mds_set_wind(self._h, capi.as_double_ptr(f)), "mds_set_wind")
+
     def set_geometric_gains(self, Kp=None, Kv=None, KR=None, Kw=None, g=None, max_tilt_angle=None):
         gains = capi.MdsGeometricGains()
         capi.check(self._lib.mds_default_geometric_gains(C.byref(gains)), "mds_default_geometric_gains")

@@ -227,7 +227,7 @@ def drag_force_world(vel, rpm_prev, c: DroneConsts):
     return -np.asarray(c.DRAG) * s[..., None] * np.asarray(vel, dtype=np.float64)
 
 
-def dyn_step_euler(pos, quat, vel, rates, rpm, dt, c: DroneConsts, drag_rpm=None):
+def dyn_step_euler(pos, quat, vel, rates, rpm, dt, c: DroneConsts, drag_rpm=None, wind=None):
     """[UPSTREAM] BaseAviary._dynamics (Physics.DYN): explicit Euler on (v, omega),
     then p with the NEW v, q with the NEW omega.  ``drag_rpm`` (build extension
     DYN_DRAG) adds the _drag force computed from the previous clipped action."""
@@ -237,6 +237,8 @@ def dyn_step_euler(pos, quat, vel, rates, rpm, dt, c: DroneConsts, drag_rpm=None
     force_w[..., 2] -= c.GRAVITY
     if drag_rpm is not None:
         force_w = force_w + drag_force_world(vel, drag_rpm, c)
+    if wind is not None:                                # EnvGeometric.py:463-467 world-frame external force
+        force_w = force_w + np.asarray(wind, dtype=np.float64)
     J = np.asarray(c.J)
     torques = torques - cross(rates, J * rates)
     rates_dot = torques / J                             # J_INV @ torques (diagonal J)
@@ -280,6 +282,7 @@ class AviaryOracle:
         self.PYB_TIMESTEP = 1.0 / pyb_freq
         self.CTRL_TIMESTEP = 1.0 / ctrl_freq
         self.physics, self.integrator = physics, integrator
+        self.wind = None
         self.init_xyzs = np.array(init_xyzs, dtype=np.float64).reshape(-1, 3)
         self.init_rpys = np.array(init_rpys, dtype=np.float64).reshape(-1, 3)
         self.reset()
@@ -305,8 +308,9 @@ class AviaryOracle:
         stepf = dyn_step_euler if self.integrator == "euler" else dyn_step_rk4
         for _ in range(self.PYB_STEPS_PER_CTRL):
             drag_rpm = self.last_clipped_action if self.physics == "dyn_drag" else None
+            kw = {"wind": self.wind} if (self.wind is not None and self.integrator == "euler") else {}
             self.pos, self.quat, self.vel, self.rates, self.ang_v = stepf(
-                self.pos, self.quat, self.vel, self.rates, clipped, self.PYB_TIMESTEP, self.c, drag_rpm)
+                self.pos, self.quat, self.vel, self.rates, clipped, self.PYB_TIMESTEP, self.c, drag_rpm, **kw)
             self.last_clipped_action = clipped
         return self.obs()
 

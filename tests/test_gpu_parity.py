@@ -326,6 +326,35 @@ def test_fused_rollout_equals_stepwise_and_logs_every_step(mds, dtype):
     b.close()
 
 
+def test_wind_force_matches_oracle(mds):
+    """EnvGeometric.py:34,463-467: constant +x world force of 2.5e-4 N on every drone, every step."""
+    E, D = 8, 2
+    xyz, rpy, P = H.c2_setup(E, D, offset=1.0)
+    wind = np.array([2.5e-4, 0.0, 0.0])
+    env = make_env(mds, E, D, xyz, rpy, "float64")
+    env.set_trajectories(P)
+    env.set_wind(wind)
+    n = E * D
+    Pf = P.reshape(-1, 7)
+    ora = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), pyb_freq=100, ctrl_freq=100)
+    ora.wind = wind
+    obs = ora.step(np.zeros((n, 4)))
+    env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+    t = 0.0
+    for k in range(200):
+        pos, vel, acc, yaw, yd = O.lemniscate(t, Pf[:, 0], Pf[:, 1], Pf[:, 2:5], Pf[:, 5], Pf[:, 6])
+        obs = ora.step(O.geometric_compute(obs, pos, vel, acc, yaw, yd))
+        gobs = env.step_geometric(t)
+        t += env.CTRL_TIMESTEP
+    np.testing.assert_allclose(np_obs(gobs), obs, atol=1e-9, rtol=1e-11)
+    calm = make_env(mds, E, D, xyz, rpy, "float64")
+    calm.set_trajectories(P)
+    calm.step(mds.torch.zeros((E, D, 4), dtype=calm.dtype))
+    assert (calm.rollout_geometric(0.0, 200) - gobs)[..., 0].abs().max().item() > 1e-4     # the wind does something
+    env.close()
+    calm.close()
+
+
 def test_fp16_storage_is_stable_and_close(mds):
     """fp16 state storage / fp32 arithmetic (config 5) is a throughput configuration: 2^-11
     relative storage rounding.  Gate: stays finite, unit quaternion, tracks the oracle to 5e-2
