@@ -131,6 +131,20 @@ int mds_step(mds_handle* h, const void* action_dev, void* obs_dev, void* stream)
  * every physics substep.  Default zero. */
 int mds_set_wind(mds_handle* h, const double force_world[3]);
 
+/* General trajectories: the reference's trajectories/ family (Lemniscate, CircleTrajectory,
+ * LineTrajectory, WaitTrajectory, CompoundTrajectory, RotateTrajectory) flattened by the caller into
+ * per-drone segment lists (layout: multidronesim_amd/csrc/mds_traj.hpp; the Python classes build it).
+ * segs_host double [total, MDS_SEG_DIM]; offsets_host int32 [n+1] (drone i owns segments
+ * offsets[i] .. offsets[i+1]-1, at most 65535); compound_host int32 [n] (1: CompoundTrajectory lookup
+ * with its past-the-end rule, 0: a single trajectory evaluated at t); anchor_host double [n,3]: local-frame
+ * origin per drone (e.g. the first segment's centre / start).  Replaces mds_set_lemniscate's trajectories:
+ * mds_step_geometric / mds_rollout_geometric then run the general kernel. */
+#define MDS_SEG_DIM 40
+int mds_set_trajectory_segments(mds_handle* h, const double* segs_host, const int32_t* offsets_host,
+                                const int32_t* compound_host, const double* anchor_host, int32_t total_segments, void* stream);
+/* Trajectory.__call__(t) for every drone from the segment tables: des_dev [n,11] world frame */
+int mds_traj_eval(mds_handle* h, double t, void* des_dev, void* stream);
+
 /* trajectories/Lemniscate.py:14-30: one Lemniscate per drone, params_host double [n,7] =
  * (a, omega, centre_x, centre_y, centre_z, yaw_rate, phase_shift). */
 int mds_set_lemniscate(mds_handle* h, const double* params_host, void* stream);

@@ -15,7 +15,7 @@ MDS_F32, MDS_F64, MDS_F16 = 0, 1, 2
 MDS_PHYSICS_DYN, MDS_PHYSICS_DYN_DRAG = 0, 1
 MDS_INTEGRATOR_EULER, MDS_INTEGRATOR_RK4 = 0, 1
 MDS_CF2X, MDS_CF2P = 0, 1
-OBS_DIM, ACT_DIM, STATE_DIM, DES_DIM, LEM_DIM, GEO_AUX_DIM = 20, 4, 13, 11, 7, 13
+OBS_DIM, ACT_DIM, STATE_DIM, DES_DIM, LEM_DIM, GEO_AUX_DIM, SEG_DIM = 20, 4, 13, 11, 7, 13, 40
 
 
 class MdsConfig(C.Structure):
@@ -64,6 +64,8 @@ PROTOTYPES = {
     "mds_step": (C.c_int, [_P, _P, _P, _P]),
     "mds_set_wind": (C.c_int, [_P, _PD]),
     "mds_set_lemniscate": (C.c_int, [_P, _PD, _P]),
+    "mds_set_trajectory_segments": (C.c_int, [_P, _PD, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _PD, C.c_int32, _P]),
+    "mds_traj_eval": (C.c_int, [_P, C.c_double, _P, _P]),
     "mds_set_geometric_gains": (C.c_int, [_P, C.POINTER(MdsGeometricGains)]),
     "mds_step_geometric": (C.c_int, [_P, C.c_double, _P, _P, _P]),
     "mds_rollout_geometric": (C.c_int, [_P, C.c_double, C.c_int, _P, C.c_int, _P]),

@@ -52,6 +52,9 @@ struct mds_handle {
   void* lem;           // T [7][ld]
   double* scratch;     // double [n*20] device staging for host<->device set-up calls
   bool has_traj;
+  int traj_mode;        // 1: per-drone Lemniscate planes (fused fp32 fast path), 2: general segment tables
+  double* segs;         // device [total, MDS_SEG_DIM]
+  int* tinfo;           // device [n, 2] = first segment, nseg | compound << 16
   Consts<float> cf;
   Consts<double> cd;
   // ECBF filter
@@ -177,6 +180,9 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   h->n = cfg->num_envs * cfg->num_drones;
   h->ld = ((size_t)h->n + 255) / 256 * 256;
   h->has_traj = false;
+  h->traj_mode = 0;
+  h->segs = nullptr;
+  h->tinfo = nullptr;
   h->wind[0] = h->wind[1] = h->wind[2] = 0.0;
   fill_consts(h->cfg, h->gains, h->cf, h->wind);
   fill_consts(h->cfg, h->gains, h->cd, h->wind);
@@ -230,6 +236,8 @@ int mds_destroy(mds_handle* h) {
   if (h->cbf_xdes) (void)hipFree(h->cbf_xdes);
   if (h->cbf_usafe) (void)hipFree(h->cbf_usafe);
   if (h->ll) (void)hipFree(h->ll);
+  if (h->segs) (void)hipFree(h->segs);
+  if (h->tinfo) (void)hipFree(h->tinfo);
   delete h;
   return MDS_OK;
 }
@@ -347,6 +355,60 @@ int mds_set_lemniscate(mds_handle* h, const double* params, void* stream) {
   MDS_HIP(hipGetLastError());
   MDS_HIP(hipStreamSynchronize(st));
   h->has_traj = true;
+  h->traj_mode = 1;
+  return MDS_OK;
+}
+
+int mds_set_trajectory_segments(mds_handle* h, const double* segs, const int32_t* offsets, const int32_t* compound,
+                                const double* anchor, int32_t total, void* stream) {
+  if (!h || !segs || !offsets || !compound || !anchor) return fail(MDS_EINVAL, "mds_set_trajectory_segments: null argument");
+  const int n = h->n;
+  if (total <= 0 || offsets[0] != 0 || offsets[n] != total) return fail(MDS_EINVAL, "mds_set_trajectory_segments: offsets");
+  int* ti = new (std::nothrow) int[(size_t)2 * n];
+  if (!ti) return fail(MDS_ENOMEM, "mds_set_trajectory_segments: host allocation");
+  for (int i = 0; i < n; ++i) {
+    const int ns = offsets[i + 1] - offsets[i];
+    if (ns < 1 || ns > 65535) {
+      delete[] ti;
+      return fail(MDS_EINVAL, "mds_set_trajectory_segments: every drone needs 1..65535 segments");
+    }
+    ti[2 * i] = offsets[i];
+    ti[2 * i + 1] = ns | ((compound[i] ? 1 : 0) << 16);
+  }
+  for (int k = 0; k < total; ++k) {
+    const int kind = (int)segs[(size_t)k * MDS_SEG_DIM];
+    if (kind < 0 || kind > 3) {
+      delete[] ti;
+      return fail(MDS_EINVAL, "mds_set_trajectory_segments: segment kind");
+    }
+  }
+  int rc = mds_set_origin(h, anchor, stream);
+  hipError_t e = hipSuccess;
+  if (rc == MDS_OK) {
+    if (h->segs) (void)hipFree(h->segs);
+    h->segs = nullptr;
+    if (!h->tinfo) e = hipMalloc((void**)&h->tinfo, sizeof(int) * 2 * n);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->segs, sizeof(double) * MDS_SEG_DIM * (size_t)total);
+    if (e == hipSuccess) e = hipMemcpy(h->segs, segs, sizeof(double) * MDS_SEG_DIM * (size_t)total, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->tinfo, ti, sizeof(int) * 2 * n, hipMemcpyHostToDevice);
+  }
+  delete[] ti;
+  if (rc != MDS_OK) return rc;
+  if (e != hipSuccess) return fail_hip(e, "mds_set_trajectory_segments");
+  h->has_traj = true;
+  h->traj_mode = 2;
+  return MDS_OK;
+}
+
+int mds_traj_eval(mds_handle* h, double t, void* des, void* stream) {
+  if (!h || !des) return fail(MDS_EINVAL, "mds_traj_eval: null argument");
+  if (h->traj_mode == 1) return mds_lemniscate_eval(h, t, des, stream);
+  if (h->traj_mode != 2) return fail(MDS_ESTATE, "mds_traj_eval: no trajectories set");
+  hipStream_t st = (hipStream_t)stream;
+  if (h->cfg.dtype == MDS_F64) k_traj_eval<double><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, t, h->segs, h->tinfo, (double*)des);
+  else if (h->cfg.dtype == MDS_F32) k_traj_eval<float><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, t, h->segs, h->tinfo, (float*)des);
+  else k_traj_eval<half_t><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, t, h->segs, h->tinfo, (half_t*)des);
+  MDS_HIP(hipGetLastError());
   return MDS_OK;
 }
 
@@ -369,6 +431,18 @@ int mds_set_wind(mds_handle* h, const double force_world[3]) {
 
 static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, hipStream_t st) {
   const unsigned nbatch = (unsigned)((h->n + kBlock - 1) / kBlock);
+  if (h->traj_mode == 2) {      // general trajectories: segment tables
+    const bool rk4_ = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag_ = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
+#define MDS_TRAJ(RK4, DRAG)                                                                                                   \
+  MDS_DISPATCH(h, (k_step_traj<T, S, RK4, DRAG><<<dim3(nbatch), kBlock, 0, st>>>(C, h->n, h->ld, t, (S*)h->state, (const T*)h->origin, \
+                                                                               h->segs, h->tinfo, (T*)h->last_rpm, (S*)obs, (S*)act)))
+    if (rk4_ && drag_) MDS_TRAJ(true, true);
+    else if (rk4_) MDS_TRAJ(true, false);
+    else if (drag_) MDS_TRAJ(false, true);
+    else MDS_TRAJ(false, false);
+#undef MDS_TRAJ
+    return MDS_OK;
+  }
 #define MDS_LAUNCH_GEO2(HAS_OBS, HAS_ACT, RK4, DRAG)                                                                           \
   MDS_DISPATCH(h, (k_step_geometric<T, S, HAS_OBS, HAS_ACT, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t, (S*)h->state, \
                                                                                                 (const T*)h->lem, (T*)h->last_rpm, \
@@ -417,6 +491,7 @@ int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs, int 
 int mds_rollout_geometric_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream) {
   if (!h || n_steps < 0) return fail(MDS_EINVAL, "mds_rollout_geometric_fused");
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_rollout_geometric_fused: call mds_set_lemniscate first");
+  if (h->traj_mode != 1) return fail(MDS_EUNSUPPORTED, "mds_rollout_geometric_fused: Lemniscate trajectories only (use mds_rollout_geometric)");
   if (!aligned16(obs_log) || !aligned16(obs_last)) return fail(MDS_EALIGN, "mds_rollout_geometric_fused: obs buffers");
   if (n_steps == 0) return MDS_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -438,7 +513,7 @@ int mds_rollout_geometric_fused(mds_handle* h, double t0, int n_steps, void* obs
 
 int mds_lemniscate_eval(mds_handle* h, double t, void* des, void* stream) {
   if (!h || !des) return fail(MDS_EINVAL, "mds_lemniscate_eval: null argument");
-  if (!h->has_traj) return fail(MDS_ESTATE, "mds_lemniscate_eval: call mds_set_lemniscate first");
+  if (!h->has_traj || h->traj_mode != 1) return fail(MDS_ESTATE, "mds_lemniscate_eval: call mds_set_lemniscate first");
   MDS_DISPATCH(h, (k_lemniscate_eval<T, S><<<grid_for(h->n, 256), 256, 0, (hipStream_t)stream>>>(h->n, h->ld, t, (const T*)h->lem, (S*)des)));
   MDS_HIP(hipGetLastError());
   return MDS_OK;
@@ -678,7 +753,7 @@ int mds_thrust_omega_from_rates(mds_handle* h, const void* u, const void* rates,
 
 int mds_step_cbf_geometric(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream) {
   if (!h || !obs || !status) return fail(MDS_EINVAL, "mds_step_cbf_geometric: null argument");
-  if (!h->has_traj) return fail(MDS_ESTATE, "mds_step_cbf_geometric: call mds_set_lemniscate first");
+  if (!h->has_traj || h->traj_mode != 1) return fail(MDS_ESTATE, "mds_step_cbf_geometric: call mds_set_lemniscate first");
   if (!h->has_cbf) return fail(MDS_ESTATE, "mds_step_cbf_geometric: call mds_cbf_configure first");
   if (h->cbf.order != 2) return fail(MDS_EUNSUPPORTED, "mds_step_cbf_geometric: order 2 only (the order-3 loop needs the yank low-level controller)");
   if (!aligned16(obs) || !aligned16(action)) return fail(MDS_EALIGN, "mds_step_cbf_geometric: obs_dev/action_dev");

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mds_math.hpp"
+#include "mds_traj.hpp"
 
 namespace mds {
 
@@ -266,6 +267,63 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && !RK4) ? MDS_GEOSIMPLE_MI
   GeoIn<T> in;
   if (i < n) load_geo_in<T, S>(state, lem, ld, i, in);
   geo_process<T, S, HAS_OBS, HAS_ACT, RK4, DRAG>(c, n, ld, t, i, in, state, last_rpm, obs, action_out, lds);
+}
+
+// ------------------------------------------------------------------------------------
+// General-trajectory form of the fused step: the drone's desired state comes from its segment
+// table (mds_traj.hpp), evaluated in double and re-expressed relative to the drone's local-frame
+// origin before the fp32 controller sees it.  obs / action_out may be NULL.
+// ------------------------------------------------------------------------------------
+template <typename T, typename S, bool RK4, bool DRAG>
+__global__ __launch_bounds__(kBlock) void k_step_traj(const Consts<T> c, const int n, const size_t ld, const double t,
+                                                      S* __restrict__ state, const T* __restrict__ origin,
+                                                      const double* __restrict__ segs, const int* __restrict__ tinfo,
+                                                      T* __restrict__ last_rpm, S* __restrict__ obs, S* __restrict__ action_out) {
+  __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = i < n;
+  T o[kObsDim];
+  State<T> s;
+  if (valid) {
+    load_state<S, T>(state, ld, i, s);
+    const V3<T> org = {origin[i], origin[ld + i], origin[2 * ld + i]};
+    double d11[11];
+    traj_eval(segs, tinfo[2 * i], tinfo[2 * i + 1] & 0xffff, tinfo[2 * i + 1] >> 16, t, d11);
+    Desired<T> des;
+    des.p = {(T)(d11[0] - (double)org.x), (T)(d11[1] - (double)org.y), (T)(d11[2] - (double)org.z)};
+    des.v = {(T)d11[3], (T)d11[4], (T)d11[5]};
+    des.a = {(T)d11[6], (T)d11[7], (T)d11[8]};
+    des.yaw = reduced_phase<T>(0.0, T(0), (T)d11[9]);
+    des.yaw_rate = (T)d11[10];
+    T prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4], act[4];
+    if (DRAG)
+      for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
+    {
+      const M3<T> R = quat_to_rot(s.q);
+      const V3<T> ang_v = mul(R, s.w);
+      T u[4];
+      geometric_control<T>(c, s.p - des.p, R, s.v, ang_v, des, u, nullptr);
+      input_to_action(c, u, act);
+    }
+    aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
+    if (DRAG)
+      for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
+    if (action_out) store4<S, T>(action_out + (size_t)i * 4, act);
+    if (obs) pack_obs(s, org, clipped, o);
+  }
+  if (obs) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
+  if (valid) store_state<S, T>(state, ld, i, s);
+}
+
+// Trajectory.__call__(t) for every drone from the segment tables: des [n,11] world frame
+template <typename S>
+__global__ void k_traj_eval(const int n, const double t, const double* __restrict__ segs, const int* __restrict__ tinfo,
+                            S* __restrict__ des) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double d11[11];
+  traj_eval(segs, tinfo[2 * i], tinfo[2 * i + 1] & 0xffff, tinfo[2 * i + 1] >> 16, t, d11);
+  for (int k = 0; k < 11; ++k) des[(size_t)i * 11 + k] = (S)d11[k];
 }
 
 // ------------------------------------------------------------------------------------

@@ -240,10 +240,23 @@ class BaseAviary:
 
     # ------------------------------------------------------------------ fused on-GPU control loop
     def set_trajectories(self, trajs):
-        """Attach one Lemniscate per drone (list of D, list of E*D, or an [E,D,7]/[D,7] parameter
-        array: a, omega, centre3, yaw_rate, phase_shift) for ``step_geometric``."""
+        """Attach one trajectory per drone for ``step_geometric``: a list of D (shared by every env) or
+        E*D trajectory objects, or an [E,D,7]/[D,7] Lemniscate parameter array (a, omega, centre3, yaw_rate,
+        phase_shift).  All-Lemniscate sets use the fused fp32 kernel; anything else (Circle, Line, Wait,
+        Compound, Rotate) is flattened into segment tables for the general kernel."""
         self._require_open()
+        from ..trajectories.Lemniscate import Lemniscate
+        from ..trajectories.base import upload_segments
         if isinstance(trajs, (list, tuple)):
+            trajs = list(trajs)
+            if len(trajs) == self.NUM_DRONES and self.NUM_ENVS > 1:
+                trajs = trajs * self.NUM_ENVS
+            if len(trajs) != self.n:
+                raise ValueError(f"need {self.NUM_DRONES} or {self.n} trajectories, got {len(trajs)}")
+            if not all(type(t) is Lemniscate for t in trajs):
+                upload_segments(self._lib, self._h, trajs, self.device)
+                self._has_traj = True
+                return
             P = np.array([t.params() for t in trajs], dtype=np.float64)
         else:
             P = np.asarray(trajs, dtype=np.float64)

@@ -387,6 +387,46 @@ def mint_lqr_omega(ref):
     print("lqr_omega K", ctrl.K.shape, "u0 range", u[:, 0].min(), u[:, 0].max())
 
 
+def trajectory_cases(T):
+    """The same constructor arguments are used for the reference classes (minting) and for the oracle /
+    GPU classes (tests): T is a namespace with Lemniscate, Circle, Line, Wait, Compound, Rotate."""
+    from scipy.spatial.transform import Rotation as Rot
+    Rz = Rot.from_euler("xyz", [0.2, -0.3, 0.9]).as_matrix()
+    a, b, c = np.array([0.0, 0.0, 0.5]), np.array([1.5, -0.5, 1.0]), np.array([1.5, 2.0, 1.0])
+    return {
+        "circle": T.Circle(r=0.8, v=0.6, center=np.array([0.2, -0.1, 0.7]), yaw_rate=0.4),
+        "circle_rev": T.Circle(r=1.5, v=1.0, center=np.array([0, 0, 1.0]), yaw_rate=-0.7, revolutions=2),
+        "wait": T.Wait(position=np.array([0.3, 0.4, 0.5]), duration=2.0, yaw=0.6),
+        "line_long": T.Line(start=a, end=b + np.array([3.0, 0, 0]), speed=0.5),
+        "line_short": T.Line(start=a, end=a + np.array([0.1, 0.05, 0.0]), speed=1.0),
+        "line_s0": T.Line(start=b, end=c + np.array([0, 4.0, 0]), speed=1.0, s0=0.3, sf=0.2),
+        "compound": T.Compound([T.Line(start=a, end=b, speed=.5), T.Wait(duration=1, position=b),
+                                T.Line(start=b, end=c, speed=1), T.Line(start=c, end=b, speed=1)]),     # EnvGeometric.py:543-550
+        "compound_mixed": T.Compound([T.Wait(position=a, duration=0.5, yaw=0.1), T.Lemniscate(a=0.5, omega=1.0, center=a, yaw_rate=0.2),
+                                      T.Circle(r=0.5, v=0.5, center=a)]),
+        "rotate": T.Rotate(T.Lemniscate(a=1.0, omega=1.5, center=np.array([0, 0, .5]), yaw_rate=0.3, phase_shift=0.4), Rz, np.array([0.1, 0.2, 0.5])),
+        "rotate_compound": T.Rotate(T.Compound([T.Line(start=a, end=b, speed=.7), T.Circle(r=0.4, v=0.3, center=b)]), Rz, b),
+    }
+
+
+def mint_trajectories():
+    import trajectories as TR     # importable as a package (no third-party imports)
+    T = types.SimpleNamespace(Lemniscate=TR.Lemniscate, Circle=TR.CircleTrajectory, Line=TR.LineTrajectory, Wait=TR.WaitTrajectory,
+                              Compound=TR.CompoundTrajectory, Rotate=TR.RotateTrajectory)
+    cases = trajectory_cases(T)
+    out = {}
+    for name, tr in cases.items():
+        tt = tr.get_total_time()
+        ts = np.concatenate([np.linspace(0, 1.25 * tt, 161), [tt, tt * (1 - 1e-9)]])
+        rows = np.zeros((len(ts), 11))
+        for k, t in enumerate(ts):
+            pos, vel, acc, yaw, om = tr(float(t))
+            rows[k] = np.hstack([pos, vel, acc * np.ones(3), yaw, om])
+        out[name + "_t"], out[name + "_out"], out[name + "_total"] = ts, rows, tt
+    np.savez_compressed(OUT + "/trajectories.npz", names=np.array(list(cases)), **out, **META)
+    print("trajectories", list(cases))
+
+
 if __name__ == "__main__":
     ref = load_reference()
     mint_lemniscate(ref)
@@ -396,3 +436,5 @@ if __name__ == "__main__":
     mint_cbf(ref)
     mint_thrust_omega()
     mint_lqr_omega(ref)
+    sys.path.insert(0, REF)
+    mint_trajectories()

@@ -148,3 +148,20 @@ def test_lqr_omega_matches_reference():
     np.testing.assert_allclose(u, d["u"], rtol=1e-10, atol=1e-10)
     lo, hi = 4 * 9440.3 ** 2 * O.CF2P.KF, O.CF2P.MAX_THRUST
     assert (np.abs(d["u"][:, 0] - lo) < 1e-12).sum() >= 8 and (np.abs(d["u"][:, 0] - hi) < 1e-12).sum() >= 8
+
+
+def test_trajectory_family_matches_reference():
+    """trajectories/{Circle,LineTrajectory,CompoundTrajectory,RotateTrajectory}.py via oracle/np_trajectories.py."""
+    import types
+    from oracle import np_trajectories as NT
+    from tests.golden.mint_golden import trajectory_cases
+    d = load("trajectories.npz")
+    cases = trajectory_cases(types.SimpleNamespace(Lemniscate=NT.Lemniscate, Circle=NT.Circle, Line=NT.Line, Wait=NT.Wait,
+                                                   Compound=NT.Compound, Rotate=NT.Rotate))
+    assert list(d["names"]) == list(cases)
+    for name, tr in cases.items():
+        np.testing.assert_allclose(tr.get_total_time(), float(d[name + "_total"]), rtol=1e-14)
+        for t, want in zip(d[name + "_t"], d[name + "_out"]):
+            pos, vel, acc, yaw, om = tr(float(t))
+            got = np.hstack([pos, vel, np.asarray(acc) * np.ones(3), yaw, om])
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-12, err_msg=f"{name} t={t}")
