@@ -243,6 +243,21 @@ int mds_thrust_omega_compute(mds_handle* h, const void* u_dev, const void* obs_d
 /* same with the current BODY rates given directly: rates_dev [n,3] (computeControlFromInput's own signature) */
 int mds_thrust_omega_from_rates(mds_handle* h, const void* u_dev, const void* rates_dev, void* rpm_dev, void* stream);
 
+/* ---- [UPSTREAM] DSLPIDControl as PIDEnv.py drives it (not in the reference tree: spec-level, unpinned) ---- */
+typedef struct mds_dslpid_gains {
+  double P_COEFF_FOR[3], I_COEFF_FOR[3], D_COEFF_FOR[3], P_COEFF_TOR[3], I_COEFF_TOR[3], D_COEFF_TOR[3];
+} mds_dslpid_gains;
+int mds_default_dslpid_gains(mds_dslpid_gains* g);           /* upstream defaults; PIDEnv.py:128-133 halves them */
+int mds_set_dslpid_gains(mds_handle* h, const mds_dslpid_gains* g);
+int mds_dslpid_reset(mds_handle* h, void* stream);           /* DSLPIDControl.reset(): zero the PID memory */
+/* computeControlFromState(CTRL_TIMESTEP, state=obs[j], target_pos, target_rpy) for every drone (PIDEnv.py:166-169):
+ * obs_dev [n,20], target_pos_dev [n,3], target_rpy_dev [n,3] -> rpm_dev [n,4].  Stateful. */
+int mds_dslpid_compute(mds_handle* h, const void* obs_dev, const void* target_pos_dev, const void* target_rpy_dev, void* rpm_dev,
+                       void* stream);
+/* MultiDroneEnv.sim_step (PIDEnv.py:161-176): the same controller on the handle's own state, fused with
+ * env.step(action).  obs_dev [n,20] / action_dev [n,4] optional. */
+int mds_step_dslpid(mds_handle* h, const void* target_pos_dev, const void* target_rpy_dev, void* obs_dev, void* action_dev, void* stream);
+
 /* LQROmegaController (control/lqr/lqr_omega_controller.py): K [4,9] row-major is the gain its
  * compute_gain_matrix() obtains from solve_continuous_are on the host (:53-57). */
 int mds_set_lqr_omega_gain(mds_handle* h, const double K[36]);

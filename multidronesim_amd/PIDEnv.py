@@ -1,14 +1,13 @@
 """PIDEnv.py of the reference: ``MultiDroneEnv`` -- a threaded hover service around
 CtrlAviary with mutable ``TARGET_POSITIONS`` (PIDEnv.py:31-187).
 
-Same constructor, ``threaded_sim() / run_sim() / sim_step(i) / stop()`` and attributes.  The
-per-drone set-point controller runs on the GPU fused with the physics step: each drone
-tracks a zero-amplitude Lemniscate centred on its target (pos = target, vel = acc = 0), i.e.
-the reference's own GeometricControl regulating to TARGET_POSITIONS.  ([UPSTREAM]
-DSLPIDControl, which the reference instantiates at PIDEnv.py:124-134, is not in the
-reference tree; porting it is listed under "next" in DESIGN.md.)  The reference's latent bugs
-(module-global ARGS, 20-vector unpacked into 4 names, missing ``logging`` import) are not
-reproduced."""
+Same constructor, ``threaded_sim() / run_sim() / sim_step(i) / stop()`` and attributes.  Like the
+reference it builds one ``DSLPIDControl`` per drone with every gain halved (PIDEnv.py:124-134);
+``sim_step`` runs that controller towards ``TARGET_POSITIONS`` / ``TARGET_RPYS`` fused with the
+physics step on the GPU (``env.step_dslpid``).  DSLPIDControl is [UPSTREAM] (not in the reference
+tree): spec-level restatement, parity unpinned.  ``controller="geometric"`` selects the reference's
+own GeometricControl regulating to the targets instead.  The reference's latent bugs (module-global
+ARGS, 20-vector unpacked into 4 names, missing ``logging`` import) are not reproduced."""
 from __future__ import annotations
 
 import argparse
@@ -51,6 +50,7 @@ class MultiDroneEnv(object):
         args['init_rad'] = 1.0
         args['num_envs'] = 1          # batch axis (build extension)
         args['realtime'] = True       # sync() to wall-clock like the reference (PIDEnv.py:179)
+        args['controller'] = 'dslpid' # 'dslpid' (PIDEnv.py:124-134) or 'geometric'
         for key, value in kwargs.items():
             if key in args:
                 args[key] = value
@@ -62,7 +62,7 @@ class MultiDroneEnv(object):
     def __init__(self, INIT_XYZS=None, INIT_RPYS=None, TARGET_POSITIONS=None, TARGET_RPYS=None, args=None, **kwargs):
         self.args = self.build_args(kwargs) if args is None else args
         a = self.args
-        for k, v in (("num_envs", 1), ("realtime", True), ("init_rad", 1.0), ("duration_sec", None)):
+        for k, v in (("num_envs", 1), ("realtime", True), ("init_rad", 1.0), ("duration_sec", None), ("controller", "dslpid")):
             if not hasattr(a, k):
                 setattr(a, k, v)
         starting_target_offset = 1
@@ -120,6 +120,21 @@ class MultiDroneEnv(object):
         self.PYB_CLIENT = self.env.getPyBulletClient()
         self.DRONE_IDS = self.env.getDroneIds()
         self.env._showDroneLocalAxes(0)
+        # PID control for set point regulation (PIDEnv.py:124-134): every gain halved
+        ctrl = []
+        if args.drone in [DroneModel.CF2X, DroneModel.CF2P]:
+            from .control.DSLPIDControl import DSLPIDControl
+            for i in range(args.num_drones):
+                ctrl.append(DSLPIDControl(drone_model=args.drone))
+                ctrl[i].P_COEFF_FOR = 0.5 * np.array([.4, .4, 1.25])
+                ctrl[i].I_COEFF_FOR = 0.5 * np.array([.05, .05, .05])
+                ctrl[i].D_COEFF_FOR = 0.5 * np.array([.2, .2, .5])
+                ctrl[i].P_COEFF_TOR = 0.5 * np.array([70000., 70000., 60000.])
+                ctrl[i].I_COEFF_TOR = 0.5 * np.array([.0, .0, 500.])
+                ctrl[i].D_COEFF_TOR = 0.5 * np.array([20000., 20000., 12000.])
+        self.ctrl = ctrl
+        if ctrl:
+            env.set_dslpid_gains(ctrl[0])      # the reference gives every drone the same gains
         self.START = time.time()
         self.action = np.zeros((args.num_drones, 4)) if args.num_envs == 1 else np.zeros((args.num_envs, args.num_drones, 4))
         self.obs, _, _, _, _ = self.env.step(self.action)
@@ -135,8 +150,13 @@ class MultiDroneEnv(object):
         self.env.close()
 
     def sim_step(self, i):
-        self._push_targets()
-        obs, act = self.env.step_geometric(i * self.env.CTRL_TIMESTEP, return_action=True)
+        if getattr(self.args, "controller", "dslpid") == "dslpid":
+            # targets are read at the step boundary (the reference's REPL thread writes them unsynchronised, PIDEnv.py:206)
+            obs, act = self.env.step_dslpid(np.array(self.TARGET_POSITIONS, dtype=np.float64), np.array(self.TARGET_RPYS, dtype=np.float64),
+                                            return_action=True)
+        else:
+            self._push_targets()
+            obs, act = self.env.step_geometric(i * self.env.CTRL_TIMESTEP, return_action=True)
         self.obs = obs
         self.action = act
         if self.args.realtime:

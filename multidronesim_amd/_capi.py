@@ -37,6 +37,10 @@ class MdsCbfParams(C.Structure):
                 ("Fmin", C.c_double), ("Fmax", C.c_double), ("tol", C.c_double)]
 
 
+class MdsDslPidGains(C.Structure):
+    _fields_ = [(k, C.c_double * 3) for k in ("P_COEFF_FOR", "I_COEFF_FOR", "D_COEFF_FOR", "P_COEFF_TOR", "I_COEFF_TOR", "D_COEFF_TOR")]
+
+
 class MdsError(RuntimeError):
     def __init__(self, status, where, detail):
         super().__init__(f"{where}: {detail} (mds_status {status})")
@@ -82,6 +86,11 @@ PROTOTYPES = {
     "mds_lowlevel_reset": (C.c_int, [_P, _P]),
     "mds_thrust_omega_compute": (C.c_int, [_P, _P, _P, _P, _P]),
     "mds_thrust_omega_from_rates": (C.c_int, [_P, _P, _P, _P, _P]),
+    "mds_default_dslpid_gains": (C.c_int, [C.POINTER(MdsDslPidGains)]),
+    "mds_set_dslpid_gains": (C.c_int, [_P, C.POINTER(MdsDslPidGains)]),
+    "mds_dslpid_reset": (C.c_int, [_P, _P]),
+    "mds_dslpid_compute": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "mds_step_dslpid": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "mds_set_lqr_omega_gain": (C.c_int, [_P, _PD]),
     "mds_lqr_omega_compute": (C.c_int, [_P, _P, _P, _P, _P]),
     "mds_cbf_set_nominal": (C.c_int, [_P, C.c_int]),

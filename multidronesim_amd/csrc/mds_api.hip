@@ -68,6 +68,9 @@ struct mds_handle {
   void* cbf_xdes;      // S [n,9]
   void* cbf_usafe;     // S [n,4]
   void* ll;            // T [6][ld]: ThrustOmega last_omega3 | integral3
+  void* pid;           // T [9][ld]: DSLPID last_rpy3 | integral_pos_e3 | integral_rpy_e3
+  DslPidGains<float> pid_f;
+  DslPidGains<double> pid_d;
   bool has_lqr;
   int cbf_nominal;     // 0 geometric, 1 lqr-omega
   LqrGain<float> lqr_f;
@@ -195,6 +198,12 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   h->cbf_unom = h->cbf_xdes = h->cbf_usafe = h->ll = nullptr;
   h->has_lqr = false;
   h->cbf_nominal = 0;
+  h->pid = nullptr;
+  {
+    mds_dslpid_gains dg;
+    mds_default_dslpid_gains(&dg);
+    mds_set_dslpid_gains(h, &dg);
+  }
   hipError_t e = hipMalloc(&h->state, 13 * h->ld * es);
   if (e == hipSuccess) e = hipMalloc(&h->origin, 3 * h->ld * cs);
   if (e == hipSuccess) e = hipMalloc(&h->last_rpm, 4 * h->ld * cs);
@@ -202,6 +211,8 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   if (e == hipSuccess) e = hipMalloc((void**)&h->scratch, (size_t)h->n * 20 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&h->ll, 6 * h->ld * cs);
   if (e == hipSuccess) e = hipMemset(h->ll, 0, 6 * h->ld * cs);
+  if (e == hipSuccess) e = hipMalloc(&h->pid, 9 * h->ld * cs);
+  if (e == hipSuccess) e = hipMemset(h->pid, 0, 9 * h->ld * cs);
   if (e == hipSuccess) e = hipMemset(h->state, 0, 13 * h->ld * es);
   if (e == hipSuccess) e = hipMemset(h->origin, 0, 3 * h->ld * cs);
   if (e == hipSuccess) e = hipMemset(h->last_rpm, 0, 4 * h->ld * cs);
@@ -236,6 +247,7 @@ int mds_destroy(mds_handle* h) {
   if (h->cbf_xdes) (void)hipFree(h->cbf_xdes);
   if (h->cbf_usafe) (void)hipFree(h->cbf_usafe);
   if (h->ll) (void)hipFree(h->ll);
+  if (h->pid) (void)hipFree(h->pid);
   if (h->segs) (void)hipFree(h->segs);
   if (h->tinfo) (void)hipFree(h->tinfo);
   delete h;
@@ -268,6 +280,7 @@ int mds_reset(mds_handle* h, const double* xyz, const double* rpy, void* stream)
                                                                         (const T*)h->origin, (S*)h->state, (T*)h->last_rpm)));
   MDS_HIP(hipGetLastError());
   MDS_HIP(hipMemsetAsync(h->ll, 0, 6 * h->ld * comp_size(h->cfg.dtype), st));
+  MDS_HIP(hipMemsetAsync(h->pid, 0, 9 * h->ld * comp_size(h->cfg.dtype), st));
   MDS_HIP(hipStreamSynchronize(st));   // host buffers may be reused by the caller
   return MDS_OK;
 }
@@ -689,6 +702,72 @@ int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void*
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }
+
+int mds_default_dslpid_gains(mds_dslpid_gains* g) {
+  if (!g) return fail(MDS_EINVAL, "mds_default_dslpid_gains");
+  const double pf[3] = {.4, .4, 1.25}, ifo[3] = {.05, .05, .05}, df[3] = {.2, .2, .5};
+  const double pt[3] = {70000., 70000., 60000.}, it[3] = {.0, .0, 500.}, dt[3] = {20000., 20000., 12000.};
+  for (int k = 0; k < 3; ++k) {
+    g->P_COEFF_FOR[k] = pf[k]; g->I_COEFF_FOR[k] = ifo[k]; g->D_COEFF_FOR[k] = df[k];
+    g->P_COEFF_TOR[k] = pt[k]; g->I_COEFF_TOR[k] = it[k]; g->D_COEFF_TOR[k] = dt[k];
+  }
+  return MDS_OK;
+}
+
+int mds_set_dslpid_gains(mds_handle* h, const mds_dslpid_gains* g) {
+  if (!h || !g) return fail(MDS_EINVAL, "mds_set_dslpid_gains: null argument");
+  for (int k = 0; k < 3; ++k) {
+    h->pid_d.Pf[k] = g->P_COEFF_FOR[k]; h->pid_d.If[k] = g->I_COEFF_FOR[k]; h->pid_d.Df[k] = g->D_COEFF_FOR[k];
+    h->pid_d.Pt[k] = g->P_COEFF_TOR[k]; h->pid_d.It[k] = g->I_COEFF_TOR[k]; h->pid_d.Dt[k] = g->D_COEFF_TOR[k];
+    h->pid_f.Pf[k] = (float)g->P_COEFF_FOR[k]; h->pid_f.If[k] = (float)g->I_COEFF_FOR[k]; h->pid_f.Df[k] = (float)g->D_COEFF_FOR[k];
+    h->pid_f.Pt[k] = (float)g->P_COEFF_TOR[k]; h->pid_f.It[k] = (float)g->I_COEFF_TOR[k]; h->pid_f.Dt[k] = (float)g->D_COEFF_TOR[k];
+  }
+  return MDS_OK;
+}
+
+int mds_dslpid_reset(mds_handle* h, void* stream) {
+  if (!h) return fail(MDS_EINVAL, "mds_dslpid_reset: null handle");
+  MDS_HIP(hipMemsetAsync(h->pid, 0, 9 * h->ld * comp_size(h->cfg.dtype), (hipStream_t)stream));
+  return MDS_OK;
+}
+
+#define MDS_PID_LAUNCH(T, S, C, G, STEP, RK4, DRAG)                                                                           \
+  k_dslpid<T, S, STEP, RK4, DRAG><<<grid_for(h->n, kBlock), kBlock, 0, st>>>(C, G, h->n, h->ld, (T)(1.0 / h->cfg.ctrl_freq), (S*)h->state, \
+                                                                             (const T*)h->origin, (T*)h->last_rpm, (T*)h->pid,             \
+                                                                             (const S*)obs_in, (const S*)tpos, (const S*)trpy, (S*)obs,    \
+                                                                             (S*)act)
+#define MDS_PID_DTYPE(STEP, RK4, DRAG)                                                        \
+  do {                                                                                        \
+    if (h->cfg.dtype == MDS_F64) MDS_PID_LAUNCH(double, double, h->cd, h->pid_d, STEP, RK4, DRAG); \
+    else if (h->cfg.dtype == MDS_F32) MDS_PID_LAUNCH(float, float, h->cf, h->pid_f, STEP, RK4, DRAG); \
+    else MDS_PID_LAUNCH(float, half_t, h->cf, h->pid_f, STEP, RK4, DRAG);                     \
+  } while (0)
+
+int mds_dslpid_compute(mds_handle* h, const void* obs_in, const void* tpos, const void* trpy, void* act, void* stream) {
+  if (!h || !obs_in || !tpos || !trpy || !act) return fail(MDS_EINVAL, "mds_dslpid_compute: null argument");
+  if (!aligned16(act)) return fail(MDS_EALIGN, "mds_dslpid_compute: rpm_dev");
+  hipStream_t st = (hipStream_t)stream;
+  void* obs = nullptr;
+  MDS_PID_DTYPE(false, false, false);
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_step_dslpid(mds_handle* h, const void* tpos, const void* trpy, void* obs, void* act, void* stream) {
+  if (!h || !tpos || !trpy) return fail(MDS_EINVAL, "mds_step_dslpid: null argument");
+  if (!aligned16(obs) || !aligned16(act)) return fail(MDS_EALIGN, "mds_step_dslpid: obs_dev/action_dev");
+  hipStream_t st = (hipStream_t)stream;
+  const void* obs_in = nullptr;
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
+  if (rk4 && drag) MDS_PID_DTYPE(true, true, true);
+  else if (rk4) MDS_PID_DTYPE(true, true, false);
+  else if (drag) MDS_PID_DTYPE(true, false, true);
+  else MDS_PID_DTYPE(true, false, false);
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+#undef MDS_PID_DTYPE
+#undef MDS_PID_LAUNCH
 
 int mds_set_lqr_omega_gain(mds_handle* h, const double K[36]) {
   if (!h || !K) return fail(MDS_EINVAL, "mds_set_lqr_omega_gain: null argument");

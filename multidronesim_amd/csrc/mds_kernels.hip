@@ -506,6 +506,60 @@ __global__ void k_thrust_omega(const Consts<T> c, const int n, const size_t ld, 
   store4<S, T>(rpm + (size_t)i * 4, act);
 }
 
+// ------------------------------------------------------------------------------------
+// PIDEnv.MultiDroneEnv.sim_step (PIDEnv.py:161-176) for every drone: [UPSTREAM] DSLPIDControl
+// towards TARGET_POSITIONS / TARGET_RPYS, then env.step(action).  pid = 9 planes:
+// last_rpy3 | integral_pos_e3 | integral_rpy_e3.  STEP = false: controller only, from an obs array.
+// ------------------------------------------------------------------------------------
+template <typename T, typename S, bool STEP, bool RK4, bool DRAG>
+__global__ __launch_bounds__(kBlock) void k_dslpid(const Consts<T> c, const DslPidGains<T> g, const int n, const size_t ld, const T ctrl_dt,
+                                                   S* __restrict__ state, const T* __restrict__ origin, T* __restrict__ last_rpm,
+                                                   T* __restrict__ pid, const S* __restrict__ obs_in, const S* __restrict__ tpos,
+                                                   const S* __restrict__ trpy, S* __restrict__ obs, S* __restrict__ action_out) {
+  __shared__ __align__(16) unsigned char lds[STEP ? (kBlock * kObsDim * sizeof(S)) : 16];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = i < n;
+  T o[kObsDim];
+  State<T> s;
+  if (valid) {
+    V3<T> org = {T(0), T(0), T(0)};
+    if (STEP) {
+      load_state<S, T>(state, ld, i, s);
+      org = {origin[i], origin[ld + i], origin[2 * ld + i]};
+    } else {
+      const S* ob = obs_in + (size_t)i * 20;
+      s.p = {(T)ob[0], (T)ob[1], (T)ob[2]};
+      for (int k = 0; k < 4; ++k) s.q[k] = (T)ob[3 + k];
+      s.v = {(T)ob[10], (T)ob[11], (T)ob[12]};
+      s.w = {T(0), T(0), T(0)};
+    }
+    DslPidState<T> P;
+    P.last_rpy = {pid[0 * ld + i], pid[1 * ld + i], pid[2 * ld + i]};
+    P.int_pos = {pid[3 * ld + i], pid[4 * ld + i], pid[5 * ld + i]};
+    P.int_rpy = {pid[6 * ld + i], pid[7 * ld + i], pid[8 * ld + i]};
+    const V3<T> pos_e = {((T)tpos[(size_t)i * 3] - org.x) - s.p.x, ((T)tpos[(size_t)i * 3 + 1] - org.y) - s.p.y,
+                         ((T)tpos[(size_t)i * 3 + 2] - org.z) - s.p.z};
+    T act[4], prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4];
+    dslpid_control<T>(c, g, ctrl_dt, pos_e, s.q, s.v, (T)trpy[(size_t)i * 3 + 2], P, act);
+    pid[0 * ld + i] = P.last_rpy.x; pid[1 * ld + i] = P.last_rpy.y; pid[2 * ld + i] = P.last_rpy.z;
+    pid[3 * ld + i] = P.int_pos.x; pid[4 * ld + i] = P.int_pos.y; pid[5 * ld + i] = P.int_pos.z;
+    pid[6 * ld + i] = P.int_rpy.x; pid[7 * ld + i] = P.int_rpy.y; pid[8 * ld + i] = P.int_rpy.z;
+    if (action_out) store4<S, T>(action_out + (size_t)i * 4, act);
+    if (STEP) {
+      if (DRAG)
+        for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
+      aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
+      if (DRAG)
+        for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
+      if (obs) pack_obs(s, org, clipped, o);
+    }
+  }
+  if (STEP) {
+    if (obs) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
+    if (valid) store_state<S, T>(state, ld, i, s);
+  }
+}
+
 // [UPSTREAM] _computeObs from the current state
 template <typename T, typename S>
 __global__ __launch_bounds__(kBlock) void k_get_obs(const int n, const size_t ld, const S* __restrict__ state,

@@ -603,6 +603,64 @@ MDS_HD void lqr_omega_control(const Consts<T>& c, const LqrGain<T>& K, V3<T> rpy
   u[0] = m_clamp(u[0], T(4) * c.min_motor_thrust, c.max_motor_thrust);                    // cap_u :116-119
 }
 
+// ------------------------------------------------------------------------------------
+// [UPSTREAM] gym_pybullet_drones DSLPIDControl.computeControl as PIDEnv.py:166-169 calls it
+// (computeControlFromState; target_vel = target_rpy_rates = 0).  Not in the reference tree:
+// restated from the published upstream source, parity unpinned.  The intermediate
+// as_euler('XYZ') / from_euler round trip of the target rotation is the identity and is skipped.
+// ------------------------------------------------------------------------------------
+template <typename T> struct DslPidGains {
+  T Pf[3], If[3], Df[3], Pt[3], It[3], Dt[3];
+};
+template <typename T> struct DslPidState {
+  V3<T> last_rpy, int_pos, int_rpy;
+};
+template <typename T>
+MDS_HD void dslpid_control(const Consts<T>& c, const DslPidGains<T>& g, T ctrl_dt, V3<T> pos_e, const T q[4], V3<T> vel, T target_yaw,
+                           DslPidState<T>& s, T rpm[4]) {
+  const T kScale = T(0.2685), kConst = T(4070.3), kMinPwm = T(20000), kMaxPwm = T(65535);
+  const M3<T> R = quat_to_rot(q);
+  // _dslPIDPositionControl
+  s.int_pos = {m_clamp(m_fma(pos_e.x, ctrl_dt, s.int_pos.x), T(-2), T(2)), m_clamp(m_fma(pos_e.y, ctrl_dt, s.int_pos.y), T(-2), T(2)),
+               m_clamp(m_clamp(m_fma(pos_e.z, ctrl_dt, s.int_pos.z), T(-2), T(2)), T(-0.15), T(0.15))};
+  const V3<T> tt = {g.Pf[0] * pos_e.x + g.If[0] * s.int_pos.x - g.Df[0] * vel.x, g.Pf[1] * pos_e.y + g.If[1] * s.int_pos.y - g.Df[1] * vel.y,
+                    g.Pf[2] * pos_e.z + g.If[2] * s.int_pos.z - g.Df[2] * vel.z + c.gravity};
+  const T scalar = m_max(T(0), dot(tt, col(R, 2)));
+  const T thrust = (m_sqrt(scalar * c.inv_kf * T(0.25)) - kConst) / kScale;
+  const V3<T> z_ax = m_rsqrt(dot(tt, tt)) * tt;
+  T sy, cy;
+  m_sincos(reduced_phase<T>(0.0, T(0), target_yaw), &sy, &cy);
+  const V3<T> yc = cross(z_ax, V3<T>{cy, sy, T(0)});
+  const V3<T> y_ax = m_rsqrt(dot(yc, yc)) * yc;
+  const V3<T> x_ax = cross(y_ax, z_ax);
+  // _dslPIDAttitudeControl
+  const V3<T> cur_rpy = euler_from_quat(q);
+  const V3<T> r0 = col(R, 0), r1 = col(R, 1), r2 = col(R, 2);
+  const V3<T> rot_e = {dot(z_ax, r1) - dot(y_ax, r2), dot(x_ax, r2) - dot(z_ax, r0), dot(y_ax, r0) - dot(x_ax, r1)};
+  const T inv_dt = T(1) / ctrl_dt;
+  const V3<T> rates_e = {-(cur_rpy.x - s.last_rpy.x) * inv_dt, -(cur_rpy.y - s.last_rpy.y) * inv_dt, -(cur_rpy.z - s.last_rpy.z) * inv_dt};
+  s.last_rpy = cur_rpy;
+  s.int_rpy = {m_clamp(m_clamp(s.int_rpy.x - rot_e.x * ctrl_dt, T(-1500), T(1500)), T(-1), T(1)),
+               m_clamp(m_clamp(s.int_rpy.y - rot_e.y * ctrl_dt, T(-1500), T(1500)), T(-1), T(1)),
+               m_clamp(s.int_rpy.z - rot_e.z * ctrl_dt, T(-1500), T(1500))};
+  const T tx = m_clamp(-g.Pt[0] * rot_e.x + g.Dt[0] * rates_e.x + g.It[0] * s.int_rpy.x, T(-3200), T(3200));
+  const T ty = m_clamp(-g.Pt[1] * rot_e.y + g.Dt[1] * rates_e.y + g.It[1] * s.int_rpy.y, T(-3200), T(3200));
+  const T tz = m_clamp(-g.Pt[2] * rot_e.z + g.Dt[2] * rates_e.z + g.It[2] * s.int_rpy.z, T(-3200), T(3200));
+  T pwm[4];
+  if (c.cf2x) {
+    pwm[0] = thrust + (T(-0.5) * tx + T(-0.5) * ty - tz);
+    pwm[1] = thrust + (T(-0.5) * tx + T(0.5) * ty + tz);
+    pwm[2] = thrust + (T(0.5) * tx + T(0.5) * ty - tz);
+    pwm[3] = thrust + (T(0.5) * tx + T(-0.5) * ty + tz);
+  } else {
+    pwm[0] = thrust + (-ty - tz);
+    pwm[1] = thrust + (tx + tz);
+    pwm[2] = thrust + (ty - tz);
+    pwm[3] = thrust + (-tx + tz);
+  }
+  for (int i = 0; i < 4; ++i) rpm[i] = m_fma(kScale, m_clamp(pwm[i], kMinPwm, kMaxPwm), kConst);
+}
+
 // model/dynamics.py:83-106: (state18, u4) -> 12 floats (x_dot = v, "R_dot" = w, v_dot, w_dot)
 template <typename T> MDS_HD void quadrotor_dynamics(const T s[18], const T u[4], T m, const T J[3], T g, T out[12]) {
   out[0] = s[12]; out[1] = s[13]; out[2] = s[14];

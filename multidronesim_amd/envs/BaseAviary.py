@@ -320,6 +320,28 @@ class BaseAviary:
         self.step_counter += n_steps * self.PYB_STEPS_PER_CTRL
         return self._obs, log_out
 
+    def set_dslpid_gains(self, ctrl):
+        """Push the P/I/D_COEFF_FOR/TOR arrays of a DSLPIDControl object to this env (PIDEnv.py:124-134)."""
+        from ..control.DSLPIDControl import gains_struct
+        capi.check(self._lib.mds_set_dslpid_gains(self._h, C.byref(gains_struct(ctrl))), "mds_set_dslpid_gains")
+
+    def step_dslpid(self, target_pos, target_rpy, return_action: bool = False):
+        """MultiDroneEnv.sim_step (PIDEnv.py:161-176) for every drone: DSLPID towards target_pos / target_rpy
+        ([E,D,3] or [D,3]), fused with env.step."""
+        self._require_open()
+        def prep(a):
+            if not isinstance(a, torch.Tensor):
+                a = np.asarray(a, dtype=np.float64)
+                if a.shape == (self.NUM_DRONES, 3):
+                    a = np.broadcast_to(a, (self.NUM_ENVS, self.NUM_DRONES, 3))
+            return to_device(a, self.device, self.dtype).reshape(self.n, 3)
+        tp, tr = prep(target_pos), prep(target_rpy)
+        act_ptr = C.c_void_p(self._act.data_ptr()) if return_action else C.c_void_p(None)
+        capi.check(self._lib.mds_step_dslpid(self._h, C.c_void_p(tp.data_ptr()), C.c_void_p(tr.data_ptr()), C.c_void_p(self._obs.data_ptr()),
+                                             act_ptr, self._stream()), "mds_step_dslpid")
+        self.step_counter += self.PYB_STEPS_PER_CTRL
+        return (self._obs, self._act) if return_action else self._obs
+
     def set_cbf_nominal(self, which: str):
         """Nominal controller of ``step_cbf_geometric``: "geometric" (GeometricControl return_omegas)
         or "lqr_omega" (LQROmegaController, needs one constructed on this env first)."""

@@ -501,6 +501,64 @@ class ThrustOmegaOracle:
 
 
 # --------------------------------------------------------------------------------------
+# f-2: [UPSTREAM] gym_pybullet_drones.control.DSLPIDControl as PIDEnv.py:124-134,166-169 uses it.
+# NOT in the reference tree and not installable: restated from the published upstream source;
+# parity UNPINNED (no golden vectors exist).
+# --------------------------------------------------------------------------------------
+
+
+class DSLPIDOracle:
+    """Position PID -> desired thrust vector / attitude, attitude PID -> PWM -> RPM (stateful), batched."""
+
+    SCALE, CONST, MIN_PWM, MAX_PWM = 0.2685, 4070.3, 20000, 65535
+
+    def __init__(self, n, c: DroneConsts = CF2P, gain_scale=1.0):
+        self.c = c
+        g = gain_scale                                   # PIDEnv.py:128-133 halves every gain
+        self.P_FOR, self.I_FOR, self.D_FOR = g * np.array([.4, .4, 1.25]), g * np.array([.05, .05, .05]), g * np.array([.2, .2, .5])
+        self.P_TOR, self.I_TOR, self.D_TOR = g * np.array([70000., 70000., 60000.]), g * np.array([.0, .0, 500.]), g * np.array([20000., 20000., 12000.])
+        self.last_rpy = np.zeros((n, 3))
+        self.integral_pos_e = np.zeros((n, 3))
+        self.integral_rpy_e = np.zeros((n, 3))
+
+    def compute_from_state(self, dt, obs, target_pos, target_rpy):
+        """computeControlFromState(control_timestep, state=obs[j], target_pos, target_rpy) -> rpm [n,4]."""
+        from scipy.spatial.transform import Rotation
+        obs = np.asarray(obs, dtype=np.float64)
+        pos, quat, vel = obs[..., 0:3], obs[..., 3:7], obs[..., 10:13]
+        target_pos = np.asarray(target_pos, dtype=np.float64)
+        target_rpy = np.asarray(target_rpy, dtype=np.float64)
+        R = quat_to_rotmat_bullet(quat)
+        # _dslPIDPositionControl
+        pos_e = target_pos - pos
+        vel_e = -vel                                      # target_vel = 0
+        self.integral_pos_e = np.clip(self.integral_pos_e + pos_e * dt, -2., 2.)
+        self.integral_pos_e[..., 2] = np.clip(self.integral_pos_e[..., 2], -0.15, .15)
+        tt = self.P_FOR * pos_e + self.I_FOR * self.integral_pos_e + self.D_FOR * vel_e + np.array([0, 0, self.c.GRAVITY])
+        scalar = np.maximum(0., np.sum(tt * R[..., :, 2], axis=-1))
+        thrust = (np.sqrt(scalar / (4 * self.c.KF)) - self.CONST) / self.SCALE
+        z_ax = tt / norm(tt)[..., None]
+        x_c = np.stack([np.cos(target_rpy[..., 2]), np.sin(target_rpy[..., 2]), np.zeros_like(target_rpy[..., 2])], axis=-1)
+        y_ax = cross(z_ax, x_c)
+        y_ax = y_ax / norm(y_ax)[..., None]
+        x_ax = cross(y_ax, z_ax)
+        Rt = np.stack([x_ax, y_ax, z_ax], axis=-1)
+        target_euler = Rotation.from_matrix(Rt).as_euler("XYZ")
+        # _dslPIDAttitudeControl (target_rpy_rates = 0)
+        cur_rpy = euler_from_quat_bullet(quat)
+        Rt2 = Rotation.from_euler("XYZ", target_euler).as_matrix()
+        E = np.einsum("...ji,...jk->...ik", Rt2, R) - np.einsum("...ji,...jk->...ik", R, Rt2)
+        rot_e = np.stack([E[..., 2, 1], E[..., 0, 2], E[..., 1, 0]], axis=-1)
+        rates_e = -(cur_rpy - self.last_rpy) / dt
+        self.last_rpy = cur_rpy.copy()
+        self.integral_rpy_e = np.clip(self.integral_rpy_e - rot_e * dt, -1500., 1500.)
+        self.integral_rpy_e[..., 0:2] = np.clip(self.integral_rpy_e[..., 0:2], -1., 1.)
+        tq = np.clip(-self.P_TOR * rot_e + self.D_TOR * rates_e + self.I_TOR * self.integral_rpy_e, -3200, 3200)
+        pwm = np.clip(thrust[..., None] + np.einsum("ij,...j->...i", ThrustOmegaOracle.MIX[self.c.MODEL], tq), self.MIN_PWM, self.MAX_PWM)
+        return self.SCALE * pwm + self.CONST
+
+
+# --------------------------------------------------------------------------------------
 # f-3: control/lqr/lqr_omega_controller.py:12-57 (gain), :90-119 (compute, cap_u)
 # --------------------------------------------------------------------------------------
 
