@@ -69,10 +69,13 @@ def dist_init(backend):
     return rank, local_rank, world
 
 
-def barrier(world):
+def barrier(world, device_index=None):
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()
+        if device_index is not None and dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[device_index])      # RCCL barrier on this rank's own GPU
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value, world, device):
@@ -106,8 +109,23 @@ def cpu_baseline(D, phase, budget_s=15.0):
         el = time.perf_counter() - t0
         if el > budget_s or steps >= 2000:
             break
-    return {"value": n * steps / el, "unit": "drone-steps/s", "cores": 1, "kind": "port",
-            "sample": f"float64 NumPy oracle (vectorised), {E} envs x {D} drones x {steps} control steps in {el:.1f} s"}
+    out = {"value": n * steps / el, "unit": "drone-steps/s", "cores": 1, "kind": "port",
+           "sample": f"float64 NumPy oracle (vectorised), {E} envs x {D} drones x {steps} control steps in {el:.1f} s"}
+    # the reference's own loop shape (simulations/EnvGeometric.py:434-469 without sync()): one Python call chain per drone
+    ora1 = [O.AviaryOracle(xyz.reshape(-1, 3)[j:j + 1], rpy.reshape(-1, 3)[j:j + 1], pyb_freq=100, ctrl_freq=100) for j in range(D)]
+    obs1 = [o.step(np.zeros((1, 4))) for o in ora1]
+    t, k1 = 0.0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < min(4.0, budget_s / 3):
+        for j in range(D):
+            pos, vel, acc, yaw, yd = O.lemniscate(t, Pf[j, 0], Pf[j, 1], Pf[j, 2:5], Pf[j, 5], Pf[j, 6])
+            obs1[j] = ora1[j].step(O.geometric_compute(obs1[j], pos[None], vel[None], acc[None], np.array([yaw]), np.array([yd])))
+        t += 0.01
+        k1 += 1
+    el1 = time.perf_counter() - t0
+    out["reference_shaped_per_drone_loop"] = {"value": D * k1 / el1, "unit": "drone-steps/s", "cores": 1,
+                                              "sample": f"{D} drones x {k1} control steps, one Python call chain per drone, {el1:.1f} s"}
+    return out
 
 
 def main(argv=None):
@@ -153,7 +171,7 @@ def main(argv=None):
     if not os.path.exists(__graft_entry__.LIB):
         if rank == 0:
             __graft_entry__.build()
-        barrier(world)
+        barrier(world, local_rank)
     from multidronesim_amd.envs.CtrlAviary import CtrlAviary, DroneModel, Physics
 
     xyz, rpy, P = make_inputs(E, D, phase, 1000 + rank)          # every rank owns different envs
@@ -227,7 +245,7 @@ def main(argv=None):
 
     run(0.0, args.warmup)
     torch.cuda.synchronize(device)
-    barrier(world)
+    barrier(world, local_rank)
     torch.cuda.synchronize(device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     wall0 = time.perf_counter()
@@ -235,7 +253,7 @@ def main(argv=None):
     run(args.warmup * dt, args.steps)
     ev1.record(torch.cuda.current_stream(device))
     torch.cuda.synchronize(device)
-    barrier(world)
+    barrier(world, local_rank)
     wall = time.perf_counter() - wall0
     dev_ms = ev0.elapsed_time(ev1)
     elapsed = max_over_ranks(wall, world, device)

@@ -122,6 +122,9 @@ def test_reference_api_names_present():
     from multidronesim_amd.utils.utils import sync, str2bool
     from multidronesim_amd.utils.model_conversions import input_to_action, action_to_input
     from multidronesim_amd.PIDEnv import MultiDroneEnv
+    from multidronesim_amd import MultiDroneExample
+    a = MultiDroneExample.parse_args(["--num_drones", "3", "--control_freq_hz", "48", "--simulation_freq_hz", "240"])
+    assert (a.num_drones, a.control_freq_hz, a.simulation_freq_hz, a.init_rad, a.duration_sec) == (3, 48, 240, 1.0, 30)
     from multidronesim_amd.model.dynamics import QuadrotorDynamics
     assert DroneModel("cf2p") is DroneModel.CF2P and Physics("pyb") is Physics.PYB
     for m in ("step", "reset", "render", "close", "getPyBulletClient", "getDroneIds", "_showDroneLocalAxes"):

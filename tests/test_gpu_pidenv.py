@@ -97,3 +97,16 @@ def test_dslpid_class_reference_signature():
         obs = ora.step(want[None, :])
     c.reset()
     assert c.control_counter == 0
+
+
+def test_multidrone_example_config1_hover():
+    """BASELINE config 1: 2-drone hover of MultiDroneExample.py, 240 Hz x 10 s (2400 control steps), no throttling."""
+    from multidronesim_amd import MultiDroneExample as M
+    args = M.parse_args(["--simulation_freq_hz", "240", "--control_freq_hz", "240", "--duration_sec", "10", "--gui", "False",
+                         "--realtime", "False"])
+    assert args.num_drones == 2 and args.drone.value == "cf2p" and args.physics.value == "pyb"
+    init, rpy, tgt, trpy = M.initial_conditions(args)
+    np.testing.assert_allclose(init[1], [-1.0, 0.0, 0.0], atol=1e-12)        # drone 1 on the circle at angle pi
+    env = M.create_env(args, init, rpy)
+    final = M.do_control(args, env, tgt, trpy).reshape(2, 20)
+    assert np.abs(final[:, 0:3] - tgt).max() < 0.12 and np.abs(final[:, 10:13]).max() < 0.05

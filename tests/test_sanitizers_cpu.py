@@ -1,0 +1,63 @@
+"""UndefinedBehaviorSanitizer run of the device arithmetic (the g++ build of csrc/mds_math.hpp, tests/emul):
+GPU sanitizers are not available on the pool, so the per-drone math is exercised under UBSan on the CPU --
+fused controller + physics (Euler, RK4, drag, substeps), saturating inputs included.  Runs in a subprocess."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+DRIVER = r'''
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, %(root)r)
+from tests.emul import emul as E
+E.SO = %(so)r
+E._lib = None
+lib = C.CDLL(E.SO)
+for sfx in ("f32", "f64"):
+    getattr(lib, "emul_create_" + sfx).restype = C.c_void_p
+E._lib = lib
+rng = np.random.default_rng(0)
+for dt in ("f32", "f64"):
+    for kw in (dict(), dict(integrator=1), dict(physics=1), dict(pyb_freq=240, ctrl_freq=48)):
+        n = 64
+        # (1) open loop with RPM far outside [0, MAX_RPM] from arbitrary attitudes (upside down included): clipping paths
+        em = E.Emul(dt, num_envs=n, **kw)
+        st = np.zeros((n, 13)); st[:, 0:3] = rng.normal(size=(n, 3)) * 3
+        q = rng.normal(size=(n, 4)); st[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+        st[:, 7:10] = rng.normal(size=(n, 3)) * 4; st[:, 10:13] = rng.normal(size=(n, 3)) * 20
+        em.set_state(st)
+        for k in range(50):
+            obs = em.step(rng.uniform(-1e4, 5e4, size=(n, 4)))
+        assert np.isfinite(obs).all(), dt
+        # (2) closed loop from large but recoverable errors (tilt clamp and motor clips active).  Twice these errors make the
+        #     reference's own loop diverge (explicit Euler at 100 Hz: 1e7 rad/s in float64 too), so that is not tested.
+        em = E.Emul(dt, num_envs=n, **kw)
+        from scipy.spatial.transform import Rotation
+        st = np.zeros((n, 13)); st[:, 0:3] = rng.normal(size=(n, 3)) * 1.5
+        st[:, 3:7] = Rotation.from_euler("xyz", rng.uniform(-0.5, 0.5, size=(n, 3))).as_quat()
+        st[:, 7:10] = rng.normal(size=(n, 3)); st[:, 10:13] = rng.normal(size=(n, 3)) * 1.5
+        em.set_state(st)
+        P = np.zeros((n, 7)); P[:, 0] = 1; P[:, 1] = rng.uniform(0.1, 2, n); P[:, 5] = rng.normal(size=n) * 0.3; P[:, 6] = rng.uniform(-7, 7, n)
+        em.set_lemniscate(P)
+        t = 0.0
+        for k in range(300):
+            obs, act = em.step_geometric(t); t += 0.01
+        assert np.isfinite(obs).all(), dt
+print("UBSAN_OK")
+'''
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_device_math_under_ubsan(tmp_path):
+    so = str(tmp_path / "libmds_emul_ubsan.so")
+    src = os.path.join(ROOT, "tests", "emul", "mds_emul.cpp")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-mfma", "-ffp-contract=fast",
+                           "-fsanitize=undefined,float-divide-by-zero", "-fno-sanitize-recover=all", "-o", so, src])
+    env = dict(os.environ, UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([sys.executable, "-c", DRIVER % {"root": ROOT, "so": so}], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "UBSAN_OK" in out.stdout, out.stderr[-3000:]
+    assert "runtime error" not in out.stderr, out.stderr[-3000:]
