@@ -67,7 +67,10 @@ typedef struct mds_config {
   int32_t pyb_freq;     /* must be a multiple of ctrl_freq ([UPSTREAM] BaseAviary.__init__) */
   int32_t ctrl_freq;
   int32_t device;       /* HIP device ordinal */
-  int32_t reserved;
+  int32_t track_last_rpm; /* 1: every step also stores the last clipped action in the handle (16 B per drone-step) so
+                           * that mds_get_obs can return obs[16:20] later.  0 (default): stored only where the path
+                           * reads it back -- DYN_DRAG physics ([UPSTREAM] _drag) and the order-3 CBF / yank path
+                           * (calc_z_thrust); otherwise the obs a step call returns is the only copy. */
   /* urdf constants ([UPSTREAM] _parseURDFParameters) */
   double M, L, KF, KM, J[3], G, thrust2weight, drag_coeff[3];
 } mds_config;
@@ -116,7 +119,8 @@ int mds_set_state(mds_handle* h, const double* state_host, void* stream);
 int mds_set_origin(mds_handle* h, const double* origin_host, void* stream);
 
 /* [UPSTREAM] BaseAviary._computeObs(): obs_dev [n,20] from the current state.  obs[16:20]
- * is the last clipped action of the most recent mds_step* call (zeros after reset). */
+ * is the last clipped action of the most recent mds_step* call (zeros after reset) when the handle
+ * tracks it (mds_config.track_last_rpm); on a handle that does not, it is NaN once a step has run. */
 int mds_get_obs(mds_handle* h, void* obs_dev, void* stream);
 
 /* [UPSTREAM] BaseAviary.step(action) for every drone: clip RPM to [0, MAX_RPM],
@@ -264,14 +268,29 @@ int mds_set_lqr_omega_gain(mds_handle* h, const double K[36]);
 /* LQROmegaController.compute(obs, skip_low_level=True) (:90-119): obs_dev [n,20], des_dev [n,11]
  * (pos, vel, -, yaw, - of set_desired_trajectory) -> u_dev [n,4] = (F, wx, wy, wz) after cap_u. */
 int mds_lqr_omega_compute(mds_handle* h, const void* obs_dev, const void* des_dev, void* u_dev, void* stream);
-/* nominal controller of mds_step_cbf_geometric: 0 = GeometricControl(return_omegas), 1 = LQROmegaController */
+/* LQRYankOmegaController (control/lqr/lqr_YO_controller.py): K [4,10] row-major from its
+ * compute_gain_matrix() (:59-64), state [r,p,y,F,vx,vy,vz,x,y,z], input [yank, wx, wy, wz]. */
+int mds_set_lqr_yank_omega_gain(mds_handle* h, const double K[40]);
+/* LQRYankOmegaController.compute(obs, skip_low_level=True) (:99-124): obs_dev [n,20] (its columns 16:20 give the
+ * thrust state through calc_z_thrust), des_dev [n,11] as mds_lqr_omega_compute -> u_dev [n,4] = -K e (no cap). */
+int mds_lqr_yank_omega_compute(mds_handle* h, const void* obs_dev, const void* des_dev, void* u_dev, void* stream);
+/* LQRYankOmegaController.compute_low_level(u, obs) (:85-97) -> YankOmegaController.computeControlFromInput
+ * (control/low_level/yank_omega_ctrl.py:39-55): thrust = calc_z_thrust(obs) + yank * CTRL_TIMESTEP, then the
+ * ThrustOmega PID of mds_thrust_omega_compute (same PID memory in the handle). */
+int mds_yank_omega_compute(mds_handle* h, const void* u_dev, const void* obs_dev, void* rpm_dev, void* stream);
+/* nominal controller of mds_step_cbf_geometric: 0 = GeometricControl(return_omegas), 1 = LQROmegaController,
+ * 2 = LQRYankOmegaController (the only one valid with an order-3 CBF, and only with it) */
 int mds_cbf_set_nominal(mds_handle* h, int which);
 
-/* One CBF-filtered control step of simulations/CBFTest.py:303-350 for every env (order 2):
- * nominal (force - M G, w_des) from the geometric controller on the handle's trajectories ->
- * ECBF QP -> + M G -> ThrustOmega low level -> env.step.  obs_dev [n,20] holds the CURRENT
- * observation on entry (as returned by the previous step) and the next one on return;
- * status_dev [E] as mds_cbf_filter; action_dev [n,4] (RPM) optional. */
+/* One CBF-filtered control step for every env.
+ * Order 2 (simulations/CBFTest.py:303-350): nominal (force - M G, w_des) from the geometric controller or the
+ * LQR on the handle's trajectories -> ECBF QP -> + M G -> ThrustOmega low level -> env.step.
+ * Order 3 (simulations/CBFTestOrd3.py:306-352): nominal (yank - M G, w) from the yank-omega LQR (the hover force is
+ * subtracted from the yank there, :341, and not added back, :350 -- kept) -> ECBF QP on xdes =
+ * [0,0,yaw, G M, vel, pos] -> YankOmega low level -> env.step.
+ * obs_dev [n,20] holds the CURRENT observation on entry (as returned by the previous step: the order-3 path reads
+ * its thrust state from columns 16:20) and the next one on return; status_dev [E] as mds_cbf_filter;
+ * action_dev [n,4] (RPM) optional. */
 int mds_step_cbf_geometric(mds_handle* h, double t, void* obs_dev, int32_t* status_dev, void* action_dev, void* stream);
 
 #ifdef __cplusplus

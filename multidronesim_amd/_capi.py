@@ -21,7 +21,7 @@ OBS_DIM, ACT_DIM, STATE_DIM, DES_DIM, LEM_DIM, GEO_AUX_DIM, SEG_DIM = 20, 4, 13,
 class MdsConfig(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("num_drones", C.c_int32), ("dtype", C.c_int32), ("physics", C.c_int32),
                 ("integrator", C.c_int32), ("drone_model", C.c_int32), ("pyb_freq", C.c_int32),
-                ("ctrl_freq", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32),
+                ("ctrl_freq", C.c_int32), ("device", C.c_int32), ("track_last_rpm", C.c_int32),
                 ("M", C.c_double), ("L", C.c_double), ("KF", C.c_double), ("KM", C.c_double), ("J", C.c_double * 3),
                 ("G", C.c_double), ("thrust2weight", C.c_double), ("drag_coeff", C.c_double * 3)]
 
@@ -93,6 +93,9 @@ PROTOTYPES = {
     "mds_step_dslpid": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "mds_set_lqr_omega_gain": (C.c_int, [_P, _PD]),
     "mds_lqr_omega_compute": (C.c_int, [_P, _P, _P, _P, _P]),
+    "mds_set_lqr_yank_omega_gain": (C.c_int, [_P, _PD]),
+    "mds_lqr_yank_omega_compute": (C.c_int, [_P, _P, _P, _P, _P]),
+    "mds_yank_omega_compute": (C.c_int, [_P, _P, _P, _P, _P]),
     "mds_cbf_set_nominal": (C.c_int, [_P, C.c_int]),
     "mds_step_cbf_geometric": (C.c_int, [_P, C.c_double, _P, _P, _P, _P]),
 }

@@ -72,10 +72,23 @@ struct mds_handle {
   DslPidGains<float> pid_f;
   DslPidGains<double> pid_d;
   bool has_lqr;
-  int cbf_nominal;     // 0 geometric, 1 lqr-omega
+  int cbf_nominal;     // 0 geometric, 1 lqr-omega, 2 lqr-yank-omega (order 3)
   LqrGain<float> lqr_f;
   LqrGain<double> lqr_d;
+  bool has_lqr_yo;
+  LqrYoGain<float> lqr_yo_f;
+  LqrYoGain<double> lqr_yo_d;
+  bool track_rpm;      // last_rpm planes maintained by every step kernel (DYN_DRAG, order-3 CBF, or cfg.track_last_rpm)
+  bool rpm_stale;      // a step ran without tracking since the last reset
 };
+
+// The last clipped action lives in the obs a step call returns.  The SoA copy costs 16 B per drone-step
+// and is kept only where something reads it back (the _drag term, calc_z_thrust of the yank path, mds_get_obs).
+static inline void* rpm_track(mds_handle* h) {
+  if (h->track_rpm) return h->last_rpm;
+  h->rpm_stale = true;
+  return nullptr;
+}
 
 // dispatch on the handle dtype: F32 -> <float,float>, F64 -> <double,double>, F16 -> <float,half_t>
 #define MDS_DISPATCH(h, EXPR)                                               \
@@ -197,8 +210,11 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   h->obstacles = nullptr;
   h->cbf_unom = h->cbf_xdes = h->cbf_usafe = h->ll = nullptr;
   h->has_lqr = false;
+  h->has_lqr_yo = false;
   h->cbf_nominal = 0;
   h->pid = nullptr;
+  h->track_rpm = cfg->track_last_rpm != 0 || cfg->physics == MDS_PHYSICS_DYN_DRAG;
+  h->rpm_stale = false;
   {
     mds_dslpid_gains dg;
     mds_default_dslpid_gains(&dg);
@@ -281,6 +297,7 @@ int mds_reset(mds_handle* h, const double* xyz, const double* rpy, void* stream)
   MDS_HIP(hipGetLastError());
   MDS_HIP(hipMemsetAsync(h->ll, 0, 6 * h->ld * comp_size(h->cfg.dtype), st));
   MDS_HIP(hipMemsetAsync(h->pid, 0, 9 * h->ld * comp_size(h->cfg.dtype), st));
+  h->rpm_stale = false;
   MDS_HIP(hipStreamSynchronize(st));   // host buffers may be reused by the caller
   return MDS_OK;
 }
@@ -322,7 +339,7 @@ int mds_get_obs(mds_handle* h, void* obs, void* stream) {
   if (!aligned16(obs)) return fail(MDS_EALIGN, "mds_get_obs: obs_dev");
   hipStream_t st = (hipStream_t)stream;
   MDS_DISPATCH(h, (k_get_obs<T, S><<<grid_for(h->n, kBlock), kBlock, 0, st>>>(h->n, h->ld, (const S*)h->state, (const T*)h->origin,
-                                                                                (const T*)h->last_rpm, (S*)obs)));
+                                                                                (const T*)(h->rpm_stale ? nullptr : h->last_rpm), (S*)obs)));
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }
@@ -334,7 +351,7 @@ int mds_step(mds_handle* h, const void* action, void* obs, void* stream) {
   const dim3 grid = grid_for(h->n, kBlock);
 #define MDS_LAUNCH_STEP(HAS_OBS, RK4, DRAG)                                                                          \
   MDS_DISPATCH(h, (k_step<T, S, HAS_OBS, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, (S*)h->state, (const T*)h->origin, \
-                                                                             (T*)h->last_rpm, (const S*)action, (S*)obs)))
+                                                                             (T*)rpm_track(h), (const S*)action, (S*)obs)))
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
 #define MDS_STEP_OBS(HAS_OBS)                           \
   do {                                                  \
@@ -448,7 +465,7 @@ static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, 
     const bool rk4_ = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag_ = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
 #define MDS_TRAJ(RK4, DRAG)                                                                                                   \
   MDS_DISPATCH(h, (k_step_traj<T, S, RK4, DRAG><<<dim3(nbatch), kBlock, 0, st>>>(C, h->n, h->ld, t, (S*)h->state, (const T*)h->origin, \
-                                                                               h->segs, h->tinfo, (T*)h->last_rpm, (S*)obs, (S*)act)))
+                                                                               h->segs, h->tinfo, (T*)rpm_track(h), (S*)obs, (S*)act)))
     if (rk4_ && drag_) MDS_TRAJ(true, true);
     else if (rk4_) MDS_TRAJ(true, false);
     else if (drag_) MDS_TRAJ(false, true);
@@ -458,7 +475,7 @@ static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, 
   }
 #define MDS_LAUNCH_GEO2(HAS_OBS, HAS_ACT, RK4, DRAG)                                                                           \
   MDS_DISPATCH(h, (k_step_geometric<T, S, HAS_OBS, HAS_ACT, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t, (S*)h->state, \
-                                                                                                (const T*)h->lem, (T*)h->last_rpm, \
+                                                                                                (const T*)h->lem, (T*)rpm_track(h), \
                                                                                                 (S*)obs, (S*)act)))
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
   const dim3 grid(nbatch);
@@ -513,7 +530,7 @@ int mds_rollout_geometric_fused(mds_handle* h, double t0, int n_steps, void* obs
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
 #define MDS_ROLL(RK4, DRAG)                                                                                              \
   MDS_DISPATCH(h, (k_rollout_geometric<T, S, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t0, dt, n_steps, (S*)h->state, \
-                                                                                 (const T*)h->lem, (T*)h->last_rpm,      \
+                                                                                 (const T*)h->lem, (T*)rpm_track(h),      \
                                                                                  (S*)obs_log, (S*)obs_last)))
   if (rk4 && drag) MDS_ROLL(true, true);
   else if (rk4) MDS_ROLL(true, false);
@@ -733,7 +750,7 @@ int mds_dslpid_reset(mds_handle* h, void* stream) {
 
 #define MDS_PID_LAUNCH(T, S, C, G, STEP, RK4, DRAG)                                                                           \
   k_dslpid<T, S, STEP, RK4, DRAG><<<grid_for(h->n, kBlock), kBlock, 0, st>>>(C, G, h->n, h->ld, (T)(1.0 / h->cfg.ctrl_freq), (S*)h->state, \
-                                                                             (const T*)h->origin, (T*)h->last_rpm, (T*)h->pid,             \
+                                                                             (const T*)h->origin, (T*)rpm_track(h), (T*)h->pid,             \
                                                                              (const S*)obs_in, (const S*)tpos, (const S*)trpy, (S*)obs,    \
                                                                              (S*)act)
 #define MDS_PID_DTYPE(STEP, RK4, DRAG)                                                        \
@@ -795,9 +812,36 @@ int mds_lqr_omega_compute(mds_handle* h, const void* obs, const void* des, void*
   return MDS_OK;
 }
 
+int mds_set_lqr_yank_omega_gain(mds_handle* h, const double K[40]) {
+  if (!h || !K) return fail(MDS_EINVAL, "mds_set_lqr_yank_omega_gain: null argument");
+  for (int r = 0; r < 4; ++r)
+    for (int k = 0; k < 10; ++k) {
+      h->lqr_yo_d.k[r][k] = K[10 * r + k];
+      h->lqr_yo_f.k[r][k] = (float)K[10 * r + k];
+    }
+  h->has_lqr_yo = true;
+  return MDS_OK;
+}
+
+int mds_lqr_yank_omega_compute(mds_handle* h, const void* obs, const void* des, void* u, void* stream) {
+  if (!h || !obs || !des || !u) return fail(MDS_EINVAL, "mds_lqr_yank_omega_compute: null argument");
+  if (!h->has_lqr_yo) return fail(MDS_ESTATE, "mds_lqr_yank_omega_compute: call mds_set_lqr_yank_omega_gain first");
+  if (!aligned16(u)) return fail(MDS_EALIGN, "mds_lqr_yank_omega_compute: u_dev");
+  hipStream_t st = (hipStream_t)stream;
+  if (h->cfg.dtype == MDS_F64)
+    k_lqr_yank_omega_compute<double, double><<<grid_for(h->n, 256), 256, 0, st>>>(h->cd, h->lqr_yo_d, h->n, (const double*)obs, (const double*)des, (double*)u);
+  else if (h->cfg.dtype == MDS_F32)
+    k_lqr_yank_omega_compute<float, float><<<grid_for(h->n, 256), 256, 0, st>>>(h->cf, h->lqr_yo_f, h->n, (const float*)obs, (const float*)des, (float*)u);
+  else
+    k_lqr_yank_omega_compute<float, half_t><<<grid_for(h->n, 256), 256, 0, st>>>(h->cf, h->lqr_yo_f, h->n, (const half_t*)obs, (const half_t*)des, (half_t*)u);
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
 int mds_cbf_set_nominal(mds_handle* h, int which) {
-  if (!h || (which != 0 && which != 1)) return fail(MDS_EINVAL, "mds_cbf_set_nominal");
+  if (!h || which < 0 || which > 2) return fail(MDS_EINVAL, "mds_cbf_set_nominal");
   if (which == 1 && !h->has_lqr) return fail(MDS_ESTATE, "mds_cbf_set_nominal: call mds_set_lqr_omega_gain first");
+  if (which == 2 && !h->has_lqr_yo) return fail(MDS_ESTATE, "mds_cbf_set_nominal: call mds_set_lqr_yank_omega_gain first");
   h->cbf_nominal = which;
   return MDS_OK;
 }
@@ -808,16 +852,24 @@ int mds_lowlevel_reset(mds_handle* h, void* stream) {
   return MDS_OK;
 }
 
-static int launch_thrust_omega(mds_handle* h, const void* u, const void* src, int rates_given, void* rpm, hipStream_t st) {
-  MDS_DISPATCH(h, (k_thrust_omega<T, S><<<grid_for(h->n, 256), 256, 0, st>>>(C, h->n, h->ld, (T)(1.0 / h->cfg.ctrl_freq), rates_given,
+static int launch_thrust_omega(mds_handle* h, const void* u, const void* src, int rates_given, int yank, void* rpm, hipStream_t st) {
+  MDS_DISPATCH(h, (k_thrust_omega<T, S><<<grid_for(h->n, 256), 256, 0, st>>>(C, h->n, h->ld, (T)(1.0 / h->cfg.ctrl_freq), rates_given, yank,
                                                                              (T*)h->ll, (const S*)u, (const S*)src, (S*)rpm)));
+  return MDS_OK;
+}
+
+int mds_yank_omega_compute(mds_handle* h, const void* u, const void* obs, void* rpm, void* stream) {
+  if (!h || !u || !obs || !rpm) return fail(MDS_EINVAL, "mds_yank_omega_compute: null argument");
+  if (!aligned16(u) || !aligned16(rpm)) return fail(MDS_EALIGN, "mds_yank_omega_compute");
+  launch_thrust_omega(h, u, obs, 0, 1, rpm, (hipStream_t)stream);
+  MDS_HIP(hipGetLastError());
   return MDS_OK;
 }
 
 int mds_thrust_omega_compute(mds_handle* h, const void* u, const void* obs, void* rpm, void* stream) {
   if (!h || !u || !obs || !rpm) return fail(MDS_EINVAL, "mds_thrust_omega_compute: null argument");
   if (!aligned16(u) || !aligned16(rpm)) return fail(MDS_EALIGN, "mds_thrust_omega_compute");
-  launch_thrust_omega(h, u, obs, 0, rpm, (hipStream_t)stream);
+  launch_thrust_omega(h, u, obs, 0, 0, rpm, (hipStream_t)stream);
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }
@@ -825,7 +877,7 @@ int mds_thrust_omega_compute(mds_handle* h, const void* u, const void* obs, void
 int mds_thrust_omega_from_rates(mds_handle* h, const void* u, const void* rates, void* rpm, void* stream) {
   if (!h || !u || !rates || !rpm) return fail(MDS_EINVAL, "mds_thrust_omega_from_rates: null argument");
   if (!aligned16(u) || !aligned16(rpm)) return fail(MDS_EALIGN, "mds_thrust_omega_from_rates");
-  launch_thrust_omega(h, u, rates, 1, rpm, (hipStream_t)stream);
+  launch_thrust_omega(h, u, rates, 1, 0, rpm, (hipStream_t)stream);
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }
@@ -834,17 +886,30 @@ int mds_step_cbf_geometric(mds_handle* h, double t, void* obs, int32_t* status, 
   if (!h || !obs || !status) return fail(MDS_EINVAL, "mds_step_cbf_geometric: null argument");
   if (!h->has_traj || h->traj_mode != 1) return fail(MDS_ESTATE, "mds_step_cbf_geometric: call mds_set_lemniscate first");
   if (!h->has_cbf) return fail(MDS_ESTATE, "mds_step_cbf_geometric: call mds_cbf_configure first");
-  if (h->cbf.order != 2) return fail(MDS_EUNSUPPORTED, "mds_step_cbf_geometric: order 2 only (the order-3 loop needs the yank low-level controller)");
+  const bool ord3 = h->cbf.order == 3;
+  // the order-3 rows act on (yank, w): only the yank-omega LQR produces that input (simulations/CBFTestOrd3.py:294-297;
+  // GeometricControl.compute has no skip_low_level there), and it is meaningless for the order-2 rows
+  if (ord3 != (h->cbf_nominal == 2))
+    return fail(MDS_EUNSUPPORTED, "mds_step_cbf_geometric: order 3 needs (and order 2 excludes) the lqr-yank-omega nominal, mds_cbf_set_nominal(h, 2)");
   if (!aligned16(obs) || !aligned16(action)) return fail(MDS_EALIGN, "mds_step_cbf_geometric: obs_dev/action_dev");
   hipStream_t st = (hipStream_t)stream;
   const size_t es = elem_size(h->cfg.dtype);
   if (!h->cbf_unom) {
     MDS_HIP(hipMalloc(&h->cbf_unom, (size_t)h->n * 4 * es));
-    MDS_HIP(hipMalloc(&h->cbf_xdes, (size_t)h->n * 9 * es));
+    MDS_HIP(hipMalloc(&h->cbf_xdes, (size_t)h->n * 10 * es));
     MDS_HIP(hipMalloc(&h->cbf_usafe, (size_t)h->n * 4 * es));
   }
   const dim3 grid = grid_for(h->n, kBlock);
-  if (h->cbf_nominal == 1) {
+  if (h->cbf_nominal == 2) {
+    if (h->cfg.dtype == MDS_F64)
+      k_cbf_nominal_lqr_yo<double, double><<<grid, kBlock, 0, st>>>(h->cd, h->lqr_yo_d, h->n, h->ld, t, (const double*)h->state,
+                                                                    (const double*)h->lem, (const double*)obs, (double*)h->cbf_unom,
+                                                                    (double*)h->cbf_xdes);
+    else
+      k_cbf_nominal_lqr_yo<float, float><<<grid, kBlock, 0, st>>>(h->cf, h->lqr_yo_f, h->n, h->ld, t, (const float*)h->state,
+                                                                  (const float*)h->lem, (const float*)obs, (float*)h->cbf_unom,
+                                                                  (float*)h->cbf_xdes);
+  } else if (h->cbf_nominal == 1) {
     if (h->cfg.dtype == MDS_F64)
       k_cbf_nominal_lqr<double, double><<<grid, kBlock, 0, st>>>(h->cd, h->lqr_d, h->n, h->ld, t, (const double*)h->state,
                                                                  (const double*)h->lem, (double*)h->cbf_unom, (double*)h->cbf_xdes);
@@ -858,15 +923,23 @@ int mds_step_cbf_geometric(mds_handle* h, double t, void* obs, int32_t* status, 
   int rc = mds_cbf_filter(h, obs, h->cbf_xdes, h->cbf_unom, h->cbf_usafe, status, stream);
   if (rc != MDS_OK) return rc;
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
-#define MDS_LL(RK4, DRAG)                                                                                                      \
-  MDS_DISPATCH(h, (k_lowlevel_step<T, S, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, (T)(1.0 / h->cfg.ctrl_freq),      \
-                                                                             (T)(h->cfg.M * h->cfg.G), (S*)h->state,           \
-                                                                             (const T*)h->origin, (T*)h->last_rpm, (T*)h->ll, \
-                                                                             (const S*)h->cbf_usafe, (S*)obs, (S*)action)))
-  if (rk4 && drag) MDS_LL(true, true);
-  else if (rk4) MDS_LL(true, false);
-  else if (drag) MDS_LL(false, true);
-  else MDS_LL(false, false);
+  // order 2: u_safe[0] += M G (CBFTest.py:346); order 3: the yank goes to the low level as it is (CBFTestOrd3.py:350)
+#define MDS_LL(RK4, DRAG, YANK)                                                                                                  \
+  MDS_DISPATCH(h, (k_lowlevel_step<T, S, RK4, DRAG, YANK><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, (T)(1.0 / h->cfg.ctrl_freq),  \
+                                                                                   (T)(YANK ? 0.0 : h->cfg.M * h->cfg.G),       \
+                                                                                   (S*)h->state, (const T*)h->origin,           \
+                                                                                   (T*)rpm_track(h), (T*)h->ll,                 \
+                                                                                   (const S*)h->cbf_usafe, (S*)obs, (S*)action)))
+#define MDS_LL_Y(YANK)                           \
+  do {                                           \
+    if (rk4 && drag) MDS_LL(true, true, YANK);   \
+    else if (rk4) MDS_LL(true, false, YANK);     \
+    else if (drag) MDS_LL(false, true, YANK);    \
+    else MDS_LL(false, false, YANK);             \
+  } while (0)
+  if (ord3) MDS_LL_Y(true);
+  else MDS_LL_Y(false);
+#undef MDS_LL_Y
 #undef MDS_LL
   MDS_HIP(hipGetLastError());
   return MDS_OK;

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && !RK4) ? MDS_STEP_MIN_WAV
       for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
     aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
     store_state<S, T>(state, ld, i, s);
-    if (DRAG)
+    if (DRAG || last_rpm)
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
     if (HAS_OBS) {
       const V3<T> org = {origin[i], origin[ld + i], origin[2 * ld + i]};
@@ -233,7 +233,7 @@ __device__ __forceinline__ void geo_process(const Consts<T>& c, const int n, con
     }
     aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
 #endif
-    if (DRAG)
+    if (DRAG || last_rpm)
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
     if (HAS_ACT) store4<S, T>(action_out + (size_t)i * 4, act);
 #if defined(MDS_TUNE_NOCOMPUTE)
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void k_step_traj(const Consts<T> c, const i
       input_to_action(c, u, act);
     }
     aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
-    if (DRAG)
+    if (DRAG || last_rpm)
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
     if (action_out) store4<S, T>(action_out + (size_t)i * 4, act);
     if (obs) pack_obs(s, org, clipped, o);
@@ -371,8 +371,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c,
   }
   if (valid) {
     store_state<S, T>(state, ld, i, in.s);
-    if (DRAG)
-      for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = prev[k];
+    if (DRAG || (last_rpm && n_steps > 0))
+      for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = DRAG ? prev[k] : clipped[k];
   }
 }
 
@@ -443,7 +443,49 @@ __global__ void k_lqr_omega_compute(const Consts<T> c, const LqrGain<T> K, const
   store4<S, T>(u_out + (size_t)i * 4, u);
 }
 
-template <typename T, typename S, bool RK4, bool DRAG>
+// Order-3 loop (simulations/CBFTestOrd3.py:306-352): LQRYankOmegaController nominal.  The thrust state is
+// calc_z_thrust(obs), i.e. the last clipped RPM in columns 16:20 of the obs the previous step returned.
+//   u_hat = (yank - M G, w)  -- the hover force is subtracted from the YANK as well (:341, kept) and never added back (:350)
+//   xdes  = [0, 0, yaw, G M, vel, pos]                                                              (:345-347)
+template <typename T, typename S>
+__global__ __launch_bounds__(kBlock) void k_cbf_nominal_lqr_yo(const Consts<T> c, const LqrYoGain<T> K, const int n, const size_t ld,
+                                                               const double t, const S* __restrict__ state,
+                                                               const T* __restrict__ lem, const S* __restrict__ obs_prev,
+                                                               S* __restrict__ unom, S* __restrict__ xdes) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  GeoIn<T> in;
+  load_geo_in<T, S>(state, lem, ld, i, in);
+  const Desired<T> des = lemniscate_local(in.P, t);
+  const V3<T> rpy = euler_from_quat(in.s.q);
+  T rpm[4], u[4];
+  load4<S, T>(obs_prev + (size_t)i * kObsDim + 16, rpm);
+  lqr_yank_omega_control<T>(c, K, rpy, rpm, in.s.v, in.s.p, des.p, des.v, des.yaw, u);
+  const T un[4] = {u[0] - c.gravity, u[1], u[2], u[3]};
+  store4<S, T>(unom + (size_t)i * 4, un);
+  S* xd = xdes + (size_t)i * 10;
+  xd[0] = (S)0; xd[1] = (S)0; xd[2] = (S)des.yaw; xd[3] = (S)c.gravity;
+  xd[4] = (S)des.v.x; xd[5] = (S)des.v.y; xd[6] = (S)des.v.z;
+  xd[7] = (S)(des.p.x + in.P.cx); xd[8] = (S)(des.p.y + in.P.cy); xd[9] = (S)(des.p.z + in.P.cz);
+}
+
+// LQRYankOmegaController.compute(obs, skip_low_level=True): obs [n,20], des [n,11] -> u [n,4]
+template <typename T, typename S>
+__global__ void k_lqr_yank_omega_compute(const Consts<T> c, const LqrYoGain<T> K, const int n, const S* __restrict__ obs,
+                                         const S* __restrict__ des, S* __restrict__ u_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const S* o = obs + (size_t)i * 20;
+  const S* d = des + (size_t)i * 11;
+  const T rpm[4] = {(T)o[16], (T)o[17], (T)o[18], (T)o[19]};
+  T u[4];
+  lqr_yank_omega_control<T>(c, K, V3<T>{(T)o[7], (T)o[8], (T)o[9]}, rpm, V3<T>{(T)o[10], (T)o[11], (T)o[12]},
+                            V3<T>{(T)o[0], (T)o[1], (T)o[2]}, V3<T>{(T)d[0], (T)d[1], (T)d[2]}, V3<T>{(T)d[3], (T)d[4], (T)d[5]},
+                            (T)d[9], u);
+  store4<S, T>(u_out + (size_t)i * 4, u);
+}
+
+template <typename T, typename S, bool RK4, bool DRAG, bool YANK>
 __global__ __launch_bounds__(kBlock) void k_lowlevel_step(const Consts<T> c, const int n, const size_t ld, const T ctrl_dt,
                                                           const T thrust_offset, S* __restrict__ state,
                                                           const T* __restrict__ origin, T* __restrict__ last_rpm,
@@ -464,13 +506,19 @@ __global__ __launch_bounds__(kBlock) void k_lowlevel_step(const Consts<T> c, con
     L.integral = {ll[3 * ld + i], ll[4 * ld + i], ll[5 * ld + i]};
     T act[4], prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4];
     // compute_low_level rotates obs[13:16] (= R w) back with R^T: the body rate is the state's w
-    thrust_omega_control(c, ctrl_dt, u, s.w, L, act);
+    if (YANK) {   // obs still holds the previous step's row here: every row is read and later rewritten by the same wave
+      T rpm_prev[4];
+      load4<S, T>(obs + (size_t)i * kObsDim + 16, rpm_prev);
+      yank_omega_control(c, ctrl_dt, u, rpm_prev, s.w, L, act);
+    } else {
+      thrust_omega_control(c, ctrl_dt, u, s.w, L, act);
+    }
     ll[0 * ld + i] = L.last_omega.x; ll[1 * ld + i] = L.last_omega.y; ll[2 * ld + i] = L.last_omega.z;
     ll[3 * ld + i] = L.integral.x; ll[4 * ld + i] = L.integral.y; ll[5 * ld + i] = L.integral.z;
     if (DRAG)
       for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
     aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
-    if (DRAG)
+    if (DRAG || last_rpm)
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
     if (action_out) store4<S, T>(action_out + (size_t)i * 4, act);
     pack_obs(s, V3<T>{origin[i], origin[ld + i], origin[2 * ld + i]}, clipped, o);
@@ -482,7 +530,7 @@ __global__ __launch_bounds__(kBlock) void k_lowlevel_step(const Consts<T> c, con
 // ThrustOmegaController.computeControlFromInput through LQROmegaController.compute_low_level
 // (lqr_omega_controller.py:77-88): u [n,4] = (thrust, w_target), obs [n,20] -> rpm [n,4]; stateful.
 template <typename T, typename S>
-__global__ void k_thrust_omega(const Consts<T> c, const int n, const size_t ld, const T ctrl_dt, const int body_rates_given,
+__global__ void k_thrust_omega(const Consts<T> c, const int n, const size_t ld, const T ctrl_dt, const int body_rates_given, const int yank,
                                T* __restrict__ ll, const S* __restrict__ u_in, const S* __restrict__ obs_or_rates,
                                S* __restrict__ rpm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -500,7 +548,13 @@ __global__ void k_thrust_omega(const Consts<T> c, const int n, const size_t ld, 
   LowLevelState<T> L;
   L.last_omega = {ll[0 * ld + i], ll[1 * ld + i], ll[2 * ld + i]};
   L.integral = {ll[3 * ld + i], ll[4 * ld + i], ll[5 * ld + i]};
-  thrust_omega_control(c, ctrl_dt, u, cur, L, act);
+  if (yank) {   // YankOmegaController: needs the obs (calc_z_thrust), never combined with body_rates_given
+    const S* o = obs_or_rates + (size_t)i * 20;
+    const T rpm_prev[4] = {(T)o[16], (T)o[17], (T)o[18], (T)o[19]};
+    yank_omega_control(c, ctrl_dt, u, rpm_prev, cur, L, act);
+  } else {
+    thrust_omega_control(c, ctrl_dt, u, cur, L, act);
+  }
   ll[0 * ld + i] = L.last_omega.x; ll[1 * ld + i] = L.last_omega.y; ll[2 * ld + i] = L.last_omega.z;
   ll[3 * ld + i] = L.integral.x; ll[4 * ld + i] = L.integral.y; ll[5 * ld + i] = L.integral.z;
   store4<S, T>(rpm + (size_t)i * 4, act);
@@ -549,7 +603,7 @@ __global__ __launch_bounds__(kBlock) void k_dslpid(const Consts<T> c, const DslP
       if (DRAG)
         for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
       aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
-      if (DRAG)
+      if (DRAG || last_rpm)
         for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
       if (obs) pack_obs(s, org, clipped, o);
     }
@@ -572,7 +626,11 @@ __global__ __launch_bounds__(kBlock) void k_get_obs(const int n, const size_t ld
   if (valid) {
     State<T> s;
     load_state<S, T>(state, ld, i, s);
-    const T rpm[4] = {last_rpm[i], last_rpm[ld + i], last_rpm[2 * ld + i], last_rpm[3 * ld + i]};
+    // last_rpm == nullptr: the handle does not track the last clipped action and a step has run since the
+    // last reset -- the columns are NaN rather than stale (include/mds.h, mds_config.track_last_rpm)
+    const T kNaN = __builtin_nanf("");
+    const T rpm[4] = {last_rpm ? last_rpm[i] : kNaN, last_rpm ? last_rpm[ld + i] : kNaN, last_rpm ? last_rpm[2 * ld + i] : kNaN,
+                      last_rpm ? last_rpm[3 * ld + i] : kNaN};
     pack_obs(s, V3<T>{origin[i], origin[ld + i], origin[2 * ld + i]}, rpm, o);
   }
   write_obs_rows<S, T>(lds, obs, n, i, valid, o);

@@ -604,6 +604,50 @@ MDS_HD void lqr_omega_control(const Consts<T>& c, const LqrGain<T>& K, V3<T> rpy
 }
 
 // ------------------------------------------------------------------------------------
+// control/lqr/lqr_YO_controller.py:99-124: u = [Y, wx, wy, wz] = -K e on the 10-state
+// x = [rpy, F, vel, pos] (obs_to_lin_model dim 10); e[3] = calc_z_thrust(obs) - M G is taken in
+// its excess form (rotor_wrench) so that near hover it keeps its digits in fp32.  No hover
+// offset and no cap (cap_u is `pass`, :126-128).
+// ------------------------------------------------------------------------------------
+template <typename T> struct LqrYoGain {
+  T k[4][10];
+};
+template <typename T> MDS_HD T thrust_excess_of(const Consts<T>& c, const T rpm[4]) {
+  const T h = c.hover_rpm;
+  return m_fma(c.kf, (dsq(rpm[0], h) + dsq(rpm[1], h)) + (dsq(rpm[2], h) + dsq(rpm[3], h)), c.thrust_corr);
+}
+template <typename T>
+MDS_HD void lqr_yank_omega_control(const Consts<T>& c, const LqrYoGain<T>& K, V3<T> rpy, const T rpm[4], V3<T> vel, V3<T> pos,
+                                   V3<T> pos_des, V3<T> vel_des, T yaw_des, T u[4]) {
+  T e[10];
+  e[0] = rpy.x;
+  e[1] = rpy.y;
+  const T dy = rpy.z - yaw_des;
+  e[2] = m_fma(T(-6.283185307179586476925), m_rint(dy * T(0.15915494309189533577)), dy);
+  e[3] = thrust_excess_of(c, rpm);
+  T sy, cy;
+  m_sincos(reduced_phase<T>(0.0, T(0), yaw_des), &sy, &cy);
+  const V3<T> dv = vel - vel_des, dp = pos - pos_des;
+  e[4] = cy * dv.x + sy * dv.y; e[5] = -sy * dv.x + cy * dv.y; e[6] = dv.z;
+  e[7] = cy * dp.x + sy * dp.y; e[8] = -sy * dp.x + cy * dp.y; e[9] = dp.z;
+  for (int r = 0; r < 4; ++r) {
+    T acc = T(0);
+    for (int k = 0; k < 10; ++k) acc = m_fma(-K.k[r][k], e[k], acc);
+    u[r] = acc;
+  }
+}
+
+// control/low_level/yank_omega_ctrl.py:39-55 under lqr_YO_controller.py:85-97:
+// thrust_cmd = calc_z_thrust(obs) + yank * dt, then the ThrustOmega PID.
+template <typename T>
+MDS_HD void yank_omega_control(const Consts<T>& c, T ctrl_dt, const T u[4], const T rpm_obs[4], V3<T> cur, LowLevelState<T>& s,
+                               T rpm[4]) {
+  const T cur_thrust = c.gravity + thrust_excess_of(c, rpm_obs);
+  const T ut[4] = {m_fma(u[0], ctrl_dt, cur_thrust), u[1], u[2], u[3]};
+  thrust_omega_control(c, ctrl_dt, ut, cur, s, rpm);
+}
+
+// ------------------------------------------------------------------------------------
 // [UPSTREAM] gym_pybullet_drones DSLPIDControl.computeControl as PIDEnv.py:166-169 calls it
 // (computeControlFromState; target_vel = target_rpy_rates = 0).  Not in the reference tree:
 // restated from the published upstream source, parity unpinned.  The intermediate

@@ -42,7 +42,7 @@ class BaseAviary:
                  initial_xyzs=None, initial_rpys=None, physics: Physics = Physics.PYB, pyb_freq: int = 240,
                  ctrl_freq: int = 240, gui=False, record=False, obstacles=False, user_debug_gui=True,
                  output_folder="results", *, num_envs: int = 1, dtype="float32", integrator: str = "euler",
-                 device: int | None = None):
+                 device: int | None = None, track_last_rpm: bool | None = None):
         lib = capi.load_library()
         if isinstance(drone_model, str):
             drone_model = DroneModel(drone_model)
@@ -78,6 +78,9 @@ class BaseAviary:
         cfg.integrator = {"euler": capi.MDS_INTEGRATOR_EULER, "rk4": capi.MDS_INTEGRATOR_RK4}[integrator]
         cfg.pyb_freq, cfg.ctrl_freq = self.PYB_FREQ, self.CTRL_FREQ
         cfg.device = self.device.index
+        # _computeObs()[..., 16:20] after a step: kept by the library when the env is used the reference's way (one env);
+        # batched envs read the last clipped RPM from the obs step() returns and skip the extra 16 B per drone-step
+        cfg.track_last_rpm = int(self.NUM_ENVS == 1 if track_last_rpm is None else track_last_rpm)
         self._cfg = cfg
         # urdf constants ([UPSTREAM] _parseURDFParameters) + derived attributes the reference reads off env
         self.M, self.L, self.KF, self.KM = cfg.M, cfg.L, cfg.KF, cfg.KM
@@ -343,14 +346,17 @@ class BaseAviary:
         return (self._obs, self._act) if return_action else self._obs
 
     def set_cbf_nominal(self, which: str):
-        """Nominal controller of ``step_cbf_geometric``: "geometric" (GeometricControl return_omegas)
-        or "lqr_omega" (LQROmegaController, needs one constructed on this env first)."""
-        capi.check(self._lib.mds_cbf_set_nominal(self._h, {"geometric": 0, "lqr_omega": 1}[which]), "mds_cbf_set_nominal")
+        """Nominal controller of ``step_cbf_geometric``: "geometric" (GeometricControl return_omegas),
+        "lqr_omega" (LQROmegaController) or "lqr_yank_omega" (LQRYankOmegaController, the order-3 loop of
+        simulations/CBFTestOrd3.py); the LQR ones need a controller constructed on this env first."""
+        capi.check(self._lib.mds_cbf_set_nominal(self._h, {"geometric": 0, "lqr_omega": 1, "lqr_yank_omega": 2}[which]),
+                   "mds_cbf_set_nominal")
 
     def step_cbf_geometric(self, t: float, tracker, x_obs=None, obs_r_list=None, return_action: bool = False):
-        """One CBF-filtered control step of simulations/CBFTest.py:303-350 for every env: geometric
-        nominal (force - M G, w_des) -> ``tracker`` (DroneQPTracker) ECBF QP -> ThrustOmega low level
-        -> env.step.  Uses and updates the env's current observation; returns (obs, status[E])."""
+        """One CBF-filtered control step of simulations/CBFTest.py:303-350 for every env: nominal
+        (force - M G, w_des) -> ``tracker`` (DroneQPTracker) ECBF QP -> ThrustOmega low level -> env.step; with an
+        order-3 ``tracker.cbf`` the loop of simulations/CBFTestOrd3.py:306-352 (yank-omega LQR nominal, YankOmega low
+        level).  Uses and updates the env's current observation; returns (obs, status[E])."""
         self._require_open()
         tracker.cbf.configure(x_obs, obs_r_list)
         if getattr(self, "_cbf_status", None) is None:

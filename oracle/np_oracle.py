@@ -607,6 +607,73 @@ def lqr_omega_compute(obs, pos_des, vel_des, yaw_des, K, c: DroneConsts = CF2P):
 
 
 # --------------------------------------------------------------------------------------
+# f-1/f-3, order-3 loop: control/lqr/lqr_YO_controller.py:14-58 (gain), :99-124 (compute),
+# :85-97 (compute_low_level) and control/low_level/yank_omega_ctrl.py:39-55
+# --------------------------------------------------------------------------------------
+
+
+def linear_yank_omega_AB(c: DroneConsts = CF2P):
+    """model/linear_yank_omega.py:45-51: x = [r,p,y,F,vx,vy,vz,x,y,z], u = [Y,wx,wy,wz]."""
+    A = np.zeros((10, 10))
+    B = np.zeros((10, 4))
+    A[7:, 4:7] = np.eye(3)
+    A[4, 1] = c.G
+    A[5, 0] = -c.G
+    A[6, 3] = 1.0 / c.M
+    B[:3, 1:] = np.eye(3)
+    B[3, 0] = 1.0
+    return A, B
+
+
+def lqr_yank_omega_gain(c: DroneConsts = CF2P, ctrl_timestep=0.01):
+    """LQRYankOmegaController.__init__/compute_gain_matrix (:14-64): Bryson weights with
+    max_yank = MAX_THRUST / CTRL_TIMESTEP / 200 and max_thrust = MAX_THRUST - M G."""
+    import scipy.linalg as la
+    max_yank = (c.MAX_THRUST / ctrl_timestep) / 200
+    R = np.diag([1 / max_yank ** 2, 1 / 0.1 ** 2, 1 / 0.1 ** 2, 1 / 0.1 ** 2])
+    Q = np.diag([1 / (np.pi / 20) ** 2] * 2 + [1 / (np.pi / 40) ** 2] + [1 / (c.MAX_THRUST - c.M * c.G) ** 2]
+                + [1 / 0.15 ** 2] * 3 + [1 / 0.05 ** 2] * 3)
+    A, B = linear_yank_omega_AB(c)
+    P = la.solve_continuous_are(A, B, Q, R, e=None, s=None, balanced=True)
+    return la.solve(R, B.T @ P)
+
+
+def lqr_yank_omega_compute(obs, pos_des, vel_des, yaw_des, K, c: DroneConsts = CF2P):
+    """LQRYankOmegaController.compute(obs, skip_low_level=True) (:99-124) -> u = [Y, wx, wy, wz] = -K e
+    (no hover offset, cap_u is a no-op :126-128).  e[3] = calc_z_thrust(obs) - M G."""
+    obs = np.asarray(obs, dtype=np.float64)
+    x = obs_to_lin_model(obs, 10, c)
+    yd = np.asarray(yaw_des, dtype=np.float64)
+    e = x.copy()
+    dy = x[..., 2] - yd
+    e[..., 2] = np.arctan2(np.sin(dy), np.cos(dy))
+    e[..., 3] = x[..., 3] - c.M * c.G
+    cy, sy = np.cos(yd), np.sin(yd)
+
+    def rot_eqT(v):
+        return np.stack([cy * v[..., 0] + sy * v[..., 1], -sy * v[..., 0] + cy * v[..., 1], v[..., 2]], axis=-1)
+    e[..., 7:10] = rot_eqT(x[..., 7:10] - np.asarray(pos_des, dtype=np.float64))
+    e[..., 4:7] = rot_eqT(x[..., 4:7] - np.asarray(vel_des, dtype=np.float64))
+    return -np.einsum("ij,...j->...i", K, e)
+
+
+class YankOmegaOracle:
+    """YankOmegaController (yank_omega_ctrl.py:39-55) through LQRYankOmegaController.compute_low_level
+    (lqr_YO_controller.py:85-97): thrust_cmd = calc_z_thrust(obs) + yank * dt, then the ThrustOmega PID."""
+
+    def __init__(self, n, c: DroneConsts = CF2P):
+        self.c = c
+        self.toc = ThrustOmegaOracle(n, c)
+
+    def compute_low_level(self, u, obs, dt):
+        obs = np.asarray(obs, dtype=np.float64)
+        u = np.array(u, dtype=np.float64)
+        cur_thrust = self.c.KF * np.sum(obs[..., 16:20] ** 2, axis=-1)      # utils.calc_z_thrust (model_conversions.py:137-143)
+        u[..., 0] = cur_thrust + u[..., 0] * dt                              # yank2thrust (:49-53)
+        return self.toc.compute_low_level(u, obs, dt)
+
+
+# --------------------------------------------------------------------------------------
 # a5: model/dynamics.py:83-106
 # --------------------------------------------------------------------------------------
 
@@ -838,10 +905,10 @@ def qp_project(uhat, G, h, tol=1e-10, max_iter=None):
 
 
 def cbf_filter(x, xdes, u_nominal, order, Kcbf, umax, safety_radius, zscale, c: DroneConsts = CF2P, x_obs=None,
-               obs_r=None):
+               obs_r=None, Fmin=None, Fmax=None):
     """DroneQPTracker.compute_control (qptracker.py:22-34) for ONE env, given linear-model
     states x [N, xdim].  Returns (u [N,4], status) with status 0 = ok, 1 = fallback."""
-    G, h = cbf_rows(x, xdes, order, Kcbf, umax, safety_radius, zscale, c, x_obs, obs_r)
+    G, h = cbf_rows(x, xdes, order, Kcbf, umax, safety_radius, zscale, c, x_obs, obs_r, Fmin, Fmax)
     u_nominal = np.asarray(u_nominal, dtype=np.float64)
     ok, u, _ = qp_project(u_nominal.reshape(-1), G, h)
     if not ok:

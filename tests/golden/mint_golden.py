@@ -387,6 +387,39 @@ def mint_lqr_omega(ref):
     print("lqr_omega K", ctrl.K.shape, "u0 range", u[:, 0].min(), u[:, 0].max())
 
 
+def mint_lqr_yank_omega(ref):
+    """control/lqr/lqr_YO_controller.py (gain, compute(obs, skip_low_level=True), compute_low_level) over
+    control/low_level/yank_omega_ctrl.py.  Needs the modules mint_lqr_omega() registered; the low level rides on the
+    base-class-stubbed ThrustOmegaController, so the rpm part is marked stubbed like thrust_omega.npz."""
+    sys.modules["model.linear_yank_omega"] = ref["lin_yo"]
+    load("control.low_level.yank_omega_ctrl", REF + "/control/low_level/yank_omega_ctrl.py")
+    mod = load("control.lqr.lqr_YO_controller", REF + "/control/lqr/lqr_YO_controller.py")
+    yo = sys.modules["control.low_level.yank_omega_ctrl"]
+    env = make_env()
+    env.DRONE_MODEL = sys.modules["gym_pybullet_drones.utils.enums"].DroneModel("cf2p")
+    rng = np.random.default_rng(7)
+    n, T = 96, 12
+    ctrls = [mod.LQRYankOmegaController(env, ref["lin_yo"].LinearizedYankOmegaModel(env), yo.YankOmegaController(env)) for _ in range(n)]
+    obs = np.zeros((T, n, 20))
+    pos_d = np.array([0.3, -0.2, 0.8]) + rng.normal(size=(T, n, 3)) * 0.2
+    vel_d = rng.normal(size=(T, n, 3)) * 0.3
+    yaw_d = rng.uniform(-3.1, 3.1, size=(T, n))
+    u = np.zeros((T, n, 4))
+    rpm = np.zeros((T, n, 4))
+    for t in range(T):
+        obs[t] = random_obs(rng, n, np.array([0.3, -0.2, 0.8]), np.zeros(3), euler_max=0.5, pos_noise=0.4, vel_noise=0.4)
+        obs[t, :, 9] = rng.uniform(-3.1, 3.1, size=n)
+        obs[t, :8, 16:20] = 0.0                                           # first obs of a run: RPM 0 -> cur_thrust 0
+        obs[t, 8:16, 16:20] *= 1.45                                       # near MAX_RPM
+        for i in range(n):
+            ctrls[i].set_desired_trajectory(0, pos_d[t, i], vel_d[t, i], np.zeros(3), yaw_d[t, i], 0.0)
+            _, u[t, i] = ctrls[i].compute(obs[t, i].copy(), skip_low_level=True)
+            rpm[t, i] = ctrls[i].compute_low_level(u[t, i].copy(), obs[t, i].copy())
+    np.savez_compressed(OUT + "/lqr_yank_omega.npz", K=ctrls[0].K, obs=obs, pos_d=pos_d, vel_d=vel_d, yaw_d=yaw_d, u=u, rpm=rpm,
+                        dt=env.CTRL_TIMESTEP, low_level_base_class="stubbed", **META)
+    print("lqr_yank_omega K", ctrls[0].K.shape, "yank range", u[..., 0].min(), u[..., 0].max())
+
+
 def trajectory_cases(T):
     """The same constructor arguments are used for the reference classes (minting) and for the oracle /
     GPU classes (tests): T is a namespace with Lemniscate, Circle, Line, Wait, Compound, Rotate."""
@@ -436,5 +469,6 @@ if __name__ == "__main__":
     mint_cbf(ref)
     mint_thrust_omega()
     mint_lqr_omega(ref)
+    mint_lqr_yank_omega(ref)
     sys.path.insert(0, REF)
     mint_trajectories()

@@ -72,17 +72,21 @@ def open_loop_setup(n, seed=1, tilt=0.02):
 
 
 def oracle_cbf_closed_loop(xyz, rpy, P, steps, Kcbf, umax, safety_radius, zscale, x_obs, obs_r, pyb_freq=100, ctrl_freq=100,
-                           consts=O.CF2P, nominal="geometric"):
+                           consts=O.CF2P, nominal="geometric", order=2, Fmin=None, Fmax=None, first_rpm=0.0):
     """simulations/CBFTest.py:303-350 on the oracle, per env: geometric nominal (return_omegas) ->
     u_hat = (force - M G, w_des), xdes = [0,0,yaw, vel, pos] -> ECBF QP (fallback to nominal) ->
-    + M G -> ThrustOmega low level -> env.step.  Returns (obs [E,D,20], status history [steps,E])."""
+    + M G -> ThrustOmega low level -> env.step.  order 3 / nominal "lqr_yank_omega": the loop of
+    simulations/CBFTestOrd3.py:306-352 (yank - M G, xdes with G M in slot 3, YankOmega low level, nothing added back).
+    Returns (obs [E,D,20], status history [steps,E])."""
     E, D = xyz.shape[0], xyz.shape[1]
     n = E * D
     Pf = P.reshape(-1, 7)
     ora = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), consts, pyb_freq, ctrl_freq)
-    ll = O.ThrustOmegaOracle(n, consts)
+    ll = O.YankOmegaOracle(n, consts) if order == 3 else O.ThrustOmegaOracle(n, consts)
     Klqr = O.lqr_omega_gain(consts) if nominal == "lqr_omega" else None
-    obs = ora.step(np.zeros((n, 4)))
+    Kyo = O.lqr_yank_omega_gain(consts, 1.0 / ctrl_freq) if nominal == "lqr_yank_omega" else None
+    assert (order == 3) == (nominal == "lqr_yank_omega")
+    obs = ora.step(np.full((n, 4), float(first_rpm)))     # the order-3 loop integrates thrust from the RPM echo: start it at hover
     t = 0.0
     hist = []
     for k in range(steps):
@@ -90,19 +94,28 @@ def oracle_cbf_closed_loop(xyz, rpy, P, steps, Kcbf, umax, safety_radius, zscale
         if nominal == "lqr_omega":       # simulations/CBFTest.py:290-293, :339
             unom = O.lqr_omega_compute(obs, pos, vel, yaw, Klqr, consts)
             unom[:, 0] -= consts.M * consts.G
+        elif nominal == "lqr_yank_omega":  # simulations/CBFTestOrd3.py:294-297, :341
+            unom = O.lqr_yank_omega_compute(obs, pos, vel, yaw, Kyo, consts)
+            unom[:, 0] -= consts.M * consts.G
         else:
             force, w_des, _ = O.geometric_compute(obs, pos, vel, acc, yaw, yd, consts, return_omegas=True)
             unom = np.concatenate([(force - consts.M * consts.G)[:, None], w_des], axis=1)
-        xdes = np.concatenate([np.zeros((n, 2)), yaw[:, None], vel, pos], axis=1)
-        x = O.obs_to_lin_model(obs, 9)
+        if order == 3:
+            xdes = np.concatenate([np.zeros((n, 2)), yaw[:, None], np.full((n, 1), consts.G * consts.M), vel, pos], axis=1)
+            x = O.obs_to_lin_model(obs, 10, consts)
+        else:
+            xdes = np.concatenate([np.zeros((n, 2)), yaw[:, None], vel, pos], axis=1)
+            x = O.obs_to_lin_model(obs, 9)
         usafe = np.zeros((n, 4))
         st = np.zeros(E, dtype=int)
+        kw = dict(Fmin=Fmin, Fmax=Fmax) if order == 3 else {}
         for e in range(E):
             sl = slice(e * D, (e + 1) * D)
-            usafe[sl], st[e] = O.cbf_filter(x[sl], xdes[sl], unom[sl], 2, Kcbf, umax, safety_radius, zscale, consts,
-                                            np.array(x_obs) if x_obs is not None else None, obs_r)
+            usafe[sl], st[e] = O.cbf_filter(x[sl], xdes[sl], unom[sl], order, Kcbf, umax, safety_radius, zscale, consts,
+                                            np.array(x_obs) if x_obs is not None else None, obs_r, **kw)
         hist.append(st)
-        usafe[:, 0] += consts.M * consts.G
+        if order == 2:
+            usafe[:, 0] += consts.M * consts.G
         rpm = ll.compute_low_level(usafe, obs, ora.CTRL_TIMESTEP)
         obs = ora.step(rpm)
         t += ora.CTRL_TIMESTEP

@@ -325,3 +325,74 @@ def test_cbf_filter_size_limits(mds, D, n_obs):
     with pytest.raises(Exception):
         big = make_env(mds, 1, 33, "float32")
         mds.DroneCBF(big, [mds.LinearizedOmegaModel(big) for _ in range(33)], order=2).configure()
+
+
+@pytest.mark.parametrize("dtype,rtol", [("float64", 1e-10), ("float32", 3e-5)])
+def test_lqr_yank_omega_golden(mds, dtype, rtol):
+    """control/lqr/lqr_YO_controller.py + control/low_level/yank_omega_ctrl.py against the reference-minted fixture:
+    host ARE gain, u = -K e with the thrust state from the obs' RPM echo, and the stateful yank -> thrust -> PID low level."""
+    from multidronesim_amd.control import LQRYankOmegaController, YankOmegaController
+    d = np.load(os.path.join(G, "lqr_yank_omega.npz"))
+    T, n = d["obs"].shape[:2]
+    env = make_env(mds, n, 1, dtype)
+    ctrl = LQRYankOmegaController(env, mds.LinearizedYankOmegaModel(env), YankOmegaController(env))
+    np.testing.assert_allclose(ctrl.K, d["K"], rtol=1e-8, atol=1e-10)
+    scale = np.abs(d["u"]).reshape(-1, 4).max(axis=0)
+    for t in range(T):
+        des = np.zeros((n, 1, 11))
+        des[:, 0, 0:3], des[:, 0, 3:6], des[:, 0, 9] = d["pos_d"][t], d["vel_d"][t], d["yaw_d"][t]
+        u = ctrl.compute_batched(d["obs"][t].reshape(n, 1, 20), des).double().cpu().numpy().reshape(n, 4)
+        assert (np.abs(u - d["u"][t]) / scale).max() < rtol
+        rpm = ctrl.yo_controller.compute_low_level_batched(d["u"][t].reshape(n, 1, 4), d["obs"][t].reshape(n, 1, 20))
+        np.testing.assert_allclose(rpm.double().cpu().numpy().reshape(n, 4), d["rpm"][t], rtol=max(rtol, 1e-12) * 10)
+    env.close()
+    env = make_env(mds, 1, 1, dtype)                                              # reference signatures, single drone
+    ctrl = LQRYankOmegaController(env, mds.LinearizedYankOmegaModel(env), YankOmegaController(env))
+    ctrl.set_desired_trajectory(0, d["pos_d"][0, 5], d["vel_d"][0, 5], np.zeros(3), d["yaw_d"][0, 5], 0.0)
+    act, u1 = ctrl.compute(d["obs"][0, 5])
+    assert (np.abs(u1 - d["u"][0, 5]) / scale).max() < rtol
+    np.testing.assert_allclose(act, d["rpm"][0, 5], rtol=max(rtol, 1e-12) * 10)
+    env.close()
+
+
+@pytest.mark.parametrize("dtype,steps,tol", [("float64", 150, 1e-6), ("float32", 90, 5e-3)])
+def test_order3_closed_loop_matches_oracle(mds, dtype, steps, tol):
+    """simulations/CBFTestOrd3.py:306-352 for every env: LQRYankOmegaController nominal (yank - M G, kept quirk) ->
+    order-3 ECBF QP (poles and radii of :452) -> YankOmega low level -> step, against the oracle loop.  The order-3
+    filter pushes hard once active (the oracle drifts ~0.7 m off the nominal path here), so fp32 gets a short horizon."""
+    from multidronesim_amd.control import LQRYankOmegaController, YankOmegaController
+    from tests import helpers as H2
+    E, D = 4, 4
+    xyz, rpy, P = H2.c2_setup(E, D, phase="c3", offset=0.0, omega=0.5)             # CBFTestOrd3.py:450
+    xyz[..., 2] = 0.5 + 0.6 * np.arange(D)
+    P[..., 4] = 0.5 + 0.6 * np.arange(D)
+    x_obs = [np.array([[0.0, 0.0, -0.3], [0, 0, 0], [0, 0, 0]])]
+    obs_r = [0.1]
+    env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                         pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype)
+    env.set_trajectories(P)
+    LQRYankOmegaController(env, mds.LinearizedYankOmegaModel(env), YankOmegaController(env))
+    cbf = mds.DroneCBF(env, [mds.LinearizedYankOmegaModel(env) for _ in range(D)], safety_radius=0.125, zscale=2.0, order=3,
+                       cbf_poles=np.array([-3.0, -3.6, -5.6]))
+    trk = mds.DroneQPTracker(cbf, order=3, num_robots=D, xdim=10, env=env)
+    with pytest.raises(RuntimeError):                                             # geometric nominal has no yank output
+        env.step_cbf_geometric(0.0, trk, x_obs, obs_r)
+    env.set_cbf_nominal("lqr_yank_omega")
+    oobs, ohist = H2.oracle_cbf_closed_loop(xyz, rpy, P, steps, cbf.Kcbf.reshape(-1), cbf.umax, 0.125, 2.0, x_obs, obs_r,
+                                            nominal="lqr_yank_omega", order=3, first_rpm=O.CF2P.HOVER_RPM)
+    plain, _ = H2.oracle_cbf_closed_loop(xyz, rpy, P, steps, cbf.Kcbf.reshape(-1), np.array([1e9] * 4), 1e-3, 2.0, None, None,
+                                         nominal="lqr_yank_omega", order=3, first_rpm=O.CF2P.HOVER_RPM, Fmin=-1e9, Fmax=1e9)
+    assert np.abs(plain[..., :3] - oobs[..., :3]).max() > (0.02 if steps >= 150 else 1e-3)   # the filter is doing something in this scene
+    env.step(mds.torch.full((E, D, 4), O.CF2P.HOVER_RPM, dtype=env.dtype))
+    t = 0.0
+    for k in range(steps):
+        gobs, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
+        if dtype == "float64":
+            np.testing.assert_array_equal(st.cpu().numpy(), ohist[k])
+        t += env.CTRL_TIMESTEP
+    g = gobs.double().cpu().numpy()
+    assert np.isfinite(g).all()
+    assert np.abs(g[..., :16] - oobs[..., :16]).max() < tol
+    rel = np.abs(g[..., 16:] - oobs[..., 16:]).max() / O.CF2P.HOVER_RPM
+    assert rel < tol * 10
+    env.close()

@@ -110,6 +110,37 @@ def test_step_clips_action_and_reference_shapes(mds):
         make_env(mds, 1, 1, np.zeros((1, 3)), np.zeros((1, 3)), pyb=240, ctrl=100)
 
 
+def test_compute_obs_last_rpm_tracking(mds):
+    """[UPSTREAM] _computeObs() after a step carries the last clipped action.  The library keeps that copy when the env
+    is used the reference's way (one env), with DYN_DRAG, or on request; a batched DYN env skips the 16 B per
+    drone-step and _computeObs() then reports NaN in those columns instead of stale values."""
+    D = 2
+    xyz = np.array([[0, 0, 1.0], [1, 0, 1.0]])
+    hover = O.CF2P.HOVER_RPM
+    for E, kw, tracked in ((1, {}, True), (3, {}, False), (3, dict(track_last_rpm=True), True), (3, dict(physics=mds.Physics.PYB_DRAG), True)):
+        env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=np.zeros((D, 3)),
+                             physics=kw.pop("physics", mds.Physics.DYN), pyb_freq=100, ctrl_freq=100, num_envs=E, dtype="float32", **kw)
+        assert (np_obs(env._computeObs())[:, 16:20] == 0).all()                      # after reset: zeros, always
+        act = mds.torch.full((E, D, 4), hover * 1.01, dtype=env.dtype)
+        act[..., 1] = 1e6
+        obs, *_ = env.step(act)
+        want = np_obs(obs)
+        got = np_obs(env._computeObs())
+        np.testing.assert_array_equal(got[:, :16], want[:, :16])
+        if tracked:
+            np.testing.assert_array_equal(got[:, 16:20], want[:, 16:20])
+            env.set_trajectories(np.tile(np.array([1.0, 1.0, 0, 0, 1.0, 0, 0]), (E, D, 1)))
+            o2 = np_obs(env.step_geometric(0.0))                                     # fused kernel keeps the copy too
+            np.testing.assert_array_equal(np_obs(env._computeObs())[:, 16:20], o2[:, 16:20])
+            o3 = np_obs(env.rollout_geometric_fused(0.01, 5)[0])                     # and the multi-step kernel
+            np.testing.assert_array_equal(np_obs(env._computeObs())[:, 16:20], o3[:, 16:20])
+        else:
+            assert np.isnan(got[:, 16:20]).all()
+            env.reset()
+            assert (np_obs(env._computeObs())[:, 16:20] == 0).all()
+        env.close()
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 255, 257, 1000])
 def test_ragged_sizes(mds, n):
     """n not a multiple of the wave (64) / workgroup (256): tail lanes and the LDS obs staging."""

@@ -150,6 +150,21 @@ def test_lqr_omega_matches_reference():
     assert (np.abs(d["u"][:, 0] - lo) < 1e-12).sum() >= 8 and (np.abs(d["u"][:, 0] - hi) < 1e-12).sum() >= 8
 
 
+def test_lqr_yank_omega_matches_reference():
+    """control/lqr/lqr_YO_controller.py + control/low_level/yank_omega_ctrl.py: ARE gain, u = -K e with the thrust state
+    from calc_z_thrust(obs), and the stateful low level (thrust = cur_thrust + yank dt -> ThrustOmega PID)."""
+    d = load("lqr_yank_omega.npz")
+    assert str(d["low_level_base_class"]) == "stubbed"
+    K = O.lqr_yank_omega_gain(O.CF2P, float(d["dt"]))
+    np.testing.assert_allclose(K, d["K"], rtol=1e-8, atol=1e-10)
+    low = O.YankOmegaOracle(d["obs"].shape[1], O.CF2P)
+    for t in range(d["obs"].shape[0]):
+        u = O.lqr_yank_omega_compute(d["obs"][t], d["pos_d"][t], d["vel_d"][t], d["yaw_d"][t], d["K"])
+        np.testing.assert_allclose(u, d["u"][t], rtol=1e-10, atol=1e-10)
+        rpm = low.compute_low_level(d["u"][t], d["obs"][t], float(d["dt"]))
+        np.testing.assert_allclose(rpm, d["rpm"][t], rtol=1e-13, atol=1e-9)
+
+
 def test_trajectory_family_matches_reference():
     """trajectories/{Circle,LineTrajectory,CompoundTrajectory,RotateTrajectory}.py via oracle/np_trajectories.py."""
     import types
