@@ -113,6 +113,8 @@ template <typename T> static void fill_cbf(const mds_handle* h, const mds_cbf_pa
   o.Ds_pair = (T)(2.0 * p.safety_radius);
   o.safety_radius = (T)p.safety_radius;
   o.zscale = (T)p.zscale;
+  o.inv_zscale = (T)(1.0 / p.zscale);
+  o.obs_magic = p.n_obs > 0 ? (65536 + p.n_obs - 1) / p.n_obs : 0;
   o.inv_c4 = (T)(1.0 / (p.zscale * p.zscale * p.zscale * p.zscale));
   o.inv_m = (T)(1.0 / h->cfg.M);
   o.g = (T)h->cfg.G;
@@ -671,27 +673,27 @@ int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void*
   const bool hildreth = solver && solver[0] == 'h' && order == 2;
   if (n > 64) return fail(MDS_EUNSUPPORTED, "mds_cbf_filter: more than 64 coupled QP variables per env");
   if (R > 17) return fail(MDS_EUNSUPPORTED, "mds_cbf_filter: too many rows per env");
-  // WPB (envs per workgroup) shrinks with the LDS footprint of Q, R: 2 * NMAX * (NMAX+1) * sizeof(T) per env
-#define MDS_GI(T, CP, RR, NMAX, ORD, WPB, TOL)                                                                               \
-  k_cbf_filter_gi<T, T, RR, NMAX, ORD, WPB><<<dim3((unsigned)((E + WPB - 1) / WPB)), 64 * WPB, 0, st>>>(                      \
-      CP, E, (T)h->cfg.KF, h->pair_ij, (const T*)h->obstacles, (const T*)obs, (const T*)xdes, (const T*)unom, (T*)usafe,      \
+  // one wavefront (= one env) per workgroup; NMAX bounds the QP variables (LDS footprint of Q, R ~ NMAX^2)
+#define MDS_GI(T, CP, RR, NMAX, ORD, TOL)                                                                                   \
+  k_cbf_filter_gi<T, T, RR, NMAX, ORD><<<dim3((unsigned)E), 64, 0, st>>>(                                                    \
+      CP, E, (T)h->cfg.KF, h->pair_ij, (const T*)h->obstacles, (const T*)obs, (const T*)xdes, (const T*)unom, (T*)usafe,     \
       (int*)status, max_iter, (T)((TOL) * (TOL)))
-#define MDS_GI_R(T, CP, NMAX, ORD, WPB, TOL)            \
-  do {                                                  \
-    if (R <= 4) MDS_GI(T, CP, 4, NMAX, ORD, WPB, TOL);  \
-    else if (R <= 8) MDS_GI(T, CP, 8, NMAX, ORD, WPB, TOL); \
-    else MDS_GI(T, CP, 17, NMAX, ORD, WPB, TOL);        \
+#define MDS_GI_R(T, CP, NMAX, ORD, TOL)            \
+  do {                                             \
+    if (R <= 4) MDS_GI(T, CP, 4, NMAX, ORD, TOL);  \
+    else if (R <= 8) MDS_GI(T, CP, 8, NMAX, ORD, TOL); \
+    else MDS_GI(T, CP, 17, NMAX, ORD, TOL);        \
   } while (0)
-#define MDS_GI_ALL(T, CP, TOL)                                                        \
-  do {                                                                                \
-    if (order == 2) {                                                                 \
-      if (n <= 16) MDS_GI_R(T, CP, 16, 2, 4, TOL);                                    \
-      else MDS_GI_R(T, CP, 32, 2, 4, TOL);                                            \
-    } else {                                                                          \
-      if (n <= 24) MDS_GI_R(T, CP, 24, 3, 4, TOL);                                    \
-      else if (n <= 48) MDS_GI_R(T, CP, 48, 3, (sizeof(T) == 4 ? 2 : 1), TOL);        \
-      else MDS_GI_R(T, CP, 63, 3, 1, TOL);                                            \
-    }                                                                                 \
+#define MDS_GI_ALL(T, CP, TOL)                                       \
+  do {                                                               \
+    if (order == 2) {                                                \
+      if (n <= 16) MDS_GI_R(T, CP, 16, 2, TOL);                      \
+      else MDS_GI_R(T, CP, 32, 2, TOL);                              \
+    } else {                                                         \
+      if (n <= 24) MDS_GI_R(T, CP, 24, 3, TOL);                      \
+      else if (n <= 48) MDS_GI_R(T, CP, 48, 3, TOL);                 \
+      else MDS_GI_R(T, CP, 63, 3, TOL);                              \
+    }                                                                \
   } while (0)
 #define MDS_HILD(T, CP, RR, TOL)                                                                                          \
   k_cbf_filter_o2<T, T, RR><<<grid, 256, 0, st>>>(CP, E, h->pair_ij, (const T*)h->obstacles, (const T*)obs, (const T*)xdes, \

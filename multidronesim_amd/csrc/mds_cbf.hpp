@@ -20,7 +20,8 @@ template <typename T> struct CbfParams {
   T umax[4];      // cbf/cbf.py:566-572
   T Ds_pair;      // 2 * safety_radius (:291)
   T safety_radius;
-  T zscale, inv_c4;
+  T zscale, inv_zscale, inv_c4;
+  int obs_magic;  // ceil(2^16 / n_obs): row index -> (agent, obstacle) without an integer division
   T inv_m, g;     // env.M, env.G (9.8) through the linear models
   T Fmin, Fmax;   // order 3 force box (:564-565)
 };
@@ -40,7 +41,7 @@ MDS_HD void cbf_pair_row(const CbfParams<T>& P, const T* xi, const T* xdi, const
 #endif
   for (int k = 0; k < xd; ++k) d[k] = (xi[k] - xdi[k]) - (obstacle ? T(0) : (xj[k] - xdj[k]));
   const T s = m_fma(ex, ex, ey * ey);
-  const T ezc = ez / P.zscale;
+  const T ezc = ez * P.inv_zscale;
   const T ezc2 = ezc * ezc;
   const T Ds2 = Ds * Ds;
   const T h = m_fma(s, s, m_fma(ezc2, ezc2, -(Ds2 * Ds2)));

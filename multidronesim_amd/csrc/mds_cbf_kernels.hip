@@ -219,13 +219,22 @@ __global__ __launch_bounds__(256) void k_cbf_filter_o2(const CbfParams<T> P, con
 
 // ------------------------------------------------------------------------------------
 // Exact solver for the same thrust sub-problem: Goldfarb-Idnani dual active set with H = I,
-// one wavefront per env.  The active normals N (n x q, q <= n = drones per env) are kept as a
+// one wavefront per env.  The active normals N (n x q, q <= n = QP variables per env) are kept as a
 // thin QR (Q: n x q orthonormal columns, R: q x q upper triangular) in the wave's LDS slice;
 // adding a row appends a Gram-Schmidt column, dropping one re-triangularises with Givens
 // rotations.  Rows are normalised to unit length so every threshold is a distance.  The number
 // of iterations is of the order of the number of active rows (Hildreth's coordinate ascent
 // needs 10^2..10^4 on crowded scenes); the result is the exact minimiser, the same the oracle's
 // qp_project computes.
+//
+// The kernel is latency-bound per wave (a chain of small dependent steps), so:
+//  * every global read of the env (obs, xdes, u_hat, pair table, obstacles) is issued before the
+//    first wait;
+//  * wave-wide reductions run on the VALU (DPP row all-reduce + 4 v_readlane), not through the
+//    LDS crossbar (__shfl = ds_bpermute, ~12 dependent LDS round trips per arg-max);
+//  * the selected row is fetched from an LDS copy of the rows by a uniform address instead of a
+//    register-array select (which the compiler turns into scratch traffic);
+//  * one wavefront per workgroup: a slow env does not pin the LDS / VGPRs of finished ones.
 // ------------------------------------------------------------------------------------
 #define MDS_WAVE_SYNC()                                   \
   do {                                                    \
@@ -234,32 +243,44 @@ __global__ __launch_bounds__(256) void k_cbf_filter_o2(const CbfParams<T> P, con
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
 
-template <typename T> __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+namespace wv {
+// DPP controls (gfx9): quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140.
+// Must be called with all 64 lanes active (wave-uniform control flow): a disabled source lane leaves `old`.
+template <int CTRL> __device__ __forceinline__ int mov(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ __forceinline__ float mov(float v) {
+  return __builtin_bit_cast(float, mov<CTRL>(__builtin_bit_cast(int, v)));
 }
-template <typename T> __device__ __forceinline__ T wave_max(T v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = m_max(v, __shfl_xor(v, off));
-  return v;
+template <int CTRL> __device__ __forceinline__ double mov(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)mov<CTRL>((int)(unsigned)(u & 0xffffffffull)), hi = (unsigned)mov<CTRL>((int)(unsigned)(u >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-template <typename T> __device__ __forceinline__ void wave_argmin(T& val, int& idx) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const T ov = __shfl_xor(val, off);
-    const int oi = __shfl_xor(idx, off);
-    const bool take = (ov < val) || (ov == val && oi < idx);
-    val = take ? ov : val;
-    idx = take ? oi : idx;
-  }
+__device__ __forceinline__ int get(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float get(float v, int l) { return __builtin_bit_cast(float, get(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ double get(double v, int l) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)get((int)(unsigned)(u & 0xffffffffull), l), hi = (unsigned)get((int)(unsigned)(u >> 32), l);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-template <typename T, int R> __device__ __forceinline__ T pick(const T (&a)[R], int k) {
-  T v = a[0];
-#pragma unroll
-  for (int q = 1; q < R; ++q) v = (q == k) ? a[q] : v;
-  return v;
+struct Max {
+  template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return b > a ? b : a; }
+};
+struct Min {
+  template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return b < a ? b : a; }
+};
+struct Add {
+  template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; }
+};
+// all-reduce over the wave; the result is wave-uniform (it comes out of v_readlane)
+template <typename T, typename Op> __device__ __forceinline__ T allreduce(T v, Op op) {
+  v = op(v, mov<0xB1>(v));
+  v = op(v, mov<0x4E>(v));
+  v = op(v, mov<0x141>(v));
+  v = op(v, mov<0x140>(v));
+  return op(op(get(v, 0), get(v, 16)), op(get(v, 32), get(v, 48)));
 }
+}  // namespace wv
+
 template <typename T> struct GiEps;
 template <> struct GiEps<float> {
   static constexpr float z = 1e-9f, r = 1e-6f, inf = 3.0e38f;
@@ -268,56 +289,92 @@ template <> struct GiEps<double> {
   static constexpr double z = 1e-16, r = 1e-12, inf = 1.0e300;
 };
 
+// one unit-norm row  sum_k ca[k] u[NV ia + k] + cb[k] u[NV ib + k] <= b,  ij = ia | ib << 8
+template <typename T, int NV> struct CbfRow {
+  T ca[NV], cb[NV], b;
+  int ij;
+};
+
 // NV = QP variables per agent (order 2: thrust only -> 1; order 3: yank, wx, wy -> 3, wz is box-only),
-// NMAX = compile-time bound on the number of QP variables n = NV * D (LDS footprint of Q, R ~ NMAX^2).
-// WPB = wavefronts (= envs) per workgroup, chosen so that the LDS slices fit 160 KiB
-template <typename T, typename S, int R, int NMAX, int ORDER, int WPB>
-__global__ __launch_bounds__(64 * WPB) void k_cbf_filter_gi(const CbfParams<T> P, const int E, const T kf, const int* __restrict__ pair_ij,
-                                                       const T* __restrict__ obstacles, const S* __restrict__ obs,
-                                                       const S* __restrict__ xdes, const S* __restrict__ unom,
-                                                       S* __restrict__ usafe, int* __restrict__ status, const int max_iter,
-                                                       const T tol2) {
+// NMAX = compile-time bound on the number of QP variables n = NV * D (LDS footprint of Q, R ~ NMAX^2),
+// R = rows per lane.  One wavefront (= one env) per workgroup.
+template <typename T, typename S, int R, int NMAX, int ORDER>
+__global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, const int E, const T kf, const int* __restrict__ pair_ij,
+                                                      const T* __restrict__ obstacles, const S* __restrict__ obs,
+                                                      const S* __restrict__ xdes, const S* __restrict__ unom,
+                                                      S* __restrict__ usafe, int* __restrict__ status, const int max_iter,
+                                                      const T tol2) {
   constexpr int NV = ORDER == 2 ? 1 : 3;
   constexpr int XD = ORDER == 2 ? 9 : 10;
   constexpr int kQS = NMAX + 1;     // padded LDS row stride (conflict-free column walks)
   constexpr int DMAX = NMAX / NV;
-  __shared__ T sx[WPB][DMAX][XD], sxd[WPB][DMAX][XD];
-  __shared__ T su_[WPB][NMAX], sd_[WPB][NMAX], slam_[WPB][NMAX];
-  __shared__ T sQ_[WPB][NMAX][kQS], sR_[WPB][NMAX][kQS];
-  __shared__ int sact_[WPB][NMAX];
-  __shared__ __align__(16) S sraw[WPB][DMAX * 20];            // the env's observation rows, loaded coalesced
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int env = blockIdx.x * WPB + wave;
-  if (env >= E) return;                                    // wave-uniform
-  T* su = su_[wave];
-  T* sd = sd_[wave];
-  T* slam = slam_[wave];
-  T(*sQ)[kQS] = sQ_[wave];
-  T(*sR)[kQS] = sR_[wave];
-  int* sact = sact_[wave];
+  constexpr int NOBS_L = (DMAX * 20 + 63) / 64, NXD_L = (DMAX * XD + 63) / 64, NUN_L = (DMAX * 4 + 63) / 64;
+  static_assert(sizeof(CbfRow<T, NV>) * R * 64 >= sizeof(S) * DMAX * 20, "raw obs staging aliases the row table");
+  __shared__ T sx[DMAX * XD], sxd[DMAX * XD];
+  __shared__ T su[NMAX], sd[NMAX], slam[NMAX], sdi[NMAX];
+  __shared__ T sQ[NMAX][kQS], sR[NMAX][kQS];
+  __shared__ int sact[NMAX];
+  __shared__ T sob[kCbfMaxObs * 4];
+  __shared__ T swz[2][DMAX];
+  __shared__ __align__(16) CbfRow<T, NV> srow[R * 64];
+  S* sraw = reinterpret_cast<S*>(srow);                     // the env's observation rows, staged before the rows are built
+  const int lane = threadIdx.x;
+  const int env = blockIdx.x;
+  if (env >= E) return;
   const int D = P.num_drones, n = NV * D;
   const size_t base = (size_t)env * D;
+  const int npairs = cbf_num_pairs(D), nobs_rows = D * P.n_obs, m = npairs + nobs_rows + 2 * n;
+
+  // ---- every global read of this env, issued back to back ----
   // an env's D x 20 observation block, its D x xdim xdes block and D x 4 nominal block are contiguous
-  for (int k = lane; k < D * 20; k += 64) sraw[wave][k] = obs[base * 20 + k];
-  for (int k = lane; k < D * XD; k += 64) sxd[wave][k / XD][k % XD] = (T)xdes[base * XD + k];
+  S robs[NOBS_L], rxd[NXD_L], run[NUN_L];
+  int rpair[R];
+#pragma unroll
+  for (int j = 0; j < NOBS_L; ++j) robs[j] = lane + 64 * j < D * 20 ? obs[base * 20 + lane + 64 * j] : (S)0;
+#pragma unroll
+  for (int j = 0; j < NXD_L; ++j) rxd[j] = lane + 64 * j < D * XD ? xdes[base * XD + lane + 64 * j] : (S)0;
+#pragma unroll
+  for (int j = 0; j < NUN_L; ++j) run[j] = lane + 64 * j < D * 4 ? unom[base * 4 + lane + 64 * j] : (S)0;
+#pragma unroll
+  for (int k = 0; k < R; ++k) rpair[k] = lane + 64 * k < npairs ? pair_ij[lane + 64 * k] : 0;
+  const T rob = lane < 4 * P.n_obs ? obstacles[lane] : T(0);
+#pragma unroll
+  for (int j = 0; j < NOBS_L; ++j)
+    if (lane + 64 * j < D * 20) sraw[lane + 64 * j] = robs[j];
+#pragma unroll
+  for (int j = 0; j < NXD_L; ++j)
+    if (lane + 64 * j < D * XD) sxd[lane + 64 * j] = (T)rxd[j];
+#pragma unroll
+  for (int j = 0; j < NUN_L; ++j) {
+    const int k = lane + 64 * j;
+    if (k < D * 4 && (k & 3) < NV) su[NV * (k >> 2) + (k & 3)] = (T)run[j];
+  }
+  sob[lane] = rob;
   MDS_WAVE_SYNC();
   bool bad = false;
-  for (int d = lane; d < D; d += 64) {       // obs_to_lin_model(obs, dim = 9 | 10) (model_conversions.py:20-58)
-    const S* o = &sraw[wave][d * 20];
-    T* x = sx[wave][d];
+  T wz_lo = -P.umax[3], wz_hi = P.umax[3];
+  if (lane < D) {                             // obs_to_lin_model(obs, dim = 9 | 10) (model_conversions.py:20-58)
+    const S* o = &sraw[lane * 20];
+    T* x = &sx[lane * XD];
     x[0] = (T)o[7]; x[1] = (T)o[8]; x[2] = (T)o[9];
     if (ORDER == 3) {
       const T r0 = (T)o[16], r1 = (T)o[17], r2 = (T)o[18], r3 = (T)o[19];
-      x[3] = kf * (r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);                                  // calc_z_thrust (:137-143)
+      const T F = kf * (r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);                             // calc_z_thrust (:137-143)
+      x[3] = F;
+      // order 3: the omega_z input only has box rows, +-umax_3 and the force box written to its column
+      // (custom_force_bound_const, cbf/cbf.py:446-464, quirk kept): a 1-D interval per agent
+      wz_hi = m_min(wz_hi, P.k[2] * (P.Fmax - F));
+      wz_lo = m_max(wz_lo, -(P.k[2] * (F - P.Fmin)));
+      if (wz_lo > wz_hi) bad = true;
     }
     x[XD - 6] = (T)o[10]; x[XD - 5] = (T)o[11]; x[XD - 4] = (T)o[12];
     x[XD - 3] = (T)o[0]; x[XD - 2] = (T)o[1]; x[XD - 1] = (T)o[2];
-    for (int k = 0; k < NV; ++k) su[NV * d + k] = (T)unom[(base + d) * 4 + k];
+    swz[0][lane] = wz_lo;
+    swz[1][lane] = wz_hi;
   }
-  MDS_WAVE_SYNC();
+  MDS_WAVE_SYNC();                            // sraw is dead from here on: srow may overwrite it
 
-  const int npairs = cbf_num_pairs(D), nobs_rows = D * P.n_obs, m = npairs + nobs_rows + 2 * n;
-  // unit-norm rows:  sum_k ca[k] u[NV ia + k] + cb[k] u[NV ib + k] <= b
+  // unit-norm rows, R per lane: registers for the violation scan, LDS copy for the broadcast fetch
   T ca[R][NV], cb[R][NV], b[R];
   int ia[R], ib[R];
   bool valid[R], act[R];
@@ -331,11 +388,10 @@ __global__ __launch_bounds__(64 * WPB) void k_cbf_filter_gi(const CbfParams<T> P
     valid[k] = false;
     act[k] = false;
     if (r < npairs) {
-      const int ij = pair_ij[r];
-      ia[k] = ij & 255;
-      ib[k] = ij >> 8;
+      ia[k] = rpair[k] & 255;
+      ib[k] = rpair[k] >> 8;
       T hr, Lg[4];
-      cbf_pair_row<T, ORDER>(P, sx[wave][ia[k]], sxd[wave][ia[k]], sx[wave][ib[k]], sxd[wave][ib[k]], false, P.Ds_pair, &hr, Lg);
+      cbf_pair_row<T, ORDER>(P, &sx[ia[k] * XD], &sxd[ia[k] * XD], &sx[ib[k] * XD], &sxd[ib[k] * XD], false, P.Ds_pair, &hr, Lg);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         ca[k][v] = -Lg[v];
@@ -343,33 +399,36 @@ __global__ __launch_bounds__(64 * WPB) void k_cbf_filter_gi(const CbfParams<T> P
       }
       b[k] = hr;
     } else if (r < npairs + nobs_rows) {
-      const int q = r - npairs, i = q / P.n_obs, o = q % P.n_obs;
+      const int q = r - npairs, i = (q * P.obs_magic) >> 16, o = q - i * P.n_obs;         // i = q / n_obs, exact for q < 4096
       T xo[XD];
 #pragma unroll
       for (int v = 0; v < XD - 3; ++v) xo[v] = T(0);
-      xo[XD - 3] = obstacles[4 * o];
-      xo[XD - 2] = obstacles[4 * o + 1];
-      xo[XD - 1] = obstacles[4 * o + 2];
+      xo[XD - 3] = sob[4 * o];
+      xo[XD - 2] = sob[4 * o + 1];
+      xo[XD - 1] = sob[4 * o + 2];
       T hr, Lg[4];
-      cbf_pair_row<T, ORDER>(P, sx[wave][i], sxd[wave][i], xo, xo, true, P.safety_radius + obstacles[4 * o + 3], &hr, Lg);
+      cbf_pair_row<T, ORDER>(P, &sx[i * XD], &sxd[i * XD], xo, xo, true, P.safety_radius + sob[4 * o + 3], &hr, Lg);
       ia[k] = ib[k] = i;
 #pragma unroll
       for (int v = 0; v < NV; ++v) ca[k][v] = -Lg[v];
       b[k] = hr;
     } else if (r < m) {                                    // +-u_var <= umax (cbf/cbf.py:400-412)
-      const int q = r - npairs - nobs_rows, var = q % n;
-      ia[k] = ib[k] = var / NV;
+      const int q = r - npairs - nobs_rows, var = q < n ? q : q - n;
+      const int ag = var / NV, vv = var - ag * NV;
+      ia[k] = ib[k] = ag;
 #pragma unroll
       for (int v = 0; v < NV; ++v)
-        if (v == var % NV) ca[k][v] = q < n ? T(1) : T(-1);
-      b[k] = P.umax[var % NV];
+        if (v == vv) {
+          ca[k][v] = q < n ? T(1) : T(-1);
+          b[k] = P.umax[v];
+        }
     }
     if (r < m) {
       T n2 = T(0);
 #pragma unroll
       for (int v = 0; v < NV; ++v) n2 = m_fma(ca[k][v], ca[k][v], m_fma(cb[k][v], cb[k][v], n2));
       if (n2 > T(0)) {
-        const T inv = T(1) / m_sqrt(n2);
+        const T inv = m_rsqrt(n2);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           ca[k][v] *= inv;
@@ -380,17 +439,18 @@ __global__ __launch_bounds__(64 * WPB) void k_cbf_filter_gi(const CbfParams<T> P
       } else if (b[k] < T(0)) {
         bad = true;                                        // 0 * u <= h with h < 0
       }
+      CbfRow<T, NV> w;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        w.ca[v] = ca[k][v];
+        w.cb[v] = cb[k][v];
+      }
+      w.b = b[k];
+      w.ij = ia[k] | (ib[k] << 8);
+      srow[r] = w;
     }
   }
-  // order 3: the omega_z input only has box rows, +-umax_3 and the force box written to its column
-  // (custom_force_bound_const, cbf/cbf.py:446-464, quirk kept): a 1-D interval per agent
-  T wz_lo = -P.umax[3], wz_hi = P.umax[3];
-  if (ORDER == 3 && lane < D) {
-    const T F = sx[wave][lane][3];
-    wz_hi = m_min(wz_hi, P.k[2] * (P.Fmax - F));
-    wz_lo = m_max(wz_lo, -(P.k[2] * (F - P.Fmin)));
-    if (wz_lo > wz_hi) bad = true;
-  }
+  MDS_WAVE_SYNC();
   bool converged = false;
   bool infeasible = __any(bad);
   int q = 0, it = 0;
@@ -409,28 +469,22 @@ __global__ __launch_bounds__(64 * WPB) void k_cbf_filter_gi(const CbfParams<T> P
         best_k = k;
       }
     }
-    T wbest = best;
-    int wrow = lane + 64 * best_k;
-    wave_argmax(wbest, wrow);
+    const T wbest = wv::allreduce(best, wv::Max());
     if (!(wbest > tol2)) {
       converged = true;
       break;
     }
+    const int wrow = wv::allreduce(best == wbest ? lane + 64 * best_k : 0x7fffffff, wv::Min());   // ties: lowest row index
     const int owner = wrow & 63, kk = wrow >> 6;
+    const CbfRow<T, NV> wr = srow[wrow];                                                   // uniform address: one broadcast read
     T wca[NV], wcb[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      T tca = ca[0][v], tcb = cb[0][v];
-#pragma unroll
-      for (int k = 1; k < R; ++k) {
-        tca = (k == kk) ? ca[k][v] : tca;
-        tcb = (k == kk) ? cb[k][v] : tcb;
-      }
-      wca[v] = __shfl(tca, owner);
-      wcb[v] = __shfl(tcb, owner);
+      wca[v] = wr.ca[v];
+      wcb[v] = wr.cb[v];
     }
-    const T wb = __shfl(pick<T, R>(b, kk), owner);
-    const int wia = __shfl(pick<int, R>(ia, kk), owner), wib = __shfl(pick<int, R>(ib, kk), owner);
+    const T wb = wr.b;
+    const int wia = wr.ij & 255, wib = wr.ij >> 8;
     const bool two = wib != wia;
     T lam_new = T(0);
     // ---- bring that row into the active set, dropping blocking rows on the way ----
@@ -457,18 +511,18 @@ __global__ __launch_bounds__(64 * WPB) void k_cbf_filter_gi(const CbfParams<T> P
           if (v == vv) zv = (ag == wia ? wca[v] : T(0)) + ((two && ag == wib) ? wcb[v] : T(0));
         for (int c = 0; c < q; ++c) zv = m_fma(-sQ[lane][c], sd[c], zv);
       }
-      const T zz = wave_sum(zv * zv);
+      const T zz = wv::allreduce(zv * zv, wv::Add());
       T rc = dc;                                                                         // r = R^-1 d
       for (int k = q - 1; k >= 0; --k) {
-        const T rk = __shfl(rc, k) / sR[k][k];
+        const T rk = wv::get(rc, k) * sdi[k];
         if (lane == k) rc = rk;
         else if (lane < k) rc = m_fma(-sR[lane][k], rk, rc);
       }
-      const T rmax = wave_max(lane < q ? m_abs(rc) : T(0));
-      T t1 = GiEps<T>::inf;
-      int drop = lane;
-      if (lane < q && rc > GiEps<T>::r * rmax && rc > T(0)) t1 = m_max(slam[lane], T(0)) / rc;
-      wave_argmin(t1, drop);
+      const T rmax = wv::allreduce(lane < q ? m_abs(rc) : T(0), wv::Max());
+      T t1v = GiEps<T>::inf;
+      if (lane < q && rc > GiEps<T>::r * rmax && rc > T(0)) t1v = m_max(slam[lane], T(0)) / rc;
+      const T t1 = wv::allreduce(t1v, wv::Min());
+      const int drop = t1 < GiEps<T>::inf ? (int)__builtin_ctzll(__ballot(t1v == t1)) : 0;  // ties: lowest column
       const bool has_z = zz > GiEps<T>::z;
       const T t2 = has_z ? res / zz : GiEps<T>::inf;
       const T t = m_min(t1, t2);
@@ -484,10 +538,12 @@ __global__ __launch_bounds__(64 * WPB) void k_cbf_filter_gi(const CbfParams<T> P
       MDS_WAVE_SYNC();
       if (full) {                                                                        // add: N <- [N a]
         const T nz = m_sqrt(zz);
-        if (lane < n) sQ[lane][q] = zv / nz;
+        const T inz = T(1) / nz;
+        if (lane < n) sQ[lane][q] = zv * inz;
         if (lane < q) sR[lane][q] = dc;
         if (lane == 0) {
           sR[q][q] = nz;
+          sdi[q] = inz;
           slam[q] = lam_new;
           sact[q] = wrow;
         }
@@ -539,6 +595,8 @@ __global__ __launch_bounds__(64 * WPB) void k_cbf_filter_gi(const CbfParams<T> P
         MDS_WAVE_SYNC();
       }
       --q;
+      if (lane >= drop && lane < q) sdi[lane] = T(1) / sR[lane][lane];
+      MDS_WAVE_SYNC();
     }
   }
   if (converged) {
@@ -552,23 +610,34 @@ __global__ __launch_bounds__(64 * WPB) void k_cbf_filter_gi(const CbfParams<T> P
       for (int v = 0; v < NV; ++v) res = m_fma(ca[k][v], su[NV * ia[k] + v], m_fma(cb[k][v], su[NV * ib[k] + v], res));
       if (valid[k]) worst = m_max(worst, res);
     }
-    worst = wave_max(worst);
+    worst = wv::allreduce(worst, wv::Max());
     if (worst * worst > T(100) * tol2) converged = false;
   }
+#if defined(MDS_TUNE_ITERS)   // tuning build: iteration count and final active-set size in the high bits of status
+  if (lane == 0) status[env] = (converged ? 0 : 1) | (it << 8) | (q << 24);
+#else
   if (lane == 0) status[env] = converged ? 0 : 1;
+#endif
   MDS_WAVE_SYNC();
-  for (int d = lane; d < D; d += 64) {
-    T u[4];
-    for (int k = 0; k < 4; ++k) u[k] = (T)unom[(base + d) * 4 + k];
-    if (converged) {
-      for (int k = 0; k < NV; ++k) u[k] = su[NV * d + k];
-      if (ORDER == 2) {
-        for (int k = 1; k < 4; ++k) u[k] = m_clamp(u[k], -P.umax[k], P.umax[k]);
-      } else {
-        u[3] = m_clamp(u[3], wz_lo, wz_hi);
+  // u_safe in the flat [D,4] layout of the nominal block that is still in registers
+#pragma unroll
+  for (int j = 0; j < NUN_L; ++j) {
+    const int k = lane + 64 * j;
+    if (k < D * 4) {
+      const int d = k >> 2, c = k & 3;
+      T u = (T)run[j];
+      if (converged) {
+        if (c < NV) {
+          u = su[NV * d + c];
+        } else if (ORDER == 2) {
+          const T um = c == 1 ? P.umax[1] : (c == 2 ? P.umax[2] : P.umax[3]);
+          u = m_clamp(u, -um, um);
+        } else {
+          u = m_clamp(u, swz[0][d], swz[1][d]);
+        }
       }
+      usafe[base * 4 + k] = (S)u;
     }
-    for (int k = 0; k < 4; ++k) usafe[(base + d) * 4 + k] = (S)u[k];
   }
 }
 
