@@ -64,6 +64,10 @@ struct mds_handle {
   CbfParams<double> cbf_d;
   int* pair_ij;        // device [D(D-1)/2]
   void* obstacles;     // device T [n_obs,4]
+  int* cbf_order;      // [3,E] env ids by cost class (longest-first dispatch of the QP kernel)
+  int* cbf_count;      // [4]
+  int* cbf_cost;       // [E] GI iterations of the last launch
+  int cbf_calls;       // launches since the classes were rebuilt; -1: no classes yet
   void* cbf_unom;      // S [n,4]  scratch of mds_step_cbf_geometric
   void* cbf_xdes;      // S [n,9]
   void* cbf_usafe;     // S [n,4]
@@ -211,6 +215,8 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   h->pair_ij = nullptr;
   h->obstacles = nullptr;
   h->cbf_unom = h->cbf_xdes = h->cbf_usafe = h->ll = nullptr;
+  h->cbf_order = h->cbf_count = h->cbf_cost = nullptr;
+  h->cbf_calls = -1;
   h->has_lqr = false;
   h->has_lqr_yo = false;
   h->cbf_nominal = 0;
@@ -261,6 +267,9 @@ int mds_destroy(mds_handle* h) {
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->pair_ij) (void)hipFree(h->pair_ij);
   if (h->obstacles) (void)hipFree(h->obstacles);
+  if (h->cbf_order) (void)hipFree(h->cbf_order);
+  if (h->cbf_count) (void)hipFree(h->cbf_count);
+  if (h->cbf_cost) (void)hipFree(h->cbf_cost);
   if (h->cbf_unom) (void)hipFree(h->cbf_unom);
   if (h->cbf_xdes) (void)hipFree(h->cbf_xdes);
   if (h->cbf_usafe) (void)hipFree(h->cbf_usafe);
@@ -627,6 +636,10 @@ int mds_cbf_configure(mds_handle* h, const mds_cbf_params* p, const double* obst
       MDS_HIP(hipMemcpy(h->obstacles, tmp, sizeof(float) * 4 * p->n_obs, hipMemcpyHostToDevice));
     }
   }
+  if (!h->cbf_order) MDS_HIP(hipMalloc((void**)&h->cbf_order, sizeof(int) * 3 * (size_t)h->cfg.num_envs));
+  if (!h->cbf_count) MDS_HIP(hipMalloc((void**)&h->cbf_count, sizeof(int) * 4));
+  if (!h->cbf_cost) MDS_HIP(hipMalloc((void**)&h->cbf_cost, sizeof(int) * (size_t)h->cfg.num_envs));
+  h->cbf_calls = -1;                                       // a new problem: forget the cost classes
   h->cbf = *p;
   fill_cbf(h, *p, h->cbf_f);
   fill_cbf(h, *p, h->cbf_d);
@@ -673,11 +686,15 @@ int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void*
   const bool hildreth = solver && solver[0] == 'h' && order == 2;
   if (n > 64) return fail(MDS_EUNSUPPORTED, "mds_cbf_filter: more than 64 coupled QP variables per env");
   if (R > 17) return fail(MDS_EUNSUPPORTED, "mds_cbf_filter: too many rows per env");
+  // longest-first dispatch (see k_cbf_filter_gi): classes from the iteration counts of an earlier launch, rebuilt every 8th call
+  const int* ord_in = h->cbf_calls < 0 ? nullptr : h->cbf_order;
+  const int* cnt_in = h->cbf_calls < 0 ? nullptr : h->cbf_count;
+  int* cost_out = hildreth ? nullptr : h->cbf_cost;
   // one wavefront (= one env) per workgroup; NMAX bounds the QP variables (LDS footprint of Q, R ~ NMAX^2)
 #define MDS_GI(T, CP, RR, NMAX, ORD, TOL)                                                                                   \
   k_cbf_filter_gi<T, T, RR, NMAX, ORD><<<dim3((unsigned)E), 64, 0, st>>>(                                                    \
       CP, E, (T)h->cfg.KF, h->pair_ij, (const T*)h->obstacles, (const T*)obs, (const T*)xdes, (const T*)unom, (T*)usafe,     \
-      (int*)status, max_iter, (T)((TOL) * (TOL)))
+      (int*)status, max_iter, (T)((TOL) * (TOL)), ord_in, cnt_in, cost_out)
 #define MDS_GI_R(T, CP, NMAX, ORD, TOL)            \
   do {                                             \
     if (R <= 4) MDS_GI(T, CP, 4, NMAX, ORD, TOL);  \
@@ -719,6 +736,15 @@ int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void*
 #undef MDS_GI_R
 #undef MDS_GI
   MDS_HIP(hipGetLastError());
+  if (!hildreth && E >= 1024) {                           // small batches have no tail to hide
+    if (h->cbf_calls < 0 || h->cbf_calls >= 7) {
+      k_cbf_order<<<1, 1024, 0, st>>>(E, h->cbf_cost, h->cbf_order, h->cbf_count);
+      MDS_HIP(hipGetLastError());
+      h->cbf_calls = 0;
+    } else {
+      ++h->cbf_calls;
+    }
+  }
   return MDS_OK;
 }
 

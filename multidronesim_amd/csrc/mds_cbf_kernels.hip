@@ -8,6 +8,7 @@ namespace mds {
 
 constexpr int kCbfMaxD = 32;      // drones per env supported by the wave-per-env kernels
 constexpr int kCbfMaxObs = 16;
+constexpr int kCbfHeavyIters = 6, kCbfMediumIters = 2;   // cost classes of the longest-first dispatch (GI iterations last step)
 
 // pair_ij[r] = i | j << 8: (i, j) of pair row r in the reference's lexicographic order
 // (cbf/cbf.py:342-346); built on the host by mds_cbf_configure.
@@ -279,7 +280,63 @@ template <typename T, typename Op> __device__ __forceinline__ T allreduce(T v, O
   v = op(v, mov<0x140>(v));
   return op(op(get(v, 0), get(v, 16)), op(get(v, 32), get(v, 48)));
 }
+// same when only lanes 0..15 hold non-neutral values: the first row's result is the wave's
+template <typename T, typename Op> __device__ __forceinline__ T allreduce_row0(T v, Op op) {
+  v = op(v, mov<0xB1>(v));
+  v = op(v, mov<0x4E>(v));
+  v = op(v, mov<0x141>(v));
+  v = op(v, mov<0x140>(v));
+  return get(v, 0);
+}
+template <bool ROW0, typename T, typename Op> __device__ __forceinline__ T allreduce_n(T v, Op op) {
+  if (ROW0) return allreduce_row0(v, op);
+  return allreduce(v, op);
+}
 }  // namespace wv
+
+// Stable 3-way partition of the envs by last step's solve cost: order[c*E + k] = k-th env of class c, count[c].
+// One workgroup; E / 1024 envs per thread.
+__global__ __launch_bounds__(1024) void k_cbf_order(const int E, const int* __restrict__ cost, int* __restrict__ order,
+                                                    int* __restrict__ count) {
+  __shared__ int wtot[3][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (E + 1023) / 1024, lo = tid * per, hi = lo + per < E ? lo + per : E;
+  int c[3] = {0, 0, 0};
+  for (int e = lo; e < hi; ++e) {
+    const int it = cost[e], cls = it >= kCbfHeavyIters ? 0 : (it >= kCbfMediumIters ? 1 : 2);
+    c[0] += cls == 0;
+    c[1] += cls == 1;
+    c[2] += cls == 2;
+  }
+  int off[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {                            // exclusive scan over the 1024 threads
+    int v = c[k];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(v, d);
+      if (lane >= d) v += o;
+    }
+    if (lane == 63) wtot[k][wave] = v;
+    off[k] = v - c[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int base = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+      if (w < wave) base += wtot[k][w];
+      total += wtot[k][w];
+    }
+    off[k] += base;
+    if (tid == 0) count[k] = total;
+  }
+  for (int e = lo; e < hi; ++e) {
+    const int it = cost[e], cls = it >= kCbfHeavyIters ? 0 : (it >= kCbfMediumIters ? 1 : 2);
+    const int pos = cls == 0 ? off[0]++ : (cls == 1 ? off[1]++ : off[2]++);
+    order[cls * E + pos] = e;
+  }
+}
 
 template <typename T> struct GiEps;
 template <> struct GiEps<float> {
@@ -303,10 +360,12 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
                                                       const T* __restrict__ obstacles, const S* __restrict__ obs,
                                                       const S* __restrict__ xdes, const S* __restrict__ unom,
                                                       S* __restrict__ usafe, int* __restrict__ status, const int max_iter,
-                                                      const T tol2) {
+                                                      const T tol2, const int* __restrict__ order_in,
+                                                      const int* __restrict__ count_in, int* __restrict__ cost_out) {
   constexpr int NV = ORDER == 2 ? 1 : 3;
   constexpr int XD = ORDER == 2 ? 9 : 10;
-  constexpr int kQS = NMAX + 1;     // padded LDS row stride (conflict-free column walks)
+  constexpr bool PRE = NMAX * sizeof(T) <= 128;   // a lane's rows of Q and R fit in registers: one LDS round trip per step instead of 2q
+  constexpr int kQS = PRE ? ((NMAX + 3) / 4 * 4 + 4) : NMAX + 1;   // LDS row stride: 16-byte rows (4 mod 16 dwords) / odd, both conflict-free column walks
   constexpr int DMAX = NMAX / NV;
   constexpr int NOBS_L = (DMAX * 20 + 63) / 64, NXD_L = (DMAX * XD + 63) / 64, NUN_L = (DMAX * 4 + 63) / 64;
   static_assert(sizeof(CbfRow<T, NV>) * R * 64 >= sizeof(S) * DMAX * 20, "raw obs staging aliases the row table");
@@ -319,8 +378,20 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
   __shared__ __align__(16) CbfRow<T, NV> srow[R * 64];
   S* sraw = reinterpret_cast<S*>(srow);                     // the env's observation rows, staged before the rows are built
   const int lane = threadIdx.x;
-  const int env = blockIdx.x;
+  // Longest-first dispatch: the solve time of an env is ~ its number of active rows, which changes slowly from one
+  // control step to the next.  Every wave records its iteration count; every few launches k_cbf_order bins the envs into
+  // cost classes, and the launches walk the classes heaviest first, so the few long solves start at t = 0 instead of
+  // forming the kernel's tail.  (One atomic per wave on a shared counter would serialise: 12 ns each, measured.)
+  int env = blockIdx.x;
+  if (order_in) {
+    const int c0 = count_in[0], c1 = count_in[1];
+    const int b = blockIdx.x;
+    env = b < c0 ? order_in[b] : (b < c0 + c1 ? order_in[E + b - c0] : order_in[2 * E + b - c0 - c1]);
+  }
   if (env >= E) return;
+#if defined(MDS_TUNE_ITERS)
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
   const int D = P.num_drones, n = NV * D;
   const size_t base = (size_t)env * D;
   const int npairs = cbf_num_pairs(D), nobs_rows = D * P.n_obs, m = npairs + nobs_rows + 2 * n;
@@ -474,8 +545,8 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
       converged = true;
       break;
     }
-    const int wrow = wv::allreduce(best == wbest ? lane + 64 * best_k : 0x7fffffff, wv::Min());   // ties: lowest row index
-    const int owner = wrow & 63, kk = wrow >> 6;
+    const int owner = (int)__builtin_ctzll(__ballot(best == wbest));                         // ties: lowest lane, then its lowest row
+    const int kk = wv::get(best_k, owner), wrow = owner + 64 * kk;
     const CbfRow<T, NV> wr = srow[wrow];                                                   // uniform address: one broadcast read
     T wca[NV], wcb[NV];
 #pragma unroll
@@ -493,6 +564,7 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
         infeasible = true;
         break;
       }
+      // ---- everything this step reads from LDS, in one round trip ----
       T res = -wb;
 #pragma unroll
       for (int v = 0; v < NV; ++v) res = m_fma(wca[v], su[NV * wia + v], m_fma(two ? wcb[v] : T(0), su[NV * wib + v], res));
@@ -501,30 +573,57 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
 #pragma unroll
         for (int v = 0; v < NV; ++v) dc = m_fma(wca[v], sQ[NV * wia + v][lane], m_fma(two ? wcb[v] : T(0), sQ[NV * wib + v][lane], dc));
       }
-      if (lane < n) sd[lane] = dc;
-      MDS_WAVE_SYNC();
-      T zv = T(0);                                                                       // z = a - Q d
-      if (lane < n) {
-        const int ag = lane / NV, vv = lane - ag * NV;
+      const int ln = lane < NMAX ? lane : NMAX - 1;                                      // lanes >= n hold no row: clamp the address only
+      const T my_lam = slam[ln], my_di = sdi[ln];
+      T zv = T(0), rc = dc;
+      if constexpr (PRE) {
+        T qrow[NMAX], rrow[NMAX];
 #pragma unroll
-        for (int v = 0; v < NV; ++v)
-          if (v == vv) zv = (ag == wia ? wca[v] : T(0)) + ((two && ag == wib) ? wcb[v] : T(0));
-        for (int c = 0; c < q; ++c) zv = m_fma(-sQ[lane][c], sd[c], zv);
+        for (int c = 0; c < NMAX; ++c) {
+          qrow[c] = sQ[ln][c];
+          rrow[c] = sR[ln][c];
+        }
+        if (lane < n) {                                                                  // z = a - Q d
+          const int ag = lane / NV, vv = lane - ag * NV;
+#pragma unroll
+          for (int v = 0; v < NV; ++v)
+            if (v == vv) zv = (ag == wia ? wca[v] : T(0)) + ((two && ag == wib) ? wcb[v] : T(0));
+        }
+#pragma unroll
+        for (int c = 0; c < NMAX; ++c)
+          if (c < q) zv = m_fma(-qrow[c], wv::get(dc, c), zv);                           // lanes >= n: garbage, masked below
+        if (lane >= n) zv = T(0);
+#pragma unroll
+        for (int k = NMAX - 1; k >= 0; --k)                                  // r = R^-1 d (back substitution, pivots pre-inverted)
+          if (k < q) {
+            const T rk = wv::get(rc * my_di, k);
+            rc = lane == k ? rk : (lane < k ? m_fma(-rrow[k], rk, rc) : rc);
+          }
+      } else {
+        if (lane < n) sd[lane] = dc;
+        MDS_WAVE_SYNC();
+        if (lane < n) {
+          const int ag = lane / NV, vv = lane - ag * NV;
+#pragma unroll
+          for (int v = 0; v < NV; ++v)
+            if (v == vv) zv = (ag == wia ? wca[v] : T(0)) + ((two && ag == wib) ? wcb[v] : T(0));
+          for (int c = 0; c < q; ++c) zv = m_fma(-sQ[lane][c], sd[c], zv);
+        }
+        for (int k = q - 1; k >= 0; --k) {
+          const T rk = wv::get(rc, k) * sdi[k];
+          if (lane == k) rc = rk;
+          else if (lane < k) rc = m_fma(-sR[lane][k], rk, rc);
+        }
       }
-      const T zz = wv::allreduce(zv * zv, wv::Add());
-      T rc = dc;                                                                         // r = R^-1 d
-      for (int k = q - 1; k >= 0; --k) {
-        const T rk = wv::get(rc, k) * sdi[k];
-        if (lane == k) rc = rk;
-        else if (lane < k) rc = m_fma(-sR[lane][k], rk, rc);
-      }
-      const T rmax = wv::allreduce(lane < q ? m_abs(rc) : T(0), wv::Max());
+      constexpr bool ROW0 = NMAX <= 16;                                                  // z, r, lambda live in lanes 0..n-1 only
+      const T zz = wv::allreduce_n<ROW0>(zv * zv, wv::Add());
+      const T rmax = wv::allreduce_n<ROW0>(lane < q ? m_abs(rc) : T(0), wv::Max());
       T t1v = GiEps<T>::inf;
-      if (lane < q && rc > GiEps<T>::r * rmax && rc > T(0)) t1v = m_max(slam[lane], T(0)) / rc;
-      const T t1 = wv::allreduce(t1v, wv::Min());
+      if (lane < q && rc > GiEps<T>::r * rmax && rc > T(0)) t1v = m_max(my_lam, T(0)) * m_rcp(rc);
+      const T t1 = wv::allreduce_n<ROW0>(t1v, wv::Min());
       const int drop = t1 < GiEps<T>::inf ? (int)__builtin_ctzll(__ballot(t1v == t1)) : 0;  // ties: lowest column
       const bool has_z = zz > GiEps<T>::z;
-      const T t2 = has_z ? res / zz : GiEps<T>::inf;
+      const T t2 = has_z ? res * m_rcp(zz) : GiEps<T>::inf;
       const T t = m_min(t1, t2);
       if (!(t < GiEps<T>::inf)) {
         infeasible = true;                                                               // no step possible: rows inconsistent
@@ -533,7 +632,7 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
       const bool full = has_z && t2 <= t1;
       MDS_WAVE_SYNC();
       if (has_z && lane < n) su[lane] = m_fma(-t, zv, su[lane]);
-      if (lane < q) slam[lane] = m_fma(-t, rc, slam[lane]);
+      if (lane < q) slam[lane] = m_fma(-t, rc, my_lam);
       lam_new += t;
       MDS_WAVE_SYNC();
       if (full) {                                                                        // add: N <- [N a]
@@ -614,10 +713,15 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
     if (worst * worst > T(100) * tol2) converged = false;
   }
 #if defined(MDS_TUNE_ITERS)   // tuning build: iteration count and final active-set size in the high bits of status
-  if (lane == 0) status[env] = (converged ? 0 : 1) | (it << 8) | (q << 24);
+  {
+    const int nbox = __popcll(__ballot(lane < q && sact[lane < NMAX ? lane : 0] >= npairs + nobs_rows));
+    if (lane == 0) status[env] = (converged ? 0 : 1) | ((it & 0x7f) << 1) | ((q & 0x1f) << 8) | ((nbox & 0x1f) << 13) |
+                                 ((int)m_min<unsigned long long>((__builtin_amdgcn_s_memtime() - t_start) >> 8, 0x1fffull) << 18);
+  }
 #else
   if (lane == 0) status[env] = converged ? 0 : 1;
 #endif
+  if (cost_out && lane == 0) cost_out[env] = it;
   MDS_WAVE_SYNC();
   // u_safe in the flat [D,4] layout of the nominal block that is still in registers
 #pragma unroll

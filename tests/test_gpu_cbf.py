@@ -396,3 +396,35 @@ def test_order3_closed_loop_matches_oracle(mds, dtype, steps, tol):
     rel = np.abs(g[..., 16:] - oobs[..., 16:]).max() / O.CF2P.HOVER_RPM
     assert rel < tol * 10
     env.close()
+
+
+def test_cbf_filter_longest_first_dispatch_is_invisible(mds):
+    """From the second call on the QP kernel walks the envs in cost classes rebuilt from earlier iteration counts
+    (k_cbf_order, batches >= 1024 envs).  The mapping must stay a bijection: same inputs -> bit-identical outputs on
+    every call, and a different batch afterwards is still solved env by env like the oracle."""
+    E, D = 2048, 6
+    obs, xdes, unom, x_obs, obs_r = c4_scene(E, D, seed=11)
+    env = make_env(mds, E, D, "float32")
+    cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2,
+                       cbf_poles=np.array([-2.2, -2.4]))
+    trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+    ref_u, ref_s = None, None
+    for call in range(11):                                  # classes are rebuilt after calls 1 and 9
+        us, st = trk.compute_control_batched(obs, xdes, unom, x_obs, obs_r)
+        us, st = us.cpu().numpy().copy(), st.cpu().numpy().copy()
+        if ref_u is None:
+            ref_u, ref_s = us, st
+            assert 0.05 < st.mean() < 0.3 and (np.abs(us[..., 0] - unom[..., 0]).max(axis=1) > 1e-6).mean() > 0.5
+        else:
+            np.testing.assert_array_equal(us, ref_u)
+            np.testing.assert_array_equal(st, ref_s)
+    obs2, xdes2, unom2, _, _ = c4_scene(E, D, seed=12)      # stale classes, new data
+    us, st = trk.compute_control_batched(obs2, xdes2, unom2, x_obs, obs_r)
+    us, st = us.double().cpu().numpy(), st.cpu().numpy()
+    for e in range(0, E, 97):
+        x = O.obs_to_lin_model(obs2[e], 9)
+        u_ref, status = O.cbf_filter(x, xdes2[e], unom2[e], 2, cbf.Kcbf.reshape(-1), cbf.umax, 0.1, 1.0, O.CF2P, np.array(x_obs), obs_r)
+        assert st[e] == status
+        if status == 0:
+            np.testing.assert_allclose(us[e], u_ref, atol=2e-5, rtol=0)
+    env.close()
