@@ -294,19 +294,19 @@ template <bool ROW0, typename T, typename Op> __device__ __forceinline__ T allre
 }
 }  // namespace wv
 
-// Stable 3-way partition of the envs by last step's solve cost: order[c*E + k] = k-th env of class c, count[c].
-// One workgroup; E / 1024 envs per thread.
+// 3-way partition of the envs by last step's solve cost: order[c*E + k] = k-th env of class c, count[c].
+// One workgroup, coalesced strided passes (thread t owns envs t, t + 1024, ...).
 __global__ __launch_bounds__(1024) void k_cbf_order(const int E, const int* __restrict__ cost, int* __restrict__ order,
                                                     int* __restrict__ count) {
   __shared__ int wtot[3][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (E + 1023) / 1024, lo = tid * per, hi = lo + per < E ? lo + per : E;
   int c[3] = {0, 0, 0};
-  for (int e = lo; e < hi; ++e) {
-    const int it = cost[e], cls = it >= kCbfHeavyIters ? 0 : (it >= kCbfMediumIters ? 1 : 2);
-    c[0] += cls == 0;
-    c[1] += cls == 1;
-    c[2] += cls == 2;
+#pragma unroll 8
+  for (int e = tid; e < E; e += 1024) {
+    const int it = cost[e];
+    c[0] += it >= kCbfHeavyIters;
+    c[1] += it >= kCbfMediumIters && it < kCbfHeavyIters;
+    c[2] += it < kCbfMediumIters;
   }
   int off[3];
 #pragma unroll
@@ -331,7 +331,8 @@ __global__ __launch_bounds__(1024) void k_cbf_order(const int E, const int* __re
     off[k] += base;
     if (tid == 0) count[k] = total;
   }
-  for (int e = lo; e < hi; ++e) {
+#pragma unroll 8
+  for (int e = tid; e < E; e += 1024) {
     const int it = cost[e], cls = it >= kCbfHeavyIters ? 0 : (it >= kCbfMediumIters ? 1 : 2);
     const int pos = cls == 0 ? off[0]++ : (cls == 1 ? off[1]++ : off[2]++);
     order[cls * E + pos] = e;
