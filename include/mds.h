@@ -268,6 +268,17 @@ int mds_set_lqr_omega_gain(mds_handle* h, const double K[36]);
 /* LQROmegaController.compute(obs, skip_low_level=True) (:90-119): obs_dev [n,20], des_dev [n,11]
  * (pos, vel, -, yaw, - of set_desired_trajectory) -> u_dev [n,4] = (F, wx, wy, wz) after cap_u. */
 int mds_lqr_omega_compute(mds_handle* h, const void* obs_dev, const void* des_dev, void* u_dev, void* stream);
+/* LQRController (control/lqr/lqr_controller.py) on LinearizedModel (model/linearized.py) -- the default 'lqr' controller of
+ * simulations/EnvGeometric.py (:32, :425-427).  K [4,12] row-major is the gain of its compute_gain_matrix() (:53-57; host ARE,
+ * also with the Ahat/Bhat of use_noisy_model); state [rpy, ang_v, vel, pos], input [F, tau_x, tau_y, tau_z]. */
+int mds_set_lqr_gain(mds_handle* h, const double K[48]);
+/* LQRController.compute(obs) (:83-113): obs_dev [n,20], des_dev [n,11] (pos, vel, -, yaw, omega) -> u_dev [n,4] (F clipped at 0,
+ * as the reference's in-place mixer leaves it, model_conversions.py:88) and action_dev [n,4] RPM; either output may be NULL. */
+int mds_lqr_compute(mds_handle* h, const void* obs_dev, const void* des_dev, void* u_dev, void* action_dev, void* stream);
+/* The do_control step of simulations/EnvGeometric.py:434-469 with that controller for every drone: trajectory sample ->
+ * LQRController.compute -> env.step.  Trajectories as for mds_step_geometric (Lemniscate planes or segment tables). */
+int mds_step_lqr(mds_handle* h, double t, void* obs_dev, void* action_dev, void* stream);
+
 /* LQRYankOmegaController (control/lqr/lqr_YO_controller.py): K [4,10] row-major from its
  * compute_gain_matrix() (:59-64), state [r,p,y,F,vx,vy,vz,x,y,z], input [yank, wx, wy, wz]. */
 int mds_set_lqr_yank_omega_gain(mds_handle* h, const double K[40]);

@@ -82,6 +82,9 @@ struct mds_handle {
   bool has_lqr_yo;
   LqrYoGain<float> lqr_yo_f;
   LqrYoGain<double> lqr_yo_d;
+  bool has_lqr12;
+  Lqr12Gain<float> lqr12_f;
+  Lqr12Gain<double> lqr12_d;
   bool track_rpm;      // last_rpm planes maintained by every step kernel (DYN_DRAG, order-3 CBF, or cfg.track_last_rpm)
   bool rpm_stale;      // a step ran without tracking since the last reset
 };
@@ -219,6 +222,7 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   h->cbf_calls = -1;
   h->has_lqr = false;
   h->has_lqr_yo = false;
+  h->has_lqr12 = false;
   h->cbf_nominal = 0;
   h->pid = nullptr;
   h->track_rpm = cfg->track_last_rpm != 0 || cfg->physics == MDS_PHYSICS_DYN_DRAG;
@@ -836,6 +840,59 @@ int mds_lqr_omega_compute(mds_handle* h, const void* obs, const void* des, void*
     k_lqr_omega_compute<float, float><<<grid_for(h->n, 256), 256, 0, st>>>(h->cf, h->lqr_f, h->n, (const float*)obs, (const float*)des, (float*)u);
   else
     k_lqr_omega_compute<float, half_t><<<grid_for(h->n, 256), 256, 0, st>>>(h->cf, h->lqr_f, h->n, (const half_t*)obs, (const half_t*)des, (half_t*)u);
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_set_lqr_gain(mds_handle* h, const double K[48]) {
+  if (!h || !K) return fail(MDS_EINVAL, "mds_set_lqr_gain: null argument");
+  for (int r = 0; r < 4; ++r)
+    for (int k = 0; k < 12; ++k) {
+      h->lqr12_d.k[r][k] = K[12 * r + k];
+      h->lqr12_f.k[r][k] = (float)K[12 * r + k];
+    }
+  h->has_lqr12 = true;
+  return MDS_OK;
+}
+
+int mds_lqr_compute(mds_handle* h, const void* obs, const void* des, void* u, void* action, void* stream) {
+  if (!h || !obs || !des || (!u && !action)) return fail(MDS_EINVAL, "mds_lqr_compute: null argument");
+  if (!h->has_lqr12) return fail(MDS_ESTATE, "mds_lqr_compute: call mds_set_lqr_gain first");
+  if (!aligned16(u) || !aligned16(action)) return fail(MDS_EALIGN, "mds_lqr_compute: u_dev/action_dev");
+  hipStream_t st = (hipStream_t)stream;
+  if (h->cfg.dtype == MDS_F64)
+    k_lqr12_compute<double, double><<<grid_for(h->n, 256), 256, 0, st>>>(h->cd, h->lqr12_d, h->n, (const double*)obs, (const double*)des, (double*)u, (double*)action);
+  else if (h->cfg.dtype == MDS_F32)
+    k_lqr12_compute<float, float><<<grid_for(h->n, 256), 256, 0, st>>>(h->cf, h->lqr12_f, h->n, (const float*)obs, (const float*)des, (float*)u, (float*)action);
+  else
+    k_lqr12_compute<float, half_t><<<grid_for(h->n, 256), 256, 0, st>>>(h->cf, h->lqr12_f, h->n, (const half_t*)obs, (const half_t*)des, (half_t*)u, (half_t*)action);
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_step_lqr(mds_handle* h, double t, void* obs, void* act, void* stream) {
+  if (!h) return fail(MDS_EINVAL, "mds_step_lqr: null handle");
+  if (!h->has_traj) return fail(MDS_ESTATE, "mds_step_lqr: call mds_set_lemniscate / mds_set_trajectory_segments first");
+  if (!h->has_lqr12) return fail(MDS_ESTATE, "mds_step_lqr: call mds_set_lqr_gain first");
+  if (!aligned16(obs) || !aligned16(act)) return fail(MDS_EALIGN, "mds_step_lqr: obs_dev/action_dev");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid = grid_for(h->n, kBlock);
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
+#define MDS_LQR_T(T, S, C, K, RK4, DRAG)                                                                                          \
+  k_step_lqr<T, S, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, K, h->n, h->ld, t, h->traj_mode, (S*)h->state, (const T*)h->origin,     \
+                                                       (const T*)h->lem, h->segs, h->tinfo, (T*)rpm_track(h), (S*)obs, (S*)act)
+#define MDS_LQR(RK4, DRAG)                                                                    \
+  do {                                                                                        \
+    if (h->cfg.dtype == MDS_F64) MDS_LQR_T(double, double, h->cd, h->lqr12_d, RK4, DRAG);     \
+    else if (h->cfg.dtype == MDS_F32) MDS_LQR_T(float, float, h->cf, h->lqr12_f, RK4, DRAG);  \
+    else MDS_LQR_T(float, half_t, h->cf, h->lqr12_f, RK4, DRAG);                              \
+  } while (0)
+  if (rk4 && drag) MDS_LQR(true, true);
+  else if (rk4) MDS_LQR(true, false);
+  else if (drag) MDS_LQR(false, true);
+  else MDS_LQR(false, false);
+#undef MDS_LQR
+#undef MDS_LQR_T
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }

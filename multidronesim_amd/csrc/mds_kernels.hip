@@ -315,6 +315,68 @@ __global__ __launch_bounds__(kBlock) void k_step_traj(const Consts<T> c, const i
   if (valid) store_state<S, T>(state, ld, i, s);
 }
 
+// The same fused step with the reference's 12-state LQR (control/lqr/lqr_controller.py) as the controller: the default
+// ('lqr') branch of simulations/EnvGeometric.py do_control.  Desired state from the Lemniscate planes (traj_mode 1, local
+// frame) or the segment tables (traj_mode 2).  obs / action_out may be NULL.
+template <typename T, typename S, bool RK4, bool DRAG>
+__global__ __launch_bounds__(kBlock) void k_step_lqr(const Consts<T> c, const Lqr12Gain<T> K, const int n, const size_t ld, const double t,
+                                                     const int traj_mode, S* __restrict__ state, const T* __restrict__ origin,
+                                                     const T* __restrict__ lem, const double* __restrict__ segs,
+                                                     const int* __restrict__ tinfo, T* __restrict__ last_rpm, S* __restrict__ obs,
+                                                     S* __restrict__ action_out) {
+  __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = i < n;
+  T o[kObsDim];
+  State<T> s;
+  if (valid) {
+    load_state<S, T>(state, ld, i, s);
+    const V3<T> org = {origin[i], origin[ld + i], origin[2 * ld + i]};
+    Desired<T> des;
+    if (traj_mode == 1) {
+      GeoIn<T> in;
+      load_geo_in<T, S>(state, lem, ld, i, in);
+      des = lemniscate_local(in.P, t);
+    } else {
+      double d11[11];
+      traj_eval(segs, tinfo[2 * i], tinfo[2 * i + 1] & 0xffff, tinfo[2 * i + 1] >> 16, t, d11);
+      des.p = {(T)(d11[0] - (double)org.x), (T)(d11[1] - (double)org.y), (T)(d11[2] - (double)org.z)};
+      des.v = {(T)d11[3], (T)d11[4], (T)d11[5]};
+      des.yaw = reduced_phase<T>(0.0, T(0), (T)d11[9]);
+      des.yaw_rate = (T)d11[10];
+    }
+    T prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4], act[4], u[4];
+    if (DRAG)
+      for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
+    lqr12_control<T>(c, K, euler_from_quat(s.q), quat_rotate(s.q, s.w), s.v, s.p - des.p, des.v, des.yaw, des.yaw_rate, u);
+    input_to_action(c, u, act);
+    aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
+    if (DRAG || last_rpm)
+      for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
+    if (action_out) store4<S, T>(action_out + (size_t)i * 4, act);
+    if (obs) pack_obs(s, org, clipped, o);
+  }
+  if (obs) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
+  if (valid) store_state<S, T>(state, ld, i, s);
+}
+
+// LQRController.compute(obs) (lqr_controller.py:83-113): obs [n,20], des [n,11] (pos, vel, -, yaw, omega) -> u [n,4], action [n,4]
+template <typename T, typename S>
+__global__ void k_lqr12_compute(const Consts<T> c, const Lqr12Gain<T> K, const int n, const S* __restrict__ obs,
+                                const S* __restrict__ des, S* __restrict__ u_out, S* __restrict__ act_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const S* o = obs + (size_t)i * 20;
+  const S* d = des + (size_t)i * 11;
+  T u[4], act[4];
+  const V3<T> perr = {(T)o[0] - (T)d[0], (T)o[1] - (T)d[1], (T)o[2] - (T)d[2]};
+  lqr12_control<T>(c, K, V3<T>{(T)o[7], (T)o[8], (T)o[9]}, V3<T>{(T)o[13], (T)o[14], (T)o[15]}, V3<T>{(T)o[10], (T)o[11], (T)o[12]}, perr,
+                   V3<T>{(T)d[3], (T)d[4], (T)d[5]}, (T)d[9], (T)d[10], u);
+  input_to_action(c, u, act);
+  if (u_out) store4<S, T>(u_out + (size_t)i * 4, u);
+  if (act_out) store4<S, T>(act_out + (size_t)i * 4, act);
+}
+
 // Trajectory.__call__(t) for every drone from the segment tables: des [n,11] world frame
 template <typename S>
 __global__ void k_traj_eval(const int n, const double t, const double* __restrict__ segs, const int* __restrict__ tinfo,

@@ -604,6 +604,37 @@ MDS_HD void lqr_omega_control(const Consts<T>& c, const LqrGain<T>& K, V3<T> rpy
 }
 
 // ------------------------------------------------------------------------------------
+// control/lqr/lqr_controller.py:83-113 on model/linearized.py -- the default 'lqr' controller of
+// simulations/EnvGeometric.py (:32, :425-427).  x = [rpy, ang_v (the obs' WORLD-frame rate), vel, pos];
+// e as in lqr_omega_control plus e[3:6] = R_eq^T (ang_v - [0,0,omega_des]); u = -K e + [M G,0,0,0], no cap;
+// the mixer then clips u[0] at 0 in place (model_conversions.py:88), which the returned u shows.
+// ------------------------------------------------------------------------------------
+template <typename T> struct Lqr12Gain {
+  T k[4][12];
+};
+template <typename T>
+MDS_HD void lqr12_control(const Consts<T>& c, const Lqr12Gain<T>& K, V3<T> rpy, V3<T> angv_world, V3<T> vel, V3<T> pos_err, V3<T> vel_des,
+                          T yaw_des, T omega_des, T u[4]) {
+  T e[12];
+  e[0] = rpy.x;
+  e[1] = rpy.y;
+  const T dy = rpy.z - yaw_des;
+  e[2] = m_fma(T(-6.283185307179586476925), m_rint(dy * T(0.15915494309189533577)), dy);
+  T sy, cy;
+  m_sincos(reduced_phase<T>(0.0, T(0), yaw_des), &sy, &cy);
+  const V3<T> dw = {angv_world.x, angv_world.y, angv_world.z - omega_des}, dv = vel - vel_des, dp = pos_err;
+  e[3] = cy * dw.x + sy * dw.y; e[4] = -sy * dw.x + cy * dw.y; e[5] = dw.z;
+  e[6] = cy * dv.x + sy * dv.y; e[7] = -sy * dv.x + cy * dv.y; e[8] = dv.z;
+  e[9] = cy * dp.x + sy * dp.y; e[10] = -sy * dp.x + cy * dp.y; e[11] = dp.z;
+  for (int r = 0; r < 4; ++r) {
+    T acc = T(0);
+    for (int k = 0; k < 12; ++k) acc = m_fma(-K.k[r][k], e[k], acc);
+    u[r] = acc;
+  }
+  u[0] = m_max(u[0] + c.gravity, T(0));
+}
+
+// ------------------------------------------------------------------------------------
 // control/lqr/lqr_YO_controller.py:99-124: u = [Y, wx, wy, wz] = -K e on the 10-state
 // x = [rpy, F, vel, pos] (obs_to_lin_model dim 10); e[3] = calc_z_thrust(obs) - M G is taken in
 // its excess form (rotor_wrench) so that near hover it keeps its digits in fp32.  No hover

@@ -298,6 +298,15 @@ class BaseAviary:
         self.step_counter += self.PYB_STEPS_PER_CTRL
         return (self._obs, self._act) if return_action else self._obs
 
+    def step_lqr(self, t: float, return_action: bool = False):
+        """The same control step with the reference's 12-state LQRController (needs one constructed on this env): the default
+        'lqr' branch of simulations/EnvGeometric.py do_control, fused for every drone."""
+        self._require_open()
+        act_ptr = C.c_void_p(self._act.data_ptr()) if return_action else C.c_void_p(None)
+        capi.check(self._lib.mds_step_lqr(self._h, C.c_double(t), C.c_void_p(self._obs.data_ptr()), act_ptr, self._stream()), "mds_step_lqr")
+        self.step_counter += self.PYB_STEPS_PER_CTRL
+        return (self._obs, self._act) if return_action else self._obs
+
     def rollout_geometric(self, t0: float, n_steps: int, want_obs: bool = True, obs_every_step: bool = False):
         """``n_steps`` fused control steps enqueued from C; returns the last observation.
         ``obs_every_step`` materialises the [E,D,20] observation on every step (as env.step does)."""

@@ -7,7 +7,8 @@ observations.append(obs) -- run as fused kernels for every drone of every env.  
 (default 1 = the reference).  ``self.observations`` ends up as the reference leaves it: one [D,20] array per
 control step (``np.save(path, geo.observations)`` -> [T,D,20], :553; with num_envs > 1: [T,E,D,20]).
 
-Out of scope here: the 'lqr' / 'dlqr' controllers of this script and ``fedCE*`` (system identification)."""
+Controllers: 'lqr' (LQRController on the 12-state LinearizedModel, the script's default, incl. ``use_noisy_model``) and
+'geometric'.  Out of scope here: 'dlqr' and ``fedCE*`` (system identification)."""
 from __future__ import annotations
 
 import argparse
@@ -31,7 +32,7 @@ DEFAULT_CONTROL_FREQ_HZ = 100
 DEFAULT_DURATION_SEC = 30
 DEFAULT_OUTPUT_FOLDER = 'results'
 DEFAULT_NUM_DRONES = 2
-controllers = ['geometric']              # reference: ['lqr', 'geometric']; the GPU path serves 'geometric'
+controllers = ['lqr', 'geometric']       # whichever is first is the default (:32); 'dlqr' (FedCE) is not on this path
 wind_force = .00025
 
 
@@ -69,6 +70,8 @@ class GeometricEnv:
         self.obs_ts = []
         self.linear_models = None
         self.wind_force = wind_force
+        self._use_noisy_model = False
+        self._step = None
         if circle_init:
             self.starting_target_offset = 1
             self.circle_initialize()
@@ -86,7 +89,8 @@ class GeometricEnv:
         return env
 
     def _make_linear_models(self, env):
-        return None                       # EnvGeometric.py uses the 12-state LinearizedModel for its LQR / FedCE parts only
+        from ..model import LinearizedModel
+        return [LinearizedModel(env) for _ in range(self.args.num_drones)]            # :103
 
     # ------------------------------------------------------------------ the loop
     def _start(self, trajs):
@@ -94,8 +98,14 @@ class GeometricEnv:
         env.getPyBulletClient()
         env.getDroneIds()
         env._showDroneLocalAxes(0)
-        if args.controller != 'geometric':
-            raise NotImplementedError(f"controller {args.controller!r}: this script's LQR / dLQR (FedCE) parts are outside the hot path")
+        if args.controller == 'lqr':      # one LQRController per drone in the reference (:425-427): same model, same gain -> one upload
+            from ..control import LQRController
+            LQRController(env, self.linear_models[0], use_noisy_model=self._use_noisy_model)
+            self._step = env.step_lqr
+        elif args.controller == 'geometric':
+            self._step = env.step_geometric
+        else:
+            raise NotImplementedError(f"controller {args.controller!r}: the dLQR / FedCE parts of this script are outside the hot path")
         if trajs is None:                 # set-point regulation towards TARGET_POSITIONS / TARGET_RPYS[:, 2] (:449-455)
             trajs = [WaitTrajectory(duration=float(args.duration_sec), position=self.TARGET_POSITIONS[j], yaw=self.TARGET_RPYS[j, 2])  # noqa: F405
                      for j in range(args.num_drones)]
@@ -112,6 +122,7 @@ class GeometricEnv:
 
     def do_control(self, trajs=None, render=False, use_noisy_model=False, wind=True):
         env = self.env
+        self._use_noisy_model = use_noisy_model
         steps = self._start(trajs)
         if wind:
             env.set_wind([self.wind_force, 0.0, 0.0])                                  # :463-467, every step, every drone
@@ -119,7 +130,7 @@ class GeometricEnv:
         t = 0.0
         if render:                        # step by step, real time, like the reference with its GUI
             for i in range(steps):
-                obs = env.step_geometric(t)
+                obs = self._step(t)
                 self._log(obs, t)
                 t += env.CTRL_TIMESTEP
                 env.render()
@@ -127,7 +138,7 @@ class GeometricEnv:
         else:                             # the same loop enqueued back to back, observations logged on the device
             log = torch.empty((steps, env.NUM_ENVS, env.NUM_DRONES, 20), dtype=env.dtype, device=env.device)
             for i in range(steps):
-                log[i].copy_(env.step_geometric(t))
+                log[i].copy_(self._step(t))
                 self.obs_ts.append(t)
                 t += env.CTRL_TIMESTEP
             o = log.double().cpu().numpy()

@@ -607,6 +607,62 @@ def lqr_omega_compute(obs, pos_des, vel_des, yaw_des, K, c: DroneConsts = CF2P):
 
 
 # --------------------------------------------------------------------------------------
+# control/lqr/lqr_controller.py (the default 'lqr' controller of simulations/EnvGeometric.py:32,425-427) on
+# model/linearized.py: 12-state x = [rpy, ang_v, vel, pos], u = [F, tau] -> input_to_action
+# --------------------------------------------------------------------------------------
+
+
+def linearized_AB(c: DroneConsts = CF2P, noisy=False):
+    """model/linearized.py:50-75 (A, B) or its deliberately wrong (Ahat, Bhat): inertia and mass off by 0.75."""
+    A = np.zeros((12, 12))
+    B = np.zeros((12, 4))
+    A[0:3, 3:6] = np.eye(3)
+    A[9:, 6:9] = np.eye(3)
+    A[6, 1] = c.G
+    A[7, 0] = -c.G
+    B[8, 0] = 1.0 / c.M
+    B[3:6, 1:] = np.diag(1.0 / np.asarray(c.J))
+    if noisy:
+        B[3:6, 1:] *= 0.75
+        B[8, 0] = 1.0 / (c.M * 0.75)
+    return A, B
+
+
+def lqr12_gain(c: DroneConsts = CF2P, noisy=False):
+    """LQRController.__init__/compute_gain_matrix (lqr_controller.py:12-57): Bryson weights, continuous ARE."""
+    import scipy.linalg as la
+    R = np.diag([1 / c.MAX_THRUST ** 2, 1 / 0.001 ** 2, 1 / 0.001 ** 2, 1 / 0.001 ** 2])
+    Q = np.diag([1 / (np.pi / 40) ** 2] * 3 + [1 / 0.25 ** 2] * 3 + [1 / 0.15 ** 2] * 3 + [1 / 0.05 ** 2] * 3)
+    A, B = linearized_AB(c, noisy)
+    P = la.solve_continuous_are(A, B, Q, R, e=None, s=None, balanced=True)
+    return la.solve(R, B.T @ P)
+
+
+def lqr12_compute(obs, pos_des, vel_des, yaw_des, omega_des, K, c: DroneConsts = CF2P):
+    """LQRController.compute(obs) (:83-113) -> (action rpm [.,4], u [.,4]).  x[3:6] is the obs' world-frame rate."""
+    obs = np.asarray(obs, dtype=np.float64)
+    x = obs_to_lin_model(obs, 12, c)
+    yd = np.asarray(yaw_des, dtype=np.float64)
+    e = x.copy()
+    dy = x[..., 2] - yd
+    e[..., 2] = np.arctan2(np.sin(dy), np.cos(dy))
+    cy, sy = np.cos(yd), np.sin(yd)
+
+    def rot_eqT(v):
+        return np.stack([cy * v[..., 0] + sy * v[..., 1], -sy * v[..., 0] + cy * v[..., 1], v[..., 2]], axis=-1)
+    wd = np.zeros(x.shape[:-1] + (3,))
+    wd[..., 2] = omega_des
+    e[..., 9:12] = rot_eqT(x[..., 9:12] - np.asarray(pos_des, dtype=np.float64))
+    e[..., 6:9] = rot_eqT(x[..., 6:9] - np.asarray(vel_des, dtype=np.float64))
+    e[..., 3:6] = rot_eqT(x[..., 3:6] - wd)
+    u = -np.einsum("ij,...j->...i", K, e)
+    u[..., 0] += c.M * c.G
+    action = input_to_action(u, c)
+    u[..., 0] = np.clip(u[..., 0], 0, None)      # the reference's input_to_action clips u[0] IN PLACE (model_conversions.py:88): the returned u carries it
+    return action, u
+
+
+# --------------------------------------------------------------------------------------
 # f-1/f-3, order-3 loop: control/lqr/lqr_YO_controller.py:14-58 (gain), :99-124 (compute),
 # :85-97 (compute_low_level) and control/low_level/yank_omega_ctrl.py:39-55
 # --------------------------------------------------------------------------------------

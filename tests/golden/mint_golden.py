@@ -420,6 +420,38 @@ def mint_lqr_yank_omega(ref):
     print("lqr_yank_omega K", ctrls[0].K.shape, "yank range", u[..., 0].min(), u[..., 0].max())
 
 
+def mint_lqr12(ref):
+    """control/lqr/lqr_controller.py on model/linearized.py: the 12-state LQR that simulations/EnvGeometric.py runs by default
+    (controllers[0] = 'lqr', :32, :425-427), with the true and the deliberately wrong model (use_noisy_model, :551)."""
+    lin = load("model.linearized", REF + "/model/linearized.py")
+    mod = load("control.lqr.lqr_controller", REF + "/control/lqr/lqr_controller.py")
+    env = make_env()
+    rng = np.random.default_rng(8)
+    n = 160
+    obs = random_obs(rng, n, np.array([0.3, -0.2, 0.8]), np.zeros(3), euler_max=0.4, pos_noise=0.3, vel_noise=0.3)
+    obs[:, 9] = rng.uniform(-3.1, 3.1, size=n)
+    pos_d = np.array([0.3, -0.2, 0.8]) + rng.normal(size=(n, 3)) * 0.1
+    vel_d = rng.normal(size=(n, 3)) * 0.3
+    yaw_d = obs[:, 9] + rng.normal(size=n) * 0.3                      # the 1000 rad^-2 attitude weights saturate the motors otherwise
+    yaw_d[:24] = rng.uniform(-3.1, 3.1, size=24)                      # ... which these cases do on purpose (min-thrust clip of the mixer)
+    om_d = rng.normal(size=n) * 0.5
+    out = {}
+    import io, contextlib
+    for noisy in (False, True):
+        with contextlib.redirect_stdout(io.StringIO()):               # the constructor prints its weights
+            ctrl = mod.LQRController(env, lin.LinearizedModel(env), use_noisy_model=noisy)
+        u = np.zeros((n, 4))
+        act = np.zeros((n, 4))
+        for i in range(n):
+            ctrl.set_desired_trajectory(0, pos_d[i], vel_d[i], np.zeros(3), yaw_d[i], om_d[i])
+            act[i], u[i] = ctrl.compute(obs[i].copy())
+        tag = "noisy" if noisy else "true"
+        out["K_" + tag], out["u_" + tag], out["act_" + tag] = ctrl.K, u, act
+    np.savez_compressed(OUT + "/lqr12.npz", obs=obs, pos_d=pos_d, vel_d=vel_d, yaw_d=yaw_d, om_d=om_d, **out, **META)
+    lo = 9440.3
+    print("lqr12 K", out["K_true"].shape, "min-thrust clips", int((np.abs(out["act_true"] - lo) < 1e-6).sum()), "of", act.size)
+
+
 def trajectory_cases(T):
     """The same constructor arguments are used for the reference classes (minting) and for the oracle /
     GPU classes (tests): T is a namespace with Lemniscate, Circle, Line, Wait, Compound, Rotate."""
@@ -470,5 +502,6 @@ if __name__ == "__main__":
     mint_thrust_omega()
     mint_lqr_omega(ref)
     mint_lqr_yank_omega(ref)
+    mint_lqr12(ref)
     sys.path.insert(0, REF)
     mint_trajectories()

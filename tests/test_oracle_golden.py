@@ -165,6 +165,18 @@ def test_lqr_yank_omega_matches_reference():
         np.testing.assert_allclose(rpm, d["rpm"][t], rtol=1e-13, atol=1e-9)
 
 
+def test_lqr12_matches_reference():
+    """control/lqr/lqr_controller.py + model/linearized.py (EnvGeometric.py's default 'lqr'): both gain matrices, u and the RPM."""
+    d = load("lqr12.npz")
+    for tag, noisy in (("true", False), ("noisy", True)):
+        K = O.lqr12_gain(O.CF2P, noisy)
+        np.testing.assert_allclose(K, d["K_" + tag], rtol=1e-7, atol=1e-9)
+        act, u = O.lqr12_compute(d["obs"], d["pos_d"], d["vel_d"], d["yaw_d"], d["om_d"], d["K_" + tag])
+        np.testing.assert_allclose(u, d["u_" + tag], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(act, d["act_" + tag], rtol=1e-10, atol=1e-7)
+    assert (np.abs(d["act_true"] - 9440.3) < 1e-6).sum() > 50 and (np.abs(d["act_true"] - 9440.3) > 1).sum() > 300
+
+
 def test_trajectory_family_matches_reference():
     """trajectories/{Circle,LineTrajectory,CompoundTrajectory,RotateTrajectory}.py via oracle/np_trajectories.py."""
     import types
