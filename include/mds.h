@@ -304,6 +304,12 @@ int mds_cbf_set_nominal(mds_handle* h, int which);
  * action_dev [n,4] (RPM) optional. */
 int mds_step_cbf_geometric(mds_handle* h, double t, void* obs_dev, int32_t* status_dev, void* action_dev, void* stream);
 
+/* The same step without the filter: nominal LQR (mds_cbf_set_nominal 1 or 2) -> its low level -> env.step, i.e.
+ * ctrl[j].compute(obs[j]) + env.step(action) of simulations/EnvGeometricOmega.py:314,327 (LQROmegaController +
+ * ThrustOmegaController) and simulations/EnvGeometricYankOmega.py:319,332 (LQRYankOmegaController + YankOmegaController).
+ * obs_dev as for mds_step_cbf_geometric. */
+int mds_step_nominal(mds_handle* h, double t, void* obs_dev, void* action_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

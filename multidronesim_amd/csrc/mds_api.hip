@@ -967,16 +967,14 @@ int mds_thrust_omega_from_rates(mds_handle* h, const void* u, const void* rates,
   return MDS_OK;
 }
 
-int mds_step_cbf_geometric(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream) {
-  if (!h || !obs || !status) return fail(MDS_EINVAL, "mds_step_cbf_geometric: null argument");
-  if (!h->has_traj || h->traj_mode != 1) return fail(MDS_ESTATE, "mds_step_cbf_geometric: call mds_set_lemniscate first");
-  if (!h->has_cbf) return fail(MDS_ESTATE, "mds_step_cbf_geometric: call mds_cbf_configure first");
-  const bool ord3 = h->cbf.order == 3;
-  // the order-3 rows act on (yank, w): only the yank-omega LQR produces that input (simulations/CBFTestOrd3.py:294-297;
-  // GeometricControl.compute has no skip_low_level there), and it is meaningless for the order-2 rows
-  if (ord3 != (h->cbf_nominal == 2))
-    return fail(MDS_EUNSUPPORTED, "mds_step_cbf_geometric: order 3 needs (and order 2 excludes) the lqr-yank-omega nominal, mds_cbf_set_nominal(h, 2)");
-  if (!aligned16(obs) || !aligned16(action)) return fail(MDS_EALIGN, "mds_step_cbf_geometric: obs_dev/action_dev");
+// nominal controller -> [ECBF QP] -> low level -> env.step.  with_filter = false: the plain loops of
+// simulations/EnvGeometricOmega.py / EnvGeometricYankOmega.py (ctrl[j].compute(obs[j]) = LQR + low level, :314 / :319).
+static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream, bool with_filter,
+                                 const char* who) {
+  if (!h->has_traj || h->traj_mode != 1) return fail(MDS_ESTATE, "mds_step_cbf_geometric / mds_step_nominal: call mds_set_lemniscate first");
+  if (!aligned16(obs) || !aligned16(action)) return fail(MDS_EALIGN, "mds_step_cbf_geometric / mds_step_nominal: obs_dev/action_dev");
+  const bool yank = h->cbf_nominal == 2;
+  (void)who;
   hipStream_t st = (hipStream_t)stream;
   const size_t es = elem_size(h->cfg.dtype);
   if (!h->cbf_unom) {
@@ -985,36 +983,43 @@ int mds_step_cbf_geometric(mds_handle* h, double t, void* obs, int32_t* status, 
     MDS_HIP(hipMalloc(&h->cbf_usafe, (size_t)h->n * 4 * es));
   }
   const dim3 grid = grid_for(h->n, kBlock);
+  // the hover force is subtracted from the nominal input only on the way into the filter (CBFTest.py:339, CBFTestOrd3.py:341)
+  const double hover_sub = with_filter ? h->cfg.M * h->cfg.G : 0.0;
   if (h->cbf_nominal == 2) {
     if (h->cfg.dtype == MDS_F64)
-      k_cbf_nominal_lqr_yo<double, double><<<grid, kBlock, 0, st>>>(h->cd, h->lqr_yo_d, h->n, h->ld, t, (const double*)h->state,
+      k_cbf_nominal_lqr_yo<double, double><<<grid, kBlock, 0, st>>>(h->cd, h->lqr_yo_d, h->n, h->ld, t, hover_sub, (const double*)h->state,
                                                                     (const double*)h->lem, (const double*)obs, (double*)h->cbf_unom,
                                                                     (double*)h->cbf_xdes);
     else
-      k_cbf_nominal_lqr_yo<float, float><<<grid, kBlock, 0, st>>>(h->cf, h->lqr_yo_f, h->n, h->ld, t, (const float*)h->state,
+      k_cbf_nominal_lqr_yo<float, float><<<grid, kBlock, 0, st>>>(h->cf, h->lqr_yo_f, h->n, h->ld, t, (float)hover_sub, (const float*)h->state,
                                                                   (const float*)h->lem, (const float*)obs, (float*)h->cbf_unom,
                                                                   (float*)h->cbf_xdes);
   } else if (h->cbf_nominal == 1) {
     if (h->cfg.dtype == MDS_F64)
-      k_cbf_nominal_lqr<double, double><<<grid, kBlock, 0, st>>>(h->cd, h->lqr_d, h->n, h->ld, t, (const double*)h->state,
+      k_cbf_nominal_lqr<double, double><<<grid, kBlock, 0, st>>>(h->cd, h->lqr_d, h->n, h->ld, t, hover_sub, (const double*)h->state,
                                                                  (const double*)h->lem, (double*)h->cbf_unom, (double*)h->cbf_xdes);
     else
-      k_cbf_nominal_lqr<float, float><<<grid, kBlock, 0, st>>>(h->cf, h->lqr_f, h->n, h->ld, t, (const float*)h->state,
+      k_cbf_nominal_lqr<float, float><<<grid, kBlock, 0, st>>>(h->cf, h->lqr_f, h->n, h->ld, t, (float)hover_sub, (const float*)h->state,
                                                                (const float*)h->lem, (float*)h->cbf_unom, (float*)h->cbf_xdes);
   } else {
     MDS_DISPATCH(h, (k_cbf_nominal<T, S><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t, (const S*)h->state, (const T*)h->lem,
                                                                   (S*)h->cbf_unom, (S*)h->cbf_xdes)));
   }
-  int rc = mds_cbf_filter(h, obs, h->cbf_xdes, h->cbf_unom, h->cbf_usafe, status, stream);
-  if (rc != MDS_OK) return rc;
+  MDS_HIP(hipGetLastError());
+  const void* u_ll = h->cbf_unom;
+  if (with_filter) {
+    int rc = mds_cbf_filter(h, obs, h->cbf_xdes, h->cbf_unom, h->cbf_usafe, status, stream);
+    if (rc != MDS_OK) return rc;
+    u_ll = h->cbf_usafe;
+  }
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
   // order 2: u_safe[0] += M G (CBFTest.py:346); order 3: the yank goes to the low level as it is (CBFTestOrd3.py:350)
+  const double ll_offset = (with_filter && !yank) ? h->cfg.M * h->cfg.G : 0.0;
 #define MDS_LL(RK4, DRAG, YANK)                                                                                                  \
   MDS_DISPATCH(h, (k_lowlevel_step<T, S, RK4, DRAG, YANK><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, (T)(1.0 / h->cfg.ctrl_freq),  \
-                                                                                   (T)(YANK ? 0.0 : h->cfg.M * h->cfg.G),       \
-                                                                                   (S*)h->state, (const T*)h->origin,           \
-                                                                                   (T*)rpm_track(h), (T*)h->ll,                 \
-                                                                                   (const S*)h->cbf_usafe, (S*)obs, (S*)action)))
+                                                                                   (T)ll_offset, (S*)h->state, (const T*)h->origin, \
+                                                                                   (T*)rpm_track(h), (T*)h->ll, (const S*)u_ll,  \
+                                                                                   (S*)obs, (S*)action)))
 #define MDS_LL_Y(YANK)                           \
   do {                                           \
     if (rk4 && drag) MDS_LL(true, true, YANK);   \
@@ -1022,12 +1027,32 @@ int mds_step_cbf_geometric(mds_handle* h, double t, void* obs, int32_t* status, 
     else if (drag) MDS_LL(false, true, YANK);    \
     else MDS_LL(false, false, YANK);             \
   } while (0)
-  if (ord3) MDS_LL_Y(true);
+  if (yank) MDS_LL_Y(true);
   else MDS_LL_Y(false);
 #undef MDS_LL_Y
 #undef MDS_LL
   MDS_HIP(hipGetLastError());
   return MDS_OK;
+}
+
+int mds_step_cbf_geometric(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream) {
+  if (!h || !obs || !status) return fail(MDS_EINVAL, "mds_step_cbf_geometric: null argument");
+  if (!h->has_cbf) return fail(MDS_ESTATE, "mds_step_cbf_geometric: call mds_cbf_configure first");
+  const bool ord3 = h->cbf.order == 3;
+  // the order-3 rows act on (yank, w): only the yank-omega LQR produces that input (simulations/CBFTestOrd3.py:294-297;
+  // GeometricControl.compute has no skip_low_level there), and it is meaningless for the order-2 rows
+  if (ord3 != (h->cbf_nominal == 2))
+    return fail(MDS_EUNSUPPORTED, "mds_step_cbf_geometric: order 3 needs (and order 2 excludes) the lqr-yank-omega nominal, mds_cbf_set_nominal(h, 2)");
+  if (h->cfg.dtype == MDS_F16) return fail(MDS_EUNSUPPORTED, "mds_step_cbf_geometric: fp16 storage");
+  return step_nominal_lowlevel(h, t, obs, status, action, stream, true, "mds_step_cbf_geometric");
+}
+
+int mds_step_nominal(mds_handle* h, double t, void* obs, void* action, void* stream) {
+  if (!h || !obs) return fail(MDS_EINVAL, "mds_step_nominal: null argument");
+  if (h->cbf_nominal != 1 && h->cbf_nominal != 2)
+    return fail(MDS_ESTATE, "mds_step_nominal: select the LQR-omega (1) or LQR-yank-omega (2) controller with mds_cbf_set_nominal first");
+  if (h->cfg.dtype == MDS_F16) return fail(MDS_EUNSUPPORTED, "mds_step_nominal: fp16 storage");
+  return step_nominal_lowlevel(h, t, obs, nullptr, action, stream, false, "mds_step_nominal");
 }
 
 }  // extern "C"

@@ -472,7 +472,7 @@ __global__ __launch_bounds__(kBlock) void k_cbf_nominal(const Consts<T> c, const
 // (simulations/CBFTest.py:290-293, control/lqr/lqr_omega_controller.py:90-119).
 template <typename T, typename S>
 __global__ __launch_bounds__(kBlock) void k_cbf_nominal_lqr(const Consts<T> c, const LqrGain<T> K, const int n, const size_t ld,
-                                                            const double t, const S* __restrict__ state,
+                                                            const double t, const T hover_sub, const S* __restrict__ state,
                                                             const T* __restrict__ lem, S* __restrict__ unom,
                                                             S* __restrict__ xdes) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(kBlock) void k_cbf_nominal_lqr(const Consts<T> c, c
   const V3<T> rpy = euler_from_quat(in.s.q);
   T u[4];
   lqr_omega_control<T>(c, K, rpy, in.s.v, in.s.p, des.p, des.v, des.yaw, u);      // local frame: the centre cancels in p - p_des
-  const T un[4] = {u[0] - c.gravity, u[1], u[2], u[3]};                            // CBFTest.py:339
+  const T un[4] = {u[0] - hover_sub, u[1], u[2], u[3]};                            // CBFTest.py:339 (hover_sub = M G; 0 without a filter)
   store4<S, T>(unom + (size_t)i * 4, un);
   S* xd = xdes + (size_t)i * 9;
   xd[0] = (S)0; xd[1] = (S)0; xd[2] = (S)des.yaw;
@@ -511,7 +511,7 @@ __global__ void k_lqr_omega_compute(const Consts<T> c, const LqrGain<T> K, const
 //   xdes  = [0, 0, yaw, G M, vel, pos]                                                              (:345-347)
 template <typename T, typename S>
 __global__ __launch_bounds__(kBlock) void k_cbf_nominal_lqr_yo(const Consts<T> c, const LqrYoGain<T> K, const int n, const size_t ld,
-                                                               const double t, const S* __restrict__ state,
+                                                               const double t, const T hover_sub, const S* __restrict__ state,
                                                                const T* __restrict__ lem, const S* __restrict__ obs_prev,
                                                                S* __restrict__ unom, S* __restrict__ xdes) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(kBlock) void k_cbf_nominal_lqr_yo(const Consts<T> c
   T rpm[4], u[4];
   load4<S, T>(obs_prev + (size_t)i * kObsDim + 16, rpm);
   lqr_yank_omega_control<T>(c, K, rpy, rpm, in.s.v, in.s.p, des.p, des.v, des.yaw, u);
-  const T un[4] = {u[0] - c.gravity, u[1], u[2], u[3]};
+  const T un[4] = {u[0] - hover_sub, u[1], u[2], u[3]};
   store4<S, T>(unom + (size_t)i * 4, un);
   S* xd = xdes + (size_t)i * 10;
   xd[0] = (S)0; xd[1] = (S)0; xd[2] = (S)des.yaw; xd[3] = (S)c.gravity;

@@ -377,6 +377,17 @@ class BaseAviary:
         self.step_counter += self.PYB_STEPS_PER_CTRL
         return (self._obs, self._cbf_status, self._act) if return_action else (self._obs, self._cbf_status)
 
+    def step_nominal(self, t: float, return_action: bool = False):
+        """``ctrl[j].compute(obs[j])`` + ``env.step(action)`` of simulations/EnvGeometricOmega.py / EnvGeometricYankOmega.py for every
+        drone: the LQR selected with ``set_cbf_nominal`` ("lqr_omega" | "lqr_yank_omega"), its low-level controller, the physics step.
+        No safety filter.  Uses and updates the env's current observation."""
+        self._require_open()
+        act_ptr = C.c_void_p(self._act.data_ptr()) if return_action else C.c_void_p(None)
+        capi.check(self._lib.mds_step_nominal(self._h, C.c_double(t), C.c_void_p(self._obs.data_ptr()), act_ptr, self._stream()),
+                   "mds_step_nominal")
+        self.step_counter += self.PYB_STEPS_PER_CTRL
+        return (self._obs, self._act) if return_action else self._obs
+
     # ------------------------------------------------------------------ gym hooks (CtrlAviary fills them)
     def _computeReward(self):
         raise NotImplementedError

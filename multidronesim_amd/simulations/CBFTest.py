@@ -42,15 +42,11 @@ class GeometricEnv(_base.GeometricEnv):
 
     def do_control(self, trajs=None, render=False, qpTracker=None, computed_K=None, use_noisy_model=False, x_obs_list=None,
                    obs_r_list=None):
-        if qpTracker is None:             # plain tracking: the EnvGeometric loop without wind
-            saved, self.args.controller = self.args.controller, 'geometric'
-            try:
-                return super().do_control(trajs=trajs, render=render, wind=False)
-            finally:
-                self.args.controller = saved
         env = self.env
+        if self.args.controller == 'geometric' and qpTracker is None:        # plain geometric tracking: the EnvGeometric loop, no wind
+            return super().do_control(trajs=trajs, render=render, wind=False)
         nominal = self._nominal(env)
-        saved, self.args.controller = self.args.controller, 'geometric'
+        saved, self.args.controller = self.args.controller, 'geometric'      # _start only needs the trajectories and the first step
         try:
             steps = self._start(trajs)
         finally:
@@ -58,13 +54,15 @@ class GeometricEnv(_base.GeometricEnv):
         env.set_cbf_nominal(nominal)
         START = time.time()
         t = 0.0
-        self.statuses = []
         log = torch.empty((steps, env.NUM_ENVS, env.NUM_DRONES, 20), dtype=env.dtype, device=env.device)
-        st_log = torch.empty((steps, env.NUM_ENVS), dtype=torch.int32, device=env.device)
+        st_log = torch.zeros((steps, env.NUM_ENVS), dtype=torch.int32, device=env.device)
         for i in range(steps):
-            obs, st = env.step_cbf_geometric(t, qpTracker, x_obs_list, obs_r_list)
+            if qpTracker is not None:     # nominal -> QP -> low level -> step (:303-350)
+                obs, st = env.step_cbf_geometric(t, qpTracker, x_obs_list, obs_r_list)
+                st_log[i].copy_(st)
+            else:                         # ctrl[j].compute(obs[j]) = LQR + low level, then step (:296-300, :350)
+                obs = env.step_nominal(t)
             log[i].copy_(obs)
-            st_log[i].copy_(st)
             self.obs_ts.append(t)
             t += env.CTRL_TIMESTEP
             if render:

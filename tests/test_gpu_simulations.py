@@ -190,3 +190,38 @@ def test_envgeometric_default_lqr_controller_matches_oracle(gpu):
         rows = [tr(t) for tr in otr]
         return (np.array([r[0] for r in rows]), np.array([r[1] for r in rows]), np.array([r[3] for r in rows]), np.array([r[4] for r in rows]))
     np.testing.assert_allclose(np.asarray(geo2.observations)[-1], oracle_loop(seg), atol=1e-7)
+
+
+@pytest.mark.parametrize("which", ["omega", "yank"])
+def test_plain_lqr_lowlevel_loop_matches_oracle(gpu, which):
+    """do_control without a qpTracker in the CBFTest / CBFTestOrd3 scripts (= the loops of EnvGeometricOmega.py:314-327 and
+    EnvGeometricYankOmega.py:319-332): LQR nominal + its low-level controller + env.step, no hover offset games."""
+    if which == "omega":
+        from multidronesim_amd.simulations import CBFTest as S
+    else:
+        from multidronesim_amd.simulations import CBFTestOrd3 as S
+    D, steps = 3, 150
+    args = S.parse_args(["--num_drones", str(D), "--duration_sec", "1", "--dtype", "float64", "--control_freq_hz", "150", "--simulation_freq_hz", "150"])
+    geo = S.GeometricEnv(args) if which == "omega" else S.GeometricEnv(args, init_type='circle', center=np.array([0, 0, 0.5]))
+    geo.INIT_XYZS[:, 2] = 0.5
+    env = geo.create_env()
+    P = np.array([[1.0, 0.5, 0, 0, 0.5 + 0.1 * k, 0.3, 0.4 * k] for k in range(D)])
+    trajs = [S.Lemniscate(a=1.0, omega=0.5, center=P[k, 2:5], yaw_rate=0.3, phase_shift=0.4 * k) for k in range(D)]
+    geo.do_control(trajs=trajs, qpTracker=None)
+    obs = np.asarray(geo.observations)
+    assert obs.shape == (steps, D, 20) and not geo.statuses.any()
+    c = O.CF2P
+    dt = 1 / 150
+    ora = O.AviaryOracle(geo.INIT_XYZS, geo.INIT_RPYS, pyb_freq=150, ctrl_freq=150)
+    first = c.HOVER_RPM if which == "yank" else 0.0
+    o = ora.step(np.full((D, 4), first))
+    ll = O.YankOmegaOracle(D, c) if which == "yank" else O.ThrustOmegaOracle(D, c)
+    K = O.lqr_yank_omega_gain(c, dt) if which == "yank" else O.lqr_omega_gain(c)
+    t = 0.0
+    for k in range(steps):
+        pos, vel, acc, yaw, yd = O.lemniscate(t, P[:, 0], P[:, 1], P[:, 2:5], P[:, 5], P[:, 6])
+        u = O.lqr_yank_omega_compute(o, pos, vel, yaw, K, c) if which == "yank" else O.lqr_omega_compute(o, pos, vel, yaw, K, c)
+        o = ora.step(ll.compute_low_level(u, o, dt))
+        t += dt
+    np.testing.assert_allclose(obs[-1][:, :16], o[:, :16], atol=1e-7)
+    assert np.abs(obs[-1][:, :3] - pos).max() < 0.5
