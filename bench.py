@@ -287,11 +287,11 @@ def main(argv=None):
     }
     # HBM traffic from the PMC counters cannot be read inside this process; the committed summary of the
     # separate rocprofv3 --pmc passes (profiles/, same kernel and workload) is reported when it matches.
-    pmc = os.path.join(ROOT, "profiles", "r01c_pmc_traffic_c3.json")
+    pmc = os.path.join(ROOT, "profiles", "r01d_pmc_traffic_c3.json")
     if args.workload == "c3" and args.dtype == "float32" and os.path.exists(pmc):
         try:
             line["roofline"]["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch"]
-            line["roofline"]["traffic_source"] = "profiles/r01c_pmc_traffic_c3.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
+            line["roofline"]["traffic_source"] = "profiles/r01d_pmc_traffic_c3.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
         except Exception:
             pass
     if fused_T:
