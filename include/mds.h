@@ -189,6 +189,9 @@ int mds_geometric_compute(mds_handle* h, const void* obs_dev, const void* des_de
 /* utils/model_conversions.py:85-103 / :69-83 */
 int mds_input_to_action(mds_handle* h, const void* u_dev /*[n,4]*/, void* rpm_dev /*[n,4]*/, void* stream);
 int mds_action_to_input(mds_handle* h, const void* rpm_dev /*[n,4]*/, int cap_rpm, void* u_dev /*[n,4]*/, void* stream);
+/* utils/model_conversions.py:20-58 obs_to_lin_model(obs, dim = 9 | 10 | 12[, env]) and :105-114 obs_to_geo_model(obs) (dim = 18):
+ * obs_dev [n,20] -> x_dev [n,dim].  dim 10 carries F = calc_z_thrust(env, obs) (:137-143); dim 18 = [pos, R row-major, vel, ang_v]. */
+int mds_obs_to_model(mds_handle* h, const void* obs_dev, int dim, void* x_dev, void* stream);
 
 /* model/dynamics.py:83-106 `QuadrotorDynamics.dynamics(t, state, u)`: state_dev [count,18]
  * (p, R row-major, v, w), u_dev [count,4] (thrust, torques) -> out_dev [count,12].

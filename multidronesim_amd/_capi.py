@@ -78,6 +78,7 @@ PROTOTYPES = {
     "mds_geometric_compute": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "mds_input_to_action": (C.c_int, [_P, _P, _P, _P]),
     "mds_action_to_input": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "mds_obs_to_model": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "mds_quadrotor_dynamics": (C.c_int, [C.c_int, C.c_int, _P, _P, C.c_double, _PD, C.c_double, _P, _P]),
     "mds_cbf_configure": (C.c_int, [_P, C.POINTER(MdsCbfParams), _PD]),
     "mds_cbf_num_rows": (C.c_int, [_P]),

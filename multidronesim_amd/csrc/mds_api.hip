@@ -581,6 +581,14 @@ int mds_input_to_action(mds_handle* h, const void* u, void* rpm, void* stream) {
   return MDS_OK;
 }
 
+int mds_obs_to_model(mds_handle* h, const void* obs, int dim, void* x, void* stream) {
+  if (!h || !obs || !x) return fail(MDS_EINVAL, "mds_obs_to_model: null argument");
+  if (dim != 9 && dim != 10 && dim != 12 && dim != 18) return fail(MDS_EINVAL, "mds_obs_to_model: dim must be 9, 10, 12 (linear models) or 18 (geometric model)");
+  MDS_DISPATCH(h, (k_obs_to_model<T, S><<<grid_for(h->n, 256), 256, 0, (hipStream_t)stream>>>(C, h->n, dim, (const S*)obs, (S*)x)));
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
 int mds_action_to_input(mds_handle* h, const void* rpm, int cap_rpm, void* u, void* stream) {
   if (!h || !u || !rpm) return fail(MDS_EINVAL, "mds_action_to_input: null argument");
   if (!aligned16(u) || !aligned16(rpm)) return fail(MDS_EALIGN, "mds_action_to_input");

@@ -809,6 +809,37 @@ __global__ void k_geometric_compute(const Consts<T> c, const int n, const S* __r
   }
 }
 
+// utils/model_conversions.py:105-114 obs_to_geo_model: x18 = [pos, R(quat) row-major (normalising, as scipy's Rotation), vel, ang_v];
+// :20-58 obs_to_lin_model(obs, dim): [rpy, (ang_v | F |), vel, pos] for dim 12 / 10 / 9, F = calc_z_thrust (:137-143).
+// Format adapters for callers written against those helpers; the fused kernels do the same in registers.
+template <typename T, typename S>
+__global__ void k_obs_to_model(const Consts<T> c, const int n, const int dim, const S* __restrict__ obs, S* __restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const S* o = obs + (size_t)i * kObsDim;
+  S* out = x + (size_t)i * dim;
+  if (dim == 18) {
+    const T q[4] = {(T)o[3], (T)o[4], (T)o[5], (T)o[6]};
+    const M3<T> R = quat_to_rot(q);
+    out[0] = o[0]; out[1] = o[1]; out[2] = o[2];
+    for (int k = 0; k < 9; ++k) out[3 + k] = (S)R.m[k];                          // row-major
+    for (int k = 0; k < 6; ++k) out[12 + k] = o[10 + k];
+    return;
+  }
+  out[0] = o[7]; out[1] = o[8]; out[2] = o[9];
+  int p = 3;
+  if (dim == 12) {
+    out[3] = o[13]; out[4] = o[14]; out[5] = o[15];
+    p = 6;
+  } else if (dim == 10) {
+    const T r0 = (T)o[16], r1 = (T)o[17], r2 = (T)o[18], r3 = (T)o[19];
+    out[3] = (S)(c.kf * (r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3));
+    p = 4;
+  }
+  out[p] = o[10]; out[p + 1] = o[11]; out[p + 2] = o[12];
+  out[p + 3] = o[0]; out[p + 4] = o[1]; out[p + 5] = o[2];
+}
+
 template <typename T, typename S>
 __global__ void k_input_to_action(const Consts<T> c, const int n, const S* __restrict__ u, S* __restrict__ rpm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -41,45 +41,48 @@ def action_to_input(env, action, cap_rpm=True):
 
 
 # ---- observation -> model-state adapters (model_conversions.py:20-58, :105-114, :137-143) -------------------------
-# Pure re-orderings of the 20-float obs (plus one quaternion -> matrix expansion).  The fused kernels do these in
-# registers (csrc/mds_cbf.hpp obs_to_lin, csrc/mds_math.hpp quat_to_rot) and never call this file; these adapters
-# exist so that code written against the reference's helpers keeps working on [..., 20] batches, on whichever
-# device the obs tensor lives (NumPy in -> NumPy out, as the reference).
+# Re-orderings of the 20-float obs (plus one quaternion -> matrix expansion) for code written against the reference's
+# helpers.  The fused kernels do these in registers and never call this file; here they run as one small kernel
+# (mds_obs_to_model) on the env's device -- like everything else in the package there is no host implementation.
 
-def _xp(a):
-    return torch if isinstance(a, torch.Tensor) else np
+def _obs_to_model(env, obs, dim):
+    numpy_in = not isinstance(obs, torch.Tensor)
+    shape = tuple(np.shape(obs)) if numpy_in else tuple(obs.shape)
+    if shape[-1] != capi.OBS_DIM:
+        raise ValueError(f"obs must end in {capi.OBS_DIM} components, got shape {shape}")
+    ot = to_device(obs, env.device, env.dtype).reshape(-1, capi.OBS_DIM)
+    rows = ot.shape[0]
+    if rows > env.n:
+        raise ValueError(f"at most {env.n} observations per call (the env's batch), got {rows}")
+    if rows != env.n:                              # single row / partial batch: pad to the handle's n
+        pad = torch.zeros((env.n, capi.OBS_DIM), dtype=env.dtype, device=env.device)
+        pad[:, 6] = 1.0
+        pad[:rows] = ot
+        ot = pad
+    out = torch.empty((env.n, dim), dtype=env.dtype, device=env.device)
+    capi.check(env._lib.mds_obs_to_model(env._h, C.c_void_p(ot.data_ptr()), C.c_int(dim), C.c_void_p(out.data_ptr()),
+                                         C.c_void_p(stream_ptr(env.device))), "mds_obs_to_model")
+    out = out[:rows].reshape(shape[:-1] + (dim,))
+    return out.double().cpu().numpy() if numpy_in else out
+
+
+def obs_to_lin_model(obs, dim=12, env=None):
+    """[rpy, (ang_v | F |), vel, pos] for dim 12 / 10 / 9 (:20-58), batched over leading axes.  ``env`` (a multidronesim_amd
+    CtrlAviary) is where it runs; the reference needs it only for dim 10 -- here it is always required."""
+    if dim not in (9, 10, 12):
+        raise ValueError("Invalid dim for linear model")
+    if env is None:
+        raise ValueError("env must be provided: the conversion runs on the env's GPU (the reference needs it for dim 10 only)")
+    return _obs_to_model(env, obs, dim)
+
+
+def obs_to_geo_model(obs, env=None):
+    """x18 = [pos, R(quat) row-major (normalising, as scipy's Rotation.from_quat), vel, ang_v] (:105-114)."""
+    if env is None:
+        raise ValueError("env must be provided: the conversion runs on the env's GPU")
+    return _obs_to_model(env, obs, 18)
 
 
 def calc_z_thrust(env, obs):
     """KF * sum(rpm^2) of the last clipped action in obs[..., -4:] (:137-143)."""
-    rpms = obs[..., -4:]
-    return (env.KF * rpms ** 2).sum(-1)
-
-
-def obs_to_lin_model(obs, dim=12, env=None):
-    """[rpy, (ang_v | F |), vel, pos] for dim 12 / 10 / 9 (:20-58), batched over leading axes."""
-    xp = _xp(obs)
-    rpy, vel, pos = obs[..., 7:10], obs[..., 10:13], obs[..., 0:3]
-    cat = (lambda parts: torch.cat(parts, dim=-1)) if xp is torch else (lambda parts: np.concatenate(parts, axis=-1))
-    if dim == 12:
-        return cat([rpy, obs[..., 13:16], vel, pos])
-    if dim == 9:
-        return cat([rpy, vel, pos])
-    if dim == 10:
-        assert env is not None, "env must be provided for 10 dim model to calculate the thrust"
-        return cat([rpy, calc_z_thrust(env, obs)[..., None], vel, pos])
-    raise ValueError("Invalid dim for linear model")
-
-
-def obs_to_geo_model(obs):
-    """x18 = [pos, R(quat) row-major (normalising, as scipy's Rotation.from_quat), vel, ang_v] (:105-114)."""
-    xp = _xp(obs)
-    q = obs[..., 3:7]
-    q = q / ((q * q).sum(-1, keepdims=True) if xp is np else (q * q).sum(-1, keepdim=True)) ** 0.5
-    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
-    rows = [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
-            2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
-            2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]
-    R = xp.stack(rows, -1) if xp is np else torch.stack(rows, dim=-1)
-    cat = (lambda parts: torch.cat(parts, dim=-1)) if xp is torch else (lambda parts: np.concatenate(parts, axis=-1))
-    return cat([obs[..., 0:3], R, obs[..., 10:13], obs[..., 13:16]])
+    return _obs_to_model(env, obs, 10)[..., 3]

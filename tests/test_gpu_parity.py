@@ -461,3 +461,38 @@ def test_capi_error_codes(mds):
     env.close()
     with pytest.raises(MdsError):
         env.step(np.zeros((2, 4)))
+
+
+@pytest.mark.parametrize("dtype,atol", [("float64", 1e-13), ("float32", 2e-6)])
+def test_obs_to_model_adapters(mds, dtype, atol):
+    """utils/model_conversions.py obs_to_lin_model (dim 9/10/12), obs_to_geo_model, calc_z_thrust through mds_obs_to_model,
+    against the oracle (itself pinned on the reference's outputs in tests/golden/geometric_compute.npz)."""
+    from multidronesim_amd.utils import calc_z_thrust, obs_to_geo_model, obs_to_lin_model
+    rng = np.random.default_rng(3)
+    n = 37
+    obs = rng.normal(size=(n, 20))
+    obs[:, 3:7] *= rng.uniform(0.5, 2.0, size=(n, 1))                 # un-normalised quaternions: Rotation.from_quat normalises
+    obs[:, 16:20] = O.CF2P.HOVER_RPM * (1 + 0.1 * rng.normal(size=(n, 4)))
+    env = make_env(mds, n, 1, np.zeros((1, 3)), np.zeros((1, 3)), dtype)
+    for dim in (9, 10, 12):
+        got = obs_to_lin_model(obs, dim, env)
+        ref = O.obs_to_lin_model(obs, dim)
+        np.testing.assert_allclose(got, ref, atol=atol * max(1.0, np.abs(ref).max()))
+    g18 = obs_to_geo_model(obs, env)
+    assert g18.shape == (n, 18)
+    np.testing.assert_allclose(g18[:, 3:12].reshape(n, 3, 3), O.quat_to_rotmat_scipy(obs[:, 3:7]), atol=atol * 10)
+    np.testing.assert_allclose(g18[:, [0, 1, 2, 12, 13, 14, 15, 16, 17]], obs[:, [0, 1, 2, 10, 11, 12, 13, 14, 15]], atol=atol * 10)
+    np.testing.assert_allclose(calc_z_thrust(env, obs[3]), O.CF2P.KF * np.sum(obs[3, 16:20] ** 2), rtol=max(atol, 1e-12) * 10)
+    env.close()
+    d = np.load(os.path.join(G, "mixer.npz"))                                    # the reference's own outputs (mint_golden.py)
+    n = d["obs"].shape[0]
+    env = make_env(mds, n, 1, np.zeros((1, 3)), np.zeros((1, 3)), dtype)
+    for dim, key in ((9, "lin9"), (10, "lin10"), (12, "lin12")):
+        np.testing.assert_allclose(obs_to_lin_model(d["obs"], dim, env), d[key], atol=atol * max(1.0, np.abs(d[key]).max()))
+    np.testing.assert_allclose(obs_to_geo_model(d["obs"], env), d["geo18"], atol=atol * 10 * max(1.0, np.abs(d["geo18"]).max()))
+    obs = d["obs"]
+    t = mds.torch.tensor(obs[:5], dtype=env.dtype, device=env.device)            # device tensor in -> device tensor out
+    assert obs_to_lin_model(t, 9, env).is_cuda and tuple(obs_to_lin_model(t, 9, env).shape) == (5, 9)
+    with pytest.raises(ValueError):
+        obs_to_lin_model(obs, 9)
+    env.close()
