@@ -294,6 +294,26 @@ def main(argv=None):
             line["roofline"]["traffic_source"] = "profiles/r01d_pmc_traffic_c3.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
         except Exception:
             pass
+    # measured ceiling in the same run: a device-to-device copy moving the same number of bytes per launch
+    if rank == 0 and not fused_T:
+        try:
+            nel = max(int(bytes_per * n_local) // 8, 1 << 20)         # copy_ reads nel*4 and writes nel*4 bytes
+            src = torch.ones(nel, dtype=torch.float32, device=device)
+            dst = torch.empty_like(src)
+            for _ in range(5):
+                dst.copy_(src)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(50):
+                dst.copy_(src)
+            c1.record()
+            torch.cuda.synchronize(device)
+            copy_gbps = 8.0 * nel / (c0.elapsed_time(c1) / 50 * 1e-3) / 1e9
+            line["roofline"]["copy_ceiling"] = {"GBps": copy_gbps, "frac_of_copy": achieved / copy_gbps,
+                                                "what": "torch copy_ (D2D) of the same bytes per launch, HIP events, same process"}
+            del src, dst
+        except Exception as exc:                                       # never let the calibration break the bench line
+            line["roofline"]["copy_ceiling"] = {"error": str(exc)}
     if fused_T:
         line["roofline"]["kernel"] = f"k_rollout_geometric<float,float,false,false> ({fused_T} control steps per launch)"
         line["roofline"]["kernel_us"] = kernel_us * fused_T
