@@ -82,6 +82,13 @@ def test_null_handle_calls_return_einval(lib):
     assert lib.mds_step(None, None, None, None) == -1
     assert lib.mds_step_geometric(None, 0.0, None, None, None) == -1
     assert lib.mds_get_obs(None, None, None) == -1
+    assert lib.mds_step_lqr(None, 0.0, None, None, None) == -1
+    assert lib.mds_step_nominal(None, 0.0, None, None, None) == -1
+    assert lib.mds_step_cbf_geometric(None, 0.0, None, None, None, None) == -1
+    assert lib.mds_obs_to_model(None, None, 9, None, None) == -1
+    assert lib.mds_lqr_compute(None, None, None, None, None, None) == -1
+    assert lib.mds_yank_omega_compute(None, None, None, None, None) == -1
+    assert lib.mds_set_lqr_gain(None, None) == -1
     assert lib.mds_destroy(None) == 0
 
 
@@ -126,6 +133,13 @@ def test_reference_api_names_present():
     a = MultiDroneExample.parse_args(["--num_drones", "3", "--control_freq_hz", "48", "--simulation_freq_hz", "240"])
     assert (a.num_drones, a.control_freq_hz, a.simulation_freq_hz, a.init_rad, a.duration_sec) == (3, 48, 240, 1.0, 30)
     from multidronesim_amd.model.dynamics import QuadrotorDynamics
+    # the reference's package-level imports (control/__init__.py, model/__init__.py, cbf/__init__.py, utils/__init__.py)
+    from multidronesim_amd.control import (GeometricControl as G2, LQRController, LQROmegaController, LQRYankOmegaController,  # noqa: F401
+                                           ThrustOmegaController, YankOmegaController)
+    from multidronesim_amd.model import LinearizedModel, LinearizedOmegaModel, LinearizedYankOmegaModel  # noqa: F401
+    from multidronesim_amd.cbf import DroneCBF, DroneQPTracker  # noqa: F401
+    from multidronesim_amd.utils import obs_to_lin_model, obs_to_geo_model, calc_z_thrust  # noqa: F401
+    assert G2 is GeometricControl
     assert DroneModel("cf2p") is DroneModel.CF2P and Physics("pyb") is Physics.PYB
     for m in ("step", "reset", "render", "close", "getPyBulletClient", "getDroneIds", "_showDroneLocalAxes"):
         assert callable(getattr(CtrlAviary, m))
@@ -142,3 +156,26 @@ def test_reference_api_names_present():
     q = QuadrotorDynamics(100)
     with pytest.raises(ValueError):
         q.step(np.zeros(4))
+
+
+def test_simulation_mirrors_set_up_on_cpu_and_need_the_gpu_to_run():
+    """simulations/{EnvGeometric,CBFTest,CBFTestOrd3}.py mirrors: argument parsing and the initial-condition arithmetic are host
+    code (as in the reference); creating the env without a GPU is a loud error, not a CPU simulation."""
+    import numpy as np
+    from multidronesim_amd import MdsError
+    from multidronesim_amd.simulations import CBFTest, CBFTestOrd3, EnvGeometric
+    a = EnvGeometric.parse_args([])
+    assert (a.controller, a.num_drones, a.duration_sec, a.init_rad, a.num_envs) == ("lqr", 2, 30, 1.0, 1)       # EnvGeometric.py:26-32,61
+    assert CBFTest.parse_args([]).init_rad == .2 and EnvGeometric.wind_force == .00025
+    geo = EnvGeometric.GeometricEnv(EnvGeometric.parse_args(["--num_drones", "4"]), circle_init=True)
+    np.testing.assert_allclose(geo.INIT_XYZS[1], [0.0, 1.0, 0.0], atol=1e-15)                                      # (i-1)/N * 2 pi, sin/cos (:507-510)
+    np.testing.assert_allclose(geo.TARGET_POSITIONS[:, 2], 1.0)
+    np.testing.assert_allclose(geo.TARGET_RPYS[:, 2], np.pi / 2)
+    g3 = CBFTestOrd3.GeometricEnv(CBFTestOrd3.parse_args(["--num_drones", "3"]), init_type="circle", center=np.array([0, 0, 0.5]))
+    np.testing.assert_allclose(g3.INIT_XYZS[1], [.2 * np.cos(2 * np.pi / 3), .2 * np.sin(2 * np.pi / 3), 0.5], atol=1e-15)   # cos/sin + centre (:418-425)
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(MdsError):
+            geo.create_env()
+        with pytest.raises(MdsError):
+            CBFTestOrd3.GeometricEnv(CBFTestOrd3.parse_args([]), init_type="lemniscate")       # evaluates a trajectory: device work
