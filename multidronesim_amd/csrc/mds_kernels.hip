@@ -251,9 +251,8 @@ __device__ __forceinline__ void geo_process(const Consts<T>& c, const int n, con
   if (valid) store_state<S, T>(state, ld, i, in.s);
 }
 
-// Generic form (f64 verification dtype, fp16 storage, RK4): one batch of 256 drones per
-// workgroup, inputs loaded straight into registers.  The fp32/Euler hot path uses
-// k_step_geometric_f32_dma below.
+// One batch of 256 drones per workgroup, inputs loaded straight into registers; every dtype / integrator / physics
+// combination is an instantiation of this kernel (the fp32 / Euler / DYN one is the bench's hot kernel).
 #ifndef MDS_GEOSIMPLE_MIN_WAVES
 #define MDS_GEOSIMPLE_MIN_WAVES 1
 #endif
