@@ -281,6 +281,8 @@ int mds_lqr_compute(mds_handle* h, const void* obs_dev, const void* des_dev, voi
 /* The do_control step of simulations/EnvGeometric.py:434-469 with that controller for every drone: trajectory sample ->
  * LQRController.compute -> env.step.  Trajectories as for mds_step_geometric (Lemniscate planes or segment tables). */
 int mds_step_lqr(mds_handle* h, double t, void* obs_dev, void* action_dev, void* stream);
+/* n_steps of that loop in ONE launch (Lemniscate trajectories), as mds_rollout_geometric_fused does for the geometric controller */
+int mds_rollout_lqr_fused(mds_handle* h, double t0, int n_steps, void* obs_log_dev, void* obs_last_dev, void* stream);
 
 /* LQRYankOmegaController (control/lqr/lqr_YO_controller.py): K [4,10] row-major from its
  * compute_gain_matrix() (:59-64), state [r,p,y,F,vx,vy,vz,x,y,z], input [yank, wx, wy, wz]. */

@@ -97,6 +97,7 @@ PROTOTYPES = {
     "mds_set_lqr_gain": (C.c_int, [_P, _PD]),
     "mds_lqr_compute": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "mds_step_lqr": (C.c_int, [_P, C.c_double, _P, _P, _P]),
+    "mds_rollout_lqr_fused": (C.c_int, [_P, C.c_double, C.c_int, _P, _P, _P]),
     "mds_set_lqr_yank_omega_gain": (C.c_int, [_P, _PD]),
     "mds_lqr_yank_omega_compute": (C.c_int, [_P, _P, _P, _P, _P]),
     "mds_yank_omega_compute": (C.c_int, [_P, _P, _P, _P, _P]),

@@ -83,6 +83,7 @@ struct mds_handle {
   LqrYoGain<float> lqr_yo_f;
   LqrYoGain<double> lqr_yo_d;
   bool has_lqr12;
+  void* lqr12_dev;     // device copy of the 12-state gain for the whole-rollout kernel
   Lqr12Gain<float> lqr12_f;
   Lqr12Gain<double> lqr12_d;
   bool track_rpm;      // last_rpm planes maintained by every step kernel (DYN_DRAG, order-3 CBF, or cfg.track_last_rpm)
@@ -223,6 +224,7 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   h->has_lqr = false;
   h->has_lqr_yo = false;
   h->has_lqr12 = false;
+  h->lqr12_dev = nullptr;
   h->cbf_nominal = 0;
   h->pid = nullptr;
   h->track_rpm = cfg->track_last_rpm != 0 || cfg->physics == MDS_PHYSICS_DYN_DRAG;
@@ -274,6 +276,7 @@ int mds_destroy(mds_handle* h) {
   if (h->cbf_order) (void)hipFree(h->cbf_order);
   if (h->cbf_count) (void)hipFree(h->cbf_count);
   if (h->cbf_cost) (void)hipFree(h->cbf_cost);
+  if (h->lqr12_dev) (void)hipFree(h->lqr12_dev);
   if (h->cbf_unom) (void)hipFree(h->cbf_unom);
   if (h->cbf_xdes) (void)hipFree(h->cbf_xdes);
   if (h->cbf_usafe) (void)hipFree(h->cbf_usafe);
@@ -533,27 +536,47 @@ int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs, int 
   return MDS_OK;
 }
 
-int mds_rollout_geometric_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream) {
-  if (!h || n_steps < 0) return fail(MDS_EINVAL, "mds_rollout_geometric_fused");
-  if (!h->has_traj) return fail(MDS_ESTATE, "mds_rollout_geometric_fused: call mds_set_lemniscate first");
-  if (h->traj_mode != 1) return fail(MDS_EUNSUPPORTED, "mds_rollout_geometric_fused: Lemniscate trajectories only (use mds_rollout_geometric)");
-  if (!aligned16(obs_log) || !aligned16(obs_last)) return fail(MDS_EALIGN, "mds_rollout_geometric_fused: obs buffers");
+static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream, bool lqr, const char* who) {
+  if (!h || n_steps < 0) return fail(MDS_EINVAL, who);
+  if (!h->has_traj) return fail(MDS_ESTATE, "mds_rollout_*_fused: call mds_set_lemniscate first");
+  if (h->traj_mode != 1) return fail(MDS_EUNSUPPORTED, "mds_rollout_*_fused: Lemniscate trajectories only (use mds_rollout_geometric / mds_step_lqr)");
+  if (lqr && !h->has_lqr12) return fail(MDS_ESTATE, "mds_rollout_lqr_fused: call mds_set_lqr_gain first");
+  if (!aligned16(obs_log) || !aligned16(obs_last)) return fail(MDS_EALIGN, "mds_rollout_*_fused: obs buffers");
   if (n_steps == 0) return MDS_OK;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid = grid_for(h->n, kBlock);
   const double dt = 1.0 / h->cfg.ctrl_freq;
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
-#define MDS_ROLL(RK4, DRAG)                                                                                              \
-  MDS_DISPATCH(h, (k_rollout_geometric<T, S, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t0, dt, n_steps, (S*)h->state, \
-                                                                                 (const T*)h->lem, (T*)rpm_track(h),      \
-                                                                                 (S*)obs_log, (S*)obs_last)))
-  if (rk4 && drag) MDS_ROLL(true, true);
-  else if (rk4) MDS_ROLL(true, false);
-  else if (drag) MDS_ROLL(false, true);
-  else MDS_ROLL(false, false);
+  if (lqr) {   // the gain (48 values) lives in device memory for this kernel: passing it by value would not fit beside Consts in SGPRs
+    if (!h->lqr12_dev) MDS_HIP(hipMalloc(&h->lqr12_dev, sizeof(Lqr12Gain<double>)));
+    if (h->cfg.dtype == MDS_F64) MDS_HIP(hipMemcpyAsync(h->lqr12_dev, &h->lqr12_d, sizeof(h->lqr12_d), hipMemcpyHostToDevice, st));
+    else MDS_HIP(hipMemcpyAsync(h->lqr12_dev, &h->lqr12_f, sizeof(h->lqr12_f), hipMemcpyHostToDevice, st));
+  }
+#define MDS_ROLL(RK4, DRAG, CTRL)                                                                                                  \
+  MDS_DISPATCH(h, (k_rollout_geometric<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, (const Lqr12Gain<T>*)h->lqr12_dev, h->n, h->ld, t0, dt, \
+                                                                                       n_steps, (S*)h->state, (const T*)h->lem,       \
+                                                                                       (T*)rpm_track(h), (S*)obs_log, (S*)obs_last)))
+#define MDS_ROLL_C(CTRL)                         \
+  do {                                           \
+    if (rk4 && drag) MDS_ROLL(true, true, CTRL);     \
+    else if (rk4) MDS_ROLL(true, false, CTRL);       \
+    else if (drag) MDS_ROLL(false, true, CTRL);      \
+    else MDS_ROLL(false, false, CTRL);               \
+  } while (0)
+  if (lqr) MDS_ROLL_C(1);
+  else MDS_ROLL_C(0);
+#undef MDS_ROLL_C
 #undef MDS_ROLL
   MDS_HIP(hipGetLastError());
   return MDS_OK;
+}
+
+int mds_rollout_geometric_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream) {
+  return rollout_fused(h, t0, n_steps, obs_log, obs_last, stream, false, "mds_rollout_geometric_fused");
+}
+
+int mds_rollout_lqr_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream) {
+  return rollout_fused(h, t0, n_steps, obs_log, obs_last, stream, true, "mds_rollout_lqr_fused");
 }
 
 int mds_lemniscate_eval(mds_handle* h, double t, void* des, void* stream) {

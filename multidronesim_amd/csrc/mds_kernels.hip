@@ -395,8 +395,9 @@ __global__ void k_traj_eval(const int n, const double t, const double* __restric
 // EnvGeometric.py:471,553) through the same per-wave LDS transposition.  t advances in
 // double exactly like the host loop (t += CTRL_TIMESTEP).
 // ------------------------------------------------------------------------------------
-template <typename T, typename S, bool RK4, bool DRAG>
-__global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c, const int n, const size_t ld, double t,
+// CTRL 0: GeometricControl; CTRL 1: the 12-state LQRController (K is only read then).
+template <typename T, typename S, bool RK4, bool DRAG, int CTRL = 0>
+__global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c, const Lqr12Gain<T>* __restrict__ Kp, const int n, const size_t ld, double t,
                                                               const double ctrl_dt, const int n_steps, S* __restrict__ state,
                                                               const T* __restrict__ lem, T* __restrict__ last_rpm,
                                                               S* __restrict__ obs_log, S* __restrict__ obs_last) {
@@ -417,10 +418,14 @@ __global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c,
       T act[4];
       {
         const Desired<T> des = lemniscate_local(in.P, t);
-        const M3<T> R = quat_to_rot(in.s.q);
-        const V3<T> ang_v = mul(R, in.s.w);
         T u[4];
-        geometric_control<T>(c, in.s.p - des.p, R, in.s.v, ang_v, des, u, nullptr);
+        if (CTRL == 0) {
+          const M3<T> R = quat_to_rot(in.s.q);
+          const V3<T> ang_v = mul(R, in.s.w);
+          geometric_control<T>(c, in.s.p - des.p, R, in.s.v, ang_v, des, u, nullptr);
+        } else {
+          lqr12_control<T>(c, *Kp, euler_from_quat(in.s.q), quat_rotate(in.s.q, in.s.w), in.s.v, in.s.p - des.p, des.v, des.yaw, des.yaw_rate, u);
+        }
         input_to_action(c, u, act);
       }
       aviary_step<T, RK4, DRAG>(c, in.s, act, prev, clipped);

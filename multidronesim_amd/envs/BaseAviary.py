@@ -318,17 +318,18 @@ class BaseAviary:
         self.step_counter += n_steps * self.PYB_STEPS_PER_CTRL
         return self._obs if want_obs else None
 
-    def rollout_geometric_fused(self, t0: float, n_steps: int, log: bool = False, log_out: torch.Tensor | None = None):
+    def rollout_geometric_fused(self, t0: float, n_steps: int, log: bool = False, log_out: torch.Tensor | None = None,
+                                controller: str = "geometric"):
         """``n_steps`` fused control steps in ONE kernel launch (state stays in registers).  With
         ``log`` every step's observation goes to a [T,E,D,20] tensor (the reference's
-        ``observations.append(obs)``, EnvGeometric.py:471); returns (last obs, log or None)."""
+        ``observations.append(obs)``, EnvGeometric.py:471); returns (last obs, log or None).  ``controller="lqr"`` runs the
+        12-state LQRController (constructed on this env) instead of GeometricControl."""
         self._require_open()
         if log and log_out is None:
             log_out = torch.empty((n_steps, self.NUM_ENVS, self.NUM_DRONES, capi.OBS_DIM), dtype=self.dtype, device=self.device)
-        capi.check(self._lib.mds_rollout_geometric_fused(self._h, C.c_double(t0), C.c_int(n_steps),
-                                                         C.c_void_p(log_out.data_ptr() if log_out is not None else None),
-                                                         C.c_void_p(self._obs.data_ptr()), self._stream()),
-                   "mds_rollout_geometric_fused")
+        fn = self._lib.mds_rollout_lqr_fused if controller == "lqr" else self._lib.mds_rollout_geometric_fused
+        capi.check(fn(self._h, C.c_double(t0), C.c_int(n_steps), C.c_void_p(log_out.data_ptr() if log_out is not None else None),
+                      C.c_void_p(self._obs.data_ptr()), self._stream()), "mds_rollout_*_fused")
         self.step_counter += n_steps * self.PYB_STEPS_PER_CTRL
         return self._obs, log_out
 

@@ -225,3 +225,35 @@ def test_plain_lqr_lowlevel_loop_matches_oracle(gpu, which):
         t += dt
     np.testing.assert_allclose(obs[-1][:, :16], o[:, :16], atol=1e-7)
     assert np.abs(obs[-1][:, :3] - pos).max() < 0.5
+
+
+@pytest.mark.parametrize("dtype,T,tol", [("float64", 120, 1e-9), ("float32", 60, 5e-5)])
+def test_lqr_whole_rollout_equals_stepwise(gpu, dtype, T, tol):
+    """mds_rollout_lqr_fused (T control steps of trajectory -> LQRController -> step in one launch, every obs logged) against
+    T calls of mds_step_lqr on an identical env.  This closed loop amplifies perturbations ~50x per 0.2 s (fp32 and float64 runs
+    of the SAME kernel drift apart at that rate), so the fp32 comparison uses a short horizon."""
+    from multidronesim_amd.envs.CtrlAviary import CtrlAviary, DroneModel, Physics
+    from multidronesim_amd.control import LQRController
+    from multidronesim_amd.model import LinearizedModel
+    E, D = 37, 3
+    xyz, rpy, P = H.c2_setup(E, D, seed=4, offset=2.0, yaw_rate=0.2)
+    envs = []
+    for _ in range(2):
+        env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN, pyb_freq=200,
+                         ctrl_freq=100, num_envs=E, dtype=dtype)
+        env.set_trajectories(P)
+        LQRController(env, LinearizedModel(env))
+        env.step(gpu.zeros((E, D, 4), dtype=env.dtype))
+        envs.append(env)
+    a, b = envs
+    last, log = a.rollout_geometric_fused(0.0, T, log=True, controller="lqr")
+    t = 0.0
+    for k in range(T):
+        o = b.step_lqr(t)
+        t += b.CTRL_TIMESTEP
+        if k in (0, T // 2, T - 1):
+            d = np.abs(log[k].double().cpu().numpy()[..., :16] - o.double().cpu().numpy()[..., :16]).max()
+            assert d < tol, (k, d)
+    np.testing.assert_allclose(last.double().cpu().numpy(), log[-1].double().cpu().numpy(), atol=0)
+    np.testing.assert_allclose(a.get_state(), b.get_state(), atol=tol)
+    a.close(); b.close()
