@@ -591,14 +591,21 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
             if (v == vv) zv = (ag == wia ? wca[v] : T(0)) + ((two && ag == wib) ? wcb[v] : T(0));
         }
 #pragma unroll
-        for (int c = 0; c < NMAX; ++c)
-          if (c < q) zv = m_fma(-qrow[c], wv::get(dc, c), zv);                           // lanes >= n: garbage, masked below
+        for (int c = 0; c < NMAX; ++c) {                                                 // one exit test per column; the compiler keeps it a loop
+          if (c >= q) break;                                                             // with indexed VGPR reads of qrow (no scratch)
+          zv = m_fma(-qrow[c], wv::get(dc, c), zv);                                      // lanes >= n: garbage, masked below
+        }
         if (lane >= n) zv = T(0);
+        // r = R^-1 d by back substitution on the row-scaled system (row l divided by its pivot, off the serial chain):
+        // per step one v_readlane and one fma -- lane k's entry is final when step k reads it
 #pragma unroll
-        for (int k = NMAX - 1; k >= 0; --k)                                  // r = R^-1 d (back substitution, pivots pre-inverted)
+        for (int c = 0; c < NMAX; ++c) rrow[c] *= my_di;
+        rc *= my_di;
+#pragma unroll
+        for (int k = NMAX - 1; k >= 0; --k)
           if (k < q) {
-            const T rk = wv::get(rc * my_di, k);
-            rc = lane == k ? rk : (lane < k ? m_fma(-rrow[k], rk, rc) : rc);
+            const T rk = wv::get(rc, k);
+            rc = lane < k ? m_fma(-rrow[k], rk, rc) : rc;
           }
       } else {
         if (lane < n) sd[lane] = dc;
