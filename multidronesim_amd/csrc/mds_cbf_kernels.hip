@@ -575,7 +575,7 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
         for (int v = 0; v < NV; ++v) dc = m_fma(wca[v], sQ[NV * wia + v][lane], m_fma(two ? wcb[v] : T(0), sQ[NV * wib + v][lane], dc));
       }
       const int ln = lane < NMAX ? lane : NMAX - 1;                                      // lanes >= n hold no row: clamp the address only
-      const T my_lam = slam[ln], my_di = sdi[ln];
+      const T my_lam = slam[ln], my_di = sdi[ln], my_u = su[ln];
       T zv = T(0), rc = dc;
       if constexpr (PRE) {
         T qrow[NMAX], rrow[NMAX];
@@ -639,13 +639,12 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
       }
       const bool full = has_z && t2 <= t1;
       MDS_WAVE_SYNC();
-      if (has_z && lane < n) su[lane] = m_fma(-t, zv, su[lane]);
+      if (has_z && lane < n) su[lane] = m_fma(-t, zv, my_u);
       if (lane < q) slam[lane] = m_fma(-t, rc, my_lam);
       lam_new += t;
       MDS_WAVE_SYNC();
       if (full) {                                                                        // add: N <- [N a]
-        const T nz = m_sqrt(zz);
-        const T inz = T(1) / nz;
+        const T inz = m_rsqrt(zz), nz = zz * inz;
         if (lane < n) sQ[lane][q] = zv * inz;
         if (lane < q) sR[lane][q] = dc;
         if (lane == 0) {
