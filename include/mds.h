@@ -51,7 +51,12 @@ typedef enum mds_status {
 } mds_status;
 
 typedef enum mds_dtype { MDS_F32 = 0, MDS_F64 = 1, MDS_F16 = 2 } mds_dtype;
-typedef enum mds_physics { MDS_PHYSICS_DYN = 0, MDS_PHYSICS_DYN_DRAG = 1 } mds_physics;
+/* DYN / DYN_DRAG: [UPSTREAM] Physics.DYN (+ _drag), every entry point.  DYN_GND / DYN_DW / DYN_GND_DRAG_DW add [UPSTREAM]
+ * _groundEffect / _downwash (Physics.PYB_GND, PYB_DW, PYB_GND_DRAG_DW: Bullet external forces there, extra terms of the DYN wrench
+ * here; spec-level): explicit Euler only, served by mds_step (the other step entry points return MDS_EUNSUPPORTED). */
+typedef enum mds_physics {
+  MDS_PHYSICS_DYN = 0, MDS_PHYSICS_DYN_DRAG = 1, MDS_PHYSICS_DYN_GND = 2, MDS_PHYSICS_DYN_DW = 3, MDS_PHYSICS_DYN_GND_DRAG_DW = 4
+} mds_physics;
 typedef enum mds_integrator { MDS_INTEGRATOR_EULER = 0, MDS_INTEGRATOR_RK4 = 1 } mds_integrator;
 typedef enum mds_drone_model { MDS_CF2X = 0, MDS_CF2P = 1 } mds_drone_model;
 

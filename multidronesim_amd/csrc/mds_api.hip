@@ -86,9 +86,17 @@ struct mds_handle {
   void* lqr12_dev;     // device copy of the 12-state gain for the whole-rollout kernel
   Lqr12Gain<float> lqr12_f;
   Lqr12Gain<double> lqr12_d;
+  void* state_alt;     // second state buffer of the ground-effect / downwash step (double-buffered substeps)
+  bool envfx;          // physics has ground effect and / or downwash
+  EnvFx<float> fx_f;
+  EnvFx<double> fx_d;
   bool track_rpm;      // last_rpm planes maintained by every step kernel (DYN_DRAG, order-3 CBF, or cfg.track_last_rpm)
   bool rpm_stale;      // a step ran without tracking since the last reset
 };
+
+static inline bool has_drag(const mds_handle* h) {
+  return h->cfg.physics == MDS_PHYSICS_DYN_DRAG || h->cfg.physics == MDS_PHYSICS_DYN_GND_DRAG_DW;
+}
 
 // The last clipped action lives in the obs a step call returns.  The SoA copy costs 16 B per drone-step
 // and is kept only where something reads it back (the _drag term, calc_z_thrust of the yank path, mds_get_obs).
@@ -191,7 +199,9 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   if (cfg->num_envs <= 0 || cfg->num_drones <= 0) return fail(MDS_EINVAL, "mds_create: num_envs/num_drones must be > 0");
   if ((long long)cfg->num_envs * cfg->num_drones > (1LL << 30)) return fail(MDS_EINVAL, "mds_create: too many drones");
   if (cfg->dtype < MDS_F32 || cfg->dtype > MDS_F16) return fail(MDS_EINVAL, "mds_create: dtype");
-  if (cfg->physics != MDS_PHYSICS_DYN && cfg->physics != MDS_PHYSICS_DYN_DRAG) return fail(MDS_EINVAL, "mds_create: physics");
+  if (cfg->physics < MDS_PHYSICS_DYN || cfg->physics > MDS_PHYSICS_DYN_GND_DRAG_DW) return fail(MDS_EINVAL, "mds_create: physics");
+  if (cfg->physics >= MDS_PHYSICS_DYN_GND && (cfg->integrator != MDS_INTEGRATOR_EULER || cfg->dtype == MDS_F16))
+    return fail(MDS_EINVAL, "mds_create: ground effect / downwash run with the explicit Euler integrator on f32 / f64 storage");
   if (cfg->integrator != MDS_INTEGRATOR_EULER && cfg->integrator != MDS_INTEGRATOR_RK4) return fail(MDS_EINVAL, "mds_create: integrator");
   if (cfg->drone_model != MDS_CF2X && cfg->drone_model != MDS_CF2P) return fail(MDS_EINVAL, "mds_create: drone_model");
   if (cfg->ctrl_freq <= 0 || cfg->pyb_freq <= 0 || cfg->pyb_freq % cfg->ctrl_freq != 0)
@@ -227,7 +237,11 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   h->lqr12_dev = nullptr;
   h->cbf_nominal = 0;
   h->pid = nullptr;
-  h->track_rpm = cfg->track_last_rpm != 0 || cfg->physics == MDS_PHYSICS_DYN_DRAG;
+  h->envfx = cfg->physics >= MDS_PHYSICS_DYN_GND;
+  h->state_alt = nullptr;
+  fill_envfx(h->cfg, h->fx_f);
+  fill_envfx(h->cfg, h->fx_d);
+  h->track_rpm = cfg->track_last_rpm != 0 || cfg->physics == MDS_PHYSICS_DYN_DRAG || cfg->physics == MDS_PHYSICS_DYN_GND_DRAG_DW;
   h->rpm_stale = false;
   {
     mds_dslpid_gains dg;
@@ -235,6 +249,8 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
     mds_set_dslpid_gains(h, &dg);
   }
   hipError_t e = hipMalloc(&h->state, 13 * h->ld * es);
+  if (e == hipSuccess && h->envfx) e = hipMalloc(&h->state_alt, 13 * h->ld * es);
+  if (e == hipSuccess && h->envfx) e = hipMemset(h->state_alt, 0, 13 * h->ld * es);
   if (e == hipSuccess) e = hipMalloc(&h->origin, 3 * h->ld * cs);
   if (e == hipSuccess) e = hipMalloc(&h->last_rpm, 4 * h->ld * cs);
   if (e == hipSuccess) e = hipMalloc(&h->lem, 7 * h->ld * cs);
@@ -267,6 +283,7 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
 int mds_destroy(mds_handle* h) {
   if (!h) return MDS_OK;
   if (h->state) (void)hipFree(h->state);
+  if (h->state_alt) (void)hipFree(h->state_alt);
   if (h->origin) (void)hipFree(h->origin);
   if (h->last_rpm) (void)hipFree(h->last_rpm);
   if (h->lem) (void)hipFree(h->lem);
@@ -367,10 +384,27 @@ int mds_step(mds_handle* h, const void* action, void* obs, void* stream) {
   if (!aligned16(action) || !aligned16(obs)) return fail(MDS_EALIGN, "mds_step: action_dev/obs_dev");
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid = grid_for(h->n, kBlock);
+  if (h->envfx) {   // one launch per physics substep, double-buffered state (k_step_env)
+    const int K = h->cfg.pyb_freq / h->cfg.ctrl_freq, D = h->cfg.num_drones;
+    void* rpm = rpm_track(h);
+    for (int k = 0; k < K; ++k) {
+      void* ob = k == K - 1 ? obs : nullptr;
+      if (h->cfg.dtype == MDS_F64) {
+        if (has_drag(h)) k_step_env<double, double, true><<<grid, kBlock, 0, st>>>(h->cd, h->fx_d, h->n, h->ld, D, (const double*)h->state, (double*)h->state_alt, (const double*)h->origin, (double*)rpm, (const double*)action, (double*)ob, k > 0, k == K - 1);
+        else k_step_env<double, double, false><<<grid, kBlock, 0, st>>>(h->cd, h->fx_d, h->n, h->ld, D, (const double*)h->state, (double*)h->state_alt, (const double*)h->origin, (double*)rpm, (const double*)action, (double*)ob, k > 0, k == K - 1);
+      } else {
+        if (has_drag(h)) k_step_env<float, float, true><<<grid, kBlock, 0, st>>>(h->cf, h->fx_f, h->n, h->ld, D, (const float*)h->state, (float*)h->state_alt, (const float*)h->origin, (float*)rpm, (const float*)action, (float*)ob, k > 0, k == K - 1);
+        else k_step_env<float, float, false><<<grid, kBlock, 0, st>>>(h->cf, h->fx_f, h->n, h->ld, D, (const float*)h->state, (float*)h->state_alt, (const float*)h->origin, (float*)rpm, (const float*)action, (float*)ob, k > 0, k == K - 1);
+      }
+      void* t = h->state; h->state = h->state_alt; h->state_alt = t;
+    }
+    MDS_HIP(hipGetLastError());
+    return MDS_OK;
+  }
 #define MDS_LAUNCH_STEP(HAS_OBS, RK4, DRAG)                                                                          \
   MDS_DISPATCH(h, (k_step<T, S, HAS_OBS, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, (S*)h->state, (const T*)h->origin, \
                                                                              (T*)rpm_track(h), (const S*)action, (S*)obs)))
-  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
 #define MDS_STEP_OBS(HAS_OBS)                           \
   do {                                                  \
     if (rk4 && drag) MDS_LAUNCH_STEP(HAS_OBS, true, true);   \
@@ -480,7 +514,7 @@ int mds_set_wind(mds_handle* h, const double force_world[3]) {
 static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, hipStream_t st) {
   const unsigned nbatch = (unsigned)((h->n + kBlock - 1) / kBlock);
   if (h->traj_mode == 2) {      // general trajectories: segment tables
-    const bool rk4_ = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag_ = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
+    const bool rk4_ = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag_ = has_drag(h);
 #define MDS_TRAJ(RK4, DRAG)                                                                                                   \
   MDS_DISPATCH(h, (k_step_traj<T, S, RK4, DRAG><<<dim3(nbatch), kBlock, 0, st>>>(C, h->n, h->ld, t, (S*)h->state, (const T*)h->origin, \
                                                                                h->segs, h->tinfo, (T*)rpm_track(h), (S*)obs, (S*)act)))
@@ -495,7 +529,7 @@ static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, 
   MDS_DISPATCH(h, (k_step_geometric<T, S, HAS_OBS, HAS_ACT, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t, (S*)h->state, \
                                                                                                 (const T*)h->lem, (T*)rpm_track(h), \
                                                                                                 (S*)obs, (S*)act)))
-  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
   const dim3 grid(nbatch);
 #define MDS_LAUNCH_GEO(HAS_OBS, HAS_ACT)                         \
   do {                                                           \
@@ -514,6 +548,7 @@ static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, 
 }
 
 int mds_step_geometric(mds_handle* h, double t, void* obs, void* act, void* stream) {
+  if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h) return fail(MDS_EINVAL, "mds_step_geometric: null handle");
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_step_geometric: call mds_set_lemniscate first");
   if (!aligned16(obs) || !aligned16(act)) return fail(MDS_EALIGN, "mds_step_geometric: obs_dev/action_dev");
@@ -523,6 +558,7 @@ int mds_step_geometric(mds_handle* h, double t, void* obs, void* act, void* stre
 }
 
 int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs, int obs_every_step, void* stream) {
+  if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h || n_steps < 0) return fail(MDS_EINVAL, "mds_rollout_geometric");
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_rollout_geometric: call mds_set_lemniscate first");
   if (!aligned16(obs)) return fail(MDS_EALIGN, "mds_rollout_geometric: obs_dev");
@@ -537,6 +573,7 @@ int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs, int 
 }
 
 static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream, bool lqr, const char* who) {
+  if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h || n_steps < 0) return fail(MDS_EINVAL, who);
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_rollout_*_fused: call mds_set_lemniscate first");
   if (h->traj_mode != 1) return fail(MDS_EUNSUPPORTED, "mds_rollout_*_fused: Lemniscate trajectories only (use mds_rollout_geometric / mds_step_lqr)");
@@ -546,7 +583,7 @@ static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, v
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid = grid_for(h->n, kBlock);
   const double dt = 1.0 / h->cfg.ctrl_freq;
-  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
   if (lqr) {   // the gain (48 values) lives in device memory for this kernel: passing it by value would not fit beside Consts in SGPRs
     if (!h->lqr12_dev) MDS_HIP(hipMalloc(&h->lqr12_dev, sizeof(Lqr12Gain<double>)));
     if (h->cfg.dtype == MDS_F64) MDS_HIP(hipMemcpyAsync(h->lqr12_dev, &h->lqr12_d, sizeof(h->lqr12_d), hipMemcpyHostToDevice, st));
@@ -834,11 +871,12 @@ int mds_dslpid_compute(mds_handle* h, const void* obs_in, const void* tpos, cons
 }
 
 int mds_step_dslpid(mds_handle* h, const void* tpos, const void* trpy, void* obs, void* act, void* stream) {
+  if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h || !tpos || !trpy) return fail(MDS_EINVAL, "mds_step_dslpid: null argument");
   if (!aligned16(obs) || !aligned16(act)) return fail(MDS_EALIGN, "mds_step_dslpid: obs_dev/action_dev");
   hipStream_t st = (hipStream_t)stream;
   const void* obs_in = nullptr;
-  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
   if (rk4 && drag) MDS_PID_DTYPE(true, true, true);
   else if (rk4) MDS_PID_DTYPE(true, true, false);
   else if (drag) MDS_PID_DTYPE(true, false, true);
@@ -902,13 +940,14 @@ int mds_lqr_compute(mds_handle* h, const void* obs, const void* des, void* u, vo
 }
 
 int mds_step_lqr(mds_handle* h, double t, void* obs, void* act, void* stream) {
+  if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h) return fail(MDS_EINVAL, "mds_step_lqr: null handle");
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_step_lqr: call mds_set_lemniscate / mds_set_trajectory_segments first");
   if (!h->has_lqr12) return fail(MDS_ESTATE, "mds_step_lqr: call mds_set_lqr_gain first");
   if (!aligned16(obs) || !aligned16(act)) return fail(MDS_EALIGN, "mds_step_lqr: obs_dev/action_dev");
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid = grid_for(h->n, kBlock);
-  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
 #define MDS_LQR_T(T, S, C, K, RK4, DRAG)                                                                                          \
   k_step_lqr<T, S, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, K, h->n, h->ld, t, h->traj_mode, (S*)h->state, (const T*)h->origin,     \
                                                        (const T*)h->lem, h->segs, h->tinfo, (T*)rpm_track(h), (S*)obs, (S*)act)
@@ -1002,6 +1041,7 @@ int mds_thrust_omega_from_rates(mds_handle* h, const void* u, const void* rates,
 // simulations/EnvGeometricOmega.py / EnvGeometricYankOmega.py (ctrl[j].compute(obs[j]) = LQR + low level, :314 / :319).
 static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream, bool with_filter,
                                  const char* who) {
+  if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h->has_traj || h->traj_mode != 1) return fail(MDS_ESTATE, "mds_step_cbf_geometric / mds_step_nominal: call mds_set_lemniscate first");
   if (!aligned16(obs) || !aligned16(action)) return fail(MDS_EALIGN, "mds_step_cbf_geometric / mds_step_nominal: obs_dev/action_dev");
   const bool yank = h->cbf_nominal == 2;
@@ -1043,7 +1083,7 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
     if (rc != MDS_OK) return rc;
     u_ll = h->cbf_usafe;
   }
-  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = h->cfg.physics == MDS_PHYSICS_DYN_DRAG;
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
   // order 2: u_safe[0] += M G (CBFTest.py:346); order 3: the yank goes to the low level as it is (CBFTestOrd3.py:350)
   const double ll_offset = (with_filter && !yank) ? h->cfg.M * h->cfg.G : 0.0;
 #define MDS_LL(RK4, DRAG, YANK)                                                                                                  \

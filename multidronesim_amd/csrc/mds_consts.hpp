@@ -31,7 +31,7 @@ template <typename T> inline void fill_consts(const mds_config& cfg, const mds_g
   c.dt = (T)(1.0 / cfg.pyb_freq);
   c.substeps = cfg.pyb_freq / cfg.ctrl_freq;
   c.cf2x = cfg.drone_model == MDS_CF2X;
-  c.use_drag = cfg.physics == MDS_PHYSICS_DYN_DRAG;
+  c.use_drag = cfg.physics == MDS_PHYSICS_DYN_DRAG || cfg.physics == MDS_PHYSICS_DYN_GND_DRAG_DW;
   c.rk4 = cfg.integrator == MDS_INTEGRATOR_RK4;
   c.g_ctrl = (T)g.g;
   c.cos_max_tilt = (T)cos(g.max_tilt_angle);
@@ -44,5 +44,25 @@ template <typename T> inline void fill_consts(const mds_config& cfg, const mds_g
   c.inv_kf = (T)(1.0 / cfg.KF);
 }
 
+// [UPSTREAM] urdf <properties> (identical in cf2x.urdf and cf2p.urdf) and BaseAviary.__init__ GND_EFF_H_CLIP
+template <typename T> inline void fill_envfx(const mds_config& cfg, EnvFx<T>& fx) {
+  fx.gnd = cfg.physics == MDS_PHYSICS_DYN_GND || cfg.physics == MDS_PHYSICS_DYN_GND_DRAG_DW;
+  fx.dw = cfg.physics == MDS_PHYSICS_DYN_DW || cfg.physics == MDS_PHYSICS_DYN_GND_DRAG_DW;
+  const double gnd = 11.36859, rad = 2.31348e-2;
+  const double max_rpm2 = cfg.thrust2weight * cfg.G * cfg.M / (4.0 * cfg.KF), max_thrust = 4.0 * cfg.KF * max_rpm2;
+  fx.gnd_coeff = (T)gnd;
+  fx.prop_radius = (T)rad;
+  fx.h_clip = (T)(0.25 * rad * sqrt(15.0 * max_rpm2 * cfg.KF * gnd / max_thrust));
+  fx.dw1 = (T)2267.18;
+  fx.dw2 = (T)0.16;
+  fx.dw3 = (T)-0.11;
+  if (cfg.drone_model == MDS_CF2X) {
+    const double x[4] = {0.028, -0.028, -0.028, 0.028}, y[4] = {-0.028, -0.028, 0.028, 0.028};
+    for (int k = 0; k < 4; ++k) { fx.prop_x[k] = (T)x[k]; fx.prop_y[k] = (T)y[k]; }
+  } else {
+    const double x[4] = {cfg.L, 0.0, -cfg.L, 0.0}, y[4] = {0.0, cfg.L, 0.0, -cfg.L};
+    for (int k = 0; k < 4; ++k) { fx.prop_x[k] = (T)x[k]; fx.prop_y[k] = (T)y[k]; }
+  }
+}
 
 }  // namespace mds

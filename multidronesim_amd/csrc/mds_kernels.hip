@@ -181,6 +181,58 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && !RK4) ? MDS_STEP_MIN_WAV
   if (HAS_OBS) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
 }
 
+// [UPSTREAM] BaseAviary.step with ground effect and / or downwash: ONE physics substep per launch (upstream refreshes the
+// kinematic information of every drone between substeps; the downwash on a drone depends on its env-mates' positions), reading
+// state_in and writing state_out (double-buffered: env-mates are read while they are being updated).  Explicit Euler only.
+// drag_from_action: substeps after the first take the _drag term from this step's clipped action (as aviary_step does).
+template <typename T, typename S, bool DRAG>
+__global__ __launch_bounds__(kBlock) void k_step_env(const Consts<T> c, const EnvFx<T> fx, const int n, const size_t ld, const int D,
+                                                     const S* __restrict__ state_in, S* __restrict__ state_out,
+                                                     const T* __restrict__ origin, T* __restrict__ last_rpm,
+                                                     const S* __restrict__ action, S* __restrict__ obs, const int drag_from_action,
+                                                     const int store_rpm) {
+  __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = i < n;
+  T o[kObsDim];
+  if (valid) {
+    State<T> s;
+    load_state<S, T>(state_in, ld, i, s);
+    const V3<T> org = {origin[i], origin[ld + i], origin[2 * ld + i]};
+    T act[4], clipped[4];
+    load4<S, T>(action + (size_t)i * 4, act);
+    for (int k = 0; k < 4; ++k) clipped[k] = m_clamp(act[k], T(0), c.max_rpm);
+    T drag_s = T(0);
+    if (DRAG) {
+      T prev[4];
+      for (int k = 0; k < 4; ++k) prev[k] = drag_from_action ? clipped[k] : last_rpm[k * ld + i];
+      drag_s = T(0.10471975511965977462) * ((prev[0] + prev[1]) + (prev[2] + prev[3]));
+    }
+    T thrust;
+    V3<T> tau;
+    rotor_wrench(c, clipped, &thrust, &tau);
+    if (fx.gnd) ground_effect(c, fx, s, s.p.z + org.z, clipped, &thrust, &tau);
+    if (fx.dw) {
+      const V3<T> me = {s.p.x + org.x, s.p.y + org.y, s.p.z + org.z};
+      const int e0 = (i / D) * D;
+      T f = T(0);
+      for (int j = e0; j < e0 + D; ++j) {
+        if (j == i) continue;
+        T a4[4];
+        load4<S, T>(state_in + 4 * (size_t)j, a4);                                // (px, py, pz, qx) of env-mate j, before this substep
+        f += downwash_pair(fx, me, V3<T>{a4[0] + origin[j], a4[1] + origin[ld + j], a4[2] + origin[2 * ld + j]});
+      }
+      thrust += f;
+    }
+    step_euler_wrench<T, DRAG>(c, s, thrust, tau, drag_s);
+    store_state<S, T>(state_out, ld, i, s);
+    if (store_rpm && (DRAG || last_rpm))
+      for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
+    if (obs) pack_obs(s, org, clipped, o);
+  }
+  if (obs) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
+}
+
 // ------------------------------------------------------------------------------------
 // fused trajectory + geometric controller + mixer + physics step (a10, a7-a9, a1-a4)
 // ------------------------------------------------------------------------------------

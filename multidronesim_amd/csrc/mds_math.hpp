@@ -48,6 +48,8 @@ MDS_HD float m_fma(float a, float b, float c) { return fmaf(a, b, c); }
 MDS_HD double m_fma(double a, double b, double c) { return fma(a, b, c); }
 MDS_HD float m_rint(float x) { return rintf(x); }
 MDS_HD double m_rint(double x) { return rint(x); }
+MDS_HD float m_exp(float x) { return expf(x); }
+MDS_HD double m_exp(double x) { return exp(x); }
 MDS_HD float m_abs(float x) { return fabsf(x); }
 MDS_HD double m_abs(double x) { return fabs(x); }
 MDS_HD double m_atan2(double y, double x) { return atan2(y, x); }
@@ -307,15 +309,58 @@ template <typename T> MDS_HD void integrate_q(T q[4], V3<T> w, T dt) {
 }
 
 // [UPSTREAM] _dynamics, Physics.DYN: explicit Euler on (v, omega); p with NEW v, q with NEW omega
-template <typename T, bool DRAG> MDS_HD void step_euler(const Consts<T>& c, State<T>& s, const T rpm[4], T drag_s) {
-  T thrust;
-  V3<T> tau, acc, wdot;
-  rotor_wrench(c, rpm, &thrust, &tau);
+template <typename T, bool DRAG>
+MDS_HD void step_euler_wrench(const Consts<T>& c, State<T>& s, T thrust, V3<T> tau, T drag_s) {
+  V3<T> acc, wdot;
   body_accel<T, DRAG>(c, s.q, s.v, s.w, thrust, tau, drag_s, &acc, &wdot);
   s.v = {m_fma(c.dt, acc.x, s.v.x), m_fma(c.dt, acc.y, s.v.y), m_fma(c.dt, acc.z, s.v.z)};
   s.w = {m_fma(c.dt, wdot.x, s.w.x), m_fma(c.dt, wdot.y, s.w.y), m_fma(c.dt, wdot.z, s.w.z)};
   s.p = {m_fma(c.dt, s.v.x, s.p.x), m_fma(c.dt, s.v.y, s.p.y), m_fma(c.dt, s.v.z, s.p.z)};
   integrate_q(s.q, s.w, c.dt);
+}
+template <typename T, bool DRAG> MDS_HD void step_euler(const Consts<T>& c, State<T>& s, const T rpm[4], T drag_s) {
+  T thrust;
+  V3<T> tau;
+  rotor_wrench(c, rpm, &thrust, &tau);
+  step_euler_wrench<T, DRAG>(c, s, thrust, tau, drag_s);
+}
+
+// [UPSTREAM] BaseAviary._groundEffect / _downwash (the Bullet external forces of Physics.PYB_GND / PYB_DW / PYB_GND_DRAG_DW,
+// urdf <properties> gnd_eff_coeff 11.36859, prop_radius 2.31348e-2, dw_coeff_1..3 2267.18, .16, -.11) as extra terms of the DYN
+// wrench: per-propeller thrust KF rpm^2 c_g (r_p / (4 h_k))^2 through the same mixing as the rotor thrusts, and a body-z
+// force -c_1 (r_p / (4 dz))^2 exp(-(dxy / (c_2 dz + c_3))^2 / 2) per drone of the same env above.  Spec-level, unpinned.
+template <typename T> struct EnvFx {
+  int gnd, dw;
+  T gnd_coeff, prop_radius, h_clip, dw1, dw2, dw3;
+  T prop_x[4], prop_y[4];          // propeller link origins, body frame
+};
+template <typename T>
+MDS_HD void ground_effect(const Consts<T>& c, const EnvFx<T>& fx, const State<T>& s, T world_z, const T rpm[4], T* thrust_excess, V3<T>* tau) {
+  const M3<T> R = quat_to_rot(s.q);
+  const V3<T> rpy = euler_from_quat(s.q);
+  if (!(m_abs(rpy.x) < T(1.57079632679489661923) && m_abs(rpy.y) < T(1.57079632679489661923))) return;
+  T g[4];
+  for (int k = 0; k < 4; ++k) {
+    const T h = m_max(world_z + R.m[6] * fx.prop_x[k] + R.m[7] * fx.prop_y[k], fx.h_clip);
+    const T ratio = fx.prop_radius / (T(4) * h);
+    g[k] = rpm[k] * rpm[k] * c.kf * fx.gnd_coeff * ratio * ratio;
+  }
+  *thrust_excess += (g[0] + g[1]) + (g[2] + g[3]);
+  if (c.cf2x) {
+    const T l = c.arm * T(0.70710678118654752440);
+    tau->x += l * ((g[0] + g[1]) - (g[2] + g[3]));
+    tau->y += l * ((g[1] + g[2]) - (g[0] + g[3]));
+  } else {
+    tau->x += c.arm * (g[1] - g[3]);
+    tau->y += c.arm * (g[2] - g[0]);
+  }
+}
+template <typename T> MDS_HD T downwash_pair(const EnvFx<T>& fx, V3<T> me, V3<T> other) {
+  const T dz = other.z - me.z, dx = other.x - me.x, dy = other.y - me.y;
+  const T dxy = m_sqrt(m_fma(dx, dx, dy * dy));
+  if (!(dz > T(0) && dxy < T(10))) return T(0);
+  const T ratio = fx.prop_radius / (T(4) * dz), beta = m_fma(fx.dw2, dz, fx.dw3), u = dxy / beta;
+  return -fx.dw1 * ratio * ratio * m_exp(T(-0.5) * u * u);
 }
 
 // classical RK4 on the 13-state (north_star integrator; qdot = 1/2 Lambda(omega) q)

@@ -21,7 +21,8 @@ from ..utils.enums import DroneModel, Physics
 __all__ = ["BaseAviary", "DroneModel", "Physics"]
 
 _PHYSICS_MAP = {Physics.DYN: capi.MDS_PHYSICS_DYN, Physics.PYB: capi.MDS_PHYSICS_DYN,
-                Physics.PYB_DRAG: capi.MDS_PHYSICS_DYN_DRAG}
+                Physics.PYB_DRAG: capi.MDS_PHYSICS_DYN_DRAG, Physics.PYB_GND: capi.MDS_PHYSICS_DYN_GND,
+                Physics.PYB_DW: capi.MDS_PHYSICS_DYN_DW, Physics.PYB_GND_DRAG_DW: capi.MDS_PHYSICS_DYN_GND_DRAG_DW}
 _MODEL_MAP = {DroneModel.CF2X: capi.MDS_CF2X, DroneModel.CF2P: capi.MDS_CF2P}
 
 
@@ -35,7 +36,8 @@ class BaseAviary:
 
     ``Physics.PYB`` (the reference's default, PIDEnv.py:19) is served by the explicit
     ``Physics.DYN`` rigid-body model -- there is no Bullet here; ``PYB_DRAG`` adds upstream's
-    ``_drag`` term.  Ground effect / downwash variants are not part of this hot path.
+    ``_drag`` term; ``PYB_GND`` / ``PYB_DW`` / ``PYB_GND_DRAG_DW`` add upstream's ``_groundEffect`` / ``_downwash`` as extra
+    terms of that model (``env.step(action)`` only: explicit Euler, f32 / f64; spec-level).
     """
 
     def __init__(self, drone_model: DroneModel = DroneModel.CF2X, num_drones: int = 1, neighbourhood_radius: float = np.inf,
@@ -51,7 +53,7 @@ class BaseAviary:
         if drone_model not in _MODEL_MAP:
             raise NotImplementedError(f"drone model {drone_model} (only CF2X / CF2P urdf constants are built in)")
         if physics not in _PHYSICS_MAP:
-            raise NotImplementedError(f"physics {physics}: ground effect / downwash are outside this hot path")
+            raise NotImplementedError(f"physics {physics}")
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("pyb_freq is not divisible by env_freq.")  # [UPSTREAM] BaseAviary.__init__
         if device is None:

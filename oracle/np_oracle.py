@@ -33,6 +33,12 @@ class DroneConsts:
     THRUST2WEIGHT: float = 2.25
     DRAG: tuple = (9.1785e-7, 9.1785e-7, 10.311e-7)
     MODEL: str = "cf2p"
+    # [UPSTREAM] cf2x.urdf / cf2p.urdf <properties>: ground effect and downwash
+    GND_EFF_COEFF: float = 11.36859
+    PROP_RADIUS: float = 2.31348e-2
+    DW_COEFF_1: float = 2267.18
+    DW_COEFF_2: float = .16
+    DW_COEFF_3: float = -.11
     GRAVITY: float = field(init=False)
     HOVER_RPM: float = field(init=False)
     MAX_RPM: float = field(init=False)
@@ -51,6 +57,13 @@ class DroneConsts:
         else:
             self.MAX_XY_TORQUE = self.L * self.KF * self.MAX_RPM ** 2
         self.MAX_Z_TORQUE = 2 * self.KM * self.MAX_RPM ** 2
+        self.GND_EFF_H_CLIP = 0.25 * self.PROP_RADIUS * np.sqrt((15 * self.MAX_RPM ** 2 * self.KF * self.GND_EFF_COEFF) / self.MAX_THRUST)
+
+    def prop_offsets(self):
+        """Propeller link origins in the body frame ([UPSTREAM] cf2p.urdf: arms along +-x / +-y at L; cf2x.urdf: (+-0.028, +-0.028))."""
+        if self.MODEL == "cf2x":
+            return np.array([[0.028, -0.028], [-0.028, -0.028], [-0.028, 0.028], [0.028, 0.028]])
+        return np.array([[self.L, 0.0], [0.0, self.L], [-self.L, 0.0], [0.0, -self.L]])
 
 
 CF2P = DroneConsts()
@@ -159,10 +172,13 @@ def euler_from_quat_bullet(q):
 # --------------------------------------------------------------------------------------
 
 
-def rotor_wrench(rpm, c: DroneConsts):
-    """[UPSTREAM] _dynamics: total thrust (body z) and body torques from 4 RPM."""
+def rotor_wrench(rpm, c: DroneConsts, extra_prop_force=None):
+    """[UPSTREAM] _dynamics: total thrust (body z) and body torques from 4 RPM.  ``extra_prop_force`` [.,4] (ground effect)
+    is added to the per-propeller thrusts before the mixing, not to the KM yaw torque."""
     rpm = np.asarray(rpm, dtype=np.float64)
     forces = rpm ** 2 * c.KF
+    if extra_prop_force is not None:
+        forces = forces + extra_prop_force
     thrust = forces[..., 0] + forces[..., 1] + forces[..., 2] + forces[..., 3]
     zt = rpm ** 2 * c.KM
     tz = -zt[..., 0] + zt[..., 1] - zt[..., 2] + zt[..., 3]
@@ -227,12 +243,44 @@ def drag_force_world(vel, rpm_prev, c: DroneConsts):
     return -np.asarray(c.DRAG) * s[..., None] * np.asarray(vel, dtype=np.float64)
 
 
-def dyn_step_euler(pos, quat, vel, rates, rpm, dt, c: DroneConsts, drag_rpm=None, wind=None):
+def ground_effect_forces(pos, quat, rpm, c: DroneConsts):
+    """[UPSTREAM] BaseAviary._groundEffect: per-propeller extra thrust KF rpm^2 GND_EFF_COEFF (PROP_RADIUS / (4 h_k))^2 with the
+    propeller heights h_k clipped from below at GND_EFF_H_CLIP, applied (in the propeller link frames, i.e. along body z) only
+    while |roll|, |pitch| < pi/2.  Upstream hands these to Bullet (PYB_GND); here they enter the DYN wrench -- spec-level."""
+    R = quat_to_rotmat_bullet(quat)
+    off = c.prop_offsets()                                             # [4,2] body x, y
+    h = pos[..., 2:3] + R[..., 2, 0:1] * off[:, 0] + R[..., 2, 1:2] * off[:, 1]
+    h = np.clip(h, c.GND_EFF_H_CLIP, np.inf)
+    g = np.asarray(rpm, dtype=np.float64) ** 2 * c.KF * c.GND_EFF_COEFF * (c.PROP_RADIUS / (4 * h)) ** 2
+    rpy = euler_from_quat_bullet(quat)
+    ok = (np.abs(rpy[..., 0]) < np.pi / 2) & (np.abs(rpy[..., 1]) < np.pi / 2)
+    return np.where(ok[..., None], g, 0.0)
+
+
+def downwash_force(pos, drones_per_env, c: DroneConsts):
+    """[UPSTREAM] BaseAviary._downwash: body-z force on drone i from every drone j of the same env above it,
+    -DW_COEFF_1 (PROP_RADIUS / (4 dz))^2 exp(-0.5 (dxy / (DW_COEFF_2 dz + DW_COEFF_3))^2), if dz > 0 and dxy < 10 m."""
+    n = pos.shape[0]
+    D = drones_per_env
+    p = pos.reshape(n // D, D, 3)
+    dz = p[:, None, :, 2] - p[:, :, None, 2]                           # [E, i, j] = z_j - z_i
+    dxy = np.linalg.norm(p[:, None, :, 0:2] - p[:, :, None, 0:2], axis=-1)
+    act = (dz > 0) & (dxy < 10)
+    dzs = np.where(act, dz, 1.0)
+    alpha = c.DW_COEFF_1 * (c.PROP_RADIUS / (4 * dzs)) ** 2
+    beta = c.DW_COEFF_2 * dzs + c.DW_COEFF_3
+    f = np.where(act, -alpha * np.exp(-0.5 * (dxy / beta) ** 2), 0.0)
+    return f.sum(axis=2).reshape(n)
+
+
+def dyn_step_euler(pos, quat, vel, rates, rpm, dt, c: DroneConsts, drag_rpm=None, wind=None, extra_prop_force=None, extra_body_z=None):
     """[UPSTREAM] BaseAviary._dynamics (Physics.DYN): explicit Euler on (v, omega),
     then p with the NEW v, q with the NEW omega.  ``drag_rpm`` (build extension
     DYN_DRAG) adds the _drag force computed from the previous clipped action."""
     R = quat_to_rotmat_bullet(quat)
-    thrust, torques = rotor_wrench(rpm, c)
+    thrust, torques = rotor_wrench(rpm, c, extra_prop_force)
+    if extra_body_z is not None:
+        thrust = thrust + extra_body_z
     force_w = R[..., :, 2] * thrust[..., None]          # R @ [0,0,thrust]
     force_w[..., 2] -= c.GRAVITY
     if drag_rpm is not None:
@@ -270,10 +318,11 @@ def dyn_step_rk4(pos, quat, vel, rates, rpm, dt, c: DroneConsts, drag_rpm=None):
 
 class AviaryOracle:
     """[UPSTREAM] CtrlAviary / BaseAviary state machine (step, obs packing), batched
-    over n drones.  physics in {"dyn", "dyn_drag"}, integrator in {"euler", "rk4"}."""
+    over n drones.  physics in {"dyn", "dyn_drag", "dyn_gnd", "dyn_dw", "dyn_gnd_drag_dw"}, integrator in {"euler", "rk4"}
+    (the ground-effect / downwash modes: Euler only; ``drones_per_env`` groups the drones that see each other's downwash)."""
 
     def __init__(self, init_xyzs, init_rpys, consts: DroneConsts = CF2P, pyb_freq=240, ctrl_freq=240,
-                 physics="dyn", integrator="euler"):
+                 physics="dyn", integrator="euler", drones_per_env=None):
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("pyb_freq must be a multiple of ctrl_freq")  # [UPSTREAM] BaseAviary.__init__
         self.c = consts
@@ -282,6 +331,7 @@ class AviaryOracle:
         self.PYB_TIMESTEP = 1.0 / pyb_freq
         self.CTRL_TIMESTEP = 1.0 / ctrl_freq
         self.physics, self.integrator = physics, integrator
+        self.drones_per_env = drones_per_env
         self.wind = None
         self.init_xyzs = np.array(init_xyzs, dtype=np.float64).reshape(-1, 3)
         self.init_rpys = np.array(init_rpys, dtype=np.float64).reshape(-1, 3)
@@ -307,8 +357,12 @@ class AviaryOracle:
         clipped = np.clip(np.asarray(action, dtype=np.float64).reshape(-1, 4), 0, self.c.MAX_RPM)
         stepf = dyn_step_euler if self.integrator == "euler" else dyn_step_rk4
         for _ in range(self.PYB_STEPS_PER_CTRL):
-            drag_rpm = self.last_clipped_action if self.physics == "dyn_drag" else None
+            drag_rpm = self.last_clipped_action if self.physics in ("dyn_drag", "dyn_gnd_drag_dw") else None
             kw = {"wind": self.wind} if (self.wind is not None and self.integrator == "euler") else {}
+            if self.physics in ("dyn_gnd", "dyn_gnd_drag_dw"):       # kinematic info as of the start of the substep ([UPSTREAM] step())
+                kw["extra_prop_force"] = ground_effect_forces(self.pos, self.quat, clipped, self.c)
+            if self.physics in ("dyn_dw", "dyn_gnd_drag_dw"):
+                kw["extra_body_z"] = downwash_force(self.pos, self.drones_per_env or self.pos.shape[0], self.c)
             self.pos, self.quat, self.vel, self.rates, self.ang_v = stepf(
                 self.pos, self.quat, self.vel, self.rates, clipped, self.PYB_TIMESTEP, self.c, drag_rpm, **kw)
             self.last_clipped_action = clipped

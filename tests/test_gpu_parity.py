@@ -496,3 +496,42 @@ def test_obs_to_model_adapters(mds, dtype, atol):
     with pytest.raises(ValueError):
         obs_to_lin_model(obs, 9)
     env.close()
+
+
+@pytest.mark.parametrize("physics,name", [("PYB_GND", "dyn_gnd"), ("PYB_DW", "dyn_dw"), ("PYB_GND_DRAG_DW", "dyn_gnd_drag_dw")])
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-10), ("float32", 3e-5)])
+def test_ground_effect_and_downwash_match_oracle(mds, physics, name, dtype, tol):
+    """[UPSTREAM] _groundEffect / _downwash as extra terms of the DYN step (env.step only): envs of 5 drones stacked above
+    each other near the ground, 3 physics substeps per control step (env-mates' positions refresh between substeps), CF2P and
+    CF2X propeller geometry, one drone rolled past 90 degrees (ground effect off there).  Spec-level: oracle == kernel."""
+    for model, consts in ((mds.DroneModel.CF2P, O.CF2P), (mds.DroneModel.CF2X, O.CF2X)):
+        E, D = 7, 5
+        rng = np.random.default_rng(9)
+        xyz = np.zeros((E, D, 3))
+        xyz[..., 0:2] = rng.normal(size=(E, D, 2)) * 0.05
+        xyz[..., 2] = 0.03 + 0.35 * np.arange(D) + rng.uniform(0, 0.02, size=(E, D))
+        rpy = rng.uniform(-0.3, 0.3, size=(E, D, 3))
+        rpy[0, 1, 0] = 1.8                                                     # |roll| > pi/2
+        env = mds.CtrlAviary(drone_model=model, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=getattr(mds.Physics, physics),
+                             pyb_freq=300, ctrl_freq=100, num_envs=E, dtype=dtype)
+        ora = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), consts, 300, 100, physics=name, drones_per_env=D)
+        ph = rng.uniform(0, 2 * np.pi, size=(E * D, 4))
+        ph[:, 1:] = rng.uniform(-1, 1, size=(E * D, 3))
+        for k in range(40):
+            a = H.open_loop_rpm(k, 0.01, ph, hover=consts.HOVER_RPM)
+            obs, *_ = env.step(mds.torch.tensor(a.reshape(E, D, 4), dtype=env.dtype, device=env.device))
+            oobs = ora.step(a)
+        g = np_obs(obs)
+        assert np.abs(g[:, :16] - oobs[:, :16]).max() < tol * max(1.0, np.abs(oobs[:, :16]).max())
+        plain = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), consts, 300, 100, physics="dyn")
+        for k in range(40):
+            pobs = plain.step(H.open_loop_rpm(k, 0.01, ph, hover=consts.HOVER_RPM))
+        assert np.abs(pobs[:, 2] - oobs[:, 2]).max() > 0.01                     # the effects are doing something in this scene
+        env.set_trajectories(np.tile(np.array([1.0, 1.0, 0, 0, 1.0, 0, 0]), (E, D, 1)))
+        with pytest.raises(RuntimeError):                                       # served by env.step only
+            env.step_geometric(0.0)
+        np.testing.assert_allclose(env.get_state()[..., 0:3].reshape(-1, 3), g[:, 0:3], atol=tol * 10)   # double-buffer bookkeeping
+        env.close()
+    with pytest.raises(RuntimeError):
+        mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=2, initial_xyzs=np.zeros((2, 3)), initial_rpys=np.zeros((2, 3)),
+                       physics=mds.Physics.PYB_DW, pyb_freq=100, ctrl_freq=100, integrator="rk4")
