@@ -153,6 +153,8 @@ def main(argv=None):
                          "every step's obs streamed to a [T,n,20] log) instead of one launch per step")
     ap.add_argument("--python-loop", action="store_true", help="issue each step from Python (env.step_geometric) instead of the C rollout loop")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU tests of the N>1 path")
+    ap.add_argument("--gather-obs", action="store_true",
+                    help="after the timed region, also time the optional whole-swarm observation all-gather (RCCL over xGMI); never part of `value`")
     args = ap.parse_args(argv)
 
     E, D, phase, desc = WORKLOADS[args.workload]
@@ -166,8 +168,14 @@ def main(argv=None):
         time.sleep(0.01 * (rank + 1))          # stand-in work; the slowest rank defines the time
         barrier(world)
         elapsed = max_over_ranks(time.perf_counter() - t0, world, device)
+        gathered = None
+        if args.gather_obs:                    # the optional swarm all-gather, on CPU tensors over gloo
+            from multidronesim_amd.swarm import all_gather_observations
+            mine = torch.full((3, 2, 20), float(rank))
+            g = all_gather_observations(mine)
+            gathered = [int(g.shape[0]), [float(g[3 * r, 0, 0]) for r in range(world)]]
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "elapsed": elapsed, "ranks_seen": world}))
+            print(json.dumps({"dry_run": True, "n_gpus": world, "elapsed": elapsed, "ranks_seen": world, "gathered": gathered}))
         if world > 1:
             torch.distributed.destroy_process_group()
         return 0
@@ -362,6 +370,23 @@ def main(argv=None):
                                  "bound": "VALU (state in registers; only the obs log leaves the chip)",
                                  "kernel": "k_rollout_geometric<float,float,false,false>"}
         del log2
+    if args.gather_obs and world > 1:      # optional whole-swarm observation packing; outside `value`
+        from multidronesim_amd.swarm import all_gather_observations
+        mine = obs.reshape(E, D, 20).contiguous()
+        buf = torch.empty((world * E, D, 20), dtype=mine.dtype, device=device)
+        for _ in range(3):
+            all_gather_observations(mine, buf)
+        torch.cuda.synchronize(device)
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record(torch.cuda.current_stream(device))
+        for _ in range(20):
+            all_gather_observations(mine, buf)
+        g1.record(torch.cuda.current_stream(device))
+        torch.cuda.synchronize(device)
+        ms = max_over_ranks(g0.elapsed_time(g1) / 20, world, device)
+        line["obs_allgather"] = {"ms": ms, "bytes_per_rank": mine.numel() * mine.element_size(), "backend": "nccl (RCCL)",
+                                 "bus_GBps": mine.numel() * mine.element_size() * (world - 1) / (ms * 1e-3) / 1e9}
+        del buf
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload not in ("c4", "c5"):
         line["cpu_baseline"] = cpu_baseline(D, phase, args.cpu_budget)
     elif rank == 0:

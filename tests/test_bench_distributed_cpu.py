@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_two_rank_gloo_dry_run():
     env = dict(os.environ, PYTHONPATH=ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu"]
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--gather-obs"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -22,6 +22,7 @@ def test_two_rank_gloo_dry_run():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2
     assert rec["elapsed"] >= 0.02               # the slower rank (sleeps 20 ms) defines the time
+    assert rec["gathered"] == [6, [0.0, 1.0]]   # optional swarm all-gather: rank-major env order, every rank's block present
 
 
 def test_each_rank_gets_different_envs_and_same_shape():
