@@ -179,3 +179,26 @@ def test_simulation_mirrors_set_up_on_cpu_and_need_the_gpu_to_run():
             geo.create_env()
         with pytest.raises(MdsError):
             CBFTestOrd3.GeometricEnv(CBFTestOrd3.parse_args([]), init_type="lemniscate")       # evaluates a trajectory: device work
+
+
+def test_library_is_plain_c_abi_without_torch(lib):
+    """The drop-in boundary is a C-ABI shared object: it links the HIP runtime and the C/C++ runtimes, nothing of PyTorch,
+    and exports unmangled mds_* entry points only (plus compiler-generated HIP registration symbols)."""
+    import subprocess
+    out = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
+    deps = " ".join(l.split()[0] for l in out.splitlines() if l.strip())          # library names only (addresses are hex noise)
+    assert "libamdhip64" in deps
+    assert "torch" not in deps and "c10" not in deps and "python" not in deps.lower()
+    syms = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = [l.split()[-1] for l in syms.splitlines() if " T " in l]
+    api = [n for n in exported if n.startswith("mds_")]
+    assert sorted(api) == header_symbols()
+
+
+def test_create_rejects_more_than_2_30_drones(lib):
+    cfg = capi.MdsConfig()
+    lib.mds_default_config(capi.MDS_CF2P, C.byref(cfg))
+    cfg.num_envs, cfg.num_drones = 1 << 20, 1 << 11
+    h = C.c_void_p()
+    assert lib.mds_create(C.byref(cfg), C.byref(h)) == -1 and not h.value
+    assert b"too many" in lib.mds_last_error()
