@@ -6,16 +6,10 @@ from .base import KIND_CIRCLE, TrajectoryBase, segment_row
 
 class CircleTrajectory(TrajectoryBase):
     def __init__(self, r=1.0, v=.5, center=np.array([0, 0, 0]), yaw_rate=0, revolutions=None, duration=None):
-        self.r = float(r)
-        self.v = float(v)
+        self.r, self.v, self.yaw_rate = float(r), float(v), float(yaw_rate)
         self.center = center
-        self.yaw_rate = float(yaw_rate)
-        if revolutions is not None:
-            self.total_time = 2 * r * np.pi * revolutions / self.v
-        elif duration is not None:
-            self.total_time = duration
-        else:
-            self.total_time = 2 * np.pi * self.r / self.v
+        lap = 2 * np.pi * self.r / self.v                  # one revolution at speed v
+        self.total_time = lap * revolutions if revolutions is not None else (duration if duration is not None else lap)
 
     def get_total_time(self):
         return self.total_time

@@ -7,20 +7,17 @@ from .base import TrajectoryBase
 
 class CompoundTrajectory(TrajectoryBase):
     def __init__(self, trajectories: list):
-        self.trajectories = trajectories
-        self.total_time = sum([t.get_total_time() for t in trajectories])
-        self.times = np.cumsum([t.get_total_time() for t in trajectories])
-        self.trajectory_index = 0
-        self.current_trajectory = self.trajectories[0]
-        self.current_trajectory_time = 0
+        self.trajectories = list(trajectories)
+        durations = [float(tr.get_total_time()) for tr in self.trajectories]
+        self.times = np.cumsum(durations)                 # end time of every piece
+        self.total_time = float(self.times[-1])
 
     def get_total_time(self):
         return self.total_time
 
     def reset(self):
-        self.trajectory_index = 0
-        self.current_trajectory = self.trajectories[0]
-        self.current_trajectory_time = 0
+        """The reference keeps a playback cursor and rewinds it here; the GPU lookup is stateless."""
+        return None
 
     def _segments(self):
         rows, t0 = [], 0.0

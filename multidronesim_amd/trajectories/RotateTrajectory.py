@@ -7,13 +7,14 @@ from .base import TrajectoryBase
 
 class RotateTrajectory(TrajectoryBase):
     def __init__(self, trajectory: TrajectoryBase, R: np.ndarray, center: np.ndarray):
-        self.trajectory = trajectory
-        self.total_time = trajectory.get_total_time()
-        self.R = R
-        self.center = center
+        self.trajectory, self.R, self.center = trajectory, R, center
+
+    @property
+    def total_time(self):
+        return self.trajectory.get_total_time()
 
     def get_total_time(self):
-        return self.trajectory.get_total_time()
+        return self.total_time
 
     def _segments(self):
         rows, compound = self.trajectory._segments()
