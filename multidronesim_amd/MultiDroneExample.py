@@ -26,21 +26,29 @@ DEFAULT_OUTPUT_FOLDER = 'results'
 DEFAULT_NUM_DRONES = 2
 
 
+# flag, default, type, help -- the reference's flags (:27-53) followed by the two this package adds
+_FLAGS = (
+    ("drone", DEFAULT_DRONES, DroneModel, "drone model (cf2p / cf2x)"),
+    ("num_drones", DEFAULT_NUM_DRONES, int, "drones per env"),
+    ("physics", DEFAULT_PHYSICS, Physics, "physics mode"),
+    ("gui", DEFAULT_GUI, str2bool, "accepted for compatibility (there is no GUI)"),
+    ("plot", DEFAULT_PLOT, str2bool, "accepted for compatibility"),
+    ("user_debug_gui", DEFAULT_USER_DEBUG_GUI, str2bool, "accepted for compatibility"),
+    ("simulation_freq_hz", DEFAULT_SIMULATION_FREQ_HZ, int, "physics rate"),
+    ("control_freq_hz", DEFAULT_CONTROL_FREQ_HZ, int, "control rate"),
+    ("duration_sec", DEFAULT_DURATION_SEC, int, "simulated seconds"),
+    ("output_folder", DEFAULT_OUTPUT_FOLDER, str, "kept for compatibility (nothing is logged to disk)"),
+    ("init_rad", 1.0, float, "radius of the start circle"),
+    ("num_envs", 1, int, "independent copies of the scene stepped together"),
+    ("realtime", True, str2bool, "throttle to the wall clock and render like the reference"),
+)
+
+
 def parse_args(argv=None):
-    parser = argparse.ArgumentParser(description='Multi-drone hover example (batched MI355X step)')
-    parser.add_argument('--drone', default=DEFAULT_DRONES, type=DroneModel, help='Drone model', metavar='', choices=DroneModel)
-    parser.add_argument('--num_drones', default=DEFAULT_NUM_DRONES, type=int, help='Number of drones', metavar='')
-    parser.add_argument('--physics', default=DEFAULT_PHYSICS, type=Physics, help='Physics updates', metavar='', choices=Physics)
-    parser.add_argument('--gui', default=DEFAULT_GUI, type=str2bool, help='accepted for compatibility (no GUI here)', metavar='')
-    parser.add_argument('--plot', default=DEFAULT_PLOT, type=str2bool, help='accepted for compatibility', metavar='')
-    parser.add_argument('--user_debug_gui', default=DEFAULT_USER_DEBUG_GUI, type=str2bool, help='accepted for compatibility', metavar='')
-    parser.add_argument('--simulation_freq_hz', default=DEFAULT_SIMULATION_FREQ_HZ, type=int, help='Simulation frequency in Hz', metavar='')
-    parser.add_argument('--control_freq_hz', default=DEFAULT_CONTROL_FREQ_HZ, type=int, help='Control frequency in Hz', metavar='')
-    parser.add_argument('--duration_sec', default=DEFAULT_DURATION_SEC, type=int, help='Duration of the simulation in seconds', metavar='')
-    parser.add_argument('--output_folder', default=DEFAULT_OUTPUT_FOLDER, type=str, help='Folder where to save logs', metavar='')
-    parser.add_argument('--init_rad', default=1.0, type=float, help='Initial radius of the drones', metavar='')
-    parser.add_argument('--num_envs', default=1, type=int, help='independent copies of the scene stepped together', metavar='')
-    parser.add_argument('--realtime', default=True, type=str2bool, help='throttle to wall-clock and render like the reference', metavar='')
+    parser = argparse.ArgumentParser(description="Multi-drone hover example on the batched MI355X step")
+    for flag, default, kind, text in _FLAGS:
+        extra = {"choices": kind} if kind in (DroneModel, Physics) else {}
+        parser.add_argument("--" + flag, default=default, type=kind, help=text, metavar="", **extra)
     return parser.parse_args(argv)
 
 

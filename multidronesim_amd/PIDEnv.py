@@ -36,28 +36,20 @@ DEFAULT_NUM_DRONES = 2
 
 class MultiDroneEnv(object):
     def build_args(self, kwargs):
-        args = {}
-        args['drone'] = DEFAULT_DRONES
-        args['num_drones'] = DEFAULT_NUM_DRONES
-        args['physics'] = DEFAULT_PHYSICS
-        args['gui'] = DEFAULT_GUI
-        args['plot'] = DEFAULT_PLOT
-        args['user_debug_gui'] = DEFAULT_USER_DEBUG_GUI
-        args['simulation_freq_hz'] = DEFAULT_SIMULATION_FREQ_HZ
-        args['control_freq_hz'] = DEFAULT_CONTROL_FREQ_HZ
-        args['duration_sec'] = None
-        args['output_folder'] = DEFAULT_OUTPUT_FOLDER
-        args['init_rad'] = 1.0
-        args['num_envs'] = 1          # batch axis (build extension)
-        args['realtime'] = True       # sync() to wall-clock like the reference (PIDEnv.py:179)
-        args['controller'] = 'dslpid' # 'dslpid' (PIDEnv.py:124-134) or 'geometric'
-        for key, value in kwargs.items():
-            if key in args:
-                args[key] = value
-            else:
-                logging.warning(f"Skipping invalid argument: {key} in creation of MultiDroneEnv,"
-                                f" must be from list {args.keys()}")
-        return argparse.Namespace(**args)
+        """Keyword arguments -> the argparse-style namespace the rest of the class reads (unknown keys are reported and
+        dropped, as the reference does).  ``num_envs`` / ``realtime`` / ``controller`` are additions of this package."""
+        defaults = dict(drone=DEFAULT_DRONES, num_drones=DEFAULT_NUM_DRONES, physics=DEFAULT_PHYSICS, gui=DEFAULT_GUI, plot=DEFAULT_PLOT,
+                        user_debug_gui=DEFAULT_USER_DEBUG_GUI, simulation_freq_hz=DEFAULT_SIMULATION_FREQ_HZ,
+                        control_freq_hz=DEFAULT_CONTROL_FREQ_HZ, duration_sec=DEFAULT_DURATION_SEC, output_folder=DEFAULT_OUTPUT_FOLDER,
+                        init_rad=1.0,
+                        num_envs=1,            # batch axis
+                        realtime=True,         # sync() to the wall clock like the reference (PIDEnv.py:179)
+                        controller='dslpid')   # 'dslpid' (PIDEnv.py:124-134) or 'geometric'
+        unknown = sorted(set(kwargs) - set(defaults))
+        if unknown:
+            logging.warning("MultiDroneEnv: ignoring unknown argument(s) %s; known: %s", unknown, sorted(defaults))
+        defaults.update({k: v for k, v in kwargs.items() if k in defaults})
+        return argparse.Namespace(**defaults)
 
     def __init__(self, INIT_XYZS=None, INIT_RPYS=None, TARGET_POSITIONS=None, TARGET_RPYS=None, args=None, **kwargs):
         self.args = self.build_args(kwargs) if args is None else args
