@@ -642,7 +642,7 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
       if (has_z && lane < n) su[lane] = m_fma(-t, zv, my_u);
       if (lane < q) slam[lane] = m_fma(-t, rc, my_lam);
       lam_new += t;
-      MDS_WAVE_SYNC();
+      if (!full) MDS_WAVE_SYNC();                                                        // the drop path reads slam / sact next; the add path only writes
       if (full) {                                                                        // add: N <- [N a]
         const T inz = m_rsqrt(zz), nz = zz * inz;
         if (lane < n) sQ[lane][q] = zv * inz;
