@@ -174,7 +174,7 @@ int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs_dev, 
 /* The same n_steps control steps in ONE kernel launch: state and trajectory parameters stay in
  * registers between steps; every step's observation is streamed to obs_log_dev [n_steps, n, 20]
  * (the reference's `observations.append(obs)` -> np.save, EnvGeometric.py:471,553) when it is not
- * NULL; obs_last_dev [n,20] (or NULL) receives the final observation.  Same arithmetic as n_steps
+ * NULL; obs_last_dev [n,20] (or NULL) receives the final observation.  Lemniscate planes or segment tables.  Same arithmetic as n_steps
  * calls of mds_step_geometric (results agree to rounding: the two kernels may contract FMAs differently). */
 int mds_rollout_geometric_fused(mds_handle* h, double t0, int n_steps, void* obs_log_dev, void* obs_last_dev, void* stream);
 

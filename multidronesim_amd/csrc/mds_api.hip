@@ -576,7 +576,6 @@ static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, v
   if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h || n_steps < 0) return fail(MDS_EINVAL, who);
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_rollout_*_fused: call mds_set_lemniscate first");
-  if (h->traj_mode != 1) return fail(MDS_EUNSUPPORTED, "mds_rollout_*_fused: Lemniscate trajectories only (use mds_rollout_geometric / mds_step_lqr)");
   if (lqr && !h->has_lqr12) return fail(MDS_ESTATE, "mds_rollout_lqr_fused: call mds_set_lqr_gain first");
   if (!aligned16(obs_log) || !aligned16(obs_last)) return fail(MDS_EALIGN, "mds_rollout_*_fused: obs buffers");
   if (n_steps == 0) return MDS_OK;
@@ -593,16 +592,26 @@ static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, v
   MDS_DISPATCH(h, (k_rollout_geometric<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, (const Lqr12Gain<T>*)h->lqr12_dev, h->n, h->ld, t0, dt, \
                                                                                        n_steps, (S*)h->state, (const T*)h->lem,       \
                                                                                        (T*)rpm_track(h), (S*)obs_log, (S*)obs_last)))
-#define MDS_ROLL_C(CTRL)                         \
-  do {                                           \
-    if (rk4 && drag) MDS_ROLL(true, true, CTRL);     \
-    else if (rk4) MDS_ROLL(true, false, CTRL);       \
-    else if (drag) MDS_ROLL(false, true, CTRL);      \
-    else MDS_ROLL(false, false, CTRL);               \
+#define MDS_ROLLT(RK4, DRAG, CTRL)                                                                                                 \
+  MDS_DISPATCH(h, (k_rollout_traj<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, (const Lqr12Gain<T>*)h->lqr12_dev, h->n, h->ld, t0, dt,   \
+                                                                                  n_steps, (S*)h->state, (const T*)h->origin, h->segs, \
+                                                                                  h->tinfo, (T*)rpm_track(h), (S*)obs_log, (S*)obs_last)))
+#define MDS_ROLL_C(CTRL)                                                    \
+  do {                                                                      \
+    if (h->traj_mode == 2) {   /* general trajectories: segment tables */   \
+      if (rk4 && drag) MDS_ROLLT(true, true, CTRL);                         \
+      else if (rk4) MDS_ROLLT(true, false, CTRL);                           \
+      else if (drag) MDS_ROLLT(false, true, CTRL);                          \
+      else MDS_ROLLT(false, false, CTRL);                                   \
+    } else if (rk4 && drag) MDS_ROLL(true, true, CTRL);                     \
+    else if (rk4) MDS_ROLL(true, false, CTRL);                              \
+    else if (drag) MDS_ROLL(false, true, CTRL);                             \
+    else MDS_ROLL(false, false, CTRL);                                      \
   } while (0)
   if (lqr) MDS_ROLL_C(1);
   else MDS_ROLL_C(0);
 #undef MDS_ROLL_C
+#undef MDS_ROLLT
 #undef MDS_ROLL
   MDS_HIP(hipGetLastError());
   return MDS_OK;

@@ -494,6 +494,62 @@ __global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c,
   }
 }
 
+// The same whole-rollout loop for general trajectories (segment tables, evaluated in double every step like k_step_traj).
+template <typename T, typename S, bool RK4, bool DRAG, int CTRL>
+__global__ __launch_bounds__(kBlock) void k_rollout_traj(const Consts<T> c, const Lqr12Gain<T>* __restrict__ Kp, const int n, const size_t ld, double t,
+                                                         const double ctrl_dt, const int n_steps, S* __restrict__ state,
+                                                         const T* __restrict__ origin, const double* __restrict__ segs,
+                                                         const int* __restrict__ tinfo, T* __restrict__ last_rpm,
+                                                         S* __restrict__ obs_log, S* __restrict__ obs_last) {
+  __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = i < n;
+  State<T> s;
+  V3<T> org = {T(0), T(0), T(0)};
+  int first = 0, info = 0;
+  T prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4] = {T(0), T(0), T(0), T(0)};
+  if (valid) {
+    load_state<S, T>(state, ld, i, s);
+    org = {origin[i], origin[ld + i], origin[2 * ld + i]};
+    first = tinfo[2 * i];
+    info = tinfo[2 * i + 1];
+    if (DRAG)
+      for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
+  }
+  for (int k = 0; k < n_steps; ++k) {
+    T o[kObsDim];
+    const bool want = obs_log != nullptr || (obs_last != nullptr && k == n_steps - 1);
+    if (valid) {
+      double d11[11];
+      traj_eval(segs, first, info & 0xffff, info >> 16, t, d11);
+      Desired<T> des;
+      des.p = {(T)(d11[0] - (double)org.x), (T)(d11[1] - (double)org.y), (T)(d11[2] - (double)org.z)};
+      des.v = {(T)d11[3], (T)d11[4], (T)d11[5]};
+      des.a = {(T)d11[6], (T)d11[7], (T)d11[8]};
+      des.yaw = reduced_phase<T>(0.0, T(0), (T)d11[9]);
+      des.yaw_rate = (T)d11[10];
+      T u[4], act[4];
+      if (CTRL == 0) {
+        const M3<T> R = quat_to_rot(s.q);
+        geometric_control<T>(c, s.p - des.p, R, s.v, mul(R, s.w), des, u, nullptr);
+      } else {
+        lqr12_control<T>(c, *Kp, euler_from_quat(s.q), quat_rotate(s.q, s.w), s.v, s.p - des.p, des.v, des.yaw, des.yaw_rate, u);
+      }
+      input_to_action(c, u, act);
+      aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
+      if (want) pack_obs(s, org, clipped, o);
+    }
+    if (obs_log != nullptr) write_obs_rows<S, T>(lds, obs_log + (size_t)k * n * kObsDim, n, i, valid, o);
+    if (obs_last != nullptr && k == n_steps - 1) write_obs_rows<S, T>(lds, obs_last, n, i, valid, o);
+    t += ctrl_dt;
+  }
+  if (valid) {
+    store_state<S, T>(state, ld, i, s);
+    if (DRAG || (last_rpm && n_steps > 0))
+      for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = DRAG ? prev[k] : clipped[k];
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // CBF-filtered control step (simulations/CBFTest.py:303-350) = three launches:
 //   k_cbf_nominal    per drone : trajs[j](t), GeometricControl.compute(return_omegas) ->

@@ -72,7 +72,6 @@ class GeometricEnv:
         self.wind_force = wind_force
         self._use_noisy_model = False
         self._step = None
-        self._all_lemniscate = False
         if circle_init:
             self.starting_target_offset = 1
             self.circle_initialize()
@@ -111,7 +110,6 @@ class GeometricEnv:
             trajs = [WaitTrajectory(duration=float(args.duration_sec), position=self.TARGET_POSITIONS[j], yaw=self.TARGET_RPYS[j, 2])  # noqa: F405
                      for j in range(args.num_drones)]
         env.set_trajectories(list(trajs))
-        self._all_lemniscate = all(type(tr) is Lemniscate for tr in trajs)   # noqa: F405  -> the whole loop can be ONE kernel launch
         shape = (env.NUM_ENVS, env.NUM_DRONES, 4)
         env.step(torch.zeros(shape, dtype=env.dtype, device=env.device))              # :431
         return int(args.duration_sec * env.CTRL_FREQ)
@@ -140,16 +138,10 @@ class GeometricEnv:
                 sync(i, START, env.CTRL_TIMESTEP)
         else:                             # the same loop on the device, observations logged there
             log = torch.empty((steps, env.NUM_ENVS, env.NUM_DRONES, 20), dtype=env.dtype, device=env.device)
-            if self._all_lemniscate:      # state in registers for the whole run, one launch (mds_rollout_*_fused)
-                env.rollout_geometric_fused(0.0, steps, log=True, log_out=log, controller=args_controller)
-                for i in range(steps):
-                    self.obs_ts.append(t)
-                    t += env.CTRL_TIMESTEP
-            else:                         # general trajectories: one fused launch per control step
-                for i in range(steps):
-                    log[i].copy_(self._step(t))
-                    self.obs_ts.append(t)
-                    t += env.CTRL_TIMESTEP
+            env.rollout_geometric_fused(0.0, steps, log=True, log_out=log, controller=args_controller)   # one launch: state in registers
+            for i in range(steps):
+                self.obs_ts.append(t)
+                t += env.CTRL_TIMESTEP
             o = log.double().cpu().numpy()
             self.observations.extend(list(o[:, 0] if env.NUM_ENVS == 1 else o))
             self.obs = self.observations[-1]

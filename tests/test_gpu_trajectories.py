@@ -72,7 +72,42 @@ def test_fused_step_on_segment_tables_matches_oracle(dtype, tol):
     assert err["rotate"] < tol * 500, err
     o2 = env.rollout_geometric(t, 10)                       # the C loop also runs the general kernel
     assert np.isfinite(o2.double().cpu().numpy()).all()
-    from multidronesim_amd import MdsError
-    with pytest.raises(MdsError):
-        env.rollout_geometric_fused(t, 5)                   # multi-step kernel is Lemniscate-only
+    o3, _ = env.rollout_geometric_fused(t + 10 * env.CTRL_TIMESTEP, 5)   # and so does the multi-step kernel (k_rollout_traj)
+    assert np.isfinite(o3.double().cpu().numpy()).all()
     env.close()
+
+
+def test_whole_rollout_on_segment_tables_equals_stepwise():
+    """mds_rollout_geometric_fused on general trajectories (k_rollout_traj): T steps in one launch == T mds_step_geometric calls."""
+    import torch
+    from multidronesim_amd.envs.CtrlAviary import CtrlAviary, DroneModel, Physics
+    from multidronesim_amd import trajectories as TR
+    E, D, T = 9, 3, 150
+    rng = np.random.default_rng(2)
+    xyz = rng.uniform(-0.5, 0.5, size=(E, D, 3)) + np.array([0, 0, 1.0])
+    def trajs():
+        out = []
+        for e in range(E):
+            for d in range(D):
+                a = xyz[e, d]
+                out.append(TR.CompoundTrajectory([TR.LineTrajectory(start=a, end=a + np.array([0.4, -0.2, 0.3]), speed=0.6),
+                                                  TR.WaitTrajectory(duration=0.3, position=a + np.array([0.4, -0.2, 0.3]), yaw=0.2),
+                                                  TR.CircleTrajectory(r=0.3, v=0.5, center=a + np.array([0.4, -0.5, 0.3]), yaw_rate=0.3)]))
+        return out
+    envs = []
+    for _ in range(2):
+        env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=np.zeros((E, D, 3)), physics=Physics.DYN,
+                         pyb_freq=200, ctrl_freq=100, num_envs=E, dtype="float64")
+        env.set_trajectories(trajs())
+        env.step(torch.zeros((E, D, 4), dtype=env.dtype))
+        envs.append(env)
+    a, b = envs
+    last, log = a.rollout_geometric_fused(0.0, T, log=True)
+    t = 0.0
+    for k in range(T):
+        o = b.step_geometric(t)
+        t += b.CTRL_TIMESTEP
+        if k in (0, 70, T - 1):
+            np.testing.assert_allclose(log[k].cpu().numpy(), o.cpu().numpy(), atol=1e-9)
+    np.testing.assert_allclose(a.get_state(), b.get_state(), atol=1e-9)
+    a.close(); b.close()
