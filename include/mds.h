@@ -319,6 +319,9 @@ int mds_step_cbf_geometric(mds_handle* h, double t, void* obs_dev, int32_t* stat
  * ThrustOmegaController) and simulations/EnvGeometricYankOmega.py:319,332 (LQRYankOmegaController + YankOmegaController).
  * obs_dev as for mds_step_cbf_geometric. */
 int mds_step_nominal(mds_handle* h, double t, void* obs_dev, void* action_dev, void* stream);
+/* n_steps of that loop in ONE launch (Lemniscate trajectories; the low level's PID memory stays in registers): obs_log_dev
+ * [n_steps, n, 20] or NULL; obs_dev [n,20] holds the current observation on entry and the last one on return. */
+int mds_rollout_nominal_fused(mds_handle* h, double t0, int n_steps, void* obs_log_dev, void* obs_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -572,28 +572,41 @@ int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs, int 
   return MDS_OK;
 }
 
-static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream, bool lqr, const char* who) {
+// ctrl: 0 GeometricControl, 1 LQRController (12-state), 2 LQROmegaController + ThrustOmega, 3 LQRYankOmegaController + YankOmega
+static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream, int ctrl, const char* who) {
   if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h || n_steps < 0) return fail(MDS_EINVAL, who);
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_rollout_*_fused: call mds_set_lemniscate first");
+  const bool lqr = ctrl == 1;
   if (lqr && !h->has_lqr12) return fail(MDS_ESTATE, "mds_rollout_lqr_fused: call mds_set_lqr_gain first");
+  if (ctrl >= 2) {
+    if (h->traj_mode != 1) return fail(MDS_EUNSUPPORTED, "mds_rollout_nominal_fused: Lemniscate trajectories only (use mds_step_nominal)");
+    if (h->cfg.dtype == MDS_F16) return fail(MDS_EUNSUPPORTED, "mds_rollout_nominal_fused: fp16 storage");
+    if (!obs_last) return fail(MDS_EINVAL, "mds_rollout_nominal_fused: obs_dev is required (in: current observation, out: last one)");
+  }
   if (!aligned16(obs_log) || !aligned16(obs_last)) return fail(MDS_EALIGN, "mds_rollout_*_fused: obs buffers");
   if (n_steps == 0) return MDS_OK;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid = grid_for(h->n, kBlock);
   const double dt = 1.0 / h->cfg.ctrl_freq;
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
-  if (lqr) {   // the gain (48 values) lives in device memory for this kernel: passing it by value would not fit beside Consts in SGPRs
-    if (!h->lqr12_dev) MDS_HIP(hipMalloc(&h->lqr12_dev, sizeof(Lqr12Gain<double>)));
-    if (h->cfg.dtype == MDS_F64) MDS_HIP(hipMemcpyAsync(h->lqr12_dev, &h->lqr12_d, sizeof(h->lqr12_d), hipMemcpyHostToDevice, st));
-    else MDS_HIP(hipMemcpyAsync(h->lqr12_dev, &h->lqr12_f, sizeof(h->lqr12_f), hipMemcpyHostToDevice, st));
+  if (ctrl >= 1) {   // the gain lives in device memory for this kernel: passing it by value would not fit beside Consts in SGPRs
+    if (!h->lqr12_dev) MDS_HIP(hipMalloc(&h->lqr12_dev, sizeof(Lqr12Gain<double>)));   // the largest of the three gain structs
+    const bool f64 = h->cfg.dtype == MDS_F64;
+    const void* src = ctrl == 1 ? (f64 ? (const void*)&h->lqr12_d : (const void*)&h->lqr12_f)
+                    : ctrl == 2 ? (f64 ? (const void*)&h->lqr_d : (const void*)&h->lqr_f)
+                                : (f64 ? (const void*)&h->lqr_yo_d : (const void*)&h->lqr_yo_f);
+    const size_t bytes = ctrl == 1 ? (f64 ? sizeof(h->lqr12_d) : sizeof(h->lqr12_f))
+                       : ctrl == 2 ? (f64 ? sizeof(h->lqr_d) : sizeof(h->lqr_f)) : (f64 ? sizeof(h->lqr_yo_d) : sizeof(h->lqr_yo_f));
+    MDS_HIP(hipMemcpyAsync(h->lqr12_dev, src, bytes, hipMemcpyHostToDevice, st));
   }
 #define MDS_ROLL(RK4, DRAG, CTRL)                                                                                                  \
-  MDS_DISPATCH(h, (k_rollout_geometric<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, (const Lqr12Gain<T>*)h->lqr12_dev, h->n, h->ld, t0, dt, \
+  MDS_DISPATCH(h, (k_rollout_geometric<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, h->lqr12_dev, h->n, h->ld, t0, dt,              \
                                                                                        n_steps, (S*)h->state, (const T*)h->lem,       \
-                                                                                       (T*)rpm_track(h), (S*)obs_log, (S*)obs_last)))
+                                                                                       (T*)rpm_track(h), (S*)obs_log, (S*)obs_last,   \
+                                                                                       (T*)h->ll, (const S*)obs_last)))
 #define MDS_ROLLT(RK4, DRAG, CTRL)                                                                                                 \
-  MDS_DISPATCH(h, (k_rollout_traj<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, (const Lqr12Gain<T>*)h->lqr12_dev, h->n, h->ld, t0, dt,   \
+  MDS_DISPATCH(h, (k_rollout_traj<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, h->lqr12_dev, h->n, h->ld, t0, dt,                        \
                                                                                   n_steps, (S*)h->state, (const T*)h->origin, h->segs, \
                                                                                   h->tinfo, (T*)rpm_track(h), (S*)obs_log, (S*)obs_last)))
 #define MDS_ROLL_C(CTRL)                                                    \
@@ -608,8 +621,18 @@ static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, v
     else if (drag) MDS_ROLL(false, true, CTRL);                             \
     else MDS_ROLL(false, false, CTRL);                                      \
   } while (0)
-  if (lqr) MDS_ROLL_C(1);
+#define MDS_ROLL_LL(CTRL)                        \
+  do {                                           \
+    if (rk4 && drag) MDS_ROLL(true, true, CTRL); \
+    else if (rk4) MDS_ROLL(true, false, CTRL);   \
+    else if (drag) MDS_ROLL(false, true, CTRL);  \
+    else MDS_ROLL(false, false, CTRL);           \
+  } while (0)
+  if (ctrl == 3) MDS_ROLL_LL(3);
+  else if (ctrl == 2) MDS_ROLL_LL(2);
+  else if (lqr) MDS_ROLL_C(1);
   else MDS_ROLL_C(0);
+#undef MDS_ROLL_LL
 #undef MDS_ROLL_C
 #undef MDS_ROLLT
 #undef MDS_ROLL
@@ -618,11 +641,18 @@ static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, v
 }
 
 int mds_rollout_geometric_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream) {
-  return rollout_fused(h, t0, n_steps, obs_log, obs_last, stream, false, "mds_rollout_geometric_fused");
+  return rollout_fused(h, t0, n_steps, obs_log, obs_last, stream, 0, "mds_rollout_geometric_fused");
 }
 
 int mds_rollout_lqr_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream) {
-  return rollout_fused(h, t0, n_steps, obs_log, obs_last, stream, true, "mds_rollout_lqr_fused");
+  return rollout_fused(h, t0, n_steps, obs_log, obs_last, stream, 1, "mds_rollout_lqr_fused");
+}
+
+int mds_rollout_nominal_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs, void* stream) {
+  if (!h) return fail(MDS_EINVAL, "mds_rollout_nominal_fused: null handle");
+  if (h->cbf_nominal != 1 && h->cbf_nominal != 2)
+    return fail(MDS_ESTATE, "mds_rollout_nominal_fused: select the LQR-omega (1) or LQR-yank-omega (2) controller with mds_cbf_set_nominal first");
+  return rollout_fused(h, t0, n_steps, obs_log, obs, stream, h->cbf_nominal == 1 ? 2 : 3, "mds_rollout_nominal_fused");
 }
 
 int mds_lemniscate_eval(mds_handle* h, double t, void* des, void* stream) {

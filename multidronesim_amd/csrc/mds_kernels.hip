@@ -447,21 +447,31 @@ __global__ void k_traj_eval(const int n, const double t, const double* __restric
 // EnvGeometric.py:471,553) through the same per-wave LDS transposition.  t advances in
 // double exactly like the host loop (t += CTRL_TIMESTEP).
 // ------------------------------------------------------------------------------------
-// CTRL 0: GeometricControl; CTRL 1: the 12-state LQRController (K is only read then).
+// CTRL 0: GeometricControl; CTRL 1: the 12-state LQRController (K is only read then); CTRL 2 / 3: LQROmegaController +
+// ThrustOmegaController / LQRYankOmegaController + YankOmegaController (Kp then points at an LqrGain / LqrYoGain; the low level's
+// PID memory `ll` stays in registers for the whole rollout, the yank path's thrust state is the previous step's clipped RPM).
 template <typename T, typename S, bool RK4, bool DRAG, int CTRL = 0>
-__global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c, const Lqr12Gain<T>* __restrict__ Kp, const int n, const size_t ld, double t,
+__global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c, const void* __restrict__ Kp, const int n, const size_t ld, double t,
                                                               const double ctrl_dt, const int n_steps, S* __restrict__ state,
                                                               const T* __restrict__ lem, T* __restrict__ last_rpm,
-                                                              S* __restrict__ obs_log, S* __restrict__ obs_last) {
+                                                              S* __restrict__ obs_log, S* __restrict__ obs_last,
+                                                              T* __restrict__ ll = nullptr, const S* __restrict__ obs_prev = nullptr) {
   __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const bool valid = i < n;
   GeoIn<T> in;
   T prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4] = {T(0), T(0), T(0), T(0)};
+  LowLevelState<T> L;
+  L.last_omega = L.integral = {T(0), T(0), T(0)};
   if (valid) {
     load_geo_in<T, S>(state, lem, ld, i, in);
     if (DRAG)
       for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
+    if (CTRL >= 2) {
+      L.last_omega = {ll[0 * ld + i], ll[1 * ld + i], ll[2 * ld + i]};
+      L.integral = {ll[3 * ld + i], ll[4 * ld + i], ll[5 * ld + i]};
+      if (CTRL == 3) load4<S, T>(obs_prev + (size_t)i * kObsDim + 16, clipped);      // calc_z_thrust(obs) of the first step
+    }
   }
   for (int k = 0; k < n_steps; ++k) {
     T o[kObsDim];
@@ -475,10 +485,18 @@ __global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c,
           const M3<T> R = quat_to_rot(in.s.q);
           const V3<T> ang_v = mul(R, in.s.w);
           geometric_control<T>(c, in.s.p - des.p, R, in.s.v, ang_v, des, u, nullptr);
+        } else if (CTRL == 1) {
+          lqr12_control<T>(c, *static_cast<const Lqr12Gain<T>*>(Kp), euler_from_quat(in.s.q), quat_rotate(in.s.q, in.s.w), in.s.v, in.s.p - des.p,
+                           des.v, des.yaw, des.yaw_rate, u);
+        } else if (CTRL == 2) {
+          lqr_omega_control<T>(c, *static_cast<const LqrGain<T>*>(Kp), euler_from_quat(in.s.q), in.s.v, in.s.p, des.p, des.v, des.yaw, u);
         } else {
-          lqr12_control<T>(c, *Kp, euler_from_quat(in.s.q), quat_rotate(in.s.q, in.s.w), in.s.v, in.s.p - des.p, des.v, des.yaw, des.yaw_rate, u);
+          lqr_yank_omega_control<T>(c, *static_cast<const LqrYoGain<T>*>(Kp), euler_from_quat(in.s.q), clipped, in.s.v, in.s.p, des.p, des.v,
+                                    des.yaw, u);
         }
-        input_to_action(c, u, act);
+        if (CTRL <= 1) input_to_action(c, u, act);
+        else if (CTRL == 2) thrust_omega_control(c, (T)ctrl_dt, u, in.s.w, L, act);
+        else yank_omega_control(c, (T)ctrl_dt, u, clipped, in.s.w, L, act);
       }
       aviary_step<T, RK4, DRAG>(c, in.s, act, prev, clipped);
       if (want) pack_obs(in.s, V3<T>{in.P.cx, in.P.cy, in.P.cz}, clipped, o);
@@ -491,12 +509,16 @@ __global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c,
     store_state<S, T>(state, ld, i, in.s);
     if (DRAG || (last_rpm && n_steps > 0))
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = DRAG ? prev[k] : clipped[k];
+    if (CTRL >= 2) {
+      ll[0 * ld + i] = L.last_omega.x; ll[1 * ld + i] = L.last_omega.y; ll[2 * ld + i] = L.last_omega.z;
+      ll[3 * ld + i] = L.integral.x; ll[4 * ld + i] = L.integral.y; ll[5 * ld + i] = L.integral.z;
+    }
   }
 }
 
 // The same whole-rollout loop for general trajectories (segment tables, evaluated in double every step like k_step_traj).
 template <typename T, typename S, bool RK4, bool DRAG, int CTRL>
-__global__ __launch_bounds__(kBlock) void k_rollout_traj(const Consts<T> c, const Lqr12Gain<T>* __restrict__ Kp, const int n, const size_t ld, double t,
+__global__ __launch_bounds__(kBlock) void k_rollout_traj(const Consts<T> c, const void* __restrict__ Kp, const int n, const size_t ld, double t,
                                                          const double ctrl_dt, const int n_steps, S* __restrict__ state,
                                                          const T* __restrict__ origin, const double* __restrict__ segs,
                                                          const int* __restrict__ tinfo, T* __restrict__ last_rpm,
@@ -533,7 +555,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_traj(const Consts<T> c, cons
         const M3<T> R = quat_to_rot(s.q);
         geometric_control<T>(c, s.p - des.p, R, s.v, mul(R, s.w), des, u, nullptr);
       } else {
-        lqr12_control<T>(c, *Kp, euler_from_quat(s.q), quat_rotate(s.q, s.w), s.v, s.p - des.p, des.v, des.yaw, des.yaw_rate, u);
+        lqr12_control<T>(c, *static_cast<const Lqr12Gain<T>*>(Kp), euler_from_quat(s.q), quat_rotate(s.q, s.w), s.v, s.p - des.p, des.v, des.yaw,
+                         des.yaw_rate, u);
       }
       input_to_action(c, u, act);
       aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);

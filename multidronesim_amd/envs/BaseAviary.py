@@ -329,7 +329,8 @@ class BaseAviary:
         self._require_open()
         if log and log_out is None:
             log_out = torch.empty((n_steps, self.NUM_ENVS, self.NUM_DRONES, capi.OBS_DIM), dtype=self.dtype, device=self.device)
-        fn = self._lib.mds_rollout_lqr_fused if controller == "lqr" else self._lib.mds_rollout_geometric_fused
+        fn = {"lqr": self._lib.mds_rollout_lqr_fused, "geometric": self._lib.mds_rollout_geometric_fused,
+              "nominal": self._lib.mds_rollout_nominal_fused}[controller]   # "nominal": the LQR + low level chosen with set_cbf_nominal
         capi.check(fn(self._h, C.c_double(t0), C.c_int(n_steps), C.c_void_p(log_out.data_ptr() if log_out is not None else None),
                       C.c_void_p(self._obs.data_ptr()), self._stream()), "mds_rollout_*_fused")
         self.step_counter += n_steps * self.PYB_STEPS_PER_CTRL

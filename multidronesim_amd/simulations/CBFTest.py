@@ -56,11 +56,17 @@ class GeometricEnv(_base.GeometricEnv):
         t = 0.0
         log = torch.empty((steps, env.NUM_ENVS, env.NUM_DRONES, 20), dtype=env.dtype, device=env.device)
         st_log = torch.zeros((steps, env.NUM_ENVS), dtype=torch.int32, device=env.device)
+        if qpTracker is None and not render:   # ctrl[j].compute(obs[j]) = LQR + low level, then step (:296-300, :350): the whole run in one launch
+            env.rollout_geometric_fused(0.0, steps, log=True, log_out=log, controller="nominal")
+            for i in range(steps):
+                self.obs_ts.append(t)
+                t += env.CTRL_TIMESTEP
+            steps = 0
         for i in range(steps):
             if qpTracker is not None:     # nominal -> QP -> low level -> step (:303-350)
                 obs, st = env.step_cbf_geometric(t, qpTracker, x_obs_list, obs_r_list)
                 st_log[i].copy_(st)
-            else:                         # ctrl[j].compute(obs[j]) = LQR + low level, then step (:296-300, :350)
+            else:
                 obs = env.step_nominal(t)
             log[i].copy_(obs)
             self.obs_ts.append(t)

@@ -257,3 +257,40 @@ def test_lqr_whole_rollout_equals_stepwise(gpu, dtype, T, tol):
     np.testing.assert_allclose(last.double().cpu().numpy(), log[-1].double().cpu().numpy(), atol=0)
     np.testing.assert_allclose(a.get_state(), b.get_state(), atol=tol)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("which", ["lqr_omega", "lqr_yank_omega"])
+def test_nominal_whole_rollout_equals_stepwise(gpu, which):
+    """mds_rollout_nominal_fused (LQR + low level + step for T control steps in one launch, PID memory in registers) against
+    T calls of mds_step_nominal; float64, with drag and two physics substeps per control step."""
+    from multidronesim_amd.envs.CtrlAviary import CtrlAviary, DroneModel, Physics
+    from multidronesim_amd.control import LQROmegaController, LQRYankOmegaController, ThrustOmegaController, YankOmegaController
+    from multidronesim_amd.model import LinearizedOmegaModel, LinearizedYankOmegaModel
+    E, D, T = 21, 3, 90
+    xyz, rpy, P = H.c2_setup(E, D, seed=6, offset=1.0, omega=0.6, yaw_rate=0.1)
+    envs = []
+    for _ in range(2):
+        env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.PYB_DRAG, pyb_freq=200,
+                         ctrl_freq=100, num_envs=E, dtype="float64")
+        env.set_trajectories(P)
+        if which == "lqr_omega":
+            LQROmegaController(env, LinearizedOmegaModel(env), ThrustOmegaController(env))
+        else:
+            LQRYankOmegaController(env, LinearizedYankOmegaModel(env), YankOmegaController(env))
+        env.set_cbf_nominal(which)
+        env.step(gpu.full((E, D, 4), float(env.HOVER_RPM), dtype=env.dtype))
+        envs.append(env)
+    a, b = envs
+    last, log = a.rollout_geometric_fused(0.0, T, log=True, controller="nominal")
+    t = 0.0
+    for k in range(T):
+        o = b.step_nominal(t)
+        t += b.CTRL_TIMESTEP
+        if k in (0, 1, T // 2, T - 1):
+            np.testing.assert_allclose(log[k].cpu().numpy(), o.cpu().numpy(), atol=1e-9, rtol=1e-12)
+    np.testing.assert_allclose(a.get_state(), b.get_state(), atol=1e-9)
+    o1 = a.rollout_geometric_fused(t, 10, controller="nominal")[0].cpu().numpy().copy()      # PID memory and RPM echo carried over
+    for k in range(10):
+        o2 = b.step_nominal(t + k * b.CTRL_TIMESTEP)
+    np.testing.assert_allclose(o1, o2.cpu().numpy(), atol=1e-9, rtol=1e-12)
+    a.close(); b.close()
