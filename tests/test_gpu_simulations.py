@@ -294,3 +294,35 @@ def test_nominal_whole_rollout_equals_stepwise(gpu, which):
         o2 = b.step_nominal(t + k * b.CTRL_TIMESTEP)
     np.testing.assert_allclose(o1, o2.cpu().numpy(), atol=1e-9, rtol=1e-12)
     a.close(); b.close()
+
+
+def test_fp16_storage_instantiations_of_the_lqr_paths(gpu):
+    """fp16 state storage / fp32 arithmetic through the entry points added around the 12-state LQR: step, whole rollout, operator,
+    obs adapters.  Throughput configuration: finite, unit quaternions, within fp16 storage accuracy of the fp32 run."""
+    from multidronesim_amd.envs.CtrlAviary import CtrlAviary, DroneModel, Physics
+    from multidronesim_amd.control import LQRController
+    from multidronesim_amd.model import LinearizedModel
+    from multidronesim_amd.utils import obs_to_lin_model
+    E, D, T = 33, 2, 40
+    xyz, rpy, P = H.c2_setup(E, D, seed=8, offset=0.0, omega=0.8)
+    out = {}
+    for dtype in ("float32", "float16"):
+        env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN, pyb_freq=100, ctrl_freq=100,
+                         num_envs=E, dtype=dtype)
+        env.set_trajectories(P)
+        ctrl = LQRController(env, LinearizedModel(env))
+        env.step(gpu.zeros((E, D, 4), dtype=env.dtype))
+        t = 0.0
+        for k in range(T // 2):
+            o = env.step_lqr(t)
+            t += env.CTRL_TIMESTEP
+        last, log = env.rollout_geometric_fused(t, T // 2, log=True, controller="lqr")
+        des = gpu.zeros((E, D, 11), dtype=env.dtype)
+        act, u = ctrl.compute_batched(last, des)
+        x12 = obs_to_lin_model(last, 12, env)
+        for name, ten in (("last", last), ("log", log), ("act", act), ("u", u), ("x12", x12)):
+            assert gpu.isfinite(ten).all(), (dtype, name)
+        out[dtype] = last.double().cpu().numpy()
+        assert np.abs(np.linalg.norm(out[dtype][..., 3:7], axis=-1) - 1).max() < 2e-3
+        env.close()
+    assert np.abs(out["float16"][..., :3] - out["float32"][..., :3]).max() < 5e-2
