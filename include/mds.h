@@ -14,8 +14,10 @@
  *     tensors); their element type is the handle's storage dtype (mds_dtype): float for
  *     MDS_F32, double for MDS_F64, IEEE half for MDS_F16 (fp16 storage, fp32 arithmetic).
  *   - "host" pointers are host double arrays (set-up / inspection only, never hot path).
- *   - `stream` is a hipStream_t (NULL = default stream).  Hot-path calls only enqueue
- *     work on it and return; they never synchronise, allocate or copy.
+ *   - `stream` is a hipStream_t (NULL = default stream).  Hot-path calls (mds_step*, mds_rollout*, the operators) only
+ *     enqueue work on it and return; they never synchronise or copy, and they allocate only once: the first
+ *     mds_step_cbf_geometric / mds_step_nominal of a handle creates its [n,18] scratch.  Set-up calls (mds_create, mds_reset,
+ *     mds_set_*, mds_cbf_configure, mds_get/set_state) may allocate, copy from host memory and synchronise.
  *   - Every call returns MDS_OK (0) or a negative mds_status; nothing throws or aborts
  *     across the ABI.  mds_strerror() names a status, mds_last_error() adds HIP detail.
  *   - A handle is not re-entrant (one simulation thread, as PIDEnv.py:99-103); distinct

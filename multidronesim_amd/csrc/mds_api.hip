@@ -83,7 +83,7 @@ struct mds_handle {
   LqrYoGain<float> lqr_yo_f;
   LqrYoGain<double> lqr_yo_d;
   bool has_lqr12;
-  void* lqr12_dev;     // device copy of the 12-state gain for the whole-rollout kernel
+  void* gain_dev[3];   // device copies of the gains for the whole-rollout kernels: 0 LQR-12, 1 LQR-omega, 2 LQR-yank-omega (written by the mds_set_*_gain calls)
   Lqr12Gain<float> lqr12_f;
   Lqr12Gain<double> lqr12_d;
   void* state_alt;     // second state buffer of the ground-effect / downwash step (double-buffered substeps)
@@ -136,6 +136,14 @@ template <typename T> static void fill_cbf(const mds_handle* h, const mds_cbf_pa
   o.g = (T)h->cfg.G;
   o.Fmin = (T)p.Fmin;
   o.Fmax = (T)p.Fmax;
+}
+
+// set-up path: (re)write one gain struct to its device copy, synchronously
+static int upload_gain(mds_handle* h, int slot, const void* f32, size_t nf, const void* f64, size_t nd) {
+  if (!h->gain_dev[slot]) MDS_HIP(hipMalloc(&h->gain_dev[slot], nd));
+  if (h->cfg.dtype == MDS_F64) MDS_HIP(hipMemcpy(h->gain_dev[slot], f64, nd, hipMemcpyHostToDevice));
+  else MDS_HIP(hipMemcpy(h->gain_dev[slot], f32, nf, hipMemcpyHostToDevice));
+  return MDS_OK;
 }
 
 extern "C" {
@@ -234,7 +242,7 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   h->has_lqr = false;
   h->has_lqr_yo = false;
   h->has_lqr12 = false;
-  h->lqr12_dev = nullptr;
+  h->gain_dev[0] = h->gain_dev[1] = h->gain_dev[2] = nullptr;
   h->cbf_nominal = 0;
   h->pid = nullptr;
   h->envfx = cfg->physics >= MDS_PHYSICS_DYN_GND;
@@ -293,7 +301,8 @@ int mds_destroy(mds_handle* h) {
   if (h->cbf_order) (void)hipFree(h->cbf_order);
   if (h->cbf_count) (void)hipFree(h->cbf_count);
   if (h->cbf_cost) (void)hipFree(h->cbf_cost);
-  if (h->lqr12_dev) (void)hipFree(h->lqr12_dev);
+  for (int k = 0; k < 3; ++k)
+    if (h->gain_dev[k]) (void)hipFree(h->gain_dev[k]);
   if (h->cbf_unom) (void)hipFree(h->cbf_unom);
   if (h->cbf_xdes) (void)hipFree(h->cbf_xdes);
   if (h->cbf_usafe) (void)hipFree(h->cbf_usafe);
@@ -590,23 +599,15 @@ static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, v
   const dim3 grid = grid_for(h->n, kBlock);
   const double dt = 1.0 / h->cfg.ctrl_freq;
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
-  if (ctrl >= 1) {   // the gain lives in device memory for this kernel: passing it by value would not fit beside Consts in SGPRs
-    if (!h->lqr12_dev) MDS_HIP(hipMalloc(&h->lqr12_dev, sizeof(Lqr12Gain<double>)));   // the largest of the three gain structs
-    const bool f64 = h->cfg.dtype == MDS_F64;
-    const void* src = ctrl == 1 ? (f64 ? (const void*)&h->lqr12_d : (const void*)&h->lqr12_f)
-                    : ctrl == 2 ? (f64 ? (const void*)&h->lqr_d : (const void*)&h->lqr_f)
-                                : (f64 ? (const void*)&h->lqr_yo_d : (const void*)&h->lqr_yo_f);
-    const size_t bytes = ctrl == 1 ? (f64 ? sizeof(h->lqr12_d) : sizeof(h->lqr12_f))
-                       : ctrl == 2 ? (f64 ? sizeof(h->lqr_d) : sizeof(h->lqr_f)) : (f64 ? sizeof(h->lqr_yo_d) : sizeof(h->lqr_yo_f));
-    MDS_HIP(hipMemcpyAsync(h->lqr12_dev, src, bytes, hipMemcpyHostToDevice, st));
-  }
+  // the gain (up to 48 values) is read from its device copy: passing it by value would not fit beside Consts in SGPRs
+  const void* gain = ctrl >= 1 ? h->gain_dev[ctrl - 1] : nullptr;
 #define MDS_ROLL(RK4, DRAG, CTRL)                                                                                                  \
-  MDS_DISPATCH(h, (k_rollout_geometric<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, h->lqr12_dev, h->n, h->ld, t0, dt,              \
+  MDS_DISPATCH(h, (k_rollout_geometric<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, gain, h->n, h->ld, t0, dt,                       \
                                                                                        n_steps, (S*)h->state, (const T*)h->lem,       \
                                                                                        (T*)rpm_track(h), (S*)obs_log, (S*)obs_last,   \
                                                                                        (T*)h->ll, (const S*)obs_last)))
 #define MDS_ROLLT(RK4, DRAG, CTRL)                                                                                                 \
-  MDS_DISPATCH(h, (k_rollout_traj<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, h->lqr12_dev, h->n, h->ld, t0, dt,                        \
+  MDS_DISPATCH(h, (k_rollout_traj<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, gain, h->n, h->ld, t0, dt,                                 \
                                                                                   n_steps, (S*)h->state, (const T*)h->origin, h->segs, \
                                                                                   h->tinfo, (T*)rpm_track(h), (S*)obs_log, (S*)obs_last)))
 #define MDS_ROLL_C(CTRL)                                                    \
@@ -934,7 +935,7 @@ int mds_set_lqr_omega_gain(mds_handle* h, const double K[36]) {
       h->lqr_f.k[r][k] = (float)K[9 * r + k];
     }
   h->has_lqr = true;
-  return MDS_OK;
+  return upload_gain(h, 1, &h->lqr_f, sizeof(h->lqr_f), &h->lqr_d, sizeof(h->lqr_d));
 }
 
 int mds_lqr_omega_compute(mds_handle* h, const void* obs, const void* des, void* u, void* stream) {
@@ -960,7 +961,7 @@ int mds_set_lqr_gain(mds_handle* h, const double K[48]) {
       h->lqr12_f.k[r][k] = (float)K[12 * r + k];
     }
   h->has_lqr12 = true;
-  return MDS_OK;
+  return upload_gain(h, 0, &h->lqr12_f, sizeof(h->lqr12_f), &h->lqr12_d, sizeof(h->lqr12_d));
 }
 
 int mds_lqr_compute(mds_handle* h, const void* obs, const void* des, void* u, void* action, void* stream) {
@@ -1014,7 +1015,7 @@ int mds_set_lqr_yank_omega_gain(mds_handle* h, const double K[40]) {
       h->lqr_yo_f.k[r][k] = (float)K[10 * r + k];
     }
   h->has_lqr_yo = true;
-  return MDS_OK;
+  return upload_gain(h, 2, &h->lqr_yo_f, sizeof(h->lqr_yo_f), &h->lqr_yo_d, sizeof(h->lqr_yo_d));
 }
 
 int mds_lqr_yank_omega_compute(mds_handle* h, const void* obs, const void* des, void* u, void* stream) {
