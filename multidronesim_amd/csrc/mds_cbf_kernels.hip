@@ -508,6 +508,15 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
         }
         b[k] *= inv;
         valid[k] = true;
+        // a barrier row that not even the corner of the input box satisfies makes the QP infeasible by itself: min over the box
+        // of a.u is -sum |a_v| umax_v.  Typical case: an agent almost level with what it must avoid (tiny L_g, very negative h).
+        // Exact (the box rows are rows of the same QP) and it spares the solver the 10-16 iterations it needs to find out.
+        if (r < npairs + nobs_rows) {
+          T reach = T(0);
+#pragma unroll
+          for (int v = 0; v < NV; ++v) reach = m_fma(m_abs(ca[k][v]) + m_abs(cb[k][v]), P.umax[v], reach);
+          if (b[k] < -reach * (T(1) + T(sizeof(T) == 4 ? 1e-5 : 1e-10))) bad = true;
+        }
       } else if (b[k] < T(0)) {
         bad = true;                                        // 0 * u <= h with h < 0
       }
