@@ -202,3 +202,12 @@ def test_create_rejects_more_than_2_30_drones(lib):
     h = C.c_void_p()
     assert lib.mds_create(C.byref(cfg), C.byref(h)) == -1 and not h.value
     assert b"too many" in lib.mds_last_error()
+
+
+def test_default_dslpid_gains(lib):
+    """[UPSTREAM] DSLPIDControl coefficients as mds_default_dslpid_gains hands them out (PIDEnv.py:124-134 halves these)."""
+    g = capi.MdsDslPidGains()
+    assert lib.mds_default_dslpid_gains(C.byref(g)) == 0
+    assert list(g.P_COEFF_FOR) == [.4, .4, 1.25] and list(g.I_COEFF_FOR) == [.05, .05, .05] and list(g.D_COEFF_FOR) == [.2, .2, .5]
+    assert list(g.P_COEFF_TOR) == [70000., 70000., 60000.] and list(g.I_COEFF_TOR) == [.0, .0, 500.] and list(g.D_COEFF_TOR) == [20000., 20000., 12000.]
+    assert lib.mds_default_dslpid_gains(None) == -1

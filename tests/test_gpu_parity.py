@@ -535,3 +535,28 @@ def test_ground_effect_and_downwash_match_oracle(mds, physics, name, dtype, tol)
     with pytest.raises(RuntimeError):
         mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=2, initial_xyzs=np.zeros((2, 3)), initial_rpys=np.zeros((2, 3)),
                        physics=mds.Physics.PYB_DW, pyb_freq=100, ctrl_freq=100, integrator="rk4")
+
+
+def test_set_origin_rebases_the_local_frame_without_moving_anything(mds):
+    """mds_set_origin: the per-drone local-frame origin (fp32 conditioning) can be moved at any time; world-frame state and
+    observations stay what they were, and stepping afterwards matches an env that never moved its origin."""
+    import ctypes as C2
+    from multidronesim_amd import _capi as capi
+    E, D = 5, 3
+    rng = np.random.default_rng(12)
+    xyz = rng.uniform(-20, 20, size=(E, D, 3))
+    rpy = rng.uniform(-0.2, 0.2, size=(E, D, 3))
+    a = make_env(mds, E, D, xyz, rpy, "float32")
+    b = make_env(mds, E, D, xyz, rpy, "float32")
+    act = mds.torch.full((E, D, 4), float(a.HOVER_RPM) * 1.02, dtype=a.dtype, device=a.device)
+    for _ in range(5):
+        a.step(act); b.step(act)
+    before = a.get_state().copy()
+    org = np.ascontiguousarray(before[..., 0:3].reshape(-1, 3) + rng.normal(size=(E * D, 3)) * 0.1)   # origin near each drone
+    capi.check(a._lib.mds_set_origin(a._h, capi.as_double_ptr(org), a._stream()), "mds_set_origin")
+    np.testing.assert_allclose(a.get_state(), before, atol=2e-6)
+    np.testing.assert_allclose(np_obs(a._computeObs())[:, :16], np_obs(b._computeObs())[:, :16], atol=2e-6)
+    for _ in range(20):
+        oa, *_ = a.step(act); ob, *_ = b.step(act)
+    np.testing.assert_allclose(np_obs(oa)[:, :16], np_obs(ob)[:, :16], atol=3e-5)      # world coordinates up to 20 m: 1 fp32 ulp = 2e-6
+    a.close(); b.close()
