@@ -128,6 +128,45 @@ def cpu_baseline(D, phase, budget_s=15.0):
     return out
 
 
+def _cpu_worker(job):
+    """One process of the all-cores CPU baseline: the vectorised oracle on its own 256 envs for ~seconds."""
+    D, phase, seed, seconds = job
+    from oracle import np_oracle as O
+    E = 256
+    xyz, rpy, P = make_inputs(E, D, phase, seed)
+    n = E * D
+    Pf = P.reshape(-1, 7)
+    ora = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), pyb_freq=100, ctrl_freq=100)
+    obs = ora.step(np.zeros((n, 4)))
+    t, steps = 0.0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        pos, vel, acc, yaw, yd = O.lemniscate(t, Pf[:, 0], Pf[:, 1], Pf[:, 2:5], Pf[:, 5], Pf[:, 6])
+        obs = ora.step(O.geometric_compute(obs, pos, vel, acc, yaw, yd))
+        t += ora.CTRL_TIMESTEP
+        steps += 1
+    return n * steps, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(D, phase, seconds=6.0):
+    """The same oracle on every host core this process may use (one process per core, each with its own envs).  Must run BEFORE
+    the GPU is initialised: the workers are forked."""
+    import multiprocessing as mp
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))                  # the GPU box gives one GPU a 16-core share
+    try:
+        with mp.get_context("fork").Pool(cores) as pool:
+            res = pool.map(_cpu_worker, [(D, phase, 500 + k, seconds) for k in range(cores)])
+        work, el = sum(r[0] for r in res), max(r[1] for r in res)
+        return {"value": work / el, "unit": "drone-steps/s", "cores": cores, "kind": "port",
+                "sample": f"float64 NumPy oracle (vectorised), {cores} processes x 256 envs x {D} drones, {el:.1f} s"}
+    except Exception as exc:                       # never let the baseline break the bench line
+        return {"error": str(exc)}
+
+
 def _baseline_metric():
     """BASELINE.json's metric string, verbatim (the judge compares it literally)."""
     try:
@@ -180,6 +219,9 @@ def main(argv=None):
             torch.distributed.destroy_process_group()
         return 0
 
+    all_cores = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and args.workload in ("c2", "c3"):
+        all_cores = cpu_baseline_all_cores(D, phase, min(6.0, args.cpu_budget))      # forks: before anything touches the GPU
     rank, local_rank, world = dist_init("nccl")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -389,6 +431,7 @@ def main(argv=None):
         del buf
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload not in ("c4", "c5"):
         line["cpu_baseline"] = cpu_baseline(D, phase, args.cpu_budget)
+        line["cpu_baseline"]["all_cores"] = all_cores
     elif rank == 0:
         line["cpu_baseline"] = None
     env.close()
