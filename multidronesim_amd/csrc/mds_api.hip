@@ -68,6 +68,9 @@ struct mds_handle {
   int* cbf_count;      // [4]
   int* cbf_cost;       // [E] GI iterations of the last launch
   int cbf_calls;       // launches since the classes were rebuilt; -1: no classes yet
+  int rollout_streams = 0;              // mds_set_rollout_streams: 0 auto, 1, 2
+  hipStream_t split_st[2] = {nullptr, nullptr};   // created on first use by a two-stream rollout
+  hipEvent_t split_ev[3] = {nullptr, nullptr, nullptr};
   void* cbf_unom;      // S [n,4]  scratch of mds_step_cbf_geometric
   void* cbf_xdes;      // S [n,9]
   void* cbf_usafe;     // S [n,4]
@@ -104,6 +107,17 @@ static inline void* rpm_track(mds_handle* h) {
   if (h->track_rpm) return h->last_rpm;
   h->rpm_stale = true;
   return nullptr;
+}
+
+// Shards at least this large step their two halves on two streams inside mds_rollout_geometric (0 = auto policy).
+constexpr size_t kSplitMinDrones = size_t(1) << 18;
+
+static int split_streams_ready(mds_handle* h) {
+  for (int k = 0; k < 2; ++k)
+    if (!h->split_st[k]) MDS_HIP(hipStreamCreateWithFlags(&h->split_st[k], hipStreamNonBlocking));
+  for (int k = 0; k < 3; ++k)
+    if (!h->split_ev[k]) MDS_HIP(hipEventCreateWithFlags(&h->split_ev[k], hipEventDisableTiming));
+  return MDS_OK;
 }
 
 // dispatch on the handle dtype: F32 -> <float,float>, F64 -> <double,double>, F16 -> <float,half_t>
@@ -310,6 +324,10 @@ int mds_destroy(mds_handle* h) {
   if (h->pid) (void)hipFree(h->pid);
   if (h->segs) (void)hipFree(h->segs);
   if (h->tinfo) (void)hipFree(h->tinfo);
+  for (int k = 0; k < 2; ++k)
+    if (h->split_st[k]) (void)hipStreamDestroy(h->split_st[k]);
+  for (int k = 0; k < 3; ++k)
+    if (h->split_ev[k]) (void)hipEventDestroy(h->split_ev[k]);
   delete h;
   return MDS_OK;
 }
@@ -520,8 +538,9 @@ int mds_set_wind(mds_handle* h, const double force_world[3]) {
   return MDS_OK;
 }
 
-static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, hipStream_t st) {
-  const unsigned nbatch = (unsigned)((h->n + kBlock - 1) / kBlock);
+// batch0 / nb: the range of 256-drone batches this launch covers (nb == 0: all of them)
+static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, hipStream_t st, unsigned batch0 = 0, unsigned nb = 0) {
+  const unsigned nbatch = nb ? nb : (unsigned)((h->n + kBlock - 1) / kBlock);
   if (h->traj_mode == 2) {      // general trajectories: segment tables
     const bool rk4_ = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag_ = has_drag(h);
 #define MDS_TRAJ(RK4, DRAG)                                                                                                   \
@@ -537,7 +556,7 @@ static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, 
 #define MDS_LAUNCH_GEO2(HAS_OBS, HAS_ACT, RK4, DRAG)                                                                           \
   MDS_DISPATCH(h, (k_step_geometric<T, S, HAS_OBS, HAS_ACT, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t, (S*)h->state, \
                                                                                                 (const T*)h->lem, (T*)rpm_track(h), \
-                                                                                                (S*)obs, (S*)act)))
+                                                                                                (S*)obs, (S*)act, (int)batch0)))
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
   const dim3 grid(nbatch);
 #define MDS_LAUNCH_GEO(HAS_OBS, HAS_ACT)                         \
@@ -572,12 +591,54 @@ int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs, int 
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_rollout_geometric: call mds_set_lemniscate first");
   if (!aligned16(obs)) return fail(MDS_EALIGN, "mds_rollout_geometric: obs_dev");
   const double dt = 1.0 / h->cfg.ctrl_freq;
+  const unsigned nbatch = (unsigned)((h->n + kBlock - 1) / kBlock);
+  // auto policy from the size sweep in DESIGN.md 4: below 2^18 drones the extra launches cost more than the overlap gains,
+  // between 2^18 and 2^19 it pays only once the chains have had ~1000 steps to drift out of phase
+  const bool big = h->n >= 2 * kSplitMinDrones ? n_steps >= 16 : (h->n >= kSplitMinDrones && n_steps >= 1000);
+  const int streams = h->rollout_streams ? h->rollout_streams : (big ? 2 : 1);
+  if (streams == 2 && h->traj_mode != 2 && nbatch >= 2 && n_steps >= 2) {
+    // Drones never read each other's rows in this kernel, so the two halves of the shard are two independent step
+    // chains.  Run on two streams they drift out of phase: one half's load/store bursts fill the other's compute
+    // phase (measured on C3: 17.5 -> 15.7-16.3 us per step).  The caller's stream orders both chains.
+    if (int rc = split_streams_ready(h)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    MDS_HIP(hipEventRecord(h->split_ev[0], st));
+    const unsigned half = nbatch / 2;
+    for (int s = 0; s < 2; ++s) MDS_HIP(hipStreamWaitEvent(h->split_st[s], h->split_ev[0], 0));
+    for (int k = 0; k < n_steps; ++k) {
+      void* o = (obs_every_step || k == n_steps - 1) ? obs : nullptr;
+      if (k == 0 && half >= 2) {
+        // phase offset: the second chain starts when the first is half way through its first step (started together
+        // the chains begin in lock step and need a few hundred steps to drift apart)
+        launch_step_geometric(h, t0, o, nullptr, h->split_st[0], 0, half / 2);
+        MDS_HIP(hipEventRecord(h->split_ev[1], h->split_st[0]));
+        MDS_HIP(hipStreamWaitEvent(h->split_st[1], h->split_ev[1], 0));
+        launch_step_geometric(h, t0, o, nullptr, h->split_st[0], half / 2, half - half / 2);
+      } else {
+        launch_step_geometric(h, t0, o, nullptr, h->split_st[0], 0, half);
+      }
+      launch_step_geometric(h, t0, o, nullptr, h->split_st[1], half, nbatch - half);
+      t0 += dt;
+    }
+    for (int s = 0; s < 2; ++s) {
+      MDS_HIP(hipEventRecord(h->split_ev[1 + s], h->split_st[s]));
+      MDS_HIP(hipStreamWaitEvent(st, h->split_ev[1 + s], 0));
+    }
+    MDS_HIP(hipGetLastError());
+    return MDS_OK;
+  }
   for (int k = 0; k < n_steps; ++k) {
     // t accumulates exactly like the reference loop (t += env.CTRL_TIMESTEP, EnvGeometric.py:473)
     launch_step_geometric(h, t0, (obs_every_step || k == n_steps - 1) ? obs : nullptr, nullptr, (hipStream_t)stream);
     t0 += dt;
   }
   MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_set_rollout_streams(mds_handle* h, int n_streams) {
+  if (!h || n_streams < 0 || n_streams > 2) return fail(MDS_EINVAL, "mds_set_rollout_streams: 0 (auto), 1 or 2");
+  h->rollout_streams = n_streams;
   return MDS_OK;
 }
 

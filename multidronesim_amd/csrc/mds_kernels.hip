@@ -312,9 +312,10 @@ template <typename T, typename S, bool HAS_OBS, bool HAS_ACT, bool RK4, bool DRA
 __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && !RK4) ? MDS_GEOSIMPLE_MIN_WAVES : 1) void k_step_geometric(const Consts<T> c, const int n, const size_t ld, const double t,
                                                            S* __restrict__ state, const T* __restrict__ lem,
                                                            T* __restrict__ last_rpm, S* __restrict__ obs,
-                                                           S* __restrict__ action_out) {
+                                                           S* __restrict__ action_out, const int batch0) {
   __shared__ __align__(16) unsigned char lds[HAS_OBS ? (kBlock * kObsDim * sizeof(S)) : 16];
-  const int i = blockIdx.x * kBlock + threadIdx.x;
+  // batch0: first 256-drone batch of this launch (a rollout may step the two halves of the shard on two streams)
+  const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
   GeoIn<T> in;
   if (i < n) load_geo_in<T, S>(state, lem, ld, i, in);
   geo_process<T, S, HAS_OBS, HAS_ACT, RK4, DRAG>(c, n, ld, t, i, in, state, last_rpm, obs, action_out, lds);

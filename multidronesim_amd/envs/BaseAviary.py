@@ -320,6 +320,12 @@ class BaseAviary:
         self.step_counter += n_steps * self.PYB_STEPS_PER_CTRL
         return self._obs if want_obs else None
 
+    def set_rollout_streams(self, n_streams: int = 0):
+        """How rollout_geometric issues its steps: 0 auto, 1 the current stream only, 2 the two halves of the shard on two
+        internal streams (mds_set_rollout_streams).  Same results either way."""
+        self._require_open()
+        capi.check(self._lib.mds_set_rollout_streams(self._h, C.c_int(int(n_streams))), "mds_set_rollout_streams")
+
     def rollout_geometric_fused(self, t0: float, n_steps: int, log: bool = False, log_out: torch.Tensor | None = None,
                                 controller: str = "geometric"):
         """``n_steps`` fused control steps in ONE kernel launch (state stays in registers).  With

@@ -322,6 +322,39 @@ def test_rollout_equals_stepwise_and_substeps_drag_rk4(mds):
             e.close()
 
 
+@pytest.mark.parametrize("dtype,physics", [("float32", "dyn"), ("float64", "drag"), ("float16", "dyn")])
+def test_two_stream_rollout_is_bit_identical_and_stream_ordered(mds, dtype, physics):
+    """mds_set_rollout_streams(2): the two halves of the shard step on two internal streams.  Same kernel per drone, so the
+    result must equal the one-stream rollout bit for bit -- with an odd number of 256-drone batches and a ragged tail
+    (7 x 199 = 1393 drones = 5 full batches + 113), on a non-default caller stream, reading obs right after the call."""
+    torch = mds.torch
+    E, D, T = 199, 7, 37
+    xyz, rpy, P = H.c2_setup(E, D, phase="c3", yaw_rate=0.2)
+    phys = mds.Physics.PYB_DRAG if physics == "drag" else mds.Physics.DYN
+    out = []
+    for streams in (1, 2):
+        env = make_env(mds, E, D, xyz, rpy, dtype, 200, 100, phys)
+        env.set_trajectories(P)
+        env.set_rollout_streams(streams)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=env.device))
+            o = env.rollout_geometric(0.0, T, obs_every_step=True)
+            snap = o.clone()                                   # ordered behind both halves by the exit events
+            o2 = env.rollout_geometric(T * env.CTRL_TIMESTEP, 3).clone()   # a second call chains behind the first
+        side.synchronize()
+        out.append((snap.cpu().numpy(), o2.cpu().numpy(), env.get_state()))
+        env.close()
+    for a, b in zip(*out):
+        assert np.isfinite(a.astype(np.float64)).all()
+        np.testing.assert_array_equal(a, b)
+    env2 = make_env(mds, 2, 2, *H.c2_setup(2, 2)[:2], "float32")
+    with pytest.raises(Exception):
+        env2.set_rollout_streams(3)
+    env2.close()
+
+
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 def test_fused_rollout_equals_stepwise_and_logs_every_step(mds, dtype):
     """mds_rollout_geometric_fused (one launch, state in registers) == n calls of mds_step_geometric
