@@ -323,13 +323,13 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && !RK4) ? MDS_GEOSIMPLE_MI
 
 // ------------------------------------------------------------------------------------
 // General-trajectory form of the fused step: the drone's desired state comes from its segment
-// table (mds_traj.hpp), evaluated in double and re-expressed relative to the drone's local-frame
-// origin before the fp32 controller sees it.  obs / action_out may be NULL.
+// table (mds_traj.hpp TrajLocal: phases and absolute positions in double, the rest in T), relative to the
+// drone's local-frame origin.  obs / action_out may be NULL.
 // ------------------------------------------------------------------------------------
 template <typename T, typename S, bool RK4, bool DRAG>
 __global__ __launch_bounds__(kBlock) void k_step_traj(const Consts<T> c, const int n, const size_t ld, const double t,
                                                       S* __restrict__ state, const T* __restrict__ origin,
-                                                      const double* __restrict__ segs, const int* __restrict__ tinfo,
+                                                      const SegTable segs, const int* __restrict__ tinfo,
                                                       T* __restrict__ last_rpm, S* __restrict__ obs, S* __restrict__ action_out) {
   __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
   const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -339,14 +339,7 @@ __global__ __launch_bounds__(kBlock) void k_step_traj(const Consts<T> c, const i
   if (valid) {
     load_state<S, T>(state, ld, i, s);
     const V3<T> org = {origin[i], origin[ld + i], origin[2 * ld + i]};
-    double d11[11];
-    traj_eval(segs, tinfo[2 * i], tinfo[2 * i + 1] & 0xffff, tinfo[2 * i + 1] >> 16, t, d11);
-    Desired<T> des;
-    des.p = {(T)(d11[0] - (double)org.x), (T)(d11[1] - (double)org.y), (T)(d11[2] - (double)org.z)};
-    des.v = {(T)d11[3], (T)d11[4], (T)d11[5]};
-    des.a = {(T)d11[6], (T)d11[7], (T)d11[8]};
-    des.yaw = reduced_phase<T>(0.0, T(0), (T)d11[9]);
-    des.yaw_rate = (T)d11[10];
+    const Desired<T> des = TrajLocal<T>::eval(segs, traj_info(tinfo, i), t, org);
     T prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4], act[4];
     if (DRAG)
       for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
@@ -373,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void k_step_traj(const Consts<T> c, const i
 template <typename T, typename S, bool RK4, bool DRAG>
 __global__ __launch_bounds__(kBlock) void k_step_lqr(const Consts<T> c, const Lqr12Gain<T> K, const int n, const size_t ld, const double t,
                                                      const int traj_mode, S* __restrict__ state, const T* __restrict__ origin,
-                                                     const T* __restrict__ lem, const double* __restrict__ segs,
+                                                     const T* __restrict__ lem, const SegTable segs,
                                                      const int* __restrict__ tinfo, T* __restrict__ last_rpm, S* __restrict__ obs,
                                                      S* __restrict__ action_out) {
   __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
@@ -390,12 +383,7 @@ __global__ __launch_bounds__(kBlock) void k_step_lqr(const Consts<T> c, const Lq
       load_geo_in<T, S>(state, lem, ld, i, in);
       des = lemniscate_local(in.P, t);
     } else {
-      double d11[11];
-      traj_eval(segs, tinfo[2 * i], tinfo[2 * i + 1] & 0xffff, tinfo[2 * i + 1] >> 16, t, d11);
-      des.p = {(T)(d11[0] - (double)org.x), (T)(d11[1] - (double)org.y), (T)(d11[2] - (double)org.z)};
-      des.v = {(T)d11[3], (T)d11[4], (T)d11[5]};
-      des.yaw = reduced_phase<T>(0.0, T(0), (T)d11[9]);
-      des.yaw_rate = (T)d11[10];
+      des = TrajLocal<T>::eval(segs, traj_info(tinfo, i), t, org);
     }
     T prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4], act[4], u[4];
     if (DRAG)
@@ -431,12 +419,12 @@ __global__ void k_lqr12_compute(const Consts<T> c, const Lqr12Gain<T> K, const i
 
 // Trajectory.__call__(t) for every drone from the segment tables: des [n,11] world frame
 template <typename S>
-__global__ void k_traj_eval(const int n, const double t, const double* __restrict__ segs, const int* __restrict__ tinfo,
+__global__ void k_traj_eval(const int n, const double t, const SegTable segs, const int* __restrict__ tinfo,
                             S* __restrict__ des) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double d11[11];
-  traj_eval(segs, tinfo[2 * i], tinfo[2 * i + 1] & 0xffff, tinfo[2 * i + 1] >> 16, t, d11);
+  traj_eval(segs, traj_info(tinfo, i), t, d11);
   for (int k = 0; k < 11; ++k) des[(size_t)i * 11 + k] = (S)d11[k];
 }
 
@@ -521,7 +509,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c,
 template <typename T, typename S, bool RK4, bool DRAG, int CTRL>
 __global__ __launch_bounds__(kBlock) void k_rollout_traj(const Consts<T> c, const void* __restrict__ Kp, const int n, const size_t ld, double t,
                                                          const double ctrl_dt, const int n_steps, S* __restrict__ state,
-                                                         const T* __restrict__ origin, const double* __restrict__ segs,
+                                                         const T* __restrict__ origin, const SegTable segs,
                                                          const int* __restrict__ tinfo, T* __restrict__ last_rpm,
                                                          S* __restrict__ obs_log, S* __restrict__ obs_last) {
   __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
@@ -529,13 +517,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout_traj(const Consts<T> c, cons
   const bool valid = i < n;
   State<T> s;
   V3<T> org = {T(0), T(0), T(0)};
-  int first = 0, info = 0;
+  TrajInfo ti = {0, 1, 0, 0};
   T prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4] = {T(0), T(0), T(0), T(0)};
   if (valid) {
     load_state<S, T>(state, ld, i, s);
     org = {origin[i], origin[ld + i], origin[2 * ld + i]};
-    first = tinfo[2 * i];
-    info = tinfo[2 * i + 1];
+    ti = traj_info(tinfo, i);
     if (DRAG)
       for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
   }
@@ -543,14 +530,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_traj(const Consts<T> c, cons
     T o[kObsDim];
     const bool want = obs_log != nullptr || (obs_last != nullptr && k == n_steps - 1);
     if (valid) {
-      double d11[11];
-      traj_eval(segs, first, info & 0xffff, info >> 16, t, d11);
-      Desired<T> des;
-      des.p = {(T)(d11[0] - (double)org.x), (T)(d11[1] - (double)org.y), (T)(d11[2] - (double)org.z)};
-      des.v = {(T)d11[3], (T)d11[4], (T)d11[5]};
-      des.a = {(T)d11[6], (T)d11[7], (T)d11[8]};
-      des.yaw = reduced_phase<T>(0.0, T(0), (T)d11[9]);
-      des.yaw_rate = (T)d11[10];
+      const Desired<T> des = TrajLocal<T>::eval(segs, ti, t, org);
       T u[4], act[4];
       if (CTRL == 0) {
         const M3<T> R = quat_to_rot(s.q);

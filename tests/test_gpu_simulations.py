@@ -284,7 +284,7 @@ def test_nominal_whole_rollout_equals_stepwise(gpu, which):
     last, log = a.rollout_geometric_fused(0.0, T, log=True, controller="nominal")
     t = 0.0
     for k in range(T):
-        o = b.step_nominal(t)
+        o = b.step_nominal(t, return_action=True)[0]       # with the action wanted: the two-launch path (nominal, low level + step)
         t += b.CTRL_TIMESTEP
         if k in (0, 1, T // 2, T - 1):
             np.testing.assert_allclose(log[k].cpu().numpy(), o.cpu().numpy(), atol=1e-9, rtol=1e-12)
