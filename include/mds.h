@@ -149,7 +149,9 @@ int mds_set_wind(mds_handle* h, const double force_world[3]);
  * offsets[i] .. offsets[i+1]-1, at most 65535); compound_host int32 [n] (1: CompoundTrajectory lookup
  * with its past-the-end rule, 0: a single trajectory evaluated at t); anchor_host double [n,3]: local-frame
  * origin per drone (e.g. the first segment's centre / start).  Replaces mds_set_lemniscate's trajectories:
- * mds_step_geometric / mds_rollout_geometric then run the general kernel. */
+ * mds_step_geometric / mds_rollout_geometric then run the general kernel.  The device image is the library's own
+ * (field-major; drones whose rows are bytewise identical share one copy; tables with equal piece counts piece-major),
+ * so broadcasting the same D tables over every env costs D tables of device memory, not n. */
 #define MDS_SEG_DIM 40
 int mds_set_trajectory_segments(mds_handle* h, const double* segs_host, const int32_t* offsets_host,
                                 const int32_t* compound_host, const double* anchor_host, int32_t total_segments, void* stream);
@@ -326,7 +328,8 @@ int mds_step_cbf_geometric(mds_handle* h, double t, void* obs_dev, int32_t* stat
 /* The same step without the filter: nominal LQR (mds_cbf_set_nominal 1 or 2) -> its low level -> env.step, i.e.
  * ctrl[j].compute(obs[j]) + env.step(action) of simulations/EnvGeometricOmega.py:314,327 (LQROmegaController +
  * ThrustOmegaController) and simulations/EnvGeometricYankOmega.py:319,332 (LQRYankOmegaController + YankOmegaController).
- * obs_dev as for mds_step_cbf_geometric. */
+ * obs_dev as for mds_step_cbf_geometric.  With action_dev NULL and Lemniscate trajectories the call is one launch (the
+ * one-step instance of the whole-rollout kernel); with the action wanted it is two (nominal, low level + step). */
 int mds_step_nominal(mds_handle* h, double t, void* obs_dev, void* action_dev, void* stream);
 /* n_steps of that loop in ONE launch (Lemniscate trajectories; the low level's PID memory stays in registers): obs_log_dev
  * [n_steps, n, 20] or NULL; obs_dev [n,20] holds the current observation on entry and the last one on return. */
