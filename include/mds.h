@@ -178,7 +178,7 @@ int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs_dev, 
 /* How mds_rollout_geometric issues its steps.  Drones never read each other's rows in the fused step, so the two
  * halves of the shard are independent step chains: on two internal streams they drift out of phase and one half's
  * load/store bursts fill the other's compute phase (C3: 17.5 -> 16 us per step).  0 = auto (two streams from 2^19
- * drones up -- from 2^18 for calls of 1000+ steps --, Lemniscate mode), 1 = the caller's stream only, 2 = always split.  Results are identical either way;
+ * drones up -- from 2^18 for calls of 1000+ steps --), 1 = the caller's stream only, 2 = always split.  Results are identical either way;
  * the caller's stream orders the whole call (events on entry and exit), so the usual stream semantics hold. */
 int mds_set_rollout_streams(mds_handle* h, int n_streams);
 

@@ -620,7 +620,7 @@ static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, 
     const bool rk4_ = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag_ = has_drag(h);
 #define MDS_TRAJ(RK4, DRAG)                                                                                                   \
   MDS_DISPATCH(h, (k_step_traj<T, S, RK4, DRAG><<<dim3(nbatch), kBlock, 0, st>>>(C, h->n, h->ld, t, (S*)h->state, (const T*)h->origin, \
-                                                                               SegTable{h->segs, h->nseg_total}, h->tinfo, (T*)rpm_track(h), (S*)obs, (S*)act)))
+                                                                               SegTable{h->segs, h->nseg_total}, h->tinfo, (T*)rpm_track(h), (S*)obs, (S*)act, (int)batch0)))
     if (rk4_ && drag_) MDS_TRAJ(true, true);
     else if (rk4_) MDS_TRAJ(true, false);
     else if (drag_) MDS_TRAJ(false, true);
@@ -671,7 +671,7 @@ int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs, int 
   // between 2^18 and 2^19 it pays only once the chains have had ~1000 steps to drift out of phase
   const bool big = h->n >= 2 * kSplitMinDrones ? n_steps >= 16 : (h->n >= kSplitMinDrones && n_steps >= 1000);
   const int streams = h->rollout_streams ? h->rollout_streams : (big ? 2 : 1);
-  if (streams == 2 && h->traj_mode != 2 && nbatch >= 2 && n_steps >= 2) {
+  if (streams == 2 && nbatch >= 2 && n_steps >= 2) {
     // Drones never read each other's rows in this kernel, so the two halves of the shard are two independent step
     // chains.  Run on two streams they drift out of phase: one half's load/store bursts fill the other's compute
     // phase (measured on C3: 17.5 -> 15.7-16.3 us per step).  The caller's stream orders both chains.

@@ -330,9 +330,10 @@ template <typename T, typename S, bool RK4, bool DRAG>
 __global__ __launch_bounds__(kBlock) void k_step_traj(const Consts<T> c, const int n, const size_t ld, const double t,
                                                       S* __restrict__ state, const T* __restrict__ origin,
                                                       const SegTable segs, const int* __restrict__ tinfo,
-                                                      T* __restrict__ last_rpm, S* __restrict__ obs, S* __restrict__ action_out) {
+                                                      T* __restrict__ last_rpm, S* __restrict__ obs, S* __restrict__ action_out,
+                                                      const int batch0) {
   __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
-  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
   const bool valid = i < n;
   T o[kObsDim];
   State<T> s;

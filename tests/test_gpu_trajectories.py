@@ -111,3 +111,29 @@ def test_whole_rollout_on_segment_tables_equals_stepwise():
             np.testing.assert_allclose(log[k].cpu().numpy(), o.cpu().numpy(), atol=1e-9)
     np.testing.assert_allclose(a.get_state(), b.get_state(), atol=1e-9)
     a.close(); b.close()
+
+
+def test_two_stream_rollout_on_segment_tables_is_bit_identical():
+    """mds_set_rollout_streams(2) on the general kernel: tables of 1 and 3 pieces (two storage blocks), shared and rotated ones,
+    1400 drones (5 full batches + 120): same bits as the one-stream loop."""
+    import torch
+    from multidronesim_amd.envs.CtrlAviary import CtrlAviary, DroneModel, Physics
+    gc = trajectory_cases(gpu_classes())
+    names = ["compound", "circle", "rotate", "line_s0", "compound_mixed", "wait", "circle"]
+    D, E, T = len(names), 200, 45
+    oc = trajectory_cases(oracle_classes())
+    xyz = np.array([np.asarray(oc[n](0.0)[0], dtype=np.float64) + np.array([0.05, -0.03, 0.02]) for n in names])
+    xyz = np.broadcast_to(xyz, (E, D, 3)).copy()
+    out = []
+    for streams in (1, 2):
+        env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=np.zeros((E, D, 3)), physics=Physics.DYN,
+                         pyb_freq=200, ctrl_freq=100, num_envs=E, dtype="float32")
+        env.set_trajectories([gc[n] for n in names])
+        env.set_rollout_streams(streams)
+        env.step(torch.zeros((E, D, 4), dtype=env.dtype))
+        o = env.rollout_geometric(0.0, T, obs_every_step=True).clone()
+        out.append((o.cpu().numpy(), env.get_state()))
+        env.close()
+    assert np.isfinite(out[0][0]).all()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
