@@ -428,3 +428,52 @@ def test_cbf_filter_longest_first_dispatch_is_invisible(mds):
         if status == 0:
             np.testing.assert_allclose(us[e], u_ref, atol=2e-5, rtol=0)
     env.close()
+
+
+def test_c4_full_size_properties(mds):
+    """BASELINE config 4 at its full size (16 384 envs x 16 drones, the bench's scene) through size-independent properties:
+    replicated envs stay bitwise equal wherever they sit in the batch (the longest-first dispatch permutes the envs between
+    calls), a 64-env batch holding the same envs gives the same bits, every row is finite with a unit quaternion and a
+    0/1 status, and a strided sample of envs follows the oracle loop."""
+    from tests import helpers as H2
+    E, D, steps = 16384, 16, 40
+    xyz, rpy, P = H2.c2_setup(E, D, phase="c3")
+    P[..., 4] = 0.5 + 0.3 * np.arange(D)
+    xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    for dst in (8192, 16384 - 64 - 5):                         # copies of envs 0..63
+        xyz[dst:dst + 64], P[dst:dst + 64] = xyz[0:64], P[0:64]
+    x_obs = [np.array([[sx * 0.5, sy * 0.5, 0.5], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
+    obs_r = [0.1] * 4
+    poles = np.array([-2.2, -2.4])
+
+    def run(lo, hi):
+        env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz[lo:hi], initial_rpys=rpy[lo:hi],
+                             physics=mds.Physics.DYN, pyb_freq=100, ctrl_freq=100, num_envs=hi - lo, dtype="float32")
+        env.set_trajectories(P[lo:hi])
+        cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2, cbf_poles=poles)
+        trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+        env.step(mds.torch.zeros((hi - lo, D, 4), dtype=env.dtype))
+        t, hist = 0.0, []
+        for k in range(steps):
+            o, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
+            hist.append(st.clone())
+            t += env.CTRL_TIMESTEP
+        out = (o.clone(), mds.torch.stack(hist), cbf.Kcbf.reshape(-1).copy(), np.array(cbf.umax, dtype=np.float64))
+        env.close()
+        return out
+
+    obs, hist, Kcbf, umax = run(0, E)
+    for dst in (8192, 16384 - 64 - 5):
+        assert mds.torch.equal(obs[0:64], obs[dst:dst + 64])
+        assert mds.torch.equal(hist[:, 0:64], hist[:, dst:dst + 64])
+    so, sh, _, _ = run(0, 64)                                    # no dispatch classes at this size
+    assert mds.torch.equal(so, obs[0:64]) and mds.torch.equal(sh, hist[:, 0:64])
+    assert mds.torch.isfinite(obs).all()
+    assert (obs[..., 3:7].norm(dim=-1) - 1).abs().max().item() < 1e-5
+    assert set(np.unique(hist.cpu().numpy()).tolist()) <= {0, 1}
+    assert 0.0 < hist.float().mean().item() < 0.9
+    idx = np.arange(0, E, E // 8)
+    oobs, ohist = H2.oracle_cbf_closed_loop(xyz[idx], rpy[idx], P[idx], steps, Kcbf, umax, 0.1, 1.0, x_obs, obs_r)
+    np.testing.assert_array_equal(hist[:, idx].cpu().numpy(), np.array(ohist))
+    g = obs[idx].double().cpu().numpy()
+    assert np.abs(g[..., :16] - oobs.reshape(g.shape)[..., :16]).max() < 1e-3

@@ -593,3 +593,40 @@ def test_set_origin_rebases_the_local_frame_without_moving_anything(mds):
         oa, *_ = a.step(act); ob, *_ = b.step(act)
     np.testing.assert_allclose(np_obs(oa)[:, :16], np_obs(ob)[:, :16], atol=3e-5)      # world coordinates up to 20 m: 1 fp32 ulp = 2e-6
     a.close(); b.close()
+
+
+def test_c5_full_size_properties(mds):
+    """BASELINE config 5 at its full size (262 144 envs x 2 drones, fp16 state storage / fp32 arithmetic, 240 Hz, random RPM around
+    hover through env.step): replicated envs bitwise equal, a small batch of the same envs bitwise equal, invariants on every
+    row, and a strided sample against the float64 oracle at fp16-storage tolerance."""
+    torch = mds.torch
+    E, D, steps = 262144, 2, 48
+    xyz, rpy, _ = H.c2_setup(E, D)
+    xyz[100000:100128] = xyz[0:128]
+    g = torch.Generator(device="cuda").manual_seed(7)
+    acts = [(16000.0 * (1 + 0.05 * torch.randn((E, D, 4), device="cuda", generator=g))).clamp(0, 21000.0) for _ in range(4)]
+    for a in acts:
+        a[100000:100128] = a[0:128]
+
+    def run(lo, hi):
+        env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz[lo:hi], initial_rpys=rpy[lo:hi],
+                             physics=mds.Physics.DYN, pyb_freq=240, ctrl_freq=240, num_envs=hi - lo, dtype="float16")
+        for k in range(steps):
+            o, *_ = env.step(acts[k % 4][lo:hi].to(env.dtype))
+        out = o.clone()
+        env.close()
+        return out
+
+    obs = run(0, E)
+    assert torch.equal(obs[0:128], obs[100000:100128])
+    assert torch.equal(run(0, 128), obs[0:128])
+    f = obs.float()
+    assert torch.isfinite(f).all()
+    assert (f[..., 3:7].norm(dim=-1) - 1).abs().max().item() < 2e-3            # fp16 storage of the quaternion
+    idx = np.arange(0, E, E // 256)
+    ora = O.AviaryOracle(xyz[idx].reshape(-1, 3), rpy[idx].reshape(-1, 3), O.CF2P, 240, 240)
+    for k in range(steps):
+        oo = ora.step(acts[k % 4][idx].to(torch.float16).double().cpu().numpy().reshape(-1, 4))
+    gg = f[idx].double().cpu().numpy().reshape(-1, 20)
+    # fp16 storage: 4e-3 m is one unit in the last place of a 5 m coordinate, and the stored state is re-rounded every step
+    assert np.abs(gg[:, :3] - oo[:, :3]).max() < 5e-2 and np.abs(gg[:, 10:13] - oo[:, 10:13]).max() < 1e-1
