@@ -630,3 +630,22 @@ def test_c5_full_size_properties(mds):
     gg = f[idx].double().cpu().numpy().reshape(-1, 20)
     # fp16 storage: 4e-3 m is one unit in the last place of a 5 m coordinate, and the stored state is re-rounded every step
     assert np.abs(gg[:, :3] - oo[:, :3]).max() < 5e-2 and np.abs(gg[:, 10:13] - oo[:, 10:13]).max() < 1e-1
+
+
+@pytest.mark.parametrize("name,physics,integrator", [("euler", "DYN", "euler"), ("rk4", "DYN", "rk4"), ("drag", "PYB_DRAG", "euler")])
+def test_step_f64_matches_committed_1000_step_rollouts(mds, name, physics, integrator):
+    """The oracle-only long-horizon fixture (tests/golden/dyn_rollouts_1000.npz): env.step in float64 for 1000
+    steps at 240 Hz under the fixture's RPM sequence (clipped commands included) against the committed observations."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "dyn_rollouts_1000.npz"))
+    xyz, rpy, rpm = d["xyz"], d["rpy"], d["rpm"]
+    n = xyz.shape[0]
+    env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=n, initial_xyzs=xyz, initial_rpys=rpy,
+                         physics=getattr(mds.Physics, physics), pyb_freq=240, ctrl_freq=240, num_envs=1, dtype="float64",
+                         integrator=integrator)
+    acts = [mds.torch.as_tensor(rpm[k], dtype=mds.torch.float64, device=env.device).reshape(1, n, 4) for k in range(8)]
+    check = {int(k): j for j, k in enumerate(d["check"])}
+    for k in range(1, 1001):
+        obs, *_ = env.step(acts[(k - 1) % 8])
+        if k in check:
+            np.testing.assert_allclose(np_obs(obs), d[name][check[k]], rtol=1e-9, atol=1e-9, err_msg=f"{name} step {k}")
+    env.close()

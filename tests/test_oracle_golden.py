@@ -192,3 +192,14 @@ def test_trajectory_family_matches_reference():
             pos, vel, acc, yaw, om = tr(float(t))
             got = np.hstack([pos, vel, np.asarray(acc) * np.ones(3), yaw, om])
             np.testing.assert_allclose(got, want, rtol=0, atol=1e-12, err_msg=f"{name} t={t}")
+
+
+def test_oracle_reproduces_its_own_1000_step_rollouts():
+    """SURVEY 8c G7 (oracle-only fixture): the restated Physics.DYN must keep producing the committed 1000-step rollouts
+    (Euler, RK4, Euler + drag; 64 drones, 240 Hz, clipped commands included)."""
+    from tests.golden import mint_oracle_rollouts as R
+    d = np.load(os.path.join(G, "dyn_rollouts_1000.npz"))
+    for name, (ph, integ) in dict(euler=("dyn", "euler"), rk4=("dyn", "rk4"), drag=("dyn_drag", "euler")).items():
+        r = R.rollout(ph, integ)
+        for j, k in enumerate(d["check"]):
+            np.testing.assert_allclose(r[int(k)], d[name][j], rtol=1e-12, atol=1e-12, err_msg=f"{name} step {k}")
