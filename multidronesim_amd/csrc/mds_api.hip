@@ -616,10 +616,19 @@ int mds_set_wind(mds_handle* h, const double force_world[3]) {
 // batch0 / nb: the range of 256-drone batches this launch covers (nb == 0: all of them)
 static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, hipStream_t st, unsigned batch0 = 0, unsigned nb = 0) {
   const unsigned nbatch = nb ? nb : (unsigned)((h->n + kBlock - 1) / kBlock);
+  // Half-shard launches of the two-stream rollout carry unused dynamic LDS up to 32 KB per workgroup: 5 workgroups per CU
+  // instead of 8.  A half then no longer fits the chip next to the other chain's half, so its workgroups enter as the other
+  // chain's retire and the two chains interleave from the first step on (C3: 15.6 -> 15.0 us per step over 20 000 steps,
+  // 16.5 -> 15.8 over 2000; on one stream the same padding costs 4 %, so full-shard launches do not get it).
+  size_t pad = 0;
+  if (nb) {
+    const size_t static_lds = (h->traj_mode == 2 || obs) ? (size_t)kBlock * kObsDim * elem_size(h->cfg.dtype) : 16;
+    pad = static_lds < 32768 ? 32768 - static_lds : 0;
+  }
   if (h->traj_mode == 2) {      // general trajectories: segment tables
     const bool rk4_ = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag_ = has_drag(h);
 #define MDS_TRAJ(RK4, DRAG)                                                                                                   \
-  MDS_DISPATCH(h, (k_step_traj<T, S, RK4, DRAG><<<dim3(nbatch), kBlock, 0, st>>>(C, h->n, h->ld, t, (S*)h->state, (const T*)h->origin, \
+  MDS_DISPATCH(h, (k_step_traj<T, S, RK4, DRAG><<<dim3(nbatch), kBlock, pad, st>>>(C, h->n, h->ld, t, (S*)h->state, (const T*)h->origin, \
                                                                                SegTable{h->segs, h->nseg_total}, h->tinfo, (T*)rpm_track(h), (S*)obs, (S*)act, (int)batch0)))
     if (rk4_ && drag_) MDS_TRAJ(true, true);
     else if (rk4_) MDS_TRAJ(true, false);
@@ -629,7 +638,7 @@ static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, 
     return MDS_OK;
   }
 #define MDS_LAUNCH_GEO2(HAS_OBS, HAS_ACT, RK4, DRAG)                                                                           \
-  MDS_DISPATCH(h, (k_step_geometric<T, S, HAS_OBS, HAS_ACT, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t, (S*)h->state, \
+  MDS_DISPATCH(h, (k_step_geometric<T, S, HAS_OBS, HAS_ACT, RK4, DRAG><<<grid, kBlock, pad, st>>>(C, h->n, h->ld, t, (S*)h->state, \
                                                                                                 (const T*)h->lem, (T*)rpm_track(h), \
                                                                                                 (S*)obs, (S*)act, (int)batch0)))
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
