@@ -181,7 +181,7 @@ METRIC = _baseline_metric()
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 20000 for c3/c5, 2000 for c2/c4)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 20000 for c3/c5, 2000 for c2, 200 for c4)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: steps / 10)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64", "float16"])
@@ -197,10 +197,10 @@ def main(argv=None):
     ap.add_argument("--gather-obs", action="store_true",
                     help="after the timed region, also time the optional whole-swarm observation all-gather (RCCL over xGMI); never part of `value`")
     args = ap.parse_args(argv)
-    # c2 is launch-bound (a longer queue only adds back-pressure) and c4's QP work depends on how far the swarm has
-    # settled, so both keep the 2000-step window their numbers in DESIGN.md were taken on
+    # c2 is launch-bound (a longer queue only adds back-pressure): 2000 steps.  c4's QP work follows the scene (the swarm closes in on
+    # the obstacles, then settles): it keeps SURVEY 8d's T = 200 window, the one its numbers in DESIGN.md were taken on.
     if args.steps is None:
-        args.steps = 20000 if args.workload in ("c3", "c5") else 2000
+        args.steps = {"c3": 20000, "c5": 20000, "c2": 2000, "c4": 200}[args.workload]
     if args.warmup is None:
         args.warmup = args.steps // 10
 
@@ -300,11 +300,13 @@ def main(argv=None):
             for _ in range(k // fused_T):
                 env.rollout_geometric_fused(t, fused_T, log=True, log_out=log_buf)
                 t += fused_T * dt
-        elif tracker is not None:
+        elif tracker is not None and args.python_loop:
             t = t0
             for _ in range(k):
                 env.step_cbf_geometric(t, tracker, c4_obs, c4_r)
                 t += dt
+        elif tracker is not None:
+            env.rollout_cbf_geometric(t0, k, tracker, c4_obs, c4_r)
         elif args.python_loop:
             t = t0
             for _ in range(k):
@@ -408,7 +410,10 @@ def main(argv=None):
         line["config"].update({"pyb_freq": 240, "ctrl_freq": 240, "launch": "python ctypes loop, obs -> rollout log slot"})
     if args.workload == "c4":
         st = env._cbf_status
-        line["roofline"]["kernel"] = "k_cbf_nominal + k_cbf_filter_o2_gi + k_lowlevel_step (3 launches per step; QP is latency/ALU bound)"
+        line["roofline"]["kernel"] = "k_cbf_nominal + k_cbf_filter_gi + k_lowlevel_step (3 launches per step and env half; QP is latency/ALU bound)"
+        if not args.python_loop:
+            line["config"]["launch"] = ("C rollout loop, env halves on 2 streams" if args.rollout_streams != 1
+                                        else "C rollout loop, one stream")
         line["cbf_fallback_frac_last_step"] = float((st != 0).float().mean().item())
     # secondary measurement (same workload, same run): the whole-rollout kernel, 50 control steps per launch with
     # every step's observation streamed to a [50,n,20] log.  Reported beside the contract's per-step line.

@@ -325,6 +325,12 @@ int mds_cbf_set_nominal(mds_handle* h, int which);
  * action_dev [n,4] (RPM) optional. */
 int mds_step_cbf_geometric(mds_handle* h, double t, void* obs_dev, int32_t* status_dev, void* action_dev, void* stream);
 
+/* n_steps of mds_step_cbf_geometric enqueued from C (t advances by 1/ctrl_freq per step, like the reference loop); status_dev
+ * holds the last step's per-env status.  Large batches run as two env halves on two internal streams (mds_set_rollout_streams
+ * policy: auto from 2^17 drones and 16 steps): a barrier couples drones of one env only, so the halves are independent step
+ * chains and one half's QP kernel overlaps the other's memory-bound kernels.  Results are those of the step-by-step loop. */
+int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs_dev, int32_t* status_dev, void* stream);
+
 /* The same step without the filter: nominal LQR (mds_cbf_set_nominal 1 or 2) -> its low level -> env.step, i.e.
  * ctrl[j].compute(obs[j]) + env.step(action) of simulations/EnvGeometricOmega.py:314,327 (LQROmegaController +
  * ThrustOmegaController) and simulations/EnvGeometricYankOmega.py:319,332 (LQRYankOmegaController + YankOmegaController).

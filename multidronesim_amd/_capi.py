@@ -104,6 +104,7 @@ PROTOTYPES = {
     "mds_yank_omega_compute": (C.c_int, [_P, _P, _P, _P, _P]),
     "mds_cbf_set_nominal": (C.c_int, [_P, C.c_int]),
     "mds_step_cbf_geometric": (C.c_int, [_P, C.c_double, _P, _P, _P, _P]),
+    "mds_rollout_cbf_geometric": (C.c_int, [_P, C.c_double, C.c_int, _P, _P, _P]),
     "mds_step_nominal": (C.c_int, [_P, C.c_double, _P, _P, _P]),
     "mds_rollout_nominal_fused": (C.c_int, [_P, C.c_double, C.c_int, _P, _P, _P]),
 }

@@ -67,8 +67,10 @@ struct mds_handle {
   CbfParams<double> cbf_d;
   int* pair_ij;        // device [D(D-1)/2]
   void* obstacles;     // device T [n_obs,4]
-  int* cbf_order;      // [3,E] env ids by cost class (longest-first dispatch of the QP kernel)
-  int* cbf_count;      // [4]
+  // slot 0: the whole batch; slots 1, 2: the two env halves of mds_rollout_cbf_geometric (each keeps its own cost classes)
+  int* cbf_order;      // [3 slots][3,E] env ids by cost class (longest-first dispatch of the QP kernel)
+  int* cbf_count;      // [3 slots][4]
+  int cbf_calls_half[2] = {-1, -1};
   int* cbf_cost;       // [E] GI iterations of the last launch
   int cbf_calls;       // launches since the classes were rebuilt; -1: no classes yet
   int rollout_streams = 0;              // mds_set_rollout_streams: 0 auto, 1, 2
@@ -893,10 +895,10 @@ int mds_cbf_configure(mds_handle* h, const mds_cbf_params* p, const double* obst
       MDS_HIP(hipMemcpy(h->obstacles, tmp, sizeof(float) * 4 * p->n_obs, hipMemcpyHostToDevice));
     }
   }
-  if (!h->cbf_order) MDS_HIP(hipMalloc((void**)&h->cbf_order, sizeof(int) * 3 * (size_t)h->cfg.num_envs));
-  if (!h->cbf_count) MDS_HIP(hipMalloc((void**)&h->cbf_count, sizeof(int) * 4));
+  if (!h->cbf_order) MDS_HIP(hipMalloc((void**)&h->cbf_order, sizeof(int) * 9 * (size_t)h->cfg.num_envs));
+  if (!h->cbf_count) MDS_HIP(hipMalloc((void**)&h->cbf_count, sizeof(int) * 12));
   if (!h->cbf_cost) MDS_HIP(hipMalloc((void**)&h->cbf_cost, sizeof(int) * (size_t)h->cfg.num_envs));
-  h->cbf_calls = -1;                                       // a new problem: forget the cost classes
+  h->cbf_calls = h->cbf_calls_half[0] = h->cbf_calls_half[1] = -1;   // a new problem: forget the cost classes
   h->cbf = *p;
   fill_cbf(h, *p, h->cbf_f);
   fill_cbf(h, *p, h->cbf_d);
@@ -928,12 +930,26 @@ int mds_cbf_rows(mds_handle* h, const void* x, const void* xdes, void* G, void* 
   return MDS_OK;
 }
 
-int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void* unom, void* usafe, int32_t* status,
-                   void* stream) {
-  if (!h || !obs || !xdes || !unom || !usafe || !status) return fail(MDS_EINVAL, "mds_cbf_filter: null argument");
-  if (!h->has_cbf) return fail(MDS_ESTATE, "mds_cbf_filter: call mds_cbf_configure first");
+// envs [e0, e0 + ne) of the batch; slot selects the cost-class tables (0: whole batch, 1 / 2: halves of a two-stream rollout)
+struct EnvRange {
+  int e0, ne, slot;
+};
+
+static int cbf_filter_range(mds_handle* h, const void* obs_, const void* xdes_, const void* unom_, void* usafe_, int32_t* status_,
+                            void* stream, EnvRange rg) {
   hipStream_t st = (hipStream_t)stream;
-  const int E = h->cfg.num_envs, D = h->cfg.num_drones, order = h->cbf.order;
+  const int E = rg.ne, D = h->cfg.num_drones, order = h->cbf.order;
+  // an env's blocks are contiguous in every operand: a range is a pointer offset
+  const size_t es = elem_size(h->cfg.dtype), d0 = (size_t)rg.e0 * D;
+  const char* obs = (const char*)obs_ + d0 * kObsDim * es;
+  const char* xdes = (const char*)xdes_ + d0 * (order == 2 ? 9 : 10) * es;
+  const char* unom = (const char*)unom_ + d0 * 4 * es;
+  char* usafe = (char*)usafe_ + d0 * 4 * es;
+  int32_t* status = status_ + rg.e0;
+  int& calls = rg.slot == 0 ? h->cbf_calls : h->cbf_calls_half[rg.slot - 1];
+  int* const order_tab = h->cbf_order + (size_t)rg.slot * 3 * h->cfg.num_envs;
+  int* const count_tab = h->cbf_count + 4 * rg.slot;
+  int* const cost_tab = h->cbf_cost + rg.e0;
   const int nv = order == 2 ? 1 : 3, n = nv * D;
   const int m = D * (D - 1) / 2 + D * h->cbf.n_obs + 2 * n;          // rows of the coupled sub-problem
   const int R = (m + 63) / 64;
@@ -944,9 +960,9 @@ int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void*
   if (n > 64) return fail(MDS_EUNSUPPORTED, "mds_cbf_filter: more than 64 coupled QP variables per env");
   if (R > 17) return fail(MDS_EUNSUPPORTED, "mds_cbf_filter: too many rows per env");
   // longest-first dispatch (see k_cbf_filter_gi): classes from the iteration counts of an earlier launch, rebuilt every 8th call
-  const int* ord_in = h->cbf_calls < 0 ? nullptr : h->cbf_order;
-  const int* cnt_in = h->cbf_calls < 0 ? nullptr : h->cbf_count;
-  int* cost_out = hildreth ? nullptr : h->cbf_cost;
+  const int* ord_in = calls < 0 ? nullptr : order_tab;
+  const int* cnt_in = calls < 0 ? nullptr : count_tab;
+  int* cost_out = hildreth ? nullptr : cost_tab;
   // one wavefront (= one env) per workgroup; NMAX bounds the QP variables (LDS footprint of Q, R ~ NMAX^2)
 #define MDS_GI(T, CP, RR, NMAX, ORD, TOL)                                                                                   \
   k_cbf_filter_gi<T, T, RR, NMAX, ORD><<<dim3((unsigned)E), 64, 0, st>>>(                                                    \
@@ -994,15 +1010,22 @@ int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void*
 #undef MDS_GI
   MDS_HIP(hipGetLastError());
   if (!hildreth && E >= 1024) {                           // small batches have no tail to hide
-    if (h->cbf_calls < 0 || h->cbf_calls >= 7) {
-      k_cbf_order<<<1, 1024, 0, st>>>(E, h->cbf_cost, h->cbf_order, h->cbf_count);
+    if (calls < 0 || calls >= 7) {
+      k_cbf_order<<<1, 1024, 0, st>>>(E, cost_tab, order_tab, count_tab);
       MDS_HIP(hipGetLastError());
-      h->cbf_calls = 0;
+      calls = 0;
     } else {
-      ++h->cbf_calls;
+      ++calls;
     }
   }
   return MDS_OK;
+}
+
+int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void* unom, void* usafe, int32_t* status,
+                   void* stream) {
+  if (!h || !obs || !xdes || !unom || !usafe || !status) return fail(MDS_EINVAL, "mds_cbf_filter: null argument");
+  if (!h->has_cbf) return fail(MDS_ESTATE, "mds_cbf_filter: call mds_cbf_configure first");
+  return cbf_filter_range(h, obs, xdes, unom, usafe, status, stream, EnvRange{0, h->cfg.num_envs, 0});
 }
 
 int mds_default_dslpid_gains(mds_dslpid_gains* g) {
@@ -1225,7 +1248,7 @@ int mds_thrust_omega_from_rates(mds_handle* h, const void* u, const void* rates,
 // nominal controller -> [ECBF QP] -> low level -> env.step.  with_filter = false: the plain loops of
 // simulations/EnvGeometricOmega.py / EnvGeometricYankOmega.py (ctrl[j].compute(obs[j]) = LQR + low level, :314 / :319).
 static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream, bool with_filter,
-                                 const char* who) {
+                                 const char* who, EnvRange rg = EnvRange{0, -1, 0}) {
   if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h->has_traj || h->traj_mode != 1) return fail(MDS_ESTATE, "mds_step_cbf_geometric / mds_step_nominal: call mds_set_lemniscate first");
   if (!aligned16(obs) || !aligned16(action)) return fail(MDS_EALIGN, "mds_step_cbf_geometric / mds_step_nominal: obs_dev/action_dev");
@@ -1238,33 +1261,37 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
     MDS_HIP(hipMalloc(&h->cbf_xdes, (size_t)h->n * 10 * es));
     MDS_HIP(hipMalloc(&h->cbf_usafe, (size_t)h->n * 4 * es));
   }
-  const dim3 grid = grid_for(h->n, kBlock);
+  // drones of the env range: whole 256-drone batches (the caller of a partial range guarantees the alignment)
+  if (rg.ne < 0) rg.ne = h->cfg.num_envs;
+  const size_t i0 = (size_t)rg.e0 * h->cfg.num_drones, i1 = i0 + (size_t)rg.ne * h->cfg.num_drones;
+  const int batch0 = (int)(i0 / kBlock), n_end = (int)i1;
+  const dim3 grid = grid_for(i1 - i0, kBlock);
   // the hover force is subtracted from the nominal input only on the way into the filter (CBFTest.py:339, CBFTestOrd3.py:341)
   const double hover_sub = with_filter ? h->cfg.M * h->cfg.G : 0.0;
   if (h->cbf_nominal == 2) {
     if (h->cfg.dtype == MDS_F64)
-      k_cbf_nominal_lqr_yo<double, double><<<grid, kBlock, 0, st>>>(h->cd, h->lqr_yo_d, h->n, h->ld, t, hover_sub, (const double*)h->state,
+      k_cbf_nominal_lqr_yo<double, double><<<grid, kBlock, 0, st>>>(h->cd, h->lqr_yo_d, n_end, h->ld, t, hover_sub, (const double*)h->state,
                                                                     (const double*)h->lem, (const double*)obs, (double*)h->cbf_unom,
-                                                                    (double*)h->cbf_xdes);
+                                                                    (double*)h->cbf_xdes, batch0);
     else
-      k_cbf_nominal_lqr_yo<float, float><<<grid, kBlock, 0, st>>>(h->cf, h->lqr_yo_f, h->n, h->ld, t, (float)hover_sub, (const float*)h->state,
+      k_cbf_nominal_lqr_yo<float, float><<<grid, kBlock, 0, st>>>(h->cf, h->lqr_yo_f, n_end, h->ld, t, (float)hover_sub, (const float*)h->state,
                                                                   (const float*)h->lem, (const float*)obs, (float*)h->cbf_unom,
-                                                                  (float*)h->cbf_xdes);
+                                                                  (float*)h->cbf_xdes, batch0);
   } else if (h->cbf_nominal == 1) {
     if (h->cfg.dtype == MDS_F64)
-      k_cbf_nominal_lqr<double, double><<<grid, kBlock, 0, st>>>(h->cd, h->lqr_d, h->n, h->ld, t, hover_sub, (const double*)h->state,
-                                                                 (const double*)h->lem, (double*)h->cbf_unom, (double*)h->cbf_xdes);
+      k_cbf_nominal_lqr<double, double><<<grid, kBlock, 0, st>>>(h->cd, h->lqr_d, n_end, h->ld, t, hover_sub, (const double*)h->state,
+                                                                 (const double*)h->lem, (double*)h->cbf_unom, (double*)h->cbf_xdes, batch0);
     else
-      k_cbf_nominal_lqr<float, float><<<grid, kBlock, 0, st>>>(h->cf, h->lqr_f, h->n, h->ld, t, (float)hover_sub, (const float*)h->state,
-                                                               (const float*)h->lem, (float*)h->cbf_unom, (float*)h->cbf_xdes);
+      k_cbf_nominal_lqr<float, float><<<grid, kBlock, 0, st>>>(h->cf, h->lqr_f, n_end, h->ld, t, (float)hover_sub, (const float*)h->state,
+                                                               (const float*)h->lem, (float*)h->cbf_unom, (float*)h->cbf_xdes, batch0);
   } else {
-    MDS_DISPATCH(h, (k_cbf_nominal<T, S><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, t, (const S*)h->state, (const T*)h->lem,
-                                                                  (S*)h->cbf_unom, (S*)h->cbf_xdes)));
+    MDS_DISPATCH(h, (k_cbf_nominal<T, S><<<grid, kBlock, 0, st>>>(C, n_end, h->ld, t, (const S*)h->state, (const T*)h->lem,
+                                                                  (S*)h->cbf_unom, (S*)h->cbf_xdes, batch0)));
   }
   MDS_HIP(hipGetLastError());
   const void* u_ll = h->cbf_unom;
   if (with_filter) {
-    int rc = mds_cbf_filter(h, obs, h->cbf_xdes, h->cbf_unom, h->cbf_usafe, status, stream);
+    int rc = cbf_filter_range(h, obs, h->cbf_xdes, h->cbf_unom, h->cbf_usafe, status, stream, rg);
     if (rc != MDS_OK) return rc;
     u_ll = h->cbf_usafe;
   }
@@ -1272,10 +1299,10 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
   // order 2: u_safe[0] += M G (CBFTest.py:346); order 3: the yank goes to the low level as it is (CBFTestOrd3.py:350)
   const double ll_offset = (with_filter && !yank) ? h->cfg.M * h->cfg.G : 0.0;
 #define MDS_LL(RK4, DRAG, YANK)                                                                                                  \
-  MDS_DISPATCH(h, (k_lowlevel_step<T, S, RK4, DRAG, YANK><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, (T)(1.0 / h->cfg.ctrl_freq),  \
+  MDS_DISPATCH(h, (k_lowlevel_step<T, S, RK4, DRAG, YANK><<<grid, kBlock, 0, st>>>(C, n_end, h->ld, (T)(1.0 / h->cfg.ctrl_freq),  \
                                                                                    (T)ll_offset, (S*)h->state, (const T*)h->origin, \
                                                                                    (T*)rpm_track(h), (T*)h->ll, (const S*)u_ll,  \
-                                                                                   (S*)obs, (S*)action)))
+                                                                                   (S*)obs, (S*)action, batch0)))
 #define MDS_LL_Y(YANK)                           \
   do {                                           \
     if (rk4 && drag) MDS_LL(true, true, YANK);   \
@@ -1301,6 +1328,46 @@ int mds_step_cbf_geometric(mds_handle* h, double t, void* obs, int32_t* status, 
     return fail(MDS_EUNSUPPORTED, "mds_step_cbf_geometric: order 3 needs (and order 2 excludes) the lqr-yank-omega nominal, mds_cbf_set_nominal(h, 2)");
   if (h->cfg.dtype == MDS_F16) return fail(MDS_EUNSUPPORTED, "mds_step_cbf_geometric: fp16 storage");
   return step_nominal_lowlevel(h, t, obs, status, action, stream, true, "mds_step_cbf_geometric");
+}
+
+int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs, int32_t* status, void* stream) {
+  if (!h || !obs || !status || n_steps < 0) return fail(MDS_EINVAL, "mds_rollout_cbf_geometric: null argument");
+  const double dt = 1.0 / h->cfg.ctrl_freq;
+  // The env halves are independent step chains (a barrier row couples drones of one env only).  On two streams one half's
+  // QP kernel (latency / ALU bound) runs beside the other half's nominal and low-level kernels (memory bound).  The split
+  // must fall on a 256-drone batch boundary; each half keeps its own cost classes for the longest-first dispatch.
+  const int E = h->cfg.num_envs, D = h->cfg.num_drones;
+  int e_mid = 0;
+  for (int e = E / 2; e > 0 && e >= E / 2 - 256; --e)
+    if (((size_t)e * D) % kBlock == 0) {
+      e_mid = e;
+      break;
+    }
+  const int streams = h->rollout_streams ? h->rollout_streams : ((size_t)h->n >= kSplitMinDrones / 2 && n_steps >= 16 ? 2 : 1);
+  if (streams == 2 && e_mid > 0 && n_steps >= 2) {
+    if (int rc = mds_step_cbf_geometric(h, t0, obs, status, nullptr, stream)) return rc;   // validation, scratch; step 1 on the caller's stream
+    if (int rc = split_streams_ready(h)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    MDS_HIP(hipEventRecord(h->split_ev[0], st));
+    const EnvRange half[2] = {EnvRange{0, e_mid, 1}, EnvRange{e_mid, E - e_mid, 2}};
+    for (int s = 0; s < 2; ++s) MDS_HIP(hipStreamWaitEvent(h->split_st[s], h->split_ev[0], 0));
+    double t = t0 + dt;
+    for (int k = 1; k < n_steps; ++k) {
+      for (int s = 0; s < 2; ++s)
+        if (int rc = step_nominal_lowlevel(h, t, obs, status, nullptr, h->split_st[s], true, "mds_rollout_cbf_geometric", half[s])) return rc;
+      t += dt;
+    }
+    for (int s = 0; s < 2; ++s) {
+      MDS_HIP(hipEventRecord(h->split_ev[1 + s], h->split_st[s]));
+      MDS_HIP(hipStreamWaitEvent(st, h->split_ev[1 + s], 0));
+    }
+    return MDS_OK;
+  }
+  for (int k = 0; k < n_steps; ++k) {
+    if (int rc = mds_step_cbf_geometric(h, t0, obs, status, nullptr, stream)) return rc;
+    t0 += dt;
+  }
+  return MDS_OK;
 }
 
 int mds_step_nominal(mds_handle* h, double t, void* obs, void* action, void* stream) {

@@ -566,8 +566,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_traj(const Consts<T> c, cons
 template <typename T, typename S>
 __global__ __launch_bounds__(kBlock) void k_cbf_nominal(const Consts<T> c, const int n, const size_t ld, const double t,
                                                         const S* __restrict__ state, const T* __restrict__ lem,
-                                                        S* __restrict__ unom, S* __restrict__ xdes) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
+                                                        S* __restrict__ unom, S* __restrict__ xdes, const int batch0) {
+  const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
   if (i >= n) return;
   GeoIn<T> in;
   load_geo_in<T, S>(state, lem, ld, i, in);
@@ -591,8 +591,8 @@ template <typename T, typename S>
 __global__ __launch_bounds__(kBlock) void k_cbf_nominal_lqr(const Consts<T> c, const LqrGain<T> K, const int n, const size_t ld,
                                                             const double t, const T hover_sub, const S* __restrict__ state,
                                                             const T* __restrict__ lem, S* __restrict__ unom,
-                                                            S* __restrict__ xdes) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
+                                                            S* __restrict__ xdes, const int batch0) {
+  const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
   if (i >= n) return;
   GeoIn<T> in;
   load_geo_in<T, S>(state, lem, ld, i, in);
@@ -630,8 +630,8 @@ template <typename T, typename S>
 __global__ __launch_bounds__(kBlock) void k_cbf_nominal_lqr_yo(const Consts<T> c, const LqrYoGain<T> K, const int n, const size_t ld,
                                                                const double t, const T hover_sub, const S* __restrict__ state,
                                                                const T* __restrict__ lem, const S* __restrict__ obs_prev,
-                                                               S* __restrict__ unom, S* __restrict__ xdes) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
+                                                               S* __restrict__ unom, S* __restrict__ xdes, const int batch0) {
+  const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
   if (i >= n) return;
   GeoIn<T> in;
   load_geo_in<T, S>(state, lem, ld, i, in);
@@ -669,9 +669,9 @@ __global__ __launch_bounds__(kBlock) void k_lowlevel_step(const Consts<T> c, con
                                                           const T thrust_offset, S* __restrict__ state,
                                                           const T* __restrict__ origin, T* __restrict__ last_rpm,
                                                           T* __restrict__ ll, const S* __restrict__ u_in, S* __restrict__ obs,
-                                                          S* __restrict__ action_out) {
+                                                          S* __restrict__ action_out, const int batch0) {
   __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
-  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
   const bool valid = i < n;
   T o[kObsDim];
   State<T> s;

@@ -387,6 +387,19 @@ class BaseAviary:
         self.step_counter += self.PYB_STEPS_PER_CTRL
         return (self._obs, self._cbf_status, self._act) if return_action else (self._obs, self._cbf_status)
 
+    def rollout_cbf_geometric(self, t0: float, n_steps: int, tracker, x_obs=None, obs_r_list=None):
+        """``n_steps`` of ``step_cbf_geometric`` enqueued from C (mds_rollout_cbf_geometric); returns (obs, status) of the last step.
+        Large batches run as two env halves on two internal streams (``set_rollout_streams``)."""
+        self._require_open()
+        tracker.cbf.configure(x_obs, obs_r_list)
+        if getattr(self, "_cbf_status", None) is None:
+            self._cbf_status = torch.zeros((self.NUM_ENVS,), dtype=torch.int32, device=self.device)
+        capi.check(self._lib.mds_rollout_cbf_geometric(self._h, C.c_double(t0), C.c_int(n_steps), C.c_void_p(self._obs.data_ptr()),
+                                                       C.c_void_p(self._cbf_status.data_ptr()), self._stream()),
+                   "mds_rollout_cbf_geometric")
+        self.step_counter += n_steps * self.PYB_STEPS_PER_CTRL
+        return self._obs, self._cbf_status
+
     def step_nominal(self, t: float, return_action: bool = False):
         """``ctrl[j].compute(obs[j])`` + ``env.step(action)`` of simulations/EnvGeometricOmega.py / EnvGeometricYankOmega.py for every
         drone: the LQR selected with ``set_cbf_nominal`` ("lqr_omega" | "lqr_yank_omega"), its low-level controller, the physics step.

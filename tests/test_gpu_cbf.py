@@ -477,3 +477,44 @@ def test_c4_full_size_properties(mds):
     np.testing.assert_array_equal(hist[:, idx].cpu().numpy(), np.array(ohist))
     g = obs[idx].double().cpu().numpy()
     assert np.abs(g[..., :16] - oobs.reshape(g.shape)[..., :16]).max() < 1e-3
+
+
+@pytest.mark.parametrize("streams", [1, 2])
+def test_cbf_rollout_equals_stepwise(mds, streams):
+    """mds_rollout_cbf_geometric (C loop; with two streams the env halves run as independent chains with their own cost
+    classes) against the same number of mds_step_cbf_geometric calls: bitwise equal observations, states and statuses.
+    2080 envs x 16 drones: the halves split at env 1040 (a 256-drone batch boundary), both above the 1024-env threshold of
+    the longest-first dispatch."""
+    from tests import helpers as H2
+    E, D, steps = 2080, 16, 26
+    xyz, rpy, P = H2.c2_setup(E, D, phase="c3")
+    P[..., 4] = 0.5 + 0.3 * np.arange(D)
+    xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    x_obs = [np.array([[sx * 0.5, sy * 0.5, 0.5], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
+    obs_r = [0.1] * 4
+    out = []
+    for mode in ("steps", "rollout"):
+        env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                             pyb_freq=100, ctrl_freq=100, num_envs=E, dtype="float32")
+        env.set_trajectories(P)
+        cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2,
+                           cbf_poles=np.array([-2.2, -2.4]))
+        trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+        env.set_rollout_streams(streams)
+        env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+        if mode == "steps":
+            t = 0.0
+            for k in range(steps):
+                o, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
+                t += env.CTRL_TIMESTEP
+        else:
+            o, st = env.rollout_cbf_geometric(0.0, steps - 6, trk, x_obs, obs_r)
+            t = 0.0
+            for k in range(steps - 6):
+                t += env.CTRL_TIMESTEP                                                       # the time the loop would have reached
+            o, st = env.rollout_cbf_geometric(t, 6, trk, x_obs, obs_r)                       # a second call chains on
+        out.append((o.cpu().numpy().copy(), st.cpu().numpy().copy(), env.get_state()))
+        env.close()
+    assert 0.0 < out[0][1].mean() < 1.0
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a, b)
