@@ -175,7 +175,19 @@ int mds_step_geometric(mds_handle* h, double t, void* obs_dev, void* action_dev,
  * obs_every_step != 0, else only the last step's. */
 int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs_dev, int obs_every_step, void* stream);
 
-/* How mds_rollout_geometric issues its steps.  Drones never read each other's rows in the fused step, so the two
+/* The plain env.step loop with a replayed action table, issued from C: step j = first_step + k (k < n_steps) applies
+ * actions_dev[j % n_action_sets] ([n_action_sets, n, 4] RPM) and writes its observation into obs_log_dev[j % log_slots]
+ * ([log_slots, n, 20]; NULL: no observations) -- the reference's `obs = env.step(action)` + per-step log (the [T, D, 20]
+ * array EnvGeometric.py:553 saves), for every env.  episode_len > 0: before every step j > 0 with j % episode_len == 0 the
+ * drones go back to the poses of the last mds_reset (zero velocities), on the device -- an open-loop rollout under the
+ * explicit-Euler model leaves every numeric range after ~1500 steps at 240 Hz.  Large shards run as two half-shard step
+ * chains on two internal streams (mds_set_rollout_streams). */
+int mds_rollout_step(mds_handle* h, const void* actions_dev, int n_action_sets, int first_step, int n_steps, void* obs_log_dev,
+                     int log_slots, int episode_len, void* stream);
+/* mds_reset's effect again from the poses it was last given, enqueued on `stream` without any host copy or synchronisation */
+int mds_reset_async(mds_handle* h, void* stream);
+
+/* How mds_rollout_geometric / mds_rollout_step / mds_rollout_cbf_geometric issue their steps.  Drones never read each other's rows in the fused step, so the two
  * halves of the shard are independent step chains: on two internal streams they drift out of phase and one half's
  * load/store bursts fill the other's compute phase (C3: 17.5 -> 16 us per step).  0 = auto (two streams from 2^19
  * drones up -- from 2^18 for calls of 1000+ steps --), 1 = the caller's stream only, 2 = always split.  Results are identical either way;

@@ -53,6 +53,7 @@ struct mds_handle {
   void* last_rpm;      // T [4][ld]
   void* lem;           // T [7][ld]
   double* scratch;     // double [n*20] device staging for host<->device set-up calls
+  double* init_pose = nullptr;   // double [n*6]: xyz, rpy of the last mds_reset (episode resets on the device, mds_reset_async)
   bool has_traj;
   int traj_mode;        // 1: per-drone Lemniscate planes (fused fp32 fast path), 2: general segment tables
   double* segs;         // device [MDS_SEG_DIM, total]: field-major (mds_traj.hpp SegTable)
@@ -299,7 +300,7 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
     const size_t nbytes = (size_t)h->n * 6 * sizeof(double);
     MDS_HIP(hipMemset(h->scratch, 0, nbytes));
     MDS_DISPATCH(h, (k_reset<T, S><<<grid_for(h->n, 256), 256, 0, 0>>>(h->n, h->ld, h->scratch, h->scratch + (size_t)3 * h->n,
-                                                                         (const T*)h->origin, (S*)h->state, (T*)h->last_rpm)));
+                                                                         (const T*)h->origin, (S*)h->state, (T*)h->last_rpm, 0)));
     MDS_HIP(hipGetLastError());
     MDS_HIP(hipDeviceSynchronize());
   }
@@ -315,6 +316,7 @@ int mds_destroy(mds_handle* h) {
   if (h->last_rpm) (void)hipFree(h->last_rpm);
   if (h->lem) (void)hipFree(h->lem);
   if (h->scratch) (void)hipFree(h->scratch);
+  if (h->init_pose) (void)hipFree(h->init_pose);
   if (h->pair_ij) (void)hipFree(h->pair_ij);
   if (h->obstacles) (void)hipFree(h->obstacles);
   if (h->cbf_order) (void)hipFree(h->cbf_order);
@@ -353,19 +355,39 @@ int mds_get_derived(const mds_handle* h, double out[8]) {
   return MDS_OK;
 }
 
+// drones [i0, i1) back to the poses of the last mds_reset (zero velocities, zero RPM echo); enqueue only
+static int launch_reset_range(mds_handle* h, hipStream_t st, size_t i0, size_t i1) {
+  const double* xyz = h->init_pose;
+  const double* rpy = h->init_pose + (size_t)3 * h->n;
+  MDS_DISPATCH(h, (k_reset<T, S><<<grid_for(i1 - i0, 256), 256, 0, st>>>((int)i1, h->ld, xyz, rpy, (const T*)h->origin, (S*)h->state,
+                                                                          (T*)h->last_rpm, (int)i0)));
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
 int mds_reset(mds_handle* h, const double* xyz, const double* rpy, void* stream) {
   if (!h || !xyz || !rpy) return fail(MDS_EINVAL, "mds_reset: null argument");
   hipStream_t st = (hipStream_t)stream;
   const size_t nb = (size_t)h->n * 3 * sizeof(double);
-  MDS_HIP(hipMemcpyAsync(h->scratch, xyz, nb, hipMemcpyHostToDevice, st));
-  MDS_HIP(hipMemcpyAsync(h->scratch + (size_t)3 * h->n, rpy, nb, hipMemcpyHostToDevice, st));
-  MDS_DISPATCH(h, (k_reset<T, S><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, h->ld, h->scratch, h->scratch + (size_t)3 * h->n,
-                                                                        (const T*)h->origin, (S*)h->state, (T*)h->last_rpm)));
-  MDS_HIP(hipGetLastError());
+  if (!h->init_pose) MDS_HIP(hipMalloc((void**)&h->init_pose, 2 * nb));
+  MDS_HIP(hipMemcpyAsync(h->init_pose, xyz, nb, hipMemcpyHostToDevice, st));
+  MDS_HIP(hipMemcpyAsync(h->init_pose + (size_t)3 * h->n, rpy, nb, hipMemcpyHostToDevice, st));
+  if (int rc = launch_reset_range(h, st, 0, h->n)) return rc;
   MDS_HIP(hipMemsetAsync(h->ll, 0, 6 * h->ld * comp_size(h->cfg.dtype), st));
   MDS_HIP(hipMemsetAsync(h->pid, 0, 9 * h->ld * comp_size(h->cfg.dtype), st));
   h->rpm_stale = false;
   MDS_HIP(hipStreamSynchronize(st));   // host buffers may be reused by the caller
+  return MDS_OK;
+}
+
+int mds_reset_async(mds_handle* h, void* stream) {
+  if (!h) return fail(MDS_EINVAL, "mds_reset_async: null handle");
+  if (!h->init_pose) return fail(MDS_ESTATE, "mds_reset_async: no mds_reset yet");
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = launch_reset_range(h, st, 0, h->n)) return rc;
+  MDS_HIP(hipMemsetAsync(h->ll, 0, 6 * h->ld * comp_size(h->cfg.dtype), st));
+  MDS_HIP(hipMemsetAsync(h->pid, 0, 9 * h->ld * comp_size(h->cfg.dtype), st));
+  h->rpm_stale = false;
   return MDS_OK;
 }
 
@@ -411,6 +433,32 @@ int mds_get_obs(mds_handle* h, void* obs, void* stream) {
   return MDS_OK;
 }
 
+// k_step over 256-drone batches [batch0, batch0 + nb) (nb == 0: the whole shard); half-shard launches of a two-stream rollout
+// are padded to 32 KB LDS like the fused step's (launch_step_geometric)
+static void launch_step_plain(mds_handle* h, const void* action, void* obs, hipStream_t st, unsigned batch0 = 0, unsigned nb = 0) {
+  const dim3 grid(nb ? nb : (unsigned)((h->n + kBlock - 1) / kBlock));
+  size_t pad = 0;
+  if (nb) {
+    const size_t static_lds = obs ? (size_t)kBlock * kObsDim * elem_size(h->cfg.dtype) : 16;
+    pad = static_lds < 32768 ? 32768 - static_lds : 0;
+  }
+#define MDS_LAUNCH_STEP(HAS_OBS, RK4, DRAG)                                                                          \
+  MDS_DISPATCH(h, (k_step<T, S, HAS_OBS, RK4, DRAG><<<grid, kBlock, pad, st>>>(C, h->n, h->ld, (S*)h->state, (const T*)h->origin, \
+                                                                               (T*)rpm_track(h), (const S*)action, (S*)obs, (int)batch0)))
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
+#define MDS_STEP_OBS(HAS_OBS)                           \
+  do {                                                  \
+    if (rk4 && drag) MDS_LAUNCH_STEP(HAS_OBS, true, true);   \
+    else if (rk4) MDS_LAUNCH_STEP(HAS_OBS, true, false);     \
+    else if (drag) MDS_LAUNCH_STEP(HAS_OBS, false, true);    \
+    else MDS_LAUNCH_STEP(HAS_OBS, false, false);             \
+  } while (0)
+  if (obs) MDS_STEP_OBS(true);
+  else MDS_STEP_OBS(false);
+#undef MDS_STEP_OBS
+#undef MDS_LAUNCH_STEP
+}
+
 int mds_step(mds_handle* h, const void* action, void* obs, void* stream) {
   if (!h || !action) return fail(MDS_EINVAL, "mds_step: null argument");
   if (!aligned16(action) || !aligned16(obs)) return fail(MDS_EALIGN, "mds_step: action_dev/obs_dev");
@@ -433,21 +481,7 @@ int mds_step(mds_handle* h, const void* action, void* obs, void* stream) {
     MDS_HIP(hipGetLastError());
     return MDS_OK;
   }
-#define MDS_LAUNCH_STEP(HAS_OBS, RK4, DRAG)                                                                          \
-  MDS_DISPATCH(h, (k_step<T, S, HAS_OBS, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, (S*)h->state, (const T*)h->origin, \
-                                                                             (T*)rpm_track(h), (const S*)action, (S*)obs)))
-  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
-#define MDS_STEP_OBS(HAS_OBS)                           \
-  do {                                                  \
-    if (rk4 && drag) MDS_LAUNCH_STEP(HAS_OBS, true, true);   \
-    else if (rk4) MDS_LAUNCH_STEP(HAS_OBS, true, false);     \
-    else if (drag) MDS_LAUNCH_STEP(HAS_OBS, false, true);    \
-    else MDS_LAUNCH_STEP(HAS_OBS, false, false);             \
-  } while (0)
-  if (obs) MDS_STEP_OBS(true);
-  else MDS_STEP_OBS(false);
-#undef MDS_STEP_OBS
-#undef MDS_LAUNCH_STEP
+  launch_step_plain(h, action, obs, st);
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }
@@ -718,6 +752,55 @@ int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs, int 
     launch_step_geometric(h, t0, (obs_every_step || k == n_steps - 1) ? obs : nullptr, nullptr, (hipStream_t)stream);
     t0 += dt;
   }
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_rollout_step(mds_handle* h, const void* actions, int n_action_sets, int first_step, int n_steps, void* obs_log, int log_slots,
+                     int episode_len, void* stream) {
+  if (!h || !actions || n_action_sets < 1 || first_step < 0 || n_steps < 0 || (obs_log && log_slots < 1) || episode_len < 0)
+    return fail(MDS_EINVAL, "mds_rollout_step: arguments");
+  if (episode_len > 0 && !h->init_pose) return fail(MDS_ESTATE, "mds_rollout_step: episode resets need an earlier mds_reset");
+  if (h->envfx) return fail(MDS_EUNSUPPORTED, "mds_rollout_step: ground effect / downwash physics is served by mds_step only");
+  const size_t es = elem_size(h->cfg.dtype), act_bytes = (size_t)h->n * 4 * es, obs_bytes = (size_t)h->n * kObsDim * es;
+  if (!aligned16(actions) || !aligned16(obs_log) || (n_action_sets > 1 && act_bytes % 16) || (obs_log && log_slots > 1 && obs_bytes % 16))
+    return fail(MDS_EALIGN, "mds_rollout_step: actions_dev/obs_log_dev (every action set and log slot must start 16-byte aligned)");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nbatch = (unsigned)((h->n + kBlock - 1) / kBlock);
+  const bool big = h->n >= 2 * kSplitMinDrones ? n_steps >= 16 : (h->n >= kSplitMinDrones && n_steps >= 1000);
+  const int streams = h->rollout_streams ? h->rollout_streams : (big ? 2 : 1);
+  const bool split = streams == 2 && nbatch >= 2 && n_steps >= 2;
+  const unsigned half = nbatch / 2;
+  if (split) {       // the two halves of the shard as independent step chains, as in mds_rollout_geometric
+    if (int rc = split_streams_ready(h)) return rc;
+    MDS_HIP(hipEventRecord(h->split_ev[0], st));
+    for (int s = 0; s < 2; ++s) MDS_HIP(hipStreamWaitEvent(h->split_st[s], h->split_ev[0], 0));
+  }
+  for (int k = 0; k < n_steps; ++k) {
+    const long long j = (long long)first_step + k;
+    const char* a = (const char*)actions + (size_t)(j % n_action_sets) * act_bytes;
+    char* o = obs_log ? (char*)obs_log + (size_t)(j % log_slots) * obs_bytes : nullptr;
+    if (episode_len > 0 && j > 0 && j % episode_len == 0) {      // a new episode starts at step j: back to the initial poses
+      const size_t mid = (size_t)half * kBlock;
+      if (split) {
+        if (int rc = launch_reset_range(h, h->split_st[0], 0, mid)) return rc;
+        if (int rc = launch_reset_range(h, h->split_st[1], mid, h->n)) return rc;
+      } else if (int rc = launch_reset_range(h, st, 0, h->n)) {
+        return rc;
+      }
+    }
+    if (split) {
+      launch_step_plain(h, a, o, h->split_st[0], 0, half);
+      launch_step_plain(h, a, o, h->split_st[1], half, nbatch - half);
+    } else {
+      launch_step_plain(h, a, o, st);
+    }
+  }
+  if (split)
+    for (int s = 0; s < 2; ++s) {
+      MDS_HIP(hipEventRecord(h->split_ev[1 + s], h->split_st[s]));
+      MDS_HIP(hipStreamWaitEvent(st, h->split_ev[1 + s], 0));
+    }
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }

@@ -157,9 +157,9 @@ __device__ __forceinline__ void write_obs_rows(unsigned char* __restrict__ lds_b
 template <typename T, typename S, bool HAS_OBS, bool RK4, bool DRAG>
 __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && !RK4) ? MDS_STEP_MIN_WAVES : 1) void k_step(const Consts<T> c, const int n, const size_t ld, S* __restrict__ state,
                                                  const T* __restrict__ origin, T* __restrict__ last_rpm,
-                                                 const S* __restrict__ action, S* __restrict__ obs) {
+                                                 const S* __restrict__ action, S* __restrict__ obs, const int batch0) {
   __shared__ __align__(16) unsigned char lds[HAS_OBS ? (kBlock * kObsDim * sizeof(S)) : 16];
-  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
   const bool valid = i < n;
   T o[kObsDim];
   if (valid) {
@@ -820,8 +820,8 @@ __global__ __launch_bounds__(kBlock) void k_get_obs(const int n, const size_t ld
 // ------------------------------------------------------------------------------------
 template <typename T, typename S>
 __global__ void k_reset(const int n, const size_t ld, const double* __restrict__ xyz, const double* __restrict__ rpy,
-                        const T* __restrict__ origin, S* __restrict__ state, T* __restrict__ last_rpm) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+                        const T* __restrict__ origin, S* __restrict__ state, T* __restrict__ last_rpm, const int i0) {
+  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double q[4];
   quat_from_euler<double>(rpy[3 * i], rpy[3 * i + 1], rpy[3 * i + 2], q);

@@ -320,6 +320,26 @@ class BaseAviary:
         self.step_counter += n_steps * self.PYB_STEPS_PER_CTRL
         return self._obs if want_obs else None
 
+    def rollout_step(self, actions: torch.Tensor, first_step: int, n_steps: int, obs_log: torch.Tensor | None = None,
+                     episode_len: int = 0):
+        """``n_steps`` plain ``env.step`` calls issued from C with a replayed action table: step j applies ``actions[j % A]``
+        ([A,E,D,4] device tensor of this env's dtype) and writes its observation into ``obs_log[j % T]`` ([T,E,D,20]).
+        ``episode_len`` > 0 puts the drones back to their initial poses before every step j > 0 with j % episode_len == 0.
+        Returns the log (or None)."""
+        self._require_open()
+        if actions.dtype != self.dtype or not actions.is_contiguous() or actions.numel() % (self.n * capi.ACT_DIM):
+            raise ValueError("actions must be a contiguous [A,E,D,4] tensor of the env's dtype")
+        if obs_log is not None and (obs_log.dtype != self.dtype or not obs_log.is_contiguous() or obs_log.numel() % (self.n * 20)):
+            raise ValueError("obs_log must be a contiguous [T,E,D,20] tensor of the env's dtype")
+        A = actions.numel() // (self.n * capi.ACT_DIM)
+        T = obs_log.numel() // (self.n * 20) if obs_log is not None else 0
+        capi.check(self._lib.mds_rollout_step(self._h, C.c_void_p(actions.data_ptr()), C.c_int(A), C.c_int(first_step), C.c_int(n_steps),
+                                              C.c_void_p(obs_log.data_ptr() if obs_log is not None else None), C.c_int(T), C.c_int(int(episode_len)),
+                                              self._stream()),
+                   "mds_rollout_step")
+        self.step_counter += n_steps * self.PYB_STEPS_PER_CTRL
+        return obs_log
+
     def set_rollout_streams(self, n_streams: int = 0):
         """How rollout_geometric issues its steps: 0 auto, 1 the current stream only, 2 the two halves of the shard on two
         internal streams (mds_set_rollout_streams).  Same results either way."""

@@ -649,3 +649,32 @@ def test_step_f64_matches_committed_1000_step_rollouts(mds, name, physics, integ
         if k in check:
             np.testing.assert_allclose(np_obs(obs), d[name][check[k]], rtol=1e-9, atol=1e-9, err_msg=f"{name} step {k}")
     env.close()
+
+
+@pytest.mark.parametrize("dtype,streams", [("float32", 1), ("float32", 2), ("float16", 2), ("float64", 2)])
+def test_rollout_step_equals_env_step_loop(mds, dtype, streams):
+    """mds_rollout_step (replayed action table, observations into a log ring; with two streams the halves of the shard are two
+    step chains) against the same env.step calls: bitwise equal log rows and state.  1393 drones = 5 batches + 113."""
+    torch = mds.torch
+    E, D, steps, A, T = (200 if dtype == "float16" else 199), 7, 29, 3, 5     # fp16 rows: n even keeps every log slot 16-byte aligned
+    xyz, rpy, _ = H.c2_setup(E, D)
+    out = []
+    for mode in ("loop", "rollout"):
+        env = make_env(mds, E, D, xyz, rpy, dtype, 240, 120, mds.Physics.PYB_DRAG)
+        acts = (env.HOVER_RPM * (1 + 0.05 * torch.randn((A, E, D, 4), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)))).to(env.dtype)
+        log = torch.zeros((T, E, D, 20), dtype=env.dtype, device="cuda")
+        env.set_rollout_streams(streams)
+        if mode == "loop":
+            for j in range(steps):
+                if j > 0 and j % 11 == 0:
+                    env.reset()                                   # episode boundary: back to the initial poses (mds_reset)
+                o, *_ = env.step(acts[j % A])
+                log[j % T].copy_(o)
+        else:
+            env.rollout_step(acts, 0, steps - 4, log, episode_len=11)
+            env.rollout_step(acts, steps - 4, 4, log, episode_len=11)               # continues the step counter
+        out.append((log.cpu().numpy().copy(), env.get_state()))
+        env.close()
+    assert np.isfinite(out[0][0].astype(np.float64)).all()
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a, b)

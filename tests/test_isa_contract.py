@@ -33,7 +33,7 @@ def kernel_ops(isa, mangled):
 
 def test_hot_kernels_have_no_scratch_and_expected_occupancy(isa):
     for name, max_vgpr in (("_ZN3mds16k_step_geometricIffLb1ELb0ELb0ELb0EEEvNS_6ConstsIT_EEimdPT0_PKS2_PS2_S5_S5_i", 64),
-                           ("_ZN3mds6k_stepIffLb1ELb0ELb0EEEvNS_6ConstsIT_EEimPT0_PKS2_PS2_PKS4_S5_", 64)):
+                           ("_ZN3mds6k_stepIffLb1ELb0ELb0EEEvNS_6ConstsIT_EEimPT0_PKS2_PS2_PKS4_S5_i", 64)):
         meta = isa[isa.index("amdhsa.kernels:"):]
         blk = next(b for b in meta.split("\n  - ") if re.search(r"\.name:\s+" + re.escape(name) + r"\n", b))
         vg = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
