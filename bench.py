@@ -292,7 +292,10 @@ def main(argv=None):
         log_buf = torch.empty((fused_T, E, D, 20), dtype=env.dtype, device=device)
 
     def run(t0, k):
-        if c5 and not args.python_loop:
+        if c5 and fused_T:
+            env.rollout_step(c5_act_tab, c5_k[0], k, c5_log, episode_len=C5_EPISODE, steps_per_launch=fused_T)
+            c5_k[0] += k
+        elif c5 and not args.python_loop:
             env.rollout_step(c5_act_tab, c5_k[0], k, c5_log, episode_len=C5_EPISODE)       # mds_rollout_step: the same loop issued from C
             c5_k[0] += k
         elif c5:
@@ -351,7 +354,9 @@ def main(argv=None):
     if c5:
         es = {torch.float16: 2, torch.float32: 4, torch.float64: 8}[env.dtype]
         bytes_per = 13 * es * 2 + 4 * es + 20 * es       # R state + W state + R action + W obs (origin read not counted)
-    if fused_T:
+    if fused_T and c5:
+        bytes_per = 24 * es + 26 * es / fused_T   # action row + obs row per step, state R/W once per launch
+    elif fused_T:
         bytes_per = 80 + (132 + 80) / fused_T     # obs row per step + (state R/W, params, final obs) once per launch
     achieved = bytes_per * n_local / (kernel_us * 1e-6) / 1e9
     # mds_rollout_geometric steps the two halves of a large shard as two independent chains on two streams
@@ -422,7 +427,11 @@ def main(argv=None):
                                "launch": "python ctypes loop, obs -> rollout log slot" if args.python_loop else
                                ("C loop (mds_rollout_step), half shards on 2 streams, obs -> rollout log slot" if args.rollout_streams != 1
                                 else "C loop (mds_rollout_step), one stream, obs -> rollout log slot")})
-        if not args.python_loop and args.rollout_streams != 1:
+        if fused_T:
+            line["roofline"]["kernel"] = f"k_rollout_step<float,_Float16,false,false> ({fused_T} control steps per launch)"
+            line["roofline"]["bound_note"] = "VALU (state in registers; the action table is read and the observation log written)"
+            line["config"]["launch"] = f"C loop (mds_rollout_step_fused), {fused_T} steps per launch, obs -> rollout log slot"
+        elif not args.python_loop and args.rollout_streams != 1:
             line["roofline"].update({"streams": 2, "bytes_per_launch": bytes_per * n_local / 2,
                                      "launches": "two concurrent half-shard launches per step, one per stream; achieved = 2 x bytes_per_launch / kernel_us"})
     if args.workload == "c4":
@@ -454,6 +463,24 @@ def main(argv=None):
                                  "bound": "VALU (state in registers; only the obs log leaves the chip)",
                                  "kernel": "k_rollout_geometric<float,float,false,false>"}
         del log2
+    if c5 and not fused_T and not args.python_loop and args.steps >= 1000:
+        # the same loop with 40 env.step per launch (mds_rollout_step_fused), one 1000-step episode per repetition
+        T2, reps = 40, 4
+        env.reset()
+        env.rollout_step(c5_act_tab, 0, C5_EPISODE, c5_log, episode_len=C5_EPISODE, steps_per_launch=T2)
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(device))
+        env.rollout_step(c5_act_tab, C5_EPISODE, reps * C5_EPISODE, c5_log, episode_len=C5_EPISODE, steps_per_launch=T2)
+        e1.record(torch.cuda.current_stream(device))
+        torch.cuda.synchronize(device)
+        us = max_over_ranks(e0.elapsed_time(e1) * 1e3 / (reps * C5_EPISODE), world, device)
+        b2 = 24 * es + 26 * es / T2
+        line["fused_rollout"] = {"steps_per_launch": T2, "us_per_step": us, "value": n_local * world / (us * 1e-6), "unit": "drone-steps/s",
+                                 "bytes_per_drone_step": b2, "achieved_GBps": b2 * n_local / (us * 1e-6) / 1e9,
+                                 "bound": "VALU (state in registers; the action table is read, the observation log written)",
+                                 "kernel": "k_rollout_step<float,_Float16,false,false>",
+                                 "state_sane": bool(torch.isfinite(c5_log).all().item())}
     if args.gather_obs and world > 1:      # optional whole-swarm observation packing; outside `value`
         from multidronesim_amd.swarm import all_gather_observations
         mine = obs.reshape(E, D, 20).contiguous()

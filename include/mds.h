@@ -184,6 +184,11 @@ int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs_dev, 
  * chains on two internal streams (mds_set_rollout_streams). */
 int mds_rollout_step(mds_handle* h, const void* actions_dev, int n_action_sets, int first_step, int n_steps, void* obs_log_dev,
                      int log_slots, int episode_len, void* stream);
+/* The same loop with steps_per_launch control steps per kernel launch (state in registers between them; a launch never
+ * crosses an episode boundary): per drone-step only the action is read and the observation written.  Same arithmetic as
+ * mds_rollout_step; with fp16 storage the state is rounded to fp16 once per launch instead of once per step. */
+int mds_rollout_step_fused(mds_handle* h, const void* actions_dev, int n_action_sets, int first_step, int n_steps, void* obs_log_dev,
+                           int log_slots, int episode_len, int steps_per_launch, void* stream);
 /* mds_reset's effect again from the poses it was last given, enqueued on `stream` without any host copy or synchronisation */
 int mds_reset_async(mds_handle* h, void* stream);
 

@@ -805,6 +805,45 @@ int mds_rollout_step(mds_handle* h, const void* actions, int n_action_sets, int 
   return MDS_OK;
 }
 
+int mds_rollout_step_fused(mds_handle* h, const void* actions, int n_action_sets, int first_step, int n_steps, void* obs_log,
+                           int log_slots, int episode_len, int steps_per_launch, void* stream) {
+  if (!h || !actions || n_action_sets < 1 || first_step < 0 || n_steps < 0 || (obs_log && log_slots < 1) || episode_len < 0 ||
+      steps_per_launch < 1)
+    return fail(MDS_EINVAL, "mds_rollout_step_fused: arguments");
+  if (h->envfx) return fail(MDS_EUNSUPPORTED, "mds_rollout_step_fused: ground effect / downwash physics is served by mds_step only");
+  if (episode_len > 0 && !h->init_pose) return fail(MDS_ESTATE, "mds_rollout_step_fused: episode resets need an earlier mds_reset");
+  const size_t es = elem_size(h->cfg.dtype), act_bytes = (size_t)h->n * 4 * es, obs_bytes = (size_t)h->n * kObsDim * es;
+  if (!aligned16(actions) || !aligned16(obs_log) || (n_action_sets > 1 && act_bytes % 16) || (obs_log && log_slots > 1 && obs_bytes % 16))
+    return fail(MDS_EALIGN, "mds_rollout_step_fused: actions_dev/obs_log_dev (every action set and log slot must start 16-byte aligned)");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid = grid_for(h->n, kBlock);
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
+  long long j = first_step;
+  const long long j_end = (long long)first_step + n_steps;
+  while (j < j_end) {
+    if (episode_len > 0 && j > 0 && j % episode_len == 0)
+      if (int rc = launch_reset_range(h, st, 0, h->n)) return rc;
+    long long chunk = j_end - j < steps_per_launch ? j_end - j : steps_per_launch;
+    if (episode_len > 0) {                                  // a launch never crosses an episode boundary
+      const long long to_boundary = episode_len - j % episode_len;
+      if (chunk > to_boundary) chunk = to_boundary;
+    }
+    const int a0 = (int)(j % n_action_sets), s0 = obs_log ? (int)(j % log_slots) : 0;
+#define MDS_RS(RK4, DRAG)                                                                                                     \
+  MDS_DISPATCH(h, (k_rollout_step<T, S, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, (S*)h->state, (const T*)h->origin,  \
+                                                                            (T*)rpm_track(h), (const S*)actions, a0, n_action_sets, \
+                                                                            (S*)obs_log, s0, obs_log ? log_slots : 1, (int)chunk)))
+    if (rk4 && drag) MDS_RS(true, true);
+    else if (rk4) MDS_RS(true, false);
+    else if (drag) MDS_RS(false, true);
+    else MDS_RS(false, false);
+#undef MDS_RS
+    j += chunk;
+  }
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
 int mds_set_rollout_streams(mds_handle* h, int n_streams) {
   if (!h || n_streams < 0 || n_streams > 2) return fail(MDS_EINVAL, "mds_set_rollout_streams: 0 (auto), 1 or 2");
   h->rollout_streams = n_streams;

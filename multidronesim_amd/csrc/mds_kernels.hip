@@ -181,6 +181,45 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && !RK4) ? MDS_STEP_MIN_WAV
   if (HAS_OBS) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
 }
 
+// n_steps of k_step in ONE launch with the state in registers: step k applies action set (a0 + k) % n_sets of the table and writes
+// its observation into slot (s0 + k) % n_slots of the log ring.  Per drone-step only the action (4 values) is read and the
+// observation (20 values) written; the 13-value state crosses HBM once per launch instead of twice per step.
+template <typename T, typename S, bool RK4, bool DRAG>
+__global__ __launch_bounds__(kBlock) void k_rollout_step(const Consts<T> c, const int n, const size_t ld, S* __restrict__ state,
+                                                         const T* __restrict__ origin, T* __restrict__ last_rpm,
+                                                         const S* __restrict__ actions, int a0, const int n_sets,
+                                                         S* __restrict__ obs_log, int s0, const int n_slots, const int n_steps) {
+  __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = i < n;
+  State<T> s;
+  V3<T> org = {T(0), T(0), T(0)};
+  T prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4] = {T(0), T(0), T(0), T(0)};
+  if (valid) {
+    load_state<S, T>(state, ld, i, s);
+    org = {origin[i], origin[ld + i], origin[2 * ld + i]};
+    if (DRAG)
+      for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
+  }
+  for (int k = 0; k < n_steps; ++k) {
+    T o[kObsDim];
+    if (valid) {
+      T act[4];
+      load4<S, T>(actions + ((size_t)a0 * n + i) * 4, act);
+      aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
+      if (obs_log != nullptr) pack_obs(s, org, clipped, o);
+    }
+    if (obs_log != nullptr) write_obs_rows<S, T>(lds, obs_log + (size_t)s0 * n * kObsDim, n, i, valid, o);
+    a0 = a0 + 1 == n_sets ? 0 : a0 + 1;
+    s0 = s0 + 1 == n_slots ? 0 : s0 + 1;
+  }
+  if (valid) {
+    store_state<S, T>(state, ld, i, s);
+    if ((DRAG || last_rpm) && n_steps > 0)
+      for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
+  }
+}
+
 // [UPSTREAM] BaseAviary.step with ground effect and / or downwash: ONE physics substep per launch (upstream refreshes the
 // kinematic information of every drone between substeps; the downwash on a drone depends on its env-mates' positions), reading
 // state_in and writing state_out (double-buffered: env-mates are read while they are being updated).  Explicit Euler only.

@@ -321,10 +321,11 @@ class BaseAviary:
         return self._obs if want_obs else None
 
     def rollout_step(self, actions: torch.Tensor, first_step: int, n_steps: int, obs_log: torch.Tensor | None = None,
-                     episode_len: int = 0):
+                     episode_len: int = 0, steps_per_launch: int = 1):
         """``n_steps`` plain ``env.step`` calls issued from C with a replayed action table: step j applies ``actions[j % A]``
         ([A,E,D,4] device tensor of this env's dtype) and writes its observation into ``obs_log[j % T]`` ([T,E,D,20]).
         ``episode_len`` > 0 puts the drones back to their initial poses before every step j > 0 with j % episode_len == 0.
+        ``steps_per_launch`` > 1 runs that many steps per kernel launch with the state in registers (mds_rollout_step_fused).
         Returns the log (or None)."""
         self._require_open()
         if actions.dtype != self.dtype or not actions.is_contiguous() or actions.numel() % (self.n * capi.ACT_DIM):
@@ -333,6 +334,13 @@ class BaseAviary:
             raise ValueError("obs_log must be a contiguous [T,E,D,20] tensor of the env's dtype")
         A = actions.numel() // (self.n * capi.ACT_DIM)
         T = obs_log.numel() // (self.n * 20) if obs_log is not None else 0
+        if steps_per_launch > 1:
+            capi.check(self._lib.mds_rollout_step_fused(self._h, C.c_void_p(actions.data_ptr()), C.c_int(A), C.c_int(first_step), C.c_int(n_steps),
+                                                        C.c_void_p(obs_log.data_ptr() if obs_log is not None else None), C.c_int(T),
+                                                        C.c_int(int(episode_len)), C.c_int(int(steps_per_launch)), self._stream()),
+                       "mds_rollout_step_fused")
+            self.step_counter += n_steps * self.PYB_STEPS_PER_CTRL
+            return obs_log
         capi.check(self._lib.mds_rollout_step(self._h, C.c_void_p(actions.data_ptr()), C.c_int(A), C.c_int(first_step), C.c_int(n_steps),
                                               C.c_void_p(obs_log.data_ptr() if obs_log is not None else None), C.c_int(T), C.c_int(int(episode_len)),
                                               self._stream()),

@@ -678,3 +678,25 @@ def test_rollout_step_equals_env_step_loop(mds, dtype, streams):
     assert np.isfinite(out[0][0].astype(np.float64)).all()
     for a, b in zip(*out):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-12), ("float32", 2e-5), ("float16", 5e-2)])
+def test_fused_rollout_step_equals_stepwise(mds, dtype, tol):
+    """mds_rollout_step_fused (several env.step per launch, state in registers, launches cut at episode boundaries) against
+    mds_rollout_step: same log ring and state to rounding (fp16 storage: the fused path rounds the state once per launch)."""
+    torch = mds.torch
+    E, D, steps, A, T = 200, 7, 37, 3, 5
+    xyz, rpy, _ = H.c2_setup(E, D)
+    out = []
+    for spl in (1, 8):
+        env = make_env(mds, E, D, xyz, rpy, dtype, 240, 120, mds.Physics.PYB_DRAG)
+        acts = (env.HOVER_RPM * (1 + 0.05 * torch.randn((A, E, D, 4), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)))).to(env.dtype)
+        log = torch.zeros((T, E, D, 20), dtype=env.dtype, device="cuda")
+        env.rollout_step(acts, 0, steps - 9, log, episode_len=13, steps_per_launch=spl)
+        env.rollout_step(acts, steps - 9, 9, log, episode_len=13, steps_per_launch=spl)
+        out.append((log.double().cpu().numpy().copy(), env.get_state(), env._computeObs().double().cpu().numpy().copy()))
+        env.close()
+    for a, b in zip(*out):
+        assert np.isfinite(a).all()
+        scale = np.maximum(1.0, np.abs(a))
+        assert (np.abs(a - b) / scale).max() < tol
