@@ -518,3 +518,43 @@ def test_cbf_rollout_equals_stepwise(mds, streams):
     assert 0.0 < out[0][1].mean() < 1.0
     for a, b in zip(*out):
         np.testing.assert_array_equal(a, b)
+
+
+def test_cbf_rollout_order3_two_chains_equals_stepwise(mds):
+    """The order-3 loop (yank-omega LQR nominal reading the RPM echo of obs, YankOmega low level) through
+    mds_rollout_cbf_geometric with the env halves on two streams: bitwise the step-by-step loop.  1088 envs x 4 drones
+    (halves of 544 envs = 2176 drones, a 256-drone batch boundary)."""
+    from multidronesim_amd.control import LQRYankOmegaController, YankOmegaController
+    from tests import helpers as H2
+    E, D, steps = 1088, 4, 20
+    xyz, rpy, P = H2.c2_setup(E, D, phase="c3", offset=0.0, omega=0.5)
+    xyz[..., 2] = 0.5 + 0.6 * np.arange(D)
+    P[..., 4] = 0.5 + 0.6 * np.arange(D)
+    rng = np.random.default_rng(3)
+    xyz[..., :2] += 0.05 * rng.standard_normal((E, D, 2))             # envs differ
+    x_obs = [np.array([[0.0, 0.0, -0.3], [0, 0, 0], [0, 0, 0]])]
+    obs_r = [0.1]
+    out = []
+    for mode in ("steps", "rollout"):
+        env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                             pyb_freq=100, ctrl_freq=100, num_envs=E, dtype="float32")
+        env.set_trajectories(P)
+        LQRYankOmegaController(env, mds.LinearizedYankOmegaModel(env), YankOmegaController(env))
+        cbf = mds.DroneCBF(env, [mds.LinearizedYankOmegaModel(env) for _ in range(D)], safety_radius=0.125, zscale=2.0, order=3,
+                           cbf_poles=np.array([-3.0, -3.6, -5.6]))
+        trk = mds.DroneQPTracker(cbf, order=3, num_robots=D, xdim=10, env=env)
+        env.set_cbf_nominal("lqr_yank_omega")
+        env.set_rollout_streams(2)
+        env.step(mds.torch.full((E, D, 4), O.CF2P.HOVER_RPM, dtype=env.dtype))
+        if mode == "steps":
+            t = 0.0
+            for k in range(steps):
+                o, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
+                t += env.CTRL_TIMESTEP
+        else:
+            o, st = env.rollout_cbf_geometric(0.0, steps, trk, x_obs, obs_r)
+        out.append((o.cpu().numpy().copy(), st.cpu().numpy().copy(), env.get_state()))
+        env.close()
+    assert np.isfinite(out[0][0]).all()
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a, b)
