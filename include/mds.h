@@ -114,6 +114,15 @@ int mds_get_derived(const mds_handle* h, double out[8]);
  * (host double [n,3] each), zero velocities, zero last action. */
 int mds_reset(mds_handle* h, const double* xyz_host, const double* rpy_host, void* stream);
 
+/* Zero-copy view of the library-owned state (SURVEY 8b `mds_state_ptrs`): comp_dev[k] points at component k of drone 0
+ * (k = 0..2 position RELATIVE to the drone's local-frame origin, 3..6 quaternion xyzw, 7..9 velocity, 10..12 body rates) in
+ * the handle's storage dtype, and component k of drone i lives stride_elems[k] * i elements further (the packed layout keeps
+ * four components per 16-byte group: stride 4 for k < 12, 1 for k = 12).  origin_dev[k] (may be NULL): the origin planes,
+ * stride 1, float for MDS_F32 / MDS_F16 handles and double for MDS_F64; world position = state position + origin.  The
+ * pointers stay valid until mds_destroy, except that the ground-effect / downwash physics modes swap their two state
+ * buffers every substep (ask again after each mds_step there). */
+int mds_state_ptrs(mds_handle* h, void* comp_dev[13], size_t stride_elems[13], void* origin_dev[3]);
+
 /* Test / checkpoint access to the 13-float state in the WORLD frame (host double [n,13]).
  * Synchronises the stream. */
 int mds_get_state(mds_handle* h, double* state_host, void* stream);

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "mds_destroy": (C.c_int, [_P]),
     "mds_get_derived": (C.c_int, [_P, _PD]),
     "mds_reset": (C.c_int, [_P, _PD, _PD, _P]),
+    "mds_state_ptrs": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]),
     "mds_get_state": (C.c_int, [_P, _PD, _P]),
     "mds_set_state": (C.c_int, [_P, _PD, _P]),
     "mds_set_origin": (C.c_int, [_P, _PD, _P]),

@@ -391,6 +391,18 @@ int mds_reset_async(mds_handle* h, void* stream) {
   return MDS_OK;
 }
 
+int mds_state_ptrs(mds_handle* h, void* comp_dev[13], size_t stride_elems[13], void* origin_dev[3]) {
+  if (!h || !comp_dev || !stride_elems) return fail(MDS_EINVAL, "mds_state_ptrs: null argument");
+  const size_t es = elem_size(h->cfg.dtype), cs = comp_size(h->cfg.dtype);
+  for (int k = 0; k < 13; ++k) {
+    comp_dev[k] = (char*)h->state + sidx(k, 0, h->ld) * es;
+    stride_elems[k] = k < 12 ? 4 : 1;
+  }
+  if (origin_dev)
+    for (int k = 0; k < 3; ++k) origin_dev[k] = (char*)h->origin + (size_t)k * h->ld * cs;
+  return MDS_OK;
+}
+
 int mds_get_state(mds_handle* h, double* out, void* stream) {
   if (!h || !out) return fail(MDS_EINVAL, "mds_get_state: null argument");
   hipStream_t st = (hipStream_t)stream;

@@ -219,6 +219,24 @@ class BaseAviary:
         capi.check(self._lib.mds_get_state(self._h, capi.as_double_ptr(out), self._stream()), "mds_get_state")
         return out.reshape(self.NUM_ENVS, self.NUM_DRONES, capi.STATE_DIM)
 
+    def state_views(self):
+        """Zero-copy torch views of the library-owned state (mds_state_ptrs): a dict with 13 strided ``[n]`` tensors
+        ``comp[k]`` in the storage dtype (positions relative to ``origin``) and the three ``origin`` planes."""
+        self._require_open()
+        comp, stride, org = (C.c_void_p * 13)(), (C.c_size_t * 13)(), (C.c_void_p * 3)()
+        capi.check(self._lib.mds_state_ptrs(self._h, comp, stride, org), "mds_state_ptrs")
+
+        class _Raw:                      # the CUDA array interface is how torch adopts a foreign device pointer
+            def __init__(self, ptr, n, stride, dt):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": dt, "data": (int(ptr), False), "version": 2,
+                                                 "strides": (stride,)}
+
+        ts = {torch.float16: "<f2", torch.float32: "<f4", torch.float64: "<f8"}
+        es = {torch.float16: 2, torch.float32: 4, torch.float64: 8}[self.dtype]
+        cdt = torch.float64 if self.dtype == torch.float64 else torch.float32
+        return {"comp": [torch.as_tensor(_Raw(comp[k], self.n, int(stride[k]) * es, ts[self.dtype]), device=self.device) for k in range(13)],
+                "origin": [torch.as_tensor(_Raw(org[k], self.n, es if cdt == self.dtype else 4, ts[cdt]), device=self.device) for k in range(3)]}
+
     def set_state(self, state):
         self._require_open()
         s = np.ascontiguousarray(np.asarray(state, dtype=np.float64).reshape(self.n, capi.STATE_DIM))

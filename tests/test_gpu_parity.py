@@ -700,3 +700,26 @@ def test_fused_rollout_step_equals_stepwise(mds, dtype, tol):
         assert np.isfinite(a).all()
         scale = np.maximum(1.0, np.abs(a))
         assert (np.abs(a - b) / scale).max() < tol
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64", "float16"])
+def test_state_ptrs_views_match_get_state(mds, dtype):
+    """mds_state_ptrs: the zero-copy strided views (+ origin) reproduce mds_get_state after a few steps, and writing through
+    a view is seen by the next step."""
+    E, D = 37, 5
+    xyz, rpy, P = H.c2_setup(E, D)
+    env = make_env(mds, E, D, xyz, rpy, dtype)
+    env.set_trajectories(P)
+    env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+    for k in range(5):
+        env.step_geometric(0.01 * k)
+    v = env.state_views()
+    st = env.get_state().reshape(-1, 13)
+    got = np.stack([c.double().cpu().numpy() for c in v["comp"]], axis=1)
+    got[:, :3] += np.stack([o.double().cpu().numpy() for o in v["origin"]], axis=1)
+    tol = 1e-12 if dtype == "float64" else (1e-6 if dtype == "float32" else 2e-3)
+    np.testing.assert_allclose(got, st, atol=tol)
+    v["comp"][9].fill_(0.25)                                  # vz of every drone, in place
+    st2 = env.get_state().reshape(-1, 13)
+    np.testing.assert_allclose(st2[:, 9], 0.25, atol=1e-3)
+    env.close()
