@@ -5,7 +5,8 @@ against the MI355X roofline and a CPU baseline (the float64 oracle) timed in the
 
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torchrun)
 
-A "step" is one control step of EVERY drone of the workload (one kernel launch).  Default
+A "step" is one control step of EVERY drone of the workload (one launch; two concurrent half-shard launches on two
+streams for shards of 2^19 drones and more, see mds_set_rollout_streams).  Default
 workload = BASELINE.json configs[2] ("C3": 65 536 envs x 8 drones, Lemniscate tracking), the
 configuration the metric's targets (>= 50 M drone-steps/s at >= 60 % of HBM roofline, 1/2/4/8
 GPU scaling) are quoted on; --workload c2 selects configs[1] (4 096 x 4), whose 3.5 MB working
@@ -481,6 +482,34 @@ def main(argv=None):
                                  "bound": "VALU (state in registers; the action table is read, the observation log written)",
                                  "kernel": "k_rollout_step<float,_Float16,false,false>",
                                  "state_sane": bool(torch.isfinite(c5_log).all().item())}
+    if args.workload == "c3" and world == 1 and not fused_T and not args.python_loop and args.steps >= 1000:
+        # BASELINE.json configs[1] (C2: 4096 envs x 4 drones) beside the headline, same process: its 3.5 MB per step are launch-latency
+        # bound, so the per-step loop and the whole-rollout kernel (50 steps per launch) are both reported
+        E2, D2, ph2, _ = WORKLOADS["c2"]
+        x2, r2, P2 = make_inputs(E2, D2, ph2, 1000)
+        env2 = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D2, initial_xyzs=x2, initial_rpys=r2, physics=Physics.DYN,
+                          pyb_freq=100, ctrl_freq=100, num_envs=E2, dtype=args.dtype, device=local_rank)
+        env2.set_trajectories(P2)
+        env2.step(torch.zeros((E2, D2, 4), dtype=env2.dtype, device=device))
+        env2.rollout_geometric(0.0, 200, want_obs=True, obs_every_step=True)
+        torch.cuda.synchronize(device)
+        a0, a1, a2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        log2 = torch.empty((50, E2, D2, 20), dtype=env2.dtype, device=device)
+        env2.rollout_geometric_fused(0.0, 50, log=True, log_out=log2)
+        a0.record(torch.cuda.current_stream(device))
+        env2.rollout_geometric(2.0, 2000, want_obs=True, obs_every_step=True)
+        a1.record(torch.cuda.current_stream(device))
+        for r_ in range(20):
+            env2.rollout_geometric_fused(22.0 + 0.5 * r_, 50, log=True, log_out=log2)
+        a2.record(torch.cuda.current_stream(device))
+        torch.cuda.synchronize(device)
+        us_step, us_fused = a0.elapsed_time(a1) * 1e3 / 2000, a1.elapsed_time(a2) * 1e3 / 1000
+        line["configs_1_c2"] = {"workload": WORKLOADS["c2"][3], "per_step": {"us_per_step": us_step, "value": E2 * D2 / (us_step * 1e-6),
+                                                                           "frac": BYTES_PER_DRONE_STEP * E2 * D2 / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                                                           "bound": "kernel launch latency (3.5 MB per launch)"},
+                                "fused_rollout_50": {"us_per_step": us_fused, "value": E2 * D2 / (us_fused * 1e-6)}, "unit": "drone-steps/s"}
+        env2.close()
+        del log2
     if args.gather_obs and world > 1:      # optional whole-swarm observation packing; outside `value`
         from multidronesim_amd.swarm import all_gather_observations
         mine = obs.reshape(E, D, 20).contiguous()
