@@ -108,8 +108,9 @@ for which in ("lqr_omega", "lqr_yank_omega"):
     else:
         LQRYankOmegaController(env, LinearizedYankOmegaModel(env), YankOmegaController(env))
     env.set_cbf_nominal(which)
-    report(f"step_nominal {which} (one launch: LQR + low level + DYN)", timed(loop(env, env.step_nominal)), 212 + 80 + 40,
-           "state R/W 104, traj 28, obs echo R 80, low-level memory R/W 40, obs W 80")
+    report(f"step_nominal {which} (one launch: LQR + low level + DYN)", timed(loop(env, env.step_nominal)),
+           212 + 48 + (80 if which == "lqr_yank_omega" else 0),
+           "state R/W 104, traj 28, low-level memory R/W 48, obs W 80" + (", RPM echo of the previous obs row R 80" if which == "lqr_yank_omega" else ""))
     report(f"step_nominal {which}, action wanted (2 launches: nominal, low level + DYN)",
            timed(loop(env, lambda t: env.step_nominal(t, return_action=True))), 132 + 260 + 16, "nominal R 80 W 52; low level R 104 (+80 obs echo) W 156 + action W 16")
     us = timed(lambda k: [env.rollout_geometric_fused(0.0, 50, controller="nominal") for _ in range(k // 50)])
