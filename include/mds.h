@@ -201,11 +201,14 @@ int mds_rollout_step_fused(mds_handle* h, const void* actions_dev, int n_action_
 /* mds_reset's effect again from the poses it was last given, enqueued on `stream` without any host copy or synchronisation */
 int mds_reset_async(mds_handle* h, void* stream);
 
-/* How mds_rollout_geometric / mds_rollout_step / mds_rollout_cbf_geometric issue their steps.  Drones never read each other's rows in the fused step, so the two
- * halves of the shard are independent step chains: on two internal streams they drift out of phase and one half's
- * load/store bursts fill the other's compute phase (C3: 17.5 -> 16 us per step).  0 = auto (two streams from 2^19
- * drones up -- from 2^18 for calls of 1000+ steps --), 1 = the caller's stream only, 2 = always split.  Results are identical either way;
- * the caller's stream orders the whole call (events on entry and exit), so the usual stream semantics hold. */
+/* How mds_rollout_geometric / mds_rollout_step / mds_rollout_cbf_geometric issue their steps.  Drones never read each
+ * other's rows in the fused step (and a barrier row couples drones of one env only), so the two halves of the shard are
+ * independent step chains: on two internal streams one half's load/store bursts fill the other's compute phase, and the
+ * gaps between dependent launches disappear (C3: 17.5 -> 15.0-15.7 us per step; half-shard launches also carry unused
+ * LDS so that 5 instead of 8 workgroups share a CU and the chains interleave from the first step).
+ * 0 = auto (geometric / plain step: two streams from 2^19 drones, from 2^18 for calls of 1000+ steps; CBF loop: from
+ * 2^17 drones), 1 = the caller's stream only, 2 = always split.  Results are bit-identical either way; the caller's
+ * stream orders the whole call (events on entry and exit), so the usual stream semantics hold. */
 int mds_set_rollout_streams(mds_handle* h, int n_streams);
 
 /* The same n_steps control steps in ONE kernel launch: state and trajectory parameters stay in
