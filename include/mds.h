@@ -207,7 +207,7 @@ int mds_reset_async(mds_handle* h, void* stream);
  * gaps between dependent launches disappear (C3: 17.5 -> 15.0-15.7 us per step; half-shard launches also carry unused
  * LDS so that 5 instead of 8 workgroups share a CU and the chains interleave from the first step).
  * 0 = auto (geometric / plain step: two streams from 2^19 drones, from 2^18 for calls of 1000+ steps; CBF loop: from
- * 2^17 drones), 1 = the caller's stream only, 2 = always split.  Results are bit-identical either way; the caller's
+ * 2^16 drones), 1 = the caller's stream only, 2 = always split.  Results are bit-identical either way; the caller's
  * stream orders the whole call (events on entry and exit), so the usual stream semantics hold. */
 int mds_set_rollout_streams(mds_handle* h, int n_streams);
 
@@ -356,7 +356,7 @@ int mds_step_cbf_geometric(mds_handle* h, double t, void* obs_dev, int32_t* stat
 
 /* n_steps of mds_step_cbf_geometric enqueued from C (t advances by 1/ctrl_freq per step, like the reference loop); status_dev
  * holds the last step's per-env status.  Large batches run as two env halves on two internal streams (mds_set_rollout_streams
- * policy: auto from 2^17 drones and 16 steps): a barrier couples drones of one env only, so the halves are independent step
+ * policy: auto from 2^16 drones and 16 steps): a barrier couples drones of one env only, so the halves are independent step
  * chains and one half's QP kernel overlaps the other's memory-bound kernels.  Results are those of the step-by-step loop. */
 int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs_dev, int32_t* status_dev, void* stream);
 

@@ -1477,7 +1477,7 @@ int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs, 
       e_mid = e;
       break;
     }
-  const int streams = h->rollout_streams ? h->rollout_streams : ((size_t)h->n >= kSplitMinDrones / 2 && n_steps >= 16 ? 2 : 1);
+  const int streams = h->rollout_streams ? h->rollout_streams : ((size_t)h->n >= kSplitMinDrones / 4 && n_steps >= 16 ? 2 : 1);   // measured: 2^15 drones 36.6 vs 36.4 us, 2^16 41.0 vs 39.4, 2^17 52.9 vs 44.7, 2^18 71.7 vs 60.3
   if (streams == 2 && e_mid > 0 && n_steps >= 2) {
     if (int rc = mds_step_cbf_geometric(h, t0, obs, status, nullptr, stream)) return rc;   // validation, scratch; step 1 on the caller's stream
     if (int rc = split_streams_ready(h)) return rc;
