@@ -387,10 +387,12 @@ def main(argv=None):
     # HBM traffic from the PMC counters cannot be read inside this process; the committed summary of the
     # separate rocprofv3 --pmc passes (profiles/, same kernel and workload) is reported when it matches.
     pmc = os.path.join(ROOT, "profiles", "r01e_pmc_traffic_c3.json")
-    if args.workload == "c3" and args.dtype == "float32" and os.path.exists(pmc):
+    if args.workload == "c3" and args.dtype == "float32" and not fused_T and os.path.exists(pmc):
         try:
-            line["roofline"]["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch"]
-            line["roofline"]["traffic_source"] = "profiles/r01e_pmc_traffic_c3.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
+            half = json.load(open(pmc))["traffic_bytes_per_launch"]            # counted on half-shard launches (262144 drones)
+            line["roofline"]["traffic"] = half if split else 2 * half
+            line["roofline"]["traffic_source"] = ("profiles/r01e_pmc_traffic_c3.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, per half-shard launch"
+                                                  + (")" if split else "; x2 for this full-shard launch)"))
         except Exception:
             pass
     # measured ceiling in the same run: a device-to-device copy moving the same number of bytes per launch
