@@ -3,7 +3,11 @@
 -> mixer -> physics step -> observation) kernel, plus the achieved algorithmic HBM bandwidth
 against the MI355X roofline and a CPU baseline (the float64 oracle) timed in the same run.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torchrun)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Launched under torch.distributed.run (RANK / WORLD_SIZE in the environment) it is one rank;
+launched plainly it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child BEFORE anything
+touches the GPU, relays rank 0's JSON line and exits with the children's return code.
 
 A "step" is one control step of EVERY drone of the workload (one launch; two concurrent half-shard launches on two
 streams for shards of 2^19 drones and more, see mds_set_rollout_streams).  Default
@@ -30,6 +34,7 @@ if ROOT not in sys.path:
 WORKLOADS = {
     # name: (envs per GPU, drones per env, phase rule, description)
     "c3": (65536, 8, "c3", "C3: 65536 envs x 8 drones per GPU, Lemniscate tracking, fused traj+geometric+DYN step, obs every step"),
+    "c3big": (524288, 8, "c3", "C3 kernel on a 524288 envs x 8 drones shard (890 MB per step, beyond the 256 MiB Infinity Cache): Lemniscate tracking, fused step, obs every step"),
     "c2": (4096, 4, "c2", "C2: 4096 envs x 4 drones per GPU, geometric controller free flight, fused step, obs every step"),
     "c4": (16384, 16, "c3", "C4: 16384 envs x 16 drones per GPU, geometric nominal -> order-2 ECBF QP (4 sphere obstacles) -> ThrustOmega -> DYN step"),
     "c5": (262144, 2, "c2", "C5: 262144 envs x 2 drones per GPU, fp16 state storage / fp32 math, env.step() with random RPM around hover, obs streamed to a rollout log"),
@@ -179,32 +184,124 @@ def _baseline_metric():
 
 METRIC = _baseline_metric()
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """--gpus N > 1 without a rendezvous in the environment: start one child process per GPU through torch.distributed.run.
+    Called before this process imports torch or touches the GPU (a GPU-initialised process must never be re-executed); the
+    parent only relays the children's stdout (rank 0 prints the one JSON line) and returns their exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "") if env.get("PYTHONPATH") else ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for ln in proc.stdout:
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def gather_over_ranks(value, world, device):
+    """[value of rank 0, value of rank 1, ...] on every rank."""
+    if world == 1:
+        return [float(value)]
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
+def _timed_steps(device, fn, steps):
+    """HIP events on the stream the kernels are launched on, around fn(); microseconds per step."""
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    e0.record(torch.cuda.current_stream(device))
+    fn()
+    e1.record(torch.cuda.current_stream(device))
+    torch.cuda.synchronize(device)
+    return e0.elapsed_time(e1) * 1e3 / steps
+
+
+def _pmc_traffic(name, drones_per_launch):
+    """HBM-side bytes per launch from the committed summary of the separate rocprofv3 --pmc passes (profiles/), scaled to the
+    launch shape actually used: the passes count per launch of `drones_per_launch_counted` drones and traffic is per drone."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
+    try:
+        rec = json.load(open(path))
+        per_drone = rec["traffic_bytes_per_launch"] / rec["drones_per_launch_counted"]
+        return per_drone * drones_per_launch, f"profiles/{name} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch, separate --pmc passes; scaled from {rec['drones_per_launch_counted']} to {drones_per_launch} drones per launch)"
+    except Exception:
+        return None, None
+
+
+def extra_c3_variant(CtrlAviary, DroneModel, Physics, torch, local_rank, device, E, D, phase, seed, dtype, integrator, steps, streams):
+    """The same fused step on another instantiation of the kernel (RK4 integrator, float64) or another shard size: its own env,
+    `steps` control steps through the C rollout loop after an untimed pass of the same length; microseconds per control step."""
+    xyz, rpy, P = make_inputs(E, D, phase, seed)
+    env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN,
+                     pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype, integrator=integrator, device=local_rank)
+    del xyz, rpy
+    env.set_trajectories(P)
+    del P
+    env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=device))
+    env.set_rollout_streams(streams)
+    dt = env.CTRL_TIMESTEP
+    env.rollout_geometric(0.0, steps, want_obs=True, obs_every_step=True)
+    us = _timed_steps(device, lambda: env.rollout_geometric(steps * dt, steps, want_obs=True, obs_every_step=True), steps)
+    used = env.last_rollout_streams()
+    obs = env._obs
+    sane = bool(torch.isfinite(obs).all().item()) and abs(float(obs[..., 3:7].norm(dim=-1).mean().item()) - 1.0) < 1e-3
+    env.close()
+    return us, used, sane
+
 
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 20000 for c3/c5, 2000 for c2, 200 for c4)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 20000 for c3/c5, 2000 for c2, 200 for c4, 50 for c3big)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: steps / 10)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64", "float16"])
+    ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the contract's line: skip the secondary measurements (profiling runs)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--fused-rollout", type=int, default=0, metavar="T",
                     help="run the steps as launches of T control steps each (mds_rollout_geometric_fused: state in registers, "
                          "every step's obs streamed to a [T,n,20] log) instead of one launch per step")
     ap.add_argument("--python-loop", action="store_true", help="issue each step from Python (env.step_geometric) instead of the C rollout loop")
     ap.add_argument("--rollout-streams", type=int, default=0, choices=[0, 1, 2],
-                    help="mds_set_rollout_streams: 0 auto (two half-shard step chains on two streams from 2^18 drones up), 1 one stream, 2 split")
+                    help="mds_set_rollout_streams: 0 auto (the library's policy for the timed call's length), 1 one stream, 2 split")
+    ap.add_argument("--c4-scene", default="level", choices=["level", "offset"],
+                    help="c4 obstacles: 'level' = SURVEY 8d's spheres at z = 0.5 (drone 0 flies level with them: its obstacle rows have "
+                         "LgLfh = 0 and the env falls back to the nominal control like the reference); 'offset' = the same spheres "
+                         "0.15 m below every drone's plane's midpoint, feasible by construction")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU tests of the N>1 path")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # CPU test of the exit-code relay
     ap.add_argument("--gather-obs", action="store_true",
                     help="after the timed region, also time the optional whole-swarm observation all-gather (RCCL over xGMI); never part of `value`")
     args = ap.parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus, argv)
     # c5 flies open loop (random RPM around hover, no controller): under the explicit-Euler model the body rates blow up after ~1500
     # steps at 240 Hz, so the rollout runs in episodes of C5_EPISODE steps (device-side reset to the initial poses, part of the loop).
     # c2 is launch-bound (a longer queue only adds back-pressure): 2000 steps.  c4's QP work follows the scene (the swarm closes in on
     # the obstacles, then settles): it keeps SURVEY 8d's T = 200 window, the one its numbers in DESIGN.md were taken on.
     if args.steps is None:
-        args.steps = {"c3": 20000, "c5": 20000, "c2": 2000, "c4": 200}[args.workload]
+        args.steps = {"c3": 20000, "c5": 20000, "c2": 2000, "c4": 200, "c3big": 50}[args.workload]
     if args.warmup is None:
         args.warmup = args.steps // 10
 
@@ -214,11 +311,15 @@ def main(argv=None):
     if args.dry_run_cpu:
         rank, local_rank, world = dist_init("gloo")
         device = torch.device("cpu")
+        if rank == args.dry_run_fail_rank:
+            raise SystemExit(3)
         barrier(world)
         t0 = time.perf_counter()
         time.sleep(0.01 * (rank + 1))          # stand-in work; the slowest rank defines the time
+        mine_s = time.perf_counter() - t0
         barrier(world)
         elapsed = max_over_ranks(time.perf_counter() - t0, world, device)
+        per_rank = gather_over_ranks(mine_s, world, device)
         gathered = None
         if args.gather_obs:                    # the optional swarm all-gather, on CPU tensors over gloo
             from multidronesim_amd.swarm import all_gather_observations
@@ -226,7 +327,8 @@ def main(argv=None):
             g = all_gather_observations(mine)
             gathered = [int(g.shape[0]), [float(g[3 * r, 0, 0]) for r in range(world)]]
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "elapsed": elapsed, "ranks_seen": world, "gathered": gathered}))
+            print(json.dumps({"dry_run": True, "n_gpus": world, "elapsed": elapsed, "ranks_seen": len(per_rank), "elapsed_per_rank": per_rank,
+                              "gathered": gathered}), flush=True)
         if world > 1:
             torch.distributed.destroy_process_group()
         return 0
@@ -248,16 +350,20 @@ def main(argv=None):
     from multidronesim_amd.envs.CtrlAviary import CtrlAviary, DroneModel, Physics
 
     xyz, rpy, P = make_inputs(E, D, phase, 1000 + rank)          # every rank owns different envs
-    env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN,
-                     pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=args.dtype, device=local_rank)
     tracker = None
     c5 = args.workload == "c5"
+    c4 = args.workload == "c4"
+    geo = args.workload in ("c2", "c3", "c3big")
+    if c4:
+        # trajectories / start heights stacked 0.3 m apart: with the omega linearisation the barrier acts through e_z only
+        P[..., 4] = 0.5 + 0.3 * np.arange(D)
+        xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
     if c5:
         # physics-only path (mds_step): external random actions, obs of step k written into slot k % T of a rollout log
         import ctypes as C
-        env.close()
         env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN,
-                         pyb_freq=240, ctrl_freq=240, num_envs=E, dtype="float16" if args.dtype == "float32" else args.dtype, device=local_rank)
+                         pyb_freq=240, ctrl_freq=240, num_envs=E, dtype="float16" if args.dtype == "float32" else args.dtype,
+                         integrator=args.integrator, device=local_rank)
         g = torch.Generator(device=device).manual_seed(1234 + rank)
         c5_actions = [(env.HOVER_RPM * (1 + 0.05 * torch.randn((E, D, 4), device=device, generator=g))).clamp(0, env.MAX_RPM).to(env.dtype)
                       for _ in range(8)]
@@ -265,34 +371,42 @@ def main(argv=None):
         c5_log = torch.empty((c5_T, E, D, 20), dtype=env.dtype, device=device)
         c5_act_tab = torch.stack(c5_actions).contiguous()                       # [8,E,D,4]: the action table of the C loop
         c5_actions = [c5_act_tab[k] for k in range(8)]
-    if args.workload == "c4":
-        # trajectories / start heights stacked 0.3 m apart: with the omega linearisation the barrier acts through e_z only
-        P[..., 4] = 0.5 + 0.3 * np.arange(D)
-        xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
-        env.close()
+    else:
         env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN,
-                         pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=args.dtype, device=local_rank)
+                         pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=args.dtype, integrator=args.integrator, device=local_rank)
+    if c4:
         from multidronesim_amd.cbf.cbf import DroneCBF
         from multidronesim_amd.cbf.qptracker import DroneQPTracker
         from multidronesim_amd.model.linear_omega import LinearizedOmegaModel
         cbf = DroneCBF(env, [LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2,
                        cbf_poles=np.array([-2.2, -2.4]))                                    # CBFTest.py:419
         tracker = DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
-        c4_obs = [np.array([[sx * 0.5, sy * 0.5, 0.5], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
+        # 'offset': the spheres sit between two drone planes (0.5 + 0.3 k), so no drone is ever level with one: every obstacle row
+        # keeps a non-zero thrust coefficient and the QP stays feasible (the 'level' scene's fallbacks are LgLfh = 0 rows)
+        c4_z = 0.5 if args.c4_scene == "level" else 0.65
+        c4_obs = [np.array([[sx * 0.5, sy * 0.5, c4_z], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
         c4_r = [0.1] * 4
     env.set_trajectories(P)
+    del xyz, rpy, P
     env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=device))     # EnvGeometric.py:431
     dt = env.CTRL_TIMESTEP
     c5_k = [0]
 
-    env.set_rollout_streams(args.rollout_streams)
     fused_T = args.fused_rollout
+    c_loop = not args.python_loop and not fused_T
+    # The library's auto policy looks at the length of the call.  Fix it to what the TIMED call will do, so that the warm-up
+    # goes through the same branch (same streams, same launch shapes) as the call that is timed.
+    env.set_rollout_streams(args.rollout_streams)
+    planned = env.rollout_streams_for(args.steps, cbf=c4) if c_loop else 1
+    env.set_rollout_streams(planned if c_loop else args.rollout_streams)
     if fused_T:
         if args.steps % fused_T or args.warmup % fused_T:
             raise SystemExit("--steps and --warmup must be multiples of --fused-rollout")
         log_buf = torch.empty((fused_T, E, D, 20), dtype=env.dtype, device=device)
 
     def run(t0, k):
+        if k <= 0:
+            return
         if c5 and fused_T:
             env.rollout_step(c5_act_tab, c5_k[0], k, c5_log, episode_len=C5_EPISODE, steps_per_launch=fused_T)
             c5_k[0] += k
@@ -339,85 +453,93 @@ def main(argv=None):
     run(args.warmup * dt, args.steps)
     ev1.record(torch.cuda.current_stream(device))
     torch.cuda.synchronize(device)
+    wall_mine = time.perf_counter() - wall0
     barrier(world, local_rank)
     wall = time.perf_counter() - wall0
     dev_ms = ev0.elapsed_time(ev1)
     elapsed = max_over_ranks(wall, world, device)
     dev_ms_max = max_over_ranks(dev_ms, world, device)
+    dev_ms_ranks = gather_over_ranks(dev_ms, world, device)
+    wall_ranks = gather_over_ranks(wall_mine, world, device)
+    used_streams = env.last_rollout_streams() if c_loop else 1
 
     obs = c5_log[(c5_k[0] - 1) % c5_T] if c5 else env._obs
     ok = bool(torch.isfinite(obs).all().item()) and abs(float(obs[..., 3:7].norm(dim=-1).mean().item()) - 1.0) < 1e-3
     n_local = E * D
     total_units = n_local * world * args.steps
     value = total_units / elapsed
-    kernel_us = dev_ms * 1e3 / args.steps                   # average launch-to-launch duration on the stream (HIP events)
-    bytes_per = BYTES_PER_DRONE_STEP_C4 if args.workload == "c4" else BYTES_PER_DRONE_STEP
+    us_per_step = dev_ms * 1e3 / args.steps                  # HIP events on the launch stream / steps (launch period, not pure kernel time)
+    es = {torch.float16: 2, torch.float32: 4, torch.float64: 8}[env.dtype]
+    bytes_per = (BYTES_PER_DRONE_STEP_C4 if c4 else BYTES_PER_DRONE_STEP) * es // 4
     if c5:
-        es = {torch.float16: 2, torch.float32: 4, torch.float64: 8}[env.dtype]
         bytes_per = 13 * es * 2 + 4 * es + 20 * es       # R state + W state + R action + W obs (origin read not counted)
     if fused_T and c5:
         bytes_per = 24 * es + 26 * es / fused_T   # action row + obs row per step, state R/W once per launch
     elif fused_T:
-        bytes_per = 80 + (132 + 80) / fused_T     # obs row per step + (state R/W, params, final obs) once per launch
-    achieved = bytes_per * n_local / (kernel_us * 1e-6) / 1e9
-    # mds_rollout_geometric steps the two halves of a large shard as two independent chains on two streams
-    split = (not c5 and not fused_T and tracker is None and not args.python_loop
-             and (args.rollout_streams == 2 or (args.rollout_streams == 0 and      # the library's auto policy (mds_api.hip)
-                                                (args.steps >= 16 if n_local >= (1 << 19) else (n_local >= (1 << 18) and args.steps >= 1000)))))
+        bytes_per = 20 * es + (33 * es + 20 * es) / fused_T     # obs row per step + (state R/W, params, final obs) once per launch
+    achieved = bytes_per * n_local / (us_per_step * 1e-6) / 1e9
+    split = used_streams == 2
+    tname = {torch.float16: "_Float16", torch.float32: "float", torch.float64: "double"}[env.dtype]
+    cname = "double" if env.dtype == torch.float64 else "float"
+    rk4 = args.integrator == "rk4"
     line = {
         "metric": METRIC,
         "value": value, "unit": "drone-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"float32": "f32", "float64": "f64", "float16": "f16-storage/f32-math"}[args.dtype], "data": "synthetic",
         "config": {"workload": desc, "envs_per_gpu": E, "drones_per_env": D, "pyb_freq": 100, "ctrl_freq": 100,
-                   "physics": "DYN (explicit Euler)", "parallelism": f"env-shard x{world}, no collective",
-                   "launch": "python" if args.python_loop else "C rollout loop"},
+                   "physics": "DYN (explicit Euler)" if not rk4 else "DYN (RK4)",
+                   "physics_note": "the reference's default Physics.PYB (Bullet multibody step + ground plane) is not reproduced: no PyBullet here, parity vs it is undemonstrated",
+                   "parallelism": f"env-shard x{world}, no collective",
+                   "launch": "python" if args.python_loop else "C rollout loop, one stream"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "kernel": "k_step_geometric<float,float,true,false,false,false>", "kernel_us": kernel_us,
-                     "bytes_per_launch": bytes_per * n_local},
-        "device_ms_per_step_max_rank": dev_ms_max / args.steps, "state_sane": ok,
+                     "traffic": None, "kernel": f"k_step_geometric<{cname},{tname},true,false,{'true' if rk4 else 'false'},false>",
+                     "us_per_step": us_per_step, "bytes_per_launch": bytes_per * n_local, "streams": used_streams},
+        "device_ms_per_step_max_rank": dev_ms_max / args.steps, "ranks_seen": len(dev_ms_ranks),
+        "device_ms_per_rank": dev_ms_ranks, "value_per_rank": [n_local * args.steps / w for w in wall_ranks], "state_sane": ok,
     }
     if split:
-        # each stream runs `steps` half-shard launches inside the timed region, so kernel_us is also the average
-        # launch duration on either stream; `achieved` adds the two concurrent launches' bytes
-        line["roofline"].update({"streams": 2, "bytes_per_launch": bytes_per * n_local / 2,
+        # each stream runs `steps` half-shard launches inside the timed region, so us_per_step is also the average
+        # launch period on either stream; `achieved` adds the two concurrent launches' bytes
+        line["roofline"].update({"bytes_per_launch": bytes_per * n_local / 2,
                                  "launches": "two concurrent half-shard launches per control step, one per stream; "
-                                             "achieved = 2 x bytes_per_launch / kernel_us"})
+                                             "achieved = 2 x bytes_per_launch / us_per_step"})
         line["config"]["launch"] = "C rollout loop, half shards on 2 streams"
-    # HBM traffic from the PMC counters cannot be read inside this process; the committed summary of the
-    # separate rocprofv3 --pmc passes (profiles/, same kernel and workload) is reported when it matches.
-    pmc = os.path.join(ROOT, "profiles", "r01e_pmc_traffic_c3.json")
-    if args.workload == "c3" and args.dtype == "float32" and not fused_T and os.path.exists(pmc):
-        try:
-            half = json.load(open(pmc))["traffic_bytes_per_launch"]            # counted on half-shard launches (262144 drones)
-            line["roofline"]["traffic"] = half if split else 2 * half
-            line["roofline"]["traffic_source"] = ("profiles/r01e_pmc_traffic_c3.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, per half-shard launch"
-                                                  + (")" if split else "; x2 for this full-shard launch)"))
-        except Exception:
-            pass
+    if geo and args.dtype == "float32" and not fused_T and not rk4:
+        if args.workload == "c3big":
+            line["roofline"]["residency"] = ("HBM-resident: 890 MB touched per control step (state 218 + parameters 117 + observations 335 MB written, "
+                                             "state 218 MB rewritten), 3.5x the 256 MiB Infinity Cache")
+        else:
+            line["roofline"]["residency"] = ("Infinity-Cache-assisted: the step's 111 MB (84 MB working set, rewritten in place every step) fit the 256 MiB "
+                                             "Infinity Cache, so `frac` is an effective bandwidth fraction, not an HBM one; `frac_hbm_resident` "
+                                             "is the same kernel on a 4 M-drone shard (890 MB per step)")
+        # HBM traffic from the PMC counters cannot be read inside this process; the committed summary of the
+        # separate rocprofv3 --pmc passes (profiles/, same kernel) is reported, scaled to this run's launch shape.
+        per_launch = n_local // 2 if split else n_local
+        tr, src = _pmc_traffic("r02_pmc_traffic_c3big.json" if args.workload == "c3big" else "r02_pmc_traffic_c3.json", per_launch)
+        if tr is None and args.workload == "c3":
+            tr, src = _pmc_traffic("r01e_pmc_traffic_c3.json", per_launch)
+        if tr is not None:
+            line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr, src
+    extras = not args.no_extras
     # measured ceiling in the same run: a device-to-device copy moving the same number of bytes per launch
-    if rank == 0 and not fused_T:
+    if rank == 0 and not fused_T and extras:
         try:
             nel = max(int(bytes_per * n_local) // 8, 1 << 20)         # copy_ reads nel*4 and writes nel*4 bytes
-            src = torch.ones(nel, dtype=torch.float32, device=device)
-            dst = torch.empty_like(src)
+            src_t = torch.ones(nel, dtype=torch.float32, device=device)
+            dst_t = torch.empty_like(src_t)
             for _ in range(5):
-                dst.copy_(src)
-            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            c0.record()
-            for _ in range(50):
-                dst.copy_(src)
-            c1.record()
-            torch.cuda.synchronize(device)
-            copy_gbps = 8.0 * nel / (c0.elapsed_time(c1) / 50 * 1e-3) / 1e9
+                dst_t.copy_(src_t)
+            copy_us = _timed_steps(device, lambda: [dst_t.copy_(src_t) for _ in range(50)], 50)
+            copy_gbps = 8.0 * nel / (copy_us * 1e-6) / 1e9
             line["roofline"]["copy_ceiling"] = {"GBps": copy_gbps, "frac_of_copy": achieved / copy_gbps,
                                                 "what": "torch copy_ (D2D) of the same bytes per launch, HIP events, same process"}
-            del src, dst
+            del src_t, dst_t
         except Exception as exc:                                       # never let the calibration break the bench line
             line["roofline"]["copy_ceiling"] = {"error": str(exc)}
     if fused_T:
         line["roofline"]["kernel"] = f"k_rollout_geometric<float,float,false,false> ({fused_T} control steps per launch)"
-        line["roofline"]["kernel_us"] = kernel_us * fused_T
+        line["roofline"]["us_per_launch"] = us_per_step * fused_T
         line["roofline"]["bytes_per_launch"] = bytes_per * n_local * fused_T
         line["roofline"]["traffic"] = None
         line["config"]["launch"] = f"fused rollout, {fused_T} steps per launch, obs log [T,n,20]"
@@ -428,113 +550,126 @@ def main(argv=None):
         line["config"].update({"pyb_freq": 240, "ctrl_freq": 240,
                                "episode_steps": C5_EPISODE,
                                "launch": "python ctypes loop, obs -> rollout log slot" if args.python_loop else
-                               ("C loop (mds_rollout_step), half shards on 2 streams, obs -> rollout log slot" if args.rollout_streams != 1
+                               ("C loop (mds_rollout_step), half shards on 2 streams, obs -> rollout log slot" if split
                                 else "C loop (mds_rollout_step), one stream, obs -> rollout log slot")})
         if fused_T:
             line["roofline"]["kernel"] = f"k_rollout_step<float,_Float16,false,false> ({fused_T} control steps per launch)"
             line["roofline"]["bound_note"] = "VALU (state in registers; the action table is read and the observation log written)"
             line["config"]["launch"] = f"C loop (mds_rollout_step_fused), {fused_T} steps per launch, obs -> rollout log slot"
-        elif not args.python_loop and args.rollout_streams != 1:
-            line["roofline"].update({"streams": 2, "bytes_per_launch": bytes_per * n_local / 2,
-                                     "launches": "two concurrent half-shard launches per step, one per stream; achieved = 2 x bytes_per_launch / kernel_us"})
-    if args.workload == "c4":
+    if c4:
         st = env._cbf_status
         line["roofline"]["kernel"] = "k_cbf_nominal + k_cbf_filter_gi + k_lowlevel_step (3 launches per step and env half; QP is latency/ALU bound)"
+        line["config"]["scene"] = args.c4_scene
         if not args.python_loop:
-            line["config"]["launch"] = ("C rollout loop, env halves on 2 streams" if args.rollout_streams != 1
-                                        else "C rollout loop, one stream")
+            line["config"]["launch"] = "C rollout loop, env halves on 2 streams" if split else "C rollout loop, one stream"
         line["cbf_fallback_frac_last_step"] = float((st != 0).float().mean().item())
-    # secondary measurement (same workload, same run): the whole-rollout kernel, 50 control steps per launch with
-    # every step's observation streamed to a [50,n,20] log.  Reported beside the contract's per-step line.
-    if args.workload in ("c2", "c3") and not fused_T and not args.python_loop and args.steps >= 100:
+        try:
+            it = tracker.cbf.last_iterations()                      # GI iterations per env of the last filter launch
+            edges = [0, 1, 2, 4, 8, 16, 32, 64, 1 << 30]
+            hist = torch.histogram(it.float().cpu(), bins=torch.tensor([float(e) for e in edges]))[0]
+            line["cbf_iterations_last_step"] = {"bins": ["0", "1", "2-3", "4-7", "8-15", "16-31", "32-63", "64+"],
+                                                "envs": [int(v) for v in hist.tolist()], "mean": float(it.float().mean().item()),
+                                                "max": int(it.max().item())}
+        except Exception as exc:
+            line["cbf_iterations_last_step"] = {"error": str(exc)}
+    # ---- secondary measurements, same run (never part of `value`) -------------------------------------------------------
+    # the whole-rollout kernel, 50 control steps per launch with every step's observation streamed to a [50,n,20] log
+    if args.workload in ("c2", "c3") and not fused_T and not args.python_loop and extras and not rk4:
         T2 = 50
         log2 = torch.empty((T2, E, D, 20), dtype=env.dtype, device=device)
         env.rollout_geometric_fused(0.0, T2, log=True, log_out=log2)
-        torch.cuda.synchronize(device)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = max(1, min(args.steps, 1000) // T2)
-        e0.record(torch.cuda.current_stream(device))
-        for r_ in range(reps):
-            env.rollout_geometric_fused(r_ * T2 * dt, T2, log=True, log_out=log2)
-        e1.record(torch.cuda.current_stream(device))
-        torch.cuda.synchronize(device)
-        us = e0.elapsed_time(e1) * 1e3 / (reps * T2)
+        reps = 10
+        us = _timed_steps(device, lambda: [env.rollout_geometric_fused(r_ * T2 * dt, T2, log=True, log_out=log2) for r_ in range(reps)], reps * T2)
         us = max_over_ranks(us, world, device)
-        b2 = 80 + 212 / T2
+        b2 = 20 * es + 53 * es / T2
         line["fused_rollout"] = {"steps_per_launch": T2, "us_per_step": us, "value": n_local * world / (us * 1e-6), "unit": "drone-steps/s",
                                  "bytes_per_drone_step": b2, "achieved_GBps": b2 * n_local / (us * 1e-6) / 1e9,
                                  "bound": "VALU (state in registers; only the obs log leaves the chip)",
-                                 "kernel": "k_rollout_geometric<float,float,false,false>"}
+                                 "kernel": f"k_rollout_geometric<{cname},{tname},false,false>"}
         del log2
-    if c5 and not fused_T and not args.python_loop and args.steps >= 1000:
+    if c5 and not fused_T and not args.python_loop and extras:
         # the same loop with 40 env.step per launch (mds_rollout_step_fused), one 1000-step episode per repetition
         T2, reps = 40, 4
         env.reset()
         env.rollout_step(c5_act_tab, 0, C5_EPISODE, c5_log, episode_len=C5_EPISODE, steps_per_launch=T2)
-        torch.cuda.synchronize(device)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(torch.cuda.current_stream(device))
-        env.rollout_step(c5_act_tab, C5_EPISODE, reps * C5_EPISODE, c5_log, episode_len=C5_EPISODE, steps_per_launch=T2)
-        e1.record(torch.cuda.current_stream(device))
-        torch.cuda.synchronize(device)
-        us = max_over_ranks(e0.elapsed_time(e1) * 1e3 / (reps * C5_EPISODE), world, device)
+        us = _timed_steps(device, lambda: env.rollout_step(c5_act_tab, C5_EPISODE, reps * C5_EPISODE, c5_log, episode_len=C5_EPISODE,
+                                                           steps_per_launch=T2), reps * C5_EPISODE)
+        us = max_over_ranks(us, world, device)
         b2 = 24 * es + 26 * es / T2
         line["fused_rollout"] = {"steps_per_launch": T2, "us_per_step": us, "value": n_local * world / (us * 1e-6), "unit": "drone-steps/s",
                                  "bytes_per_drone_step": b2, "achieved_GBps": b2 * n_local / (us * 1e-6) / 1e9,
                                  "bound": "VALU (state in registers; the action table is read, the observation log written)",
                                  "kernel": "k_rollout_step<float,_Float16,false,false>",
                                  "state_sane": bool(torch.isfinite(c5_log).all().item())}
-    if args.workload == "c3" and world == 1 and not fused_T and not args.python_loop and args.steps >= 1000:
+    env.close()
+    del env
+    if args.workload == "c3" and world == 1 and not fused_T and not args.python_loop and extras and not rk4:
+        torch.cuda.empty_cache()
         # BASELINE.json configs[1] (C2: 4096 envs x 4 drones) beside the headline, same process: its 3.5 MB per step are launch-latency
         # bound, so the per-step loop and the whole-rollout kernel (50 steps per launch) are both reported
-        E2, D2, ph2, _ = WORKLOADS["c2"]
-        x2, r2, P2 = make_inputs(E2, D2, ph2, 1000)
-        env2 = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D2, initial_xyzs=x2, initial_rpys=r2, physics=Physics.DYN,
-                          pyb_freq=100, ctrl_freq=100, num_envs=E2, dtype=args.dtype, device=local_rank)
-        env2.set_trajectories(P2)
-        env2.step(torch.zeros((E2, D2, 4), dtype=env2.dtype, device=device))
-        env2.rollout_geometric(0.0, 200, want_obs=True, obs_every_step=True)
-        torch.cuda.synchronize(device)
-        a0, a1, a2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        log2 = torch.empty((50, E2, D2, 20), dtype=env2.dtype, device=device)
-        env2.rollout_geometric_fused(0.0, 50, log=True, log_out=log2)
-        a0.record(torch.cuda.current_stream(device))
-        env2.rollout_geometric(2.0, 2000, want_obs=True, obs_every_step=True)
-        a1.record(torch.cuda.current_stream(device))
-        for r_ in range(20):
-            env2.rollout_geometric_fused(22.0 + 0.5 * r_, 50, log=True, log_out=log2)
-        a2.record(torch.cuda.current_stream(device))
-        torch.cuda.synchronize(device)
-        us_step, us_fused = a0.elapsed_time(a1) * 1e3 / 2000, a1.elapsed_time(a2) * 1e3 / 1000
-        line["configs_1_c2"] = {"workload": WORKLOADS["c2"][3], "per_step": {"us_per_step": us_step, "value": E2 * D2 / (us_step * 1e-6),
-                                                                           "frac": BYTES_PER_DRONE_STEP * E2 * D2 / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                                                                           "bound": "kernel launch latency (3.5 MB per launch)"},
-                                "fused_rollout_50": {"us_per_step": us_fused, "value": E2 * D2 / (us_fused * 1e-6)}, "unit": "drone-steps/s"}
-        env2.close()
-        del log2
+        try:
+            E2, D2, ph2, _ = WORKLOADS["c2"]
+            x2, r2, P2 = make_inputs(E2, D2, ph2, 1000)
+            env2 = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D2, initial_xyzs=x2, initial_rpys=r2, physics=Physics.DYN,
+                              pyb_freq=100, ctrl_freq=100, num_envs=E2, dtype=args.dtype, device=local_rank)
+            env2.set_trajectories(P2)
+            env2.step(torch.zeros((E2, D2, 4), dtype=env2.dtype, device=device))
+            env2.rollout_geometric(0.0, 200, want_obs=True, obs_every_step=True)
+            log2 = torch.empty((50, E2, D2, 20), dtype=env2.dtype, device=device)
+            env2.rollout_geometric_fused(0.0, 50, log=True, log_out=log2)
+            us_step = _timed_steps(device, lambda: env2.rollout_geometric(2.0, 2000, want_obs=True, obs_every_step=True), 2000)
+            us_fused = _timed_steps(device, lambda: [env2.rollout_geometric_fused(22.0 + 0.5 * r_, 50, log=True, log_out=log2) for r_ in range(20)], 1000)
+            line["configs_1_c2"] = {"workload": WORKLOADS["c2"][3], "per_step": {"us_per_step": us_step, "value": E2 * D2 / (us_step * 1e-6),
+                                                                               "frac": bytes_per * E2 * D2 / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                                                               "bound": "kernel launch latency (3.5 MB per launch)"},
+                                    "fused_rollout_50": {"us_per_step": us_fused, "value": E2 * D2 / (us_fused * 1e-6)}, "unit": "drone-steps/s"}
+            env2.close()
+            del log2, env2
+        except Exception as exc:
+            line["configs_1_c2"] = {"error": str(exc)}
+        if args.dtype == "float32":
+            # the same kernel beyond the Infinity Cache, north_star's integrator, and the reference's own precision, each on its own env
+            try:
+                EB, DB, phB, _ = WORKLOADS["c3big"]
+                us, used, sane = extra_c3_variant(CtrlAviary, DroneModel, Physics, torch, local_rank, device, EB, DB, phB, 2000, "float32", "euler", 50, 0)
+                gb = BYTES_PER_DRONE_STEP * EB * DB / (us * 1e-6) / 1e9
+                nl = EB * DB // 2 if used == 2 else EB * DB
+                tr, src = _pmc_traffic("r02_pmc_traffic_c3big.json", nl)
+                line["roofline"]["frac_hbm_resident"] = gb / HBM_PEAK_GBPS
+                line["roofline"]["hbm_resident"] = {"workload": WORKLOADS["c3big"][3], "drones": EB * DB, "steps": 50, "us_per_step": us,
+                                                    "value": EB * DB / (us * 1e-6), "achieved": gb, "unit": "GB/s", "frac": gb / HBM_PEAK_GBPS,
+                                                    "frac_of_achievable_6300": gb / 6300.0, "bytes_per_step": BYTES_PER_DRONE_STEP * EB * DB,
+                                                    "streams": used, "traffic": tr, "traffic_source": src, "state_sane": sane}
+            except Exception as exc:
+                line["roofline"]["hbm_resident"] = {"error": str(exc)}
+            torch.cuda.empty_cache()
+            for key, dty, integ, bpd in (("rk4", "float32", "rk4", BYTES_PER_DRONE_STEP), ("f64", "float64", "euler", 2 * BYTES_PER_DRONE_STEP)):
+                try:
+                    us, used, sane = extra_c3_variant(CtrlAviary, DroneModel, Physics, torch, local_rank, device, E, D, phase, 1000, dty, integ, 200, 0)
+                    gb = bpd * n_local / (us * 1e-6) / 1e9
+                    line[key] = {"what": {"rk4": "same C3 step with the classical RK4 integrator (north_star's), fp32",
+                                          "f64": "same C3 step in float64 (the reference's precision), explicit Euler"}[key],
+                                 "us_per_step": us, "value": n_local / (us * 1e-6), "unit": "drone-steps/s", "bytes_per_drone_step": bpd,
+                                 "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBPS, "streams": used, "steps": 200, "state_sane": sane}
+                except Exception as exc:
+                    line[key] = {"error": str(exc)}
+                torch.cuda.empty_cache()
     if args.gather_obs and world > 1:      # optional whole-swarm observation packing; outside `value`
         from multidronesim_amd.swarm import all_gather_observations
         mine = obs.reshape(E, D, 20).contiguous()
         buf = torch.empty((world * E, D, 20), dtype=mine.dtype, device=device)
         for _ in range(3):
             all_gather_observations(mine, buf)
-        torch.cuda.synchronize(device)
-        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        g0.record(torch.cuda.current_stream(device))
-        for _ in range(20):
-            all_gather_observations(mine, buf)
-        g1.record(torch.cuda.current_stream(device))
-        torch.cuda.synchronize(device)
-        ms = max_over_ranks(g0.elapsed_time(g1) / 20, world, device)
+        ms = _timed_steps(device, lambda: [all_gather_observations(mine, buf) for _ in range(20)], 20) * 1e-3
+        ms = max_over_ranks(ms, world, device)
         line["obs_allgather"] = {"ms": ms, "bytes_per_rank": mine.numel() * mine.element_size(), "backend": "nccl (RCCL)",
                                  "bus_GBps": mine.numel() * mine.element_size() * (world - 1) / (ms * 1e-3) / 1e9}
         del buf
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload not in ("c4", "c5"):
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("c2", "c3"):
         line["cpu_baseline"] = cpu_baseline(D, phase, args.cpu_budget)
         line["cpu_baseline"]["all_cores"] = all_cores
     elif rank == 0:
         line["cpu_baseline"] = None
-    env.close()
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

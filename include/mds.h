@@ -16,8 +16,12 @@
  *   - "host" pointers are host double arrays (set-up / inspection only, never hot path).
  *   - `stream` is a hipStream_t (NULL = default stream).  Hot-path calls (mds_step*, mds_rollout*, the operators) only
  *     enqueue work on it and return; they never synchronise or copy, and they allocate only once: the first
- *     mds_step_cbf_geometric / mds_step_nominal of a handle creates its [n,18] scratch.  Set-up calls (mds_create, mds_reset,
+ *     mds_step_cbf_geometric / mds_step_nominal of a handle creates its [n,18] scratch.  The internal streams and events of
+ *     the two-chain rollouts are created and primed by mds_create (shards of 2^16 drones and more) or by
+ *     mds_set_rollout_streams(h, 2), never by a rollout.  Set-up calls (mds_create, mds_reset,
  *     mds_set_*, mds_cbf_configure, mds_get/set_state) may allocate, copy from host memory and synchronise.
+ *   - Every call taking a handle runs on the handle's device (mds_config.device) and leaves the calling thread's current
+ *     HIP device as it found it; device pointers passed in must belong to that device.
  *   - Every call returns MDS_OK (0) or a negative mds_status; nothing throws or aborts
  *     across the ABI.  mds_strerror() names a status, mds_last_error() adds HIP detail.
  *   - A handle is not re-entrant (one simulation thread, as PIDEnv.py:99-103); distinct
@@ -34,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 100 /* 0.1.0 */
+#define MDS_VERSION 200 /* 0.2.0 */
 #define MDS_OBS_DIM 20  /* [UPSTREAM] _getDroneStateVector */
 #define MDS_ACT_DIM 4
 #define MDS_STATE_DIM 13 /* pos3 | quat4 xyzw | vel3 (world) | body rates3 */
@@ -207,9 +211,17 @@ int mds_reset_async(mds_handle* h, void* stream);
  * gaps between dependent launches disappear (C3: 17.5 -> 15.0-15.7 us per step; half-shard launches also carry unused
  * LDS so that 5 instead of 8 workgroups share a CU and the chains interleave from the first step).
  * 0 = auto (geometric / plain step: two streams from 2^19 drones, from 2^18 for calls of 1000+ steps; CBF loop: from
- * 2^16 drones), 1 = the caller's stream only, 2 = always split.  Results are bit-identical either way; the caller's
- * stream orders the whole call (events on entry and exit), so the usual stream semantics hold. */
+ * 2^16 drones), 1 = the caller's stream only, 2 = always split (a set-up call then: it creates the internal streams of a
+ * handle that mds_create gave none).  Results are bit-identical either way; the caller's stream orders the whole call
+ * (events on entry and exit -- the exit events are recorded even when a launch in between failed), so the usual stream
+ * semantics hold. */
 int mds_set_rollout_streams(mds_handle* h, int n_streams);
+/* What the most recent mds_rollout_geometric / mds_rollout_step / mds_rollout_cbf_geometric of this handle did: 1 = the
+ * caller's stream only, 2 = two chains on the internal streams, 0 = no rollout yet. */
+int mds_get_last_rollout_streams(const mds_handle* h);
+/* What a call of n_steps would do under the current setting: loop 0 = mds_rollout_geometric / mds_rollout_step, loop 1 =
+ * mds_rollout_cbf_geometric.  Returns 1 or 2.  (A caller that warms a path up asks this for the length it is going to time.) */
+int mds_rollout_streams_for(const mds_handle* h, int loop, int n_steps);
 
 /* The same n_steps control steps in ONE kernel launch: state and trajectory parameters stay in
  * registers between steps; every step's observation is streamed to obs_log_dev [n_steps, n, 20]

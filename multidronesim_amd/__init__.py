@@ -6,4 +6,4 @@ reference drives through gym-pybullet-drones), ``GeometricControl``, ``Lemniscat
 reached through the C-ABI in ``include/mds.h`` (``libmds.so``).  There is no CPU path."""
 from ._capi import MdsError, load_library  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

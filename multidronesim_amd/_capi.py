@@ -75,6 +75,8 @@ PROTOTYPES = {
     "mds_step_geometric": (C.c_int, [_P, C.c_double, _P, _P, _P]),
     "mds_rollout_geometric": (C.c_int, [_P, C.c_double, C.c_int, _P, C.c_int, _P]),
     "mds_set_rollout_streams": (C.c_int, [_P, C.c_int]),
+    "mds_get_last_rollout_streams": (C.c_int, [_P]),
+    "mds_rollout_streams_for": (C.c_int, [_P, C.c_int, C.c_int]),
     "mds_rollout_step": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
     "mds_rollout_step_fused": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "mds_reset_async": (C.c_int, [_P, _P]),

@@ -19,6 +19,17 @@ def require_gpu(device_index: int) -> torch.device:
     return torch.device("cuda", device_index)
 
 
+def default_device_index() -> int:
+    """The GPU a handle is created on when the caller names none: this rank's own (LOCAL_RANK, one process per GPU) when the
+    process sees several, else the thread's current torch device."""
+    import os
+    if not torch.cuda.is_available():
+        return 0
+    if torch.cuda.device_count() > 1 and "LOCAL_RANK" in os.environ:
+        return int(os.environ["LOCAL_RANK"]) % torch.cuda.device_count()
+    return torch.cuda.current_device()
+
+
 def stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from .. import _capi as capi
-from .._device import require_gpu, stream_ptr
+from .._device import default_device_index, require_gpu, stream_ptr
 from ..utils.enums import DroneModel
 
 
@@ -48,12 +48,13 @@ class DSLPIDControl:
     def _handle(self, control_timestep):
         if self._h is None:
             lib = capi.load_library()
-            dev = require_gpu(0)
+            dev = require_gpu(default_device_index())
             cfg = capi.MdsConfig()
             capi.check(lib.mds_default_config(capi.MDS_CF2P if self.DRONE_MODEL == DroneModel.CF2P else capi.MDS_CF2X, C.byref(cfg)),
                        "mds_default_config")
             f = int(round(1.0 / control_timestep))
             cfg.num_envs, cfg.num_drones, cfg.dtype, cfg.pyb_freq, cfg.ctrl_freq = 1, 1, capi.MDS_F64, f, f
+            cfg.device = dev.index
             h = C.c_void_p()
             capi.check(lib.mds_create(C.byref(cfg), C.byref(h)), "mds_create")
             self._h, self._lib, self._dev, self._dt = h, lib, dev, 1.0 / f

@@ -40,6 +40,31 @@ size_t elem_size(int dtype) { return dtype == MDS_F64 ? 8 : (dtype == MDS_F16 ? 
 size_t comp_size(int dtype) { return dtype == MDS_F64 ? 8 : 4; }
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Every entry point runs with the handle's device current and restores the caller's on return: a process may hold
+// handles on several GPUs (one env per device, or a trajectory-evaluation handle next to an env), and neither the
+// launches nor the set-up allocations may land on whatever device the calling thread happened to have selected.
+struct DevGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DevGuard(int dev) {
+    if (dev < 0) return;
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) {
+      err = hipSetDevice(dev);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DevGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DevGuard(const DevGuard&) = delete;
+  DevGuard& operator=(const DevGuard&) = delete;
+};
+#define MDS_DEV(h) DevGuard dev_guard__((h) ? (h)->cfg.device : -1)
+
+__global__ void k_noop() {}
+
 }  // namespace
 
 struct mds_handle {
@@ -75,8 +100,15 @@ struct mds_handle {
   int* cbf_cost;       // [E] GI iterations of the last launch
   int cbf_calls;       // launches since the classes were rebuilt; -1: no classes yet
   int rollout_streams = 0;              // mds_set_rollout_streams: 0 auto, 1, 2
-  hipStream_t split_st[2] = {nullptr, nullptr};   // created on first use by a two-stream rollout
-  hipEvent_t split_ev[3] = {nullptr, nullptr, nullptr};
+  // two-chain rollouts: chain 0 runs on the caller's stream, chain 1 on this internal stream; ev[0] forks it off the caller's
+  // stream, ev[1] joins it back.  Created (and primed) by mds_create for shards that can split, else by mds_set_rollout_streams(h, 2).
+  hipStream_t split_st = nullptr;
+  hipEvent_t split_ev[2] = {nullptr, nullptr};
+  int split_offset = 0;                 // 1: the fork event sits half way through chain 0's first step (MDS_TUNE_SPLIT_OFFSET, tuning only; the
+                                        // fork's own latency already starts chain 1 about half a kernel late: 20-step calls 17.3 vs 17.6 us)
+  int split_min_steps = 0;              // auto policy: calls shorter than this stay on one stream (MDS_TUNE_SPLIT_MIN_STEPS, tuning only)
+  int last_rollout_streams = 0;         // what the last mds_rollout_* call did (mds_get_last_rollout_streams)
+  bool cbf_hildreth = false;            // MDS_CBF_SOLVER=hildreth, read once by mds_cbf_configure
   void* cbf_unom;      // S [n,4]  scratch of mds_step_cbf_geometric
   void* cbf_xdes;      // S [n,9]
   void* cbf_usafe;     // S [n,4]
@@ -117,13 +149,62 @@ static inline void* rpm_track(mds_handle* h) {
 
 // Shards at least this large step their two halves on two streams inside mds_rollout_geometric (0 = auto policy).
 constexpr size_t kSplitMinDrones = size_t(1) << 18;
+// Calls shorter than this stay on the caller's stream under the auto policy: the two chains cost a fork and a join (two
+// cross-stream dependencies, ~25 us per call) and start in lock step.  C3, us per control step by call length, one stream ->
+// two chains: 5 steps 17.9 -> 21.2, 20 steps 17.5 -> 17.6, 50 steps 17.3 -> 16.2, 100 steps 17.7 -> 15.7, 2000 steps 17.6 -> 15.4
+// (profiles/r02_short_calls.log).
+#ifndef MDS_SPLIT_MIN_STEPS
+#define MDS_SPLIT_MIN_STEPS 32
+#endif
+constexpr int kSplitMinSteps = MDS_SPLIT_MIN_STEPS;
 
+// The stream policy in one place (mds_set_rollout_streams; mds_rollout_streams_for reports it).  loop 0: the fused geometric /
+// plain env.step loops (size sweep of DESIGN.md 4: below 2^18 drones the extra launches cost more than the overlap gains,
+// between 2^18 and 2^19 it pays only once the chains have had ~1000 steps to drift out of phase); loop 1: the CBF loop
+// (2^15 drones 36.6 vs 36.4 us, 2^16 41.0 vs 39.4, 2^17 52.9 vs 44.7, 2^18 71.7 vs 60.3).
+static int rollout_streams_policy(const mds_handle* h, int loop, int n_steps) {
+  if (n_steps < 2 || !h->split_st) return 1;
+  if (h->rollout_streams) return h->rollout_streams;
+  const size_t n = (size_t)h->n;
+  const int min_steps = h->split_min_steps > 0 ? h->split_min_steps : kSplitMinSteps;
+  if (loop == 1) return (n >= kSplitMinDrones / 4 && n_steps >= min_steps) ? 2 : 1;
+  const bool big = n >= 2 * kSplitMinDrones ? n_steps >= min_steps : (n >= kSplitMinDrones && n_steps >= 1000);
+  return big ? 2 : 1;
+}
+
+// Set-up path (mds_create / mds_set_rollout_streams): the internal stream and the two events of the two-chain rollouts.
+// The new stream runs one empty kernel and is drained, so that its hardware queue exists and has dispatched before any
+// rollout uses it -- the rollouts themselves never create or initialise anything (mds.h: hot-path calls only enqueue).
 static int split_streams_ready(mds_handle* h) {
+  if (h->split_st && h->split_ev[0] && h->split_ev[1]) return MDS_OK;
+  if (!h->split_st) {
+    MDS_HIP(hipStreamCreateWithFlags(&h->split_st, hipStreamNonBlocking));
+    k_noop<<<1, 64, 0, h->split_st>>>();
+    MDS_HIP(hipGetLastError());
+  }
   for (int k = 0; k < 2; ++k)
-    if (!h->split_st[k]) MDS_HIP(hipStreamCreateWithFlags(&h->split_st[k], hipStreamNonBlocking));
-  for (int k = 0; k < 3; ++k)
     if (!h->split_ev[k]) MDS_HIP(hipEventCreateWithFlags(&h->split_ev[k], hipEventDisableTiming));
+  MDS_HIP(hipEventRecord(h->split_ev[1], h->split_st));
+  MDS_HIP(hipStreamSynchronize(h->split_st));
   return MDS_OK;
+}
+
+// Entry / exit of a two-chain rollout.  Chain 0 is the caller's stream itself: its launches wait for nothing, and the call
+// costs two cross-stream dependencies in all (four, and 50 us per call, when both chains ran on internal streams).
+// fork: the internal stream waits for everything enqueued on the caller's stream so far.
+// join: the caller's stream waits for chain 1 -- ALWAYS run once fork has been attempted, also when a launch in between
+// failed, so that the caller's stream keeps ordering whatever was enqueued (mds.h: the caller's stream orders the whole call).
+static int split_fork(mds_handle* h, hipStream_t st) {
+  MDS_HIP(hipEventRecord(h->split_ev[0], st));
+  MDS_HIP(hipStreamWaitEvent(h->split_st, h->split_ev[0], 0));
+  return MDS_OK;
+}
+static int split_join(mds_handle* h, hipStream_t st, int rc_body) {
+  int rc = rc_body;
+  hipError_t e = hipEventRecord(h->split_ev[1], h->split_st);
+  if (e == hipSuccess) e = hipStreamWaitEvent(st, h->split_ev[1], 0);
+  if (e != hipSuccess && rc == MDS_OK) rc = fail_hip(e, "two-chain rollout: join");
+  return rc;
 }
 
 // dispatch on the handle dtype: F32 -> <float,float>, F64 -> <double,double>, F16 -> <float,half_t>
@@ -236,7 +317,8 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
     return fail(MDS_EINVAL, "mds_create: pyb_freq must be a positive multiple of ctrl_freq");
   if (!(cfg->M > 0) || !(cfg->KF > 0) || !(cfg->KM > 0) || !(cfg->L > 0) || !(cfg->J[0] > 0) || !(cfg->J[1] > 0) || !(cfg->J[2] > 0))
     return fail(MDS_EINVAL, "mds_create: non-positive drone constant");
-  MDS_HIP(hipSetDevice(cfg->device));
+  DevGuard dev_guard__(cfg->device);        // the caller's current device is restored on return
+  if (dev_guard__.err != hipSuccess) return fail_hip(dev_guard__.err, "mds_create: hipSetDevice(cfg->device)");
   mds_handle* h = new (std::nothrow) mds_handle();
   if (!h) return fail(MDS_ENOMEM, "mds_create: host allocation");
   h->cfg = *cfg;
@@ -304,12 +386,23 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
     MDS_HIP(hipGetLastError());
     MDS_HIP(hipDeviceSynchronize());
   }
+  // shards large enough for the auto policy of the two-chain rollouts get their streams and events now (smallest auto
+  // threshold: the CBF loop, 2^16 drones); smaller ones only if mds_set_rollout_streams(h, 2) asks for them
+  if (const char* v = getenv("MDS_TUNE_SPLIT_OFFSET")) h->split_offset = atoi(v);
+  if (const char* v = getenv("MDS_TUNE_SPLIT_MIN_STEPS")) h->split_min_steps = atoi(v);
+  if ((size_t)h->n >= kSplitMinDrones / 4) {
+    if (int rc = split_streams_ready(h)) {
+      mds_destroy(h);
+      return rc;
+    }
+  }
   *out = h;
   return MDS_OK;
 }
 
 int mds_destroy(mds_handle* h) {
   if (!h) return MDS_OK;
+  MDS_DEV(h);
   if (h->state) (void)hipFree(h->state);
   if (h->state_alt) (void)hipFree(h->state_alt);
   if (h->origin) (void)hipFree(h->origin);
@@ -331,9 +424,8 @@ int mds_destroy(mds_handle* h) {
   if (h->pid) (void)hipFree(h->pid);
   if (h->segs) (void)hipFree(h->segs);
   if (h->tinfo) (void)hipFree(h->tinfo);
+  if (h->split_st) (void)hipStreamDestroy(h->split_st);
   for (int k = 0; k < 2; ++k)
-    if (h->split_st[k]) (void)hipStreamDestroy(h->split_st[k]);
-  for (int k = 0; k < 3; ++k)
     if (h->split_ev[k]) (void)hipEventDestroy(h->split_ev[k]);
   delete h;
   return MDS_OK;
@@ -366,6 +458,7 @@ static int launch_reset_range(mds_handle* h, hipStream_t st, size_t i0, size_t i
 }
 
 int mds_reset(mds_handle* h, const double* xyz, const double* rpy, void* stream) {
+  MDS_DEV(h);
   if (!h || !xyz || !rpy) return fail(MDS_EINVAL, "mds_reset: null argument");
   hipStream_t st = (hipStream_t)stream;
   const size_t nb = (size_t)h->n * 3 * sizeof(double);
@@ -381,6 +474,7 @@ int mds_reset(mds_handle* h, const double* xyz, const double* rpy, void* stream)
 }
 
 int mds_reset_async(mds_handle* h, void* stream) {
+  MDS_DEV(h);
   if (!h) return fail(MDS_EINVAL, "mds_reset_async: null handle");
   if (!h->init_pose) return fail(MDS_ESTATE, "mds_reset_async: no mds_reset yet");
   hipStream_t st = (hipStream_t)stream;
@@ -392,6 +486,7 @@ int mds_reset_async(mds_handle* h, void* stream) {
 }
 
 int mds_state_ptrs(mds_handle* h, void* comp_dev[13], size_t stride_elems[13], void* origin_dev[3]) {
+  MDS_DEV(h);
   if (!h || !comp_dev || !stride_elems) return fail(MDS_EINVAL, "mds_state_ptrs: null argument");
   const size_t es = elem_size(h->cfg.dtype), cs = comp_size(h->cfg.dtype);
   for (int k = 0; k < 13; ++k) {
@@ -404,6 +499,7 @@ int mds_state_ptrs(mds_handle* h, void* comp_dev[13], size_t stride_elems[13], v
 }
 
 int mds_get_state(mds_handle* h, double* out, void* stream) {
+  MDS_DEV(h);
   if (!h || !out) return fail(MDS_EINVAL, "mds_get_state: null argument");
   hipStream_t st = (hipStream_t)stream;
   MDS_DISPATCH(h, (k_get_state<T, S><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, h->ld, (const S*)h->state, (const T*)h->origin,
@@ -415,6 +511,7 @@ int mds_get_state(mds_handle* h, double* out, void* stream) {
 }
 
 int mds_set_state(mds_handle* h, const double* in, void* stream) {
+  MDS_DEV(h);
   if (!h || !in) return fail(MDS_EINVAL, "mds_set_state: null argument");
   hipStream_t st = (hipStream_t)stream;
   MDS_HIP(hipMemcpyAsync(h->scratch, in, (size_t)h->n * 13 * sizeof(double), hipMemcpyHostToDevice, st));
@@ -426,6 +523,7 @@ int mds_set_state(mds_handle* h, const double* in, void* stream) {
 }
 
 int mds_set_origin(mds_handle* h, const double* origin, void* stream) {
+  MDS_DEV(h);
   if (!h || !origin) return fail(MDS_EINVAL, "mds_set_origin: null argument");
   hipStream_t st = (hipStream_t)stream;
   MDS_HIP(hipMemcpyAsync(h->scratch, origin, (size_t)h->n * 3 * sizeof(double), hipMemcpyHostToDevice, st));
@@ -436,6 +534,7 @@ int mds_set_origin(mds_handle* h, const double* origin, void* stream) {
 }
 
 int mds_get_obs(mds_handle* h, void* obs, void* stream) {
+  MDS_DEV(h);
   if (!h || !obs) return fail(MDS_EINVAL, "mds_get_obs: null argument");
   if (!aligned16(obs)) return fail(MDS_EALIGN, "mds_get_obs: obs_dev");
   hipStream_t st = (hipStream_t)stream;
@@ -472,6 +571,7 @@ static void launch_step_plain(mds_handle* h, const void* action, void* obs, hipS
 }
 
 int mds_step(mds_handle* h, const void* action, void* obs, void* stream) {
+  MDS_DEV(h);
   if (!h || !action) return fail(MDS_EINVAL, "mds_step: null argument");
   if (!aligned16(action) || !aligned16(obs)) return fail(MDS_EALIGN, "mds_step: action_dev/obs_dev");
   hipStream_t st = (hipStream_t)stream;
@@ -499,6 +599,7 @@ int mds_step(mds_handle* h, const void* action, void* obs, void* stream) {
 }
 
 int mds_set_lemniscate(mds_handle* h, const double* params, void* stream) {
+  MDS_DEV(h);
   if (!h || !params) return fail(MDS_EINVAL, "mds_set_lemniscate: null argument");
   hipStream_t st = (hipStream_t)stream;
   const int n = h->n;
@@ -521,6 +622,7 @@ int mds_set_lemniscate(mds_handle* h, const double* params, void* stream) {
 
 int mds_set_trajectory_segments(mds_handle* h, const double* segs, const int32_t* offsets, const int32_t* compound,
                                 const double* anchor, int32_t total, void* stream) {
+  MDS_DEV(h);
   if (!h || !segs || !offsets || !compound || !anchor) return fail(MDS_EINVAL, "mds_set_trajectory_segments: null argument");
   const int n = h->n;
   if (total <= 0 || offsets[0] != 0 || offsets[n] != total) return fail(MDS_EINVAL, "mds_set_trajectory_segments: offsets");
@@ -633,6 +735,7 @@ int mds_set_trajectory_segments(mds_handle* h, const double* segs, const int32_t
 }
 
 int mds_traj_eval(mds_handle* h, double t, void* des, void* stream) {
+  MDS_DEV(h);
   if (!h || !des) return fail(MDS_EINVAL, "mds_traj_eval: null argument");
   if (h->traj_mode == 1) return mds_lemniscate_eval(h, t, des, stream);
   if (h->traj_mode != 2) return fail(MDS_ESTATE, "mds_traj_eval: no trajectories set");
@@ -708,6 +811,7 @@ static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, 
 }
 
 int mds_step_geometric(mds_handle* h, double t, void* obs, void* act, void* stream) {
+  MDS_DEV(h);
   if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h) return fail(MDS_EINVAL, "mds_step_geometric: null handle");
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_step_geometric: call mds_set_lemniscate first");
@@ -718,47 +822,44 @@ int mds_step_geometric(mds_handle* h, double t, void* obs, void* act, void* stre
 }
 
 int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs, int obs_every_step, void* stream) {
+  MDS_DEV(h);
   if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h || n_steps < 0) return fail(MDS_EINVAL, "mds_rollout_geometric");
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_rollout_geometric: call mds_set_lemniscate first");
   if (!aligned16(obs)) return fail(MDS_EALIGN, "mds_rollout_geometric: obs_dev");
   const double dt = 1.0 / h->cfg.ctrl_freq;
   const unsigned nbatch = (unsigned)((h->n + kBlock - 1) / kBlock);
-  // auto policy from the size sweep in DESIGN.md 4: below 2^18 drones the extra launches cost more than the overlap gains,
-  // between 2^18 and 2^19 it pays only once the chains have had ~1000 steps to drift out of phase
-  const bool big = h->n >= 2 * kSplitMinDrones ? n_steps >= 16 : (h->n >= kSplitMinDrones && n_steps >= 1000);
-  const int streams = h->rollout_streams ? h->rollout_streams : (big ? 2 : 1);
-  if (streams == 2 && nbatch >= 2 && n_steps >= 2) {
+  const int streams = rollout_streams_policy(h, 0, n_steps);
+  if (streams == 2 && nbatch >= 2) {
     // Drones never read each other's rows in this kernel, so the two halves of the shard are two independent step
     // chains.  Run on two streams they drift out of phase: one half's load/store bursts fill the other's compute
     // phase (measured on C3: 17.5 -> 15.7-16.3 us per step).  The caller's stream orders both chains.
-    if (int rc = split_streams_ready(h)) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    MDS_HIP(hipEventRecord(h->split_ev[0], st));
+    hipStream_t st = (hipStream_t)stream, sb = h->split_st;
+    h->last_rollout_streams = 2;
     const unsigned half = nbatch / 2;
-    for (int s = 0; s < 2; ++s) MDS_HIP(hipStreamWaitEvent(h->split_st[s], h->split_ev[0], 0));
-    for (int k = 0; k < n_steps; ++k) {
-      void* o = (obs_every_step || k == n_steps - 1) ? obs : nullptr;
-      if (k == 0 && half >= 2) {
-        // phase offset: the second chain starts when the first is half way through its first step (started together
-        // the chains begin in lock step and need a few hundred steps to drift apart)
-        launch_step_geometric(h, t0, o, nullptr, h->split_st[0], 0, half / 2);
-        MDS_HIP(hipEventRecord(h->split_ev[1], h->split_st[0]));
-        MDS_HIP(hipStreamWaitEvent(h->split_st[1], h->split_ev[1], 0));
-        launch_step_geometric(h, t0, o, nullptr, h->split_st[0], half / 2, half - half / 2);
-      } else {
-        launch_step_geometric(h, t0, o, nullptr, h->split_st[0], 0, half);
+    auto body = [&]() -> int {
+      for (int k = 0; k < n_steps; ++k) {
+        void* o = (obs_every_step || k == n_steps - 1) ? obs : nullptr;
+        if (k == 0 && h->split_offset && half >= 2) {
+          // phase offset: the fork event sits half way through chain 0's first step, so chain 1 starts half a kernel late
+          // (started together the chains begin in lock step and need a few hundred steps to drift apart)
+          launch_step_geometric(h, t0, o, nullptr, st, 0, half / 2);
+          if (int rc = split_fork(h, st)) return rc;
+          launch_step_geometric(h, t0, o, nullptr, st, half / 2, half - half / 2);
+        } else {
+          if (k == 0)
+            if (int rc = split_fork(h, st)) return rc;
+          launch_step_geometric(h, t0, o, nullptr, st, 0, half);
+        }
+        launch_step_geometric(h, t0, o, nullptr, sb, half, nbatch - half);
+        t0 += dt;
       }
-      launch_step_geometric(h, t0, o, nullptr, h->split_st[1], half, nbatch - half);
-      t0 += dt;
-    }
-    for (int s = 0; s < 2; ++s) {
-      MDS_HIP(hipEventRecord(h->split_ev[1 + s], h->split_st[s]));
-      MDS_HIP(hipStreamWaitEvent(st, h->split_ev[1 + s], 0));
-    }
-    MDS_HIP(hipGetLastError());
-    return MDS_OK;
+      MDS_HIP(hipGetLastError());
+      return MDS_OK;
+    };
+    return split_join(h, st, body());
   }
+  h->last_rollout_streams = 1;
   for (int k = 0; k < n_steps; ++k) {
     // t accumulates exactly like the reference loop (t += env.CTRL_TIMESTEP, EnvGeometric.py:473)
     launch_step_geometric(h, t0, (obs_every_step || k == n_steps - 1) ? obs : nullptr, nullptr, (hipStream_t)stream);
@@ -770,6 +871,7 @@ int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs, int 
 
 int mds_rollout_step(mds_handle* h, const void* actions, int n_action_sets, int first_step, int n_steps, void* obs_log, int log_slots,
                      int episode_len, void* stream) {
+  MDS_DEV(h);
   if (!h || !actions || n_action_sets < 1 || first_step < 0 || n_steps < 0 || (obs_log && log_slots < 1) || episode_len < 0)
     return fail(MDS_EINVAL, "mds_rollout_step: arguments");
   if (episode_len > 0 && !h->init_pose) return fail(MDS_ESTATE, "mds_rollout_step: episode resets need an earlier mds_reset");
@@ -779,46 +881,42 @@ int mds_rollout_step(mds_handle* h, const void* actions, int n_action_sets, int 
     return fail(MDS_EALIGN, "mds_rollout_step: actions_dev/obs_log_dev (every action set and log slot must start 16-byte aligned)");
   hipStream_t st = (hipStream_t)stream;
   const unsigned nbatch = (unsigned)((h->n + kBlock - 1) / kBlock);
-  const bool big = h->n >= 2 * kSplitMinDrones ? n_steps >= 16 : (h->n >= kSplitMinDrones && n_steps >= 1000);
-  const int streams = h->rollout_streams ? h->rollout_streams : (big ? 2 : 1);
-  const bool split = streams == 2 && nbatch >= 2 && n_steps >= 2;
+  const bool split = rollout_streams_policy(h, 0, n_steps) == 2 && nbatch >= 2;
   const unsigned half = nbatch / 2;
-  if (split) {       // the two halves of the shard as independent step chains, as in mds_rollout_geometric
-    if (int rc = split_streams_ready(h)) return rc;
-    MDS_HIP(hipEventRecord(h->split_ev[0], st));
-    for (int s = 0; s < 2; ++s) MDS_HIP(hipStreamWaitEvent(h->split_st[s], h->split_ev[0], 0));
-  }
-  for (int k = 0; k < n_steps; ++k) {
-    const long long j = (long long)first_step + k;
-    const char* a = (const char*)actions + (size_t)(j % n_action_sets) * act_bytes;
-    char* o = obs_log ? (char*)obs_log + (size_t)(j % log_slots) * obs_bytes : nullptr;
-    if (episode_len > 0 && j > 0 && j % episode_len == 0) {      // a new episode starts at step j: back to the initial poses
-      const size_t mid = (size_t)half * kBlock;
+  if (split)         // the two halves of the shard as independent step chains, as in mds_rollout_geometric
+    if (int rc = split_fork(h, st)) return rc;
+  h->last_rollout_streams = split ? 2 : 1;
+  auto body = [&]() -> int {
+    for (int k = 0; k < n_steps; ++k) {
+      const long long j = (long long)first_step + k;
+      const char* a = (const char*)actions + (size_t)(j % n_action_sets) * act_bytes;
+      char* o = obs_log ? (char*)obs_log + (size_t)(j % log_slots) * obs_bytes : nullptr;
+      if (episode_len > 0 && j > 0 && j % episode_len == 0) {      // a new episode starts at step j: back to the initial poses
+        const size_t mid = (size_t)half * kBlock;
+        if (split) {
+          if (int rc = launch_reset_range(h, st, 0, mid)) return rc;
+          if (int rc = launch_reset_range(h, h->split_st, mid, h->n)) return rc;
+        } else if (int rc = launch_reset_range(h, st, 0, h->n)) {
+          return rc;
+        }
+      }
       if (split) {
-        if (int rc = launch_reset_range(h, h->split_st[0], 0, mid)) return rc;
-        if (int rc = launch_reset_range(h, h->split_st[1], mid, h->n)) return rc;
-      } else if (int rc = launch_reset_range(h, st, 0, h->n)) {
-        return rc;
+        launch_step_plain(h, a, o, st, 0, half);
+        launch_step_plain(h, a, o, h->split_st, half, nbatch - half);
+      } else {
+        launch_step_plain(h, a, o, st);
       }
     }
-    if (split) {
-      launch_step_plain(h, a, o, h->split_st[0], 0, half);
-      launch_step_plain(h, a, o, h->split_st[1], half, nbatch - half);
-    } else {
-      launch_step_plain(h, a, o, st);
-    }
-  }
-  if (split)
-    for (int s = 0; s < 2; ++s) {
-      MDS_HIP(hipEventRecord(h->split_ev[1 + s], h->split_st[s]));
-      MDS_HIP(hipStreamWaitEvent(st, h->split_ev[1 + s], 0));
-    }
-  MDS_HIP(hipGetLastError());
-  return MDS_OK;
+    MDS_HIP(hipGetLastError());
+    return MDS_OK;
+  };
+  const int rc = body();
+  return split ? split_join(h, st, rc) : rc;
 }
 
 int mds_rollout_step_fused(mds_handle* h, const void* actions, int n_action_sets, int first_step, int n_steps, void* obs_log,
                            int log_slots, int episode_len, int steps_per_launch, void* stream) {
+  MDS_DEV(h);
   if (!h || !actions || n_action_sets < 1 || first_step < 0 || n_steps < 0 || (obs_log && log_slots < 1) || episode_len < 0 ||
       steps_per_launch < 1)
     return fail(MDS_EINVAL, "mds_rollout_step_fused: arguments");
@@ -858,8 +956,21 @@ int mds_rollout_step_fused(mds_handle* h, const void* actions, int n_action_sets
 
 int mds_set_rollout_streams(mds_handle* h, int n_streams) {
   if (!h || n_streams < 0 || n_streams > 2) return fail(MDS_EINVAL, "mds_set_rollout_streams: 0 (auto), 1 or 2");
+  MDS_DEV(h);
+  if (n_streams == 2)          // a set-up call: the only place besides mds_create that creates the internal streams
+    if (int rc = split_streams_ready(h)) return rc;
   h->rollout_streams = n_streams;
   return MDS_OK;
+}
+
+int mds_rollout_streams_for(const mds_handle* h, int loop, int n_steps) {
+  if (!h || loop < 0 || loop > 1 || n_steps < 0) return fail(MDS_EINVAL, "mds_rollout_streams_for");
+  return rollout_streams_policy(h, loop, n_steps);
+}
+
+int mds_get_last_rollout_streams(const mds_handle* h) {
+  if (!h) return fail(MDS_EINVAL, "mds_get_last_rollout_streams: null handle");
+  return h->last_rollout_streams;
 }
 
 // ctrl: 0 GeometricControl, 1 LQRController (12-state), 2 LQROmegaController + ThrustOmega, 3 LQRYankOmegaController + YankOmega
@@ -923,14 +1034,17 @@ static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, v
 }
 
 int mds_rollout_geometric_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream) {
+  MDS_DEV(h);
   return rollout_fused(h, t0, n_steps, obs_log, obs_last, stream, 0, "mds_rollout_geometric_fused");
 }
 
 int mds_rollout_lqr_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream) {
+  MDS_DEV(h);
   return rollout_fused(h, t0, n_steps, obs_log, obs_last, stream, 1, "mds_rollout_lqr_fused");
 }
 
 int mds_rollout_nominal_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs, void* stream) {
+  MDS_DEV(h);
   if (!h) return fail(MDS_EINVAL, "mds_rollout_nominal_fused: null handle");
   if (h->cbf_nominal != 1 && h->cbf_nominal != 2)
     return fail(MDS_ESTATE, "mds_rollout_nominal_fused: select the LQR-omega (1) or LQR-yank-omega (2) controller with mds_cbf_set_nominal first");
@@ -938,6 +1052,7 @@ int mds_rollout_nominal_fused(mds_handle* h, double t0, int n_steps, void* obs_l
 }
 
 int mds_lemniscate_eval(mds_handle* h, double t, void* des, void* stream) {
+  MDS_DEV(h);
   if (!h || !des) return fail(MDS_EINVAL, "mds_lemniscate_eval: null argument");
   if (!h->has_traj || h->traj_mode != 1) return fail(MDS_ESTATE, "mds_lemniscate_eval: call mds_set_lemniscate first");
   MDS_DISPATCH(h, (k_lemniscate_eval<T, S><<<grid_for(h->n, 256), 256, 0, (hipStream_t)stream>>>(h->n, h->ld, t, (const T*)h->lem, (S*)des)));
@@ -946,6 +1061,7 @@ int mds_lemniscate_eval(mds_handle* h, double t, void* des, void* stream) {
 }
 
 int mds_geometric_compute(mds_handle* h, const void* obs, const void* des, void* rpm, void* aux, void* stream) {
+  MDS_DEV(h);
   if (!h || !obs || !des || !rpm) return fail(MDS_EINVAL, "mds_geometric_compute: null argument");
   if (!aligned16(rpm)) return fail(MDS_EALIGN, "mds_geometric_compute: rpm_dev");
   MDS_DISPATCH(h, (k_geometric_compute<T, S><<<grid_for(h->n, 256), 256, 0, (hipStream_t)stream>>>(C, h->n, (const S*)obs, (const S*)des,
@@ -955,6 +1071,7 @@ int mds_geometric_compute(mds_handle* h, const void* obs, const void* des, void*
 }
 
 int mds_input_to_action(mds_handle* h, const void* u, void* rpm, void* stream) {
+  MDS_DEV(h);
   if (!h || !u || !rpm) return fail(MDS_EINVAL, "mds_input_to_action: null argument");
   if (!aligned16(u) || !aligned16(rpm)) return fail(MDS_EALIGN, "mds_input_to_action");
   MDS_DISPATCH(h, (k_input_to_action<T, S><<<grid_for(h->n, 256), 256, 0, (hipStream_t)stream>>>(C, h->n, (const S*)u, (S*)rpm)));
@@ -963,6 +1080,7 @@ int mds_input_to_action(mds_handle* h, const void* u, void* rpm, void* stream) {
 }
 
 int mds_obs_to_model(mds_handle* h, const void* obs, int dim, void* x, void* stream) {
+  MDS_DEV(h);
   if (!h || !obs || !x) return fail(MDS_EINVAL, "mds_obs_to_model: null argument");
   if (dim != 9 && dim != 10 && dim != 12 && dim != 18) return fail(MDS_EINVAL, "mds_obs_to_model: dim must be 9, 10, 12 (linear models) or 18 (geometric model)");
   MDS_DISPATCH(h, (k_obs_to_model<T, S><<<grid_for(h->n, 256), 256, 0, (hipStream_t)stream>>>(C, h->n, dim, (const S*)obs, (S*)x)));
@@ -971,6 +1089,7 @@ int mds_obs_to_model(mds_handle* h, const void* obs, int dim, void* x, void* str
 }
 
 int mds_action_to_input(mds_handle* h, const void* rpm, int cap_rpm, void* u, void* stream) {
+  MDS_DEV(h);
   if (!h || !u || !rpm) return fail(MDS_EINVAL, "mds_action_to_input: null argument");
   if (!aligned16(u) || !aligned16(rpm)) return fail(MDS_EALIGN, "mds_action_to_input");
   MDS_DISPATCH(h, (k_action_to_input<T, S><<<grid_for(h->n, 256), 256, 0, (hipStream_t)stream>>>(C, h->n, cap_rpm, (const S*)rpm, (S*)u)));
@@ -1000,6 +1119,7 @@ int mds_quadrotor_dynamics(int dtype, int count, const void* state, const void* 
 }
 
 int mds_cbf_configure(mds_handle* h, const mds_cbf_params* p, const double* obstacles) {
+  MDS_DEV(h);
   if (!h || !p) return fail(MDS_EINVAL, "mds_cbf_configure: null argument");
   if (p->order != 2 && p->order != 3) return fail(MDS_EINVAL, "mds_cbf_configure: order must be 2 or 3");
   if (p->n_obs < 0 || p->n_obs > kCbfMaxObs) return fail(MDS_EINVAL, "mds_cbf_configure: n_obs out of range");
@@ -1033,6 +1153,10 @@ int mds_cbf_configure(mds_handle* h, const mds_cbf_params* p, const double* obst
   if (!h->cbf_count) MDS_HIP(hipMalloc((void**)&h->cbf_count, sizeof(int) * 12));
   if (!h->cbf_cost) MDS_HIP(hipMalloc((void**)&h->cbf_cost, sizeof(int) * (size_t)h->cfg.num_envs));
   h->cbf_calls = h->cbf_calls_half[0] = h->cbf_calls_half[1] = -1;   // a new problem: forget the cost classes
+  {
+    const char* solver = getenv("MDS_CBF_SOLVER");
+    h->cbf_hildreth = solver && solver[0] == 'h';
+  }
   h->cbf = *p;
   fill_cbf(h, *p, h->cbf_f);
   fill_cbf(h, *p, h->cbf_d);
@@ -1046,6 +1170,7 @@ int mds_cbf_num_rows(const mds_handle* h) {
 }
 
 int mds_cbf_rows(mds_handle* h, const void* x, const void* xdes, void* G, void* hv, void* stream) {
+  MDS_DEV(h);
   if (!h || !x || !xdes || !G || !hv) return fail(MDS_EINVAL, "mds_cbf_rows: null argument");
   if (!h->has_cbf) return fail(MDS_ESTATE, "mds_cbf_rows: call mds_cbf_configure first");
   hipStream_t st = (hipStream_t)stream;
@@ -1089,8 +1214,7 @@ static int cbf_filter_range(mds_handle* h, const void* obs_, const void* xdes_, 
   const int R = (m + 63) / 64;
   const int max_iter = h->cbf.max_iter > 0 ? h->cbf.max_iter : 64 * m;
   const dim3 grid((unsigned)((E + 3) / 4));                // Hildreth kernel: 4 envs per workgroup
-  const char* solver = getenv("MDS_CBF_SOLVER");          // "hildreth" selects the coordinate-ascent kernel (order 2, A/B)
-  const bool hildreth = solver && solver[0] == 'h' && order == 2;
+  const bool hildreth = h->cbf_hildreth && order == 2;     // MDS_CBF_SOLVER=hildreth at configure time: the coordinate-ascent kernel (A/B)
   if (n > 64) return fail(MDS_EUNSUPPORTED, "mds_cbf_filter: more than 64 coupled QP variables per env");
   if (R > 17) return fail(MDS_EUNSUPPORTED, "mds_cbf_filter: too many rows per env");
   // longest-first dispatch (see k_cbf_filter_gi): classes from the iteration counts of an earlier launch, rebuilt every 8th call
@@ -1157,6 +1281,7 @@ static int cbf_filter_range(mds_handle* h, const void* obs_, const void* xdes_, 
 
 int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void* unom, void* usafe, int32_t* status,
                    void* stream) {
+  MDS_DEV(h);
   if (!h || !obs || !xdes || !unom || !usafe || !status) return fail(MDS_EINVAL, "mds_cbf_filter: null argument");
   if (!h->has_cbf) return fail(MDS_ESTATE, "mds_cbf_filter: call mds_cbf_configure first");
   return cbf_filter_range(h, obs, xdes, unom, usafe, status, stream, EnvRange{0, h->cfg.num_envs, 0});
@@ -1185,6 +1310,7 @@ int mds_set_dslpid_gains(mds_handle* h, const mds_dslpid_gains* g) {
 }
 
 int mds_dslpid_reset(mds_handle* h, void* stream) {
+  MDS_DEV(h);
   if (!h) return fail(MDS_EINVAL, "mds_dslpid_reset: null handle");
   MDS_HIP(hipMemsetAsync(h->pid, 0, 9 * h->ld * comp_size(h->cfg.dtype), (hipStream_t)stream));
   return MDS_OK;
@@ -1203,6 +1329,7 @@ int mds_dslpid_reset(mds_handle* h, void* stream) {
   } while (0)
 
 int mds_dslpid_compute(mds_handle* h, const void* obs_in, const void* tpos, const void* trpy, void* act, void* stream) {
+  MDS_DEV(h);
   if (!h || !obs_in || !tpos || !trpy || !act) return fail(MDS_EINVAL, "mds_dslpid_compute: null argument");
   if (!aligned16(act)) return fail(MDS_EALIGN, "mds_dslpid_compute: rpm_dev");
   hipStream_t st = (hipStream_t)stream;
@@ -1213,6 +1340,7 @@ int mds_dslpid_compute(mds_handle* h, const void* obs_in, const void* tpos, cons
 }
 
 int mds_step_dslpid(mds_handle* h, const void* tpos, const void* trpy, void* obs, void* act, void* stream) {
+  MDS_DEV(h);
   if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h || !tpos || !trpy) return fail(MDS_EINVAL, "mds_step_dslpid: null argument");
   if (!aligned16(obs) || !aligned16(act)) return fail(MDS_EALIGN, "mds_step_dslpid: obs_dev/action_dev");
@@ -1230,6 +1358,7 @@ int mds_step_dslpid(mds_handle* h, const void* tpos, const void* trpy, void* obs
 #undef MDS_PID_LAUNCH
 
 int mds_set_lqr_omega_gain(mds_handle* h, const double K[36]) {
+  MDS_DEV(h);
   if (!h || !K) return fail(MDS_EINVAL, "mds_set_lqr_omega_gain: null argument");
   for (int r = 0; r < 4; ++r)
     for (int k = 0; k < 9; ++k) {
@@ -1241,6 +1370,7 @@ int mds_set_lqr_omega_gain(mds_handle* h, const double K[36]) {
 }
 
 int mds_lqr_omega_compute(mds_handle* h, const void* obs, const void* des, void* u, void* stream) {
+  MDS_DEV(h);
   if (!h || !obs || !des || !u) return fail(MDS_EINVAL, "mds_lqr_omega_compute: null argument");
   if (!h->has_lqr) return fail(MDS_ESTATE, "mds_lqr_omega_compute: call mds_set_lqr_omega_gain first");
   if (!aligned16(u)) return fail(MDS_EALIGN, "mds_lqr_omega_compute: u_dev");
@@ -1256,6 +1386,7 @@ int mds_lqr_omega_compute(mds_handle* h, const void* obs, const void* des, void*
 }
 
 int mds_set_lqr_gain(mds_handle* h, const double K[48]) {
+  MDS_DEV(h);
   if (!h || !K) return fail(MDS_EINVAL, "mds_set_lqr_gain: null argument");
   for (int r = 0; r < 4; ++r)
     for (int k = 0; k < 12; ++k) {
@@ -1267,6 +1398,7 @@ int mds_set_lqr_gain(mds_handle* h, const double K[48]) {
 }
 
 int mds_lqr_compute(mds_handle* h, const void* obs, const void* des, void* u, void* action, void* stream) {
+  MDS_DEV(h);
   if (!h || !obs || !des || (!u && !action)) return fail(MDS_EINVAL, "mds_lqr_compute: null argument");
   if (!h->has_lqr12) return fail(MDS_ESTATE, "mds_lqr_compute: call mds_set_lqr_gain first");
   if (!aligned16(u) || !aligned16(action)) return fail(MDS_EALIGN, "mds_lqr_compute: u_dev/action_dev");
@@ -1282,6 +1414,7 @@ int mds_lqr_compute(mds_handle* h, const void* obs, const void* des, void* u, vo
 }
 
 int mds_step_lqr(mds_handle* h, double t, void* obs, void* act, void* stream) {
+  MDS_DEV(h);
   if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h) return fail(MDS_EINVAL, "mds_step_lqr: null handle");
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_step_lqr: call mds_set_lemniscate / mds_set_trajectory_segments first");
@@ -1310,6 +1443,7 @@ int mds_step_lqr(mds_handle* h, double t, void* obs, void* act, void* stream) {
 }
 
 int mds_set_lqr_yank_omega_gain(mds_handle* h, const double K[40]) {
+  MDS_DEV(h);
   if (!h || !K) return fail(MDS_EINVAL, "mds_set_lqr_yank_omega_gain: null argument");
   for (int r = 0; r < 4; ++r)
     for (int k = 0; k < 10; ++k) {
@@ -1321,6 +1455,7 @@ int mds_set_lqr_yank_omega_gain(mds_handle* h, const double K[40]) {
 }
 
 int mds_lqr_yank_omega_compute(mds_handle* h, const void* obs, const void* des, void* u, void* stream) {
+  MDS_DEV(h);
   if (!h || !obs || !des || !u) return fail(MDS_EINVAL, "mds_lqr_yank_omega_compute: null argument");
   if (!h->has_lqr_yo) return fail(MDS_ESTATE, "mds_lqr_yank_omega_compute: call mds_set_lqr_yank_omega_gain first");
   if (!aligned16(u)) return fail(MDS_EALIGN, "mds_lqr_yank_omega_compute: u_dev");
@@ -1344,6 +1479,7 @@ int mds_cbf_set_nominal(mds_handle* h, int which) {
 }
 
 int mds_lowlevel_reset(mds_handle* h, void* stream) {
+  MDS_DEV(h);
   if (!h) return fail(MDS_EINVAL, "mds_lowlevel_reset: null handle");
   MDS_HIP(hipMemsetAsync(h->ll, 0, 6 * h->ld * comp_size(h->cfg.dtype), (hipStream_t)stream));
   return MDS_OK;
@@ -1356,6 +1492,7 @@ static int launch_thrust_omega(mds_handle* h, const void* u, const void* src, in
 }
 
 int mds_yank_omega_compute(mds_handle* h, const void* u, const void* obs, void* rpm, void* stream) {
+  MDS_DEV(h);
   if (!h || !u || !obs || !rpm) return fail(MDS_EINVAL, "mds_yank_omega_compute: null argument");
   if (!aligned16(u) || !aligned16(rpm)) return fail(MDS_EALIGN, "mds_yank_omega_compute");
   launch_thrust_omega(h, u, obs, 0, 1, rpm, (hipStream_t)stream);
@@ -1364,6 +1501,7 @@ int mds_yank_omega_compute(mds_handle* h, const void* u, const void* obs, void* 
 }
 
 int mds_thrust_omega_compute(mds_handle* h, const void* u, const void* obs, void* rpm, void* stream) {
+  MDS_DEV(h);
   if (!h || !u || !obs || !rpm) return fail(MDS_EINVAL, "mds_thrust_omega_compute: null argument");
   if (!aligned16(u) || !aligned16(rpm)) return fail(MDS_EALIGN, "mds_thrust_omega_compute");
   launch_thrust_omega(h, u, obs, 0, 0, rpm, (hipStream_t)stream);
@@ -1372,6 +1510,7 @@ int mds_thrust_omega_compute(mds_handle* h, const void* u, const void* obs, void
 }
 
 int mds_thrust_omega_from_rates(mds_handle* h, const void* u, const void* rates, void* rpm, void* stream) {
+  MDS_DEV(h);
   if (!h || !u || !rates || !rpm) return fail(MDS_EINVAL, "mds_thrust_omega_from_rates: null argument");
   if (!aligned16(u) || !aligned16(rpm)) return fail(MDS_EALIGN, "mds_thrust_omega_from_rates");
   launch_thrust_omega(h, u, rates, 1, 0, rpm, (hipStream_t)stream);
@@ -1453,6 +1592,7 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
 }
 
 int mds_step_cbf_geometric(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream) {
+  MDS_DEV(h);
   if (!h || !obs || !status) return fail(MDS_EINVAL, "mds_step_cbf_geometric: null argument");
   if (!h->has_cbf) return fail(MDS_ESTATE, "mds_step_cbf_geometric: call mds_cbf_configure first");
   const bool ord3 = h->cbf.order == 3;
@@ -1465,6 +1605,7 @@ int mds_step_cbf_geometric(mds_handle* h, double t, void* obs, int32_t* status, 
 }
 
 int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs, int32_t* status, void* stream) {
+  MDS_DEV(h);
   if (!h || !obs || !status || n_steps < 0) return fail(MDS_EINVAL, "mds_rollout_cbf_geometric: null argument");
   const double dt = 1.0 / h->cfg.ctrl_freq;
   // The env halves are independent step chains (a barrier row couples drones of one env only).  On two streams one half's
@@ -1477,26 +1618,25 @@ int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs, 
       e_mid = e;
       break;
     }
-  const int streams = h->rollout_streams ? h->rollout_streams : ((size_t)h->n >= kSplitMinDrones / 4 && n_steps >= 16 ? 2 : 1);   // measured: 2^15 drones 36.6 vs 36.4 us, 2^16 41.0 vs 39.4, 2^17 52.9 vs 44.7, 2^18 71.7 vs 60.3
-  if (streams == 2 && e_mid > 0 && n_steps >= 2) {
+  const int streams = rollout_streams_policy(h, 1, n_steps);
+  if (streams == 2 && e_mid > 0) {
     if (int rc = mds_step_cbf_geometric(h, t0, obs, status, nullptr, stream)) return rc;   // validation, scratch; step 1 on the caller's stream
-    if (int rc = split_streams_ready(h)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    MDS_HIP(hipEventRecord(h->split_ev[0], st));
+    if (int rc = split_fork(h, st)) return rc;
+    h->last_rollout_streams = 2;
     const EnvRange half[2] = {EnvRange{0, e_mid, 1}, EnvRange{e_mid, E - e_mid, 2}};
-    for (int s = 0; s < 2; ++s) MDS_HIP(hipStreamWaitEvent(h->split_st[s], h->split_ev[0], 0));
-    double t = t0 + dt;
-    for (int k = 1; k < n_steps; ++k) {
-      for (int s = 0; s < 2; ++s)
-        if (int rc = step_nominal_lowlevel(h, t, obs, status, nullptr, h->split_st[s], true, "mds_rollout_cbf_geometric", half[s])) return rc;
-      t += dt;
-    }
-    for (int s = 0; s < 2; ++s) {
-      MDS_HIP(hipEventRecord(h->split_ev[1 + s], h->split_st[s]));
-      MDS_HIP(hipStreamWaitEvent(st, h->split_ev[1 + s], 0));
-    }
-    return MDS_OK;
+    auto body = [&]() -> int {
+      double t = t0 + dt;
+      for (int k = 1; k < n_steps; ++k) {
+        for (int s = 0; s < 2; ++s)
+          if (int rc = step_nominal_lowlevel(h, t, obs, status, nullptr, s == 0 ? st : h->split_st, true, "mds_rollout_cbf_geometric", half[s])) return rc;
+        t += dt;
+      }
+      return MDS_OK;
+    };
+    return split_join(h, st, body());
   }
+  h->last_rollout_streams = 1;
   for (int k = 0; k < n_steps; ++k) {
     if (int rc = mds_step_cbf_geometric(h, t0, obs, status, nullptr, stream)) return rc;
     t0 += dt;
@@ -1505,6 +1645,7 @@ int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs, 
 }
 
 int mds_step_nominal(mds_handle* h, double t, void* obs, void* action, void* stream) {
+  MDS_DEV(h);
   if (!h || !obs) return fail(MDS_EINVAL, "mds_step_nominal: null argument");
   if (h->cbf_nominal != 1 && h->cbf_nominal != 2)
     return fail(MDS_ESTATE, "mds_step_nominal: select the LQR-omega (1) or LQR-yank-omega (2) controller with mds_cbf_set_nominal first");

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .. import _capi as capi
-from .._device import DTYPE_BY_NAME, TORCH_DTYPE, require_gpu, stream_ptr, to_device
+from .._device import DTYPE_BY_NAME, TORCH_DTYPE, default_device_index, require_gpu, stream_ptr, to_device
 from ..utils.enums import DroneModel, Physics
 
 __all__ = ["BaseAviary", "DroneModel", "Physics"]
@@ -57,8 +57,7 @@ class BaseAviary:
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("pyb_freq is not divisible by env_freq.")  # [UPSTREAM] BaseAviary.__init__
         if device is None:
-            import os
-            device = int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() and torch.cuda.device_count() > 1 else 0
+            device = default_device_index()
         self.device = require_gpu(device)
         self._lib = lib
         self.DRONE_MODEL, self.PHYSICS = drone_model, physics
@@ -371,6 +370,16 @@ class BaseAviary:
         internal streams (mds_set_rollout_streams).  Same results either way."""
         self._require_open()
         capi.check(self._lib.mds_set_rollout_streams(self._h, C.c_int(int(n_streams))), "mds_set_rollout_streams")
+
+    def last_rollout_streams(self) -> int:
+        """1 or 2: how the most recent rollout_* call of this env was issued (0: none yet)."""
+        self._require_open()
+        return int(self._lib.mds_get_last_rollout_streams(self._h))
+
+    def rollout_streams_for(self, n_steps: int, cbf: bool = False) -> int:
+        """1 or 2: how a rollout of ``n_steps`` would be issued under the current ``set_rollout_streams`` setting."""
+        self._require_open()
+        return int(self._lib.mds_rollout_streams_for(self._h, C.c_int(1 if cbf else 0), C.c_int(int(n_steps))))
 
     def rollout_geometric_fused(self, t0: float, n_steps: int, log: bool = False, log_out: torch.Tensor | None = None,
                                 controller: str = "geometric"):

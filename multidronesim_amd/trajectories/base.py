@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from .. import _capi as capi
-from .._device import require_gpu, stream_ptr
+from .._device import default_device_index, require_gpu, stream_ptr
 
 KIND_LEMNISCATE, KIND_CIRCLE, KIND_LINE, KIND_WAIT = 0, 1, 2, 3
 
@@ -54,10 +54,11 @@ class TrajectoryBase:
         key = rows.tobytes() + bytes([compound])
         if getattr(self, "_h", None) is None:
             lib = capi.load_library()
-            dev = require_gpu(0)
+            dev = require_gpu(default_device_index())        # this rank's GPU, never a hard-coded device 0
             cfg = capi.MdsConfig()
             capi.check(lib.mds_default_config(capi.MDS_CF2P, C.byref(cfg)), "mds_default_config")
             cfg.num_envs, cfg.num_drones, cfg.dtype = 1, 1, capi.MDS_F64
+            cfg.device = dev.index
             h = C.c_void_p()
             capi.check(lib.mds_create(C.byref(cfg), C.byref(h)), "mds_create")
             self._h, self._lib, self._dev = h, lib, dev

@@ -25,6 +25,39 @@ def test_two_rank_gloo_dry_run():
     assert rec["gathered"] == [6, [0.0, 1.0]]   # optional swarm all-gather: rank-major env order, every rank's block present
 
 
+def test_self_launch_without_torchrun():
+    """`python bench.py --gpus 2` as the driver calls it (no torchrun, no rendezvous in the environment): the parent starts the two
+    ranks itself, before it imports torch, relays rank 0's line and returns the children's exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and len(rec["elapsed_per_rank"]) == 2
+    assert rec["elapsed_per_rank"][1] > rec["elapsed_per_rank"][0] and rec["elapsed"] >= max(rec["elapsed_per_rank"]) - 1e-9
+
+
+def test_self_launch_propagates_a_failing_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--dry-run-fail-rank", "1"], cwd=ROOT,
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode != 0
+
+
+def test_parent_of_self_launch_never_imports_torch():
+    """The parent must not touch the GPU (a GPU-initialised process may not start ranks that re-initialise it): it returns from
+    main() before `import torch`."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main("):]
+    assert main.index("return self_launch(") < main.index("import torch")
+    head = src[:src.index("def main(")]
+    assert "import torch\n" not in "\n".join(l for l in head.splitlines() if not l.startswith(" "))      # no module-level torch import
+
+
 def test_each_rank_gets_different_envs_and_same_shape():
     sys.path.insert(0, ROOT)
     import bench

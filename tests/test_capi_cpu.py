@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.mds_version() == 100
+    assert lib.mds_version() == 200
     assert lib.mds_strerror(0) == b"ok"
     assert b"aligned" in lib.mds_strerror(-4)
     assert lib.mds_strerror(-99) == b"unknown status"
