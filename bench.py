@@ -285,10 +285,12 @@ def main(argv=None):
     ap.add_argument("--python-loop", action="store_true", help="issue each step from Python (env.step_geometric) instead of the C rollout loop")
     ap.add_argument("--rollout-streams", type=int, default=0, choices=[0, 1, 2],
                     help="mds_set_rollout_streams: 0 auto (the library's policy for the timed call's length), 1 one stream, 2 split")
-    ap.add_argument("--c4-scene", default="level", choices=["level", "offset"],
-                    help="c4 obstacles: 'level' = SURVEY 8d's spheres at z = 0.5 (drone 0 flies level with them: its obstacle rows have "
-                         "LgLfh = 0 and the env falls back to the nominal control like the reference); 'offset' = the same spheres "
-                         "0.15 m below every drone's plane's midpoint, feasible by construction")
+    ap.add_argument("--c4-scene", default="level", choices=["level", "far"],
+                    help="c4 obstacles.  'level': SURVEY 8d's four spheres at (+-0.5, +-0.5, 0.5) -- about a third of the envs fall back to "
+                         "the nominal control like the reference (qptracker.py:30-34): with the omega linearisation the thrust reaches the "
+                         "barrier through e_z only, so an obstacle row of a drone flying towards a sphere's axis leaves the reach of the "
+                         "input box (profiles/tools/c4_scene.py).  'far': the same spheres at (+-12, +-12, 0.65), at least 7 m from every "
+                         "drone: r / v > 2.6 s keeps every obstacle row positive, the QP work is the 120 inter-agent rows per env")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU tests of the N>1 path")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # CPU test of the exit-code relay
     ap.add_argument("--gather-obs", action="store_true",
@@ -381,10 +383,8 @@ def main(argv=None):
         cbf = DroneCBF(env, [LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2,
                        cbf_poles=np.array([-2.2, -2.4]))                                    # CBFTest.py:419
         tracker = DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
-        # 'offset': the spheres sit between two drone planes (0.5 + 0.3 k), so no drone is ever level with one: every obstacle row
-        # keeps a non-zero thrust coefficient and the QP stays feasible (the 'level' scene's fallbacks are LgLfh = 0 rows)
-        c4_z = 0.5 if args.c4_scene == "level" else 0.65
-        c4_obs = [np.array([[sx * 0.5, sy * 0.5, c4_z], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
+        c4_xy, c4_z = (0.5, 0.5) if args.c4_scene == "level" else (12.0, 0.65)
+        c4_obs = [np.array([[sx * c4_xy, sy * c4_xy, c4_z], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
         c4_r = [0.1] * 4
     env.set_trajectories(P)
     del xyz, rpy, P

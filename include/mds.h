@@ -293,6 +293,11 @@ int mds_cbf_rows(mds_handle* h, const void* x_dev, const void* xdes_dev, void* G
 int mds_cbf_filter(mds_handle* h, const void* obs_dev, const void* xdes_dev, const void* u_nominal_dev, void* u_safe_dev,
                    int32_t* status_dev, void* stream);
 
+/* Solver work of the most recent filter launch: iters_dev [E] int32 = active-set iterations (rows added or dropped) each env's QP
+ * took; 0 = the nominal input already satisfied every row (or the env was declared infeasible while its rows were built).
+ * A device-to-device copy enqueued on `stream`; for profiling the scene, not part of the control path. */
+int mds_cbf_last_iterations(mds_handle* h, int32_t* iters_dev, void* stream);
+
 /* ---- low-level body-rate controller (control/low_level/thrust_omega_ctrl.py) ---------------- */
 
 /* ThrustOmegaController.reset(): zero last_omega and the integral of every drone (mds_reset does

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "mds_cbf_num_rows": (C.c_int, [_P]),
     "mds_cbf_rows": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "mds_cbf_filter": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "mds_cbf_last_iterations": (C.c_int, [_P, _P, _P]),
     "mds_lowlevel_reset": (C.c_int, [_P, _P]),
     "mds_thrust_omega_compute": (C.c_int, [_P, _P, _P, _P, _P]),
     "mds_thrust_omega_from_rates": (C.c_int, [_P, _P, _P, _P, _P]),

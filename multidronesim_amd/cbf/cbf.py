@@ -107,6 +107,14 @@ class DroneCBF:
         self._configured = key
         return obst.shape[0]
 
+    def last_iterations(self):
+        """[E] int32 device tensor: active-set iterations each env's QP took in the most recent filter launch."""
+        env = self.env
+        out = torch.empty((env.NUM_ENVS,), dtype=torch.int32, device=env.device)
+        capi.check(env._lib.mds_cbf_last_iterations(env._h, C.c_void_p(out.data_ptr()), C.c_void_p(stream_ptr(env.device))),
+                   "mds_cbf_last_iterations")
+        return out
+
     def build_ineq_const_batched(self, x, xdes, x_obs=None, obs_r_list=None):
         """x, xdes [E,D,xdim] -> (G [E,m,4D], h [E,m]) device tensors."""
         env = self.env

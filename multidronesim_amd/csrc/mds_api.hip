@@ -1151,7 +1151,10 @@ int mds_cbf_configure(mds_handle* h, const mds_cbf_params* p, const double* obst
   }
   if (!h->cbf_order) MDS_HIP(hipMalloc((void**)&h->cbf_order, sizeof(int) * 9 * (size_t)h->cfg.num_envs));
   if (!h->cbf_count) MDS_HIP(hipMalloc((void**)&h->cbf_count, sizeof(int) * 12));
-  if (!h->cbf_cost) MDS_HIP(hipMalloc((void**)&h->cbf_cost, sizeof(int) * (size_t)h->cfg.num_envs));
+  if (!h->cbf_cost) {
+    MDS_HIP(hipMalloc((void**)&h->cbf_cost, sizeof(int) * (size_t)h->cfg.num_envs));
+    MDS_HIP(hipMemset(h->cbf_cost, 0, sizeof(int) * (size_t)h->cfg.num_envs));
+  }
   h->cbf_calls = h->cbf_calls_half[0] = h->cbf_calls_half[1] = -1;   // a new problem: forget the cost classes
   {
     const char* solver = getenv("MDS_CBF_SOLVER");
@@ -1285,6 +1288,14 @@ int mds_cbf_filter(mds_handle* h, const void* obs, const void* xdes, const void*
   if (!h || !obs || !xdes || !unom || !usafe || !status) return fail(MDS_EINVAL, "mds_cbf_filter: null argument");
   if (!h->has_cbf) return fail(MDS_ESTATE, "mds_cbf_filter: call mds_cbf_configure first");
   return cbf_filter_range(h, obs, xdes, unom, usafe, status, stream, EnvRange{0, h->cfg.num_envs, 0});
+}
+
+int mds_cbf_last_iterations(mds_handle* h, int32_t* iters_dev, void* stream) {
+  MDS_DEV(h);
+  if (!h || !iters_dev) return fail(MDS_EINVAL, "mds_cbf_last_iterations: null argument");
+  if (!h->has_cbf || !h->cbf_cost) return fail(MDS_ESTATE, "mds_cbf_last_iterations: call mds_cbf_configure first");
+  MDS_HIP(hipMemcpyAsync(iters_dev, h->cbf_cost, sizeof(int) * (size_t)h->cfg.num_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MDS_OK;
 }
 
 int mds_default_dslpid_gains(mds_dslpid_gains* g) {

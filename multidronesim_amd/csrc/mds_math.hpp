@@ -325,6 +325,76 @@ template <typename T, bool DRAG> MDS_HD void step_euler(const Consts<T>& c, Stat
   step_euler_wrench<T, DRAG>(c, s, thrust, tau, drag_s);
 }
 
+// ------------------------------------------------------------------------------------
+// Compensated state accumulation (storage dtype MDS_F32C: fp32 arithmetic, every one of the 13 state components carried as an
+// fp32 value plus an fp32 residual).  The integrators only ever ADD small increments to the state; stored in plain fp32 each
+// addition rounds at the state's magnitude (6e-8 relative) and an uncontrolled quadrotor integrates that four times (rates ->
+// attitude -> velocity -> position: ~t^2.5).  Here the rounding error of every addition goes into the residual (two-sum) and is
+// fed back into the next one, so what is left is the rounding of the increments themselves (~1e-7 of a step's change).
+// Same update order and formulas as step_euler_wrench / step_rk4; the quaternion update is written in its additive form.
+// ------------------------------------------------------------------------------------
+template <typename T> struct Resid {
+  V3<T> p;
+  T q[4];
+  V3<T> v, w;
+};
+template <typename T> MDS_HD void resid_zero(Resid<T>& r) {
+  r.p = r.v = r.w = {T(0), T(0), T(0)};
+  for (int i = 0; i < 4; ++i) r.q[i] = T(0);
+}
+// s + r += d: s gets the rounded sum, r what the rounding dropped (Knuth two-sum, no magnitude assumption)
+template <typename T> MDS_HD void comp_add(T& s, T& r, T d) {
+  const T y = d + r;
+  const T t = s + y;
+  const T bp = t - s;
+  r = (s - (t - bp)) + (y - bp);
+  s = t;
+}
+template <typename T> MDS_HD void comp_add3(V3<T>& s, V3<T>& r, V3<T> d) {
+  comp_add(s.x, r.x, d.x);
+  comp_add(s.y, r.y, d.y);
+  comp_add(s.z, r.z, d.z);
+}
+// unit-norm pull in additive form: q += q (1 - |q|^2) / 2 (the first-order step of the re-normalisation integrate_q does;
+// |q|^2 - 1 stays ~1e-7, so the second-order term is below 1e-14).  A radial error does not turn the attitude.
+template <typename T> MDS_HD void comp_renorm(T q[4], T rq[4]) {
+  T n2m1 = m_fma(q[0], q[0], m_fma(q[1], q[1], m_fma(q[2], q[2], m_fma(q[3], q[3], T(-1)))));
+  n2m1 = m_fma(T(2), m_fma(q[0], rq[0], m_fma(q[1], rq[1], m_fma(q[2], rq[2], q[3] * rq[3]))), n2m1);
+  const T eps = T(-0.5) * n2m1;
+  for (int i = 0; i < 4; ++i) comp_add(q[i], rq[i], q[i] * eps);
+}
+// [UPSTREAM] _integrateQ as an increment: q' - q = (cos th - 1) q + (sin th / |w|) Lambda(w) q, cos th - 1 = -sin^2 th / (1 + cos th)
+template <typename T> MDS_HD void integrate_q_comp(T q[4], T rq[4], V3<T> w, T dt) {
+  const T w2 = dot(w, w);
+  if (w2 <= T(1e-16)) return;                 // |omega| <= 1e-8
+  const T inv_wn = m_rsqrt(w2);
+  const T wn = w2 * inv_wn;
+  T st, ct;
+  m_sincos(wn * dt * T(0.5), &st, &ct);
+  const T k = st * inv_wn;
+  const T cm1 = -(st * st) * m_rcp(T(1) + ct);
+  const T x = q[0], y = q[1], z = q[2], ww = q[3];
+  const T p = w.x, qq = w.y, r = w.z;
+  const T dx = m_fma(cm1, x, k * (r * y - qq * z + p * ww));
+  const T dy = m_fma(cm1, y, k * (-r * x + p * z + qq * ww));
+  const T dz = m_fma(cm1, z, k * (qq * x - p * y + r * ww));
+  const T dw = m_fma(cm1, ww, k * (-p * x - qq * y - r * z));
+  comp_add(q[0], rq[0], dx);
+  comp_add(q[1], rq[1], dy);
+  comp_add(q[2], rq[2], dz);
+  comp_add(q[3], rq[3], dw);
+  comp_renorm(q, rq);
+}
+template <typename T, bool DRAG>
+MDS_HD void step_euler_wrench_comp(const Consts<T>& c, State<T>& s, Resid<T>& r, T thrust, V3<T> tau, T drag_s) {
+  V3<T> acc, wdot;
+  body_accel<T, DRAG>(c, s.q, s.v, s.w, thrust, tau, drag_s, &acc, &wdot);
+  comp_add3(s.v, r.v, c.dt * acc);
+  comp_add3(s.w, r.w, c.dt * wdot);
+  comp_add3(s.p, r.p, V3<T>{m_fma(c.dt, s.v.x, c.dt * r.v.x), m_fma(c.dt, s.v.y, c.dt * r.v.y), m_fma(c.dt, s.v.z, c.dt * r.v.z)});
+  integrate_q_comp(s.q, r.q, V3<T>{s.w.x + r.w.x, s.w.y + r.w.y, s.w.z + r.w.z}, c.dt);
+}
+
 // [UPSTREAM] BaseAviary._groundEffect / _downwash (the Bullet external forces of Physics.PYB_GND / PYB_DW / PYB_GND_DRAG_DW,
 // urdf <properties> gnd_eff_coeff 11.36859, prop_radius 2.31348e-2, dw_coeff_1..3 2267.18, .16, -.11) as extra terms of the DYN
 // wrench: per-propeller thrust KF rpm^2 c_g (r_p / (4 h_k))^2 through the same mixing as the rotor thrusts, and a body-z
@@ -420,6 +490,41 @@ MDS_HD void aviary_step(const Consts<T>& c, State<T>& s, const T action[4], T rp
     if (DRAG) drag_s = T(0.10471975511965977462) * ((rpm_prev[0] + rpm_prev[1]) + (rpm_prev[2] + rpm_prev[3]));
     if (RK4) step_rk4<T, DRAG>(c, s, clipped, drag_s);
     else step_euler<T, DRAG>(c, s, clipped, drag_s);
+    if (DRAG)
+      for (int i = 0; i < 4; ++i) rpm_prev[i] = clipped[i];
+  }
+}
+
+template <typename T, bool DRAG> MDS_HD void step_rk4_comp(const Consts<T>& c, State<T>& s, Resid<T>& r, const T rpm[4], T drag_s) {
+  T thrust;
+  V3<T> tau;
+  rotor_wrench(c, rpm, &thrust, &tau);
+  const Deriv<T> k1 = deriv13<T, DRAG>(c, s, thrust, tau, drag_s);
+  const Deriv<T> k2 = deriv13<T, DRAG>(c, axpy13(s, T(0.5) * c.dt, k1), thrust, tau, drag_s);
+  const Deriv<T> k3 = deriv13<T, DRAG>(c, axpy13(s, T(0.5) * c.dt, k2), thrust, tau, drag_s);
+  const Deriv<T> k4 = deriv13<T, DRAG>(c, axpy13(s, c.dt, k3), thrust, tau, drag_s);
+  const T h6 = c.dt / T(6);
+  comp_add3(s.p, r.p, h6 * ((k1.dp + k4.dp) + T(2) * (k2.dp + k3.dp)));
+  comp_add3(s.v, r.v, h6 * ((k1.dv + k4.dv) + T(2) * (k2.dv + k3.dv)));
+  comp_add3(s.w, r.w, h6 * ((k1.dw + k4.dw) + T(2) * (k2.dw + k3.dw)));
+  for (int i = 0; i < 4; ++i) comp_add(s.q[i], r.q[i], h6 * ((k1.dq[i] + k4.dq[i]) + T(2) * (k2.dq[i] + k3.dq[i])));
+  // |q|^2 - 1 after one RK4 step is O(dt^4 |w|^4): the first-order pull is exact to rounding at these rates
+  comp_renorm(s.q, r.q);
+}
+template <typename T, bool RK4, bool DRAG>
+MDS_HD void aviary_step_comp(const Consts<T>& c, State<T>& s, Resid<T>& r, const T action[4], T rpm_prev[4], T clipped[4]) {
+  for (int i = 0; i < 4; ++i) clipped[i] = m_clamp(action[i], T(0), c.max_rpm);
+  for (int k = 0; k < c.substeps; ++k) {
+    T drag_s = T(0);
+    if (DRAG) drag_s = T(0.10471975511965977462) * ((rpm_prev[0] + rpm_prev[1]) + (rpm_prev[2] + rpm_prev[3]));
+    if (RK4) {
+      step_rk4_comp<T, DRAG>(c, s, r, clipped, drag_s);
+    } else {
+      T thrust;
+      V3<T> tau;
+      rotor_wrench(c, clipped, &thrust, &tau);
+      step_euler_wrench_comp<T, DRAG>(c, s, r, thrust, tau, drag_s);
+    }
     if (DRAG)
       for (int i = 0; i < 4; ++i) rpm_prev[i] = clipped[i];
   }

@@ -24,6 +24,7 @@ _PHYSICS_MAP = {Physics.DYN: capi.MDS_PHYSICS_DYN, Physics.PYB: capi.MDS_PHYSICS
                 Physics.PYB_DRAG: capi.MDS_PHYSICS_DYN_DRAG, Physics.PYB_GND: capi.MDS_PHYSICS_DYN_GND,
                 Physics.PYB_DW: capi.MDS_PHYSICS_DYN_DW, Physics.PYB_GND_DRAG_DW: capi.MDS_PHYSICS_DYN_GND_DRAG_DW}
 _MODEL_MAP = {DroneModel.CF2X: capi.MDS_CF2X, DroneModel.CF2P: capi.MDS_CF2P}
+_PYB_SUBSTITUTED = (Physics.PYB, Physics.PYB_DRAG, Physics.PYB_GND, Physics.PYB_DW, Physics.PYB_GND_DRAG_DW)
 
 
 class BaseAviary:
@@ -37,8 +38,11 @@ class BaseAviary:
     ``Physics.PYB`` (the reference's default, PIDEnv.py:19) is served by the explicit
     ``Physics.DYN`` rigid-body model -- there is no Bullet here; ``PYB_DRAG`` adds upstream's
     ``_drag`` term; ``PYB_GND`` / ``PYB_DW`` / ``PYB_GND_DRAG_DW`` add upstream's ``_groundEffect`` / ``_downwash`` as extra
-    terms of that model (``env.step(action)`` only: explicit Euler, f32 / f64; spec-level).
+    terms of that model (``env.step(action)`` only: explicit Euler, f32 / f64; spec-level).  The first env
+    created with a ``PYB*`` mode says so once (RuntimeWarning).
     """
+
+    _warned_pyb = False
 
     def __init__(self, drone_model: DroneModel = DroneModel.CF2X, num_drones: int = 1, neighbourhood_radius: float = np.inf,
                  initial_xyzs=None, initial_rpys=None, physics: Physics = Physics.PYB, pyb_freq: int = 240,
@@ -56,6 +60,13 @@ class BaseAviary:
             raise NotImplementedError(f"physics {physics}")
         if pyb_freq % ctrl_freq != 0:
             raise ValueError("pyb_freq is not divisible by env_freq.")  # [UPSTREAM] BaseAviary.__init__
+        if physics in _PYB_SUBSTITUTED and not BaseAviary._warned_pyb:
+            import warnings
+            BaseAviary._warned_pyb = True
+            warnings.warn(f"Physics.{physics.name}: there is no Bullet here -- served by the explicit-Euler Physics.DYN rigid-body model "
+                          "(no ground plane, no btMultiBody semi-implicit step); trajectories differ from the reference's PyBullet "
+                          "runs from the first step (the reference starts on the floor at z = 0). Pass Physics.DYN to select it knowingly.",
+                          RuntimeWarning, stacklevel=3)
         if device is None:
             device = default_device_index()
         self.device = require_gpu(device)

@@ -42,6 +42,8 @@ class Emul:
     def __init__(self, dtype="f32", num_envs=1, num_drones=1, pyb_freq=100, ctrl_freq=100, physics=0, integrator=0,
                  model=MDS_CF2P):
         L = lib()
+        comp = dtype == "f32c"           # fp32 arithmetic, compensated state accumulation (MDS_F32C)
+        dtype = "f32" if comp else dtype
         self.sfx = dtype
         self.cfg = MdsConfig()
         self.gains = MdsGeometricGains()
@@ -51,6 +53,8 @@ class Emul:
         self.cfg.physics, self.cfg.integrator = physics, integrator
         self.n = num_envs * num_drones
         self.h = C.c_void_p(getattr(L, f"emul_create_{dtype}")(C.byref(self.cfg), C.byref(self.gains)))
+        if comp:
+            self._f("emul_set_comp")(self.h, C.c_int(1))
 
     def _f(self, name):
         return getattr(lib(), f"{name}_{self.sfx}")

@@ -22,10 +22,19 @@ template <typename T> static void emul_aviary_step(const Consts<T>& c, State<T>&
   else aviary_step<T, false, false>(c, s, act, prev, clipped);
 }
 
+template <typename T> static void emul_aviary_step_comp(const Consts<T>& c, State<T>& s, Resid<T>& r, const T act[4], T prev[4], T clipped[4]) {
+  if (c.rk4 && c.use_drag) aviary_step_comp<T, true, true>(c, s, r, act, prev, clipped);
+  else if (c.rk4) aviary_step_comp<T, true, false>(c, s, r, act, prev, clipped);
+  else if (c.use_drag) aviary_step_comp<T, false, true>(c, s, r, act, prev, clipped);
+  else aviary_step_comp<T, false, false>(c, s, r, act, prev, clipped);
+}
+
 // Persistent emulated handle: state kept in T (like the device SoA), I/O in double.
 template <typename T> struct Emul {
   Consts<T> c;
   int n;
+  int comp = 0;          // 1: compensated accumulation (MDS_F32C)
+  Resid<T>* r;
   State<T>* s;
   T (*prev)[4];
   LemniscateParams<T>* P;
@@ -37,6 +46,8 @@ template <typename T> static void* emul_create(const mds_config* cfg, const mds_
   fill_consts(*cfg, *g, e->c);
   e->n = cfg->num_envs * cfg->num_drones;
   e->s = new State<T>[e->n];
+  e->r = new Resid<T>[e->n];
+  for (int i = 0; i < e->n; ++i) resid_zero(e->r[i]);
   e->prev = new T[e->n][4];
   e->P = new LemniscateParams<T>[e->n];
   e->org = new double[e->n][3];
@@ -47,7 +58,19 @@ template <typename T> static void* emul_create(const mds_config* cfg, const mds_
 
 template <typename T> static void emul_set_state(void* h, const double* st) {
   Emul<T>* e = (Emul<T>*)h;
-  for (int i = 0; i < e->n; ++i) load_state<T>(st + 13 * i, e->s[i], e->org[i]);
+  for (int i = 0; i < e->n; ++i) {
+    load_state<T>(st + 13 * i, e->s[i], e->org[i]);
+    resid_zero(e->r[i]);
+    if (e->comp) {          // residual = what the rounding to T dropped
+      const double* o = st + 13 * i;
+      State<T>& s = e->s[i];
+      Resid<T>& r = e->r[i];
+      r.p = {(T)((o[0] - e->org[i][0]) - (double)s.p.x), (T)((o[1] - e->org[i][1]) - (double)s.p.y), (T)((o[2] - e->org[i][2]) - (double)s.p.z)};
+      for (int k = 0; k < 4; ++k) r.q[k] = (T)(o[3 + k] - (double)s.q[k]);
+      r.v = {(T)(o[7] - (double)s.v.x), (T)(o[8] - (double)s.v.y), (T)(o[9] - (double)s.v.z)};
+      r.w = {(T)(o[10] - (double)s.w.x), (T)(o[11] - (double)s.w.y), (T)(o[12] - (double)s.w.z)};
+    }
+  }
 }
 template <typename T> static void emul_get_state(void* h, double* st) {
   Emul<T>* e = (Emul<T>*)h;
@@ -57,6 +80,12 @@ template <typename T> static void emul_get_state(void* h, double* st) {
     o[0] = (double)s.p.x + e->org[i][0]; o[1] = (double)s.p.y + e->org[i][1]; o[2] = (double)s.p.z + e->org[i][2];
     for (int k = 0; k < 4; ++k) o[3 + k] = s.q[k];
     o[7] = s.v.x; o[8] = s.v.y; o[9] = s.v.z; o[10] = s.w.x; o[11] = s.w.y; o[12] = s.w.z;
+    if (e->comp) {
+      const Resid<T>& r = e->r[i];
+      o[0] += r.p.x; o[1] += r.p.y; o[2] += r.p.z;
+      for (int k = 0; k < 4; ++k) o[3 + k] += r.q[k];
+      o[7] += r.v.x; o[8] += r.v.y; o[9] += r.v.z; o[10] += r.w.x; o[11] += r.w.y; o[12] += r.w.z;
+    }
   }
 }
 template <typename T> static void emul_set_lem(void* h, const double* p) {
@@ -76,7 +105,8 @@ template <typename T> static void emul_step(void* h, const double* action, doubl
   for (int i = 0; i < e->n; ++i) {
     T act[4], clipped[4], o[20];
     for (int k = 0; k < 4; ++k) act[k] = (T)action[4 * i + k];
-    emul_aviary_step(e->c, e->s[i], act, e->prev[i], clipped);
+    if (e->comp) emul_aviary_step_comp(e->c, e->s[i], e->r[i], act, e->prev[i], clipped);
+    else emul_aviary_step(e->c, e->s[i], act, e->prev[i], clipped);
     if (obs) {
       pack_obs(e->s[i], V3<T>{(T)e->org[i][0], (T)e->org[i][1], (T)e->org[i][2]}, clipped, o);
       for (int k = 0; k < 20; ++k) obs[20 * i + k] = o[k];
@@ -93,7 +123,8 @@ template <typename T> static void emul_step_geo(void* h, double t, double* obs, 
     const V3<T> ang_v = mul(R, s.w);
     geometric_control<T>(e->c, s.p - des.p, R, s.v, ang_v, des, u, nullptr);
     input_to_action(e->c, u, act);
-    emul_aviary_step(e->c, s, act, e->prev[i], clipped);
+    if (e->comp) emul_aviary_step_comp(e->c, s, e->r[i], act, e->prev[i], clipped);
+    else emul_aviary_step(e->c, s, act, e->prev[i], clipped);
     if (act_out)
       for (int k = 0; k < 4; ++k) act_out[4 * i + k] = act[k];
     if (obs) {
@@ -142,6 +173,8 @@ template <typename T> static void emul_lem(void* h, double t, double* des) {
 extern "C" {
 void* emul_create_f32(const mds_config* c, const mds_geometric_gains* g) { return emul_create<float>(c, g); }
 void* emul_create_f64(const mds_config* c, const mds_geometric_gains* g) { return emul_create<double>(c, g); }
+void emul_set_comp_f32(void* h, int on) { ((Emul<float>*)h)->comp = on; }
+void emul_set_comp_f64(void* h, int on) { ((Emul<double>*)h)->comp = on; }
 void emul_set_state_f32(void* h, const double* s) { emul_set_state<float>(h, s); }
 void emul_set_state_f64(void* h, const double* s) { emul_set_state<double>(h, s); }
 void emul_get_state_f32(void* h, double* s) { emul_get_state<float>(h, s); }

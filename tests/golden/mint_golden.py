@@ -231,6 +231,39 @@ def mint_dynamics(ref):
     print("dynamics", out_hb.shape, "step() raises:", step_raises)
 
 
+def mint_dyn_wrench_accel(ref):
+    """The part of [UPSTREAM] _dynamics the reference tree itself restates: RPM -> (thrust, torques) is action_to_input
+    (utils/model_conversions.py:69-83, CF2P "+" frame, RPM clipped at MAX_RPM like the simulator) and (v_dot, w_dot) is
+    QuadrotorDynamics.dynamics (model/dynamics.py:83-106) once its m, g, J are the env's (CF2P, g = 9.8).  Random attitudes,
+    velocities, body rates and RPM (near hover, wide, and beyond MAX_RPM): inputs + the reference's outputs."""
+    env = make_env()
+    mc = ref["mc"]
+    Q = ref["dyn"].QuadrotorDynamics
+    q = Q(sim_freq=240)
+    q.m, q.g = env.M, env.G
+    q.Jxx, q.Jyy, q.Jzz = env.J[0, 0], env.J[1, 1], env.J[2, 2]
+    q.J = np.diag([q.Jxx, q.Jyy, q.Jzz])
+    q.J_inv = np.linalg.inv(q.J)
+    rng = np.random.default_rng(11)
+    n = 384
+    hover = np.sqrt(env.M * env.G / (4 * env.KF))
+    rpm = np.empty((n, 4))
+    rpm[:128] = hover * (1 + 0.03 * rng.normal(size=(128, 4)))
+    rpm[128:256] = rng.uniform(0, env.MAX_RPM, size=(128, 4))
+    rpm[256:] = rng.uniform(-0.1 * env.MAX_RPM, 1.3 * env.MAX_RPM, size=(128, 4))      # clipped on both sides
+    quat = Rotation.from_euler("xyz", rng.uniform(-1.2, 1.2, size=(n, 3))).as_quat()
+    R = Rotation.from_quat(quat).as_matrix()
+    pos = rng.normal(size=(n, 3))
+    vel = rng.normal(size=(n, 3)) * 2
+    rates = rng.normal(size=(n, 3)) * 3
+    u = np.array([mc.action_to_input(env, a.copy()) for a in rpm])
+    state = np.hstack([pos, R.reshape(n, 9), vel, rates])
+    ydot = np.array([q.dynamics(0.0, s, ui) for s, ui in zip(state, u)])
+    np.savez_compressed(OUT + "/dyn_wrench_accel.npz", rpm=rpm, quat=quat, pos=pos, vel=vel, rates=rates, u=u, v_dot=ydot[:, 6:9],
+                        w_dot=ydot[:, 9:12], max_rpm=env.MAX_RPM, m=env.M, g=env.G, J=np.diag(env.J), **META)
+    print("dyn_wrench_accel", u.shape, "clipped rows:", int(((rpm < 0) | (rpm > env.MAX_RPM)).any(axis=1).sum()))
+
+
 def mint_cbf(ref):
     env = make_env()
     cbf = ref["cbf"]
@@ -498,6 +531,7 @@ if __name__ == "__main__":
     mint_geometric(ref)
     mint_mixer(ref)
     mint_dynamics(ref)
+    mint_dyn_wrench_accel(ref)
     mint_cbf(ref)
     mint_thrust_omega()
     mint_lqr_omega(ref)

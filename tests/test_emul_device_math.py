@@ -70,3 +70,19 @@ def test_closed_loop_f32_within_1e5_over_1000_steps():
         t += 0.01
     assert np.abs(eobs[:, :16] - obs[:, :16]).max() < 1e-5      # north_star tolerance, fp32 state
     assert np.abs(eobs[:, 16:] / obs[:, 16:] - 1).max() < 2e-6  # RPM echo: relative
+
+
+@pytest.mark.parametrize("dt,atol_v,rtol_w", [("f64", 1e-9, 1e-9), ("f32", 2e-3, 2e-4)])
+def test_device_step_accelerations_match_the_reference_tree(dt, atol_v, rtol_w):
+    """The device templates (rotor_wrench in its hover-excess form, body_accel, step_euler) against the reference tree's own
+    RPM -> wrench -> (v_dot, w_dot) (tests/golden/dyn_wrench_accel.npz), one 240 Hz substep."""
+    d = np.load(os.path.join(G, "dyn_wrench_accel.npz"))
+    n = d["rpm"].shape[0]
+    em = E.Emul(dt, num_envs=n, pyb_freq=240, ctrl_freq=240)
+    em.set_state(np.hstack([d["pos"], d["quat"], d["vel"], d["rates"]]))
+    s0 = em.get_state()
+    obs = em.step(d["rpm"])
+    s1 = em.get_state()
+    assert np.abs((s1[:, 7:10] - s0[:, 7:10]) * 240 - d["v_dot"]).max() <= atol_v
+    assert np.abs((s1[:, 10:13] - s0[:, 10:13]) * 240 - d["w_dot"]).max() <= rtol_w * np.abs(d["w_dot"]).max()
+    np.testing.assert_allclose(obs[:, 16:20], np.clip(d["rpm"], 0, float(d["max_rpm"])), rtol=1e-6 if dt == "f32" else 1e-14)

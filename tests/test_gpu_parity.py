@@ -86,6 +86,28 @@ def test_step_f32_open_loop(mds):
     env.close()
 
 
+@pytest.mark.parametrize("dtype,atol_v,rtol_w", [("float64", 1e-9, 1e-9), ("float32", 2e-3, 2e-4)])
+def test_step_accelerations_match_the_reference_tree(mds, dtype, atol_v, rtol_w):
+    """a3 against the reference's own files (tests/golden/dyn_wrench_accel.npz, minted from utils/model_conversions.py:69-83 and
+    model/dynamics.py:83-106 with the env's constants): after ONE physics substep of k_step, (v' - v) / dt and (w' - w) / dt are
+    the reference's v_dot and w_dot, RPM beyond [0, MAX_RPM] included.  fp32: the quotient amplifies the state's rounding by
+    1 / dt = 240 (|v| ~ 2 -> 2.4e-7 * 240)."""
+    d = np.load(os.path.join(G, "dyn_wrench_accel.npz"))
+    n = d["rpm"].shape[0]
+    env = make_env(mds, 1, n, d["pos"], np.zeros((n, 3)), dtype, 240, 240)
+    st = np.hstack([d["pos"], d["quat"], d["vel"], d["rates"]])
+    env.set_state(st)
+    s0 = env.get_state().reshape(n, 13)
+    obs, *_ = env.step(mds.torch.as_tensor(d["rpm"], dtype=env.dtype, device=env.device).reshape(1, n, 4))
+    s1 = env.get_state().reshape(n, 13)
+    dt = 1.0 / 240
+    np.testing.assert_allclose((s1[:, 7:10] - s0[:, 7:10]) / dt, d["v_dot"], rtol=0, atol=atol_v)
+    wd = (s1[:, 10:13] - s0[:, 10:13]) / dt
+    assert np.abs(wd - d["w_dot"]).max() <= rtol_w * np.abs(d["w_dot"]).max()
+    np.testing.assert_allclose(np_obs(obs)[:, 16:20], np.clip(d["rpm"], 0, float(d["max_rpm"])), rtol=1e-6 if dtype == "float32" else 1e-14)
+    env.close()
+
+
 def test_step_clips_action_and_reference_shapes(mds):
     """E=1 with NumPy in -> reference shapes: obs [D,20]; RPM clipped to [0, MAX_RPM] lands in obs[16:20]."""
     D = 3
@@ -342,7 +364,9 @@ def test_two_stream_rollout_is_bit_identical_and_stream_ordered(mds, dtype, phys
             env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=env.device))
             o = env.rollout_geometric(0.0, T, obs_every_step=True)
             snap = o.clone()                                   # ordered behind both halves by the exit events
+            assert env.last_rollout_streams() == streams          # the library reports what it did
             o2 = env.rollout_geometric(T * env.CTRL_TIMESTEP, 3).clone()   # a second call chains behind the first
+            assert env.rollout_streams_for(1) == 1 and env.rollout_streams_for(T) == streams
         side.synchronize()
         out.append((snap.cpu().numpy(), o2.cpu().numpy(), env.get_state()))
         env.close()
@@ -352,6 +376,9 @@ def test_two_stream_rollout_is_bit_identical_and_stream_ordered(mds, dtype, phys
     env2 = make_env(mds, 2, 2, *H.c2_setup(2, 2)[:2], "float32")
     with pytest.raises(Exception):
         env2.set_rollout_streams(3)
+    # auto policy: a small shard never splits, whatever the call length; the thread's current device is left alone
+    assert env2.last_rollout_streams() == 0 and env2.rollout_streams_for(100000) == 1
+    assert torch.cuda.current_device() == env2.device.index
     env2.close()
 
 

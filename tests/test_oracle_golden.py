@@ -203,3 +203,33 @@ def test_oracle_reproduces_its_own_1000_step_rollouts():
         r = R.rollout(ph, integ)
         for j, k in enumerate(d["check"]):
             np.testing.assert_allclose(r[int(k)], d[name][j], rtol=1e-12, atol=1e-12, err_msg=f"{name} step {k}")
+
+
+def test_dyn_wrench_and_accelerations_match_the_reference_tree():
+    """a3 pinned where the reference tree restates it: RPM -> (thrust, torques) against utils/model_conversions.py:69-83
+    (action_to_input) and (v_dot, w_dot) against model/dynamics.py:83-106 with the env's m, g, J.  What stays spec-level
+    ([UPSTREAM]-only) in a1-a4 after this: the update ORDER (v, w first; p with the new v, q with the new w), _integrateQ
+    and the pybullet euler / quaternion conversions."""
+    d = load("dyn_wrench_accel.npz")
+    c = O.CF2P
+    assert abs(c.MAX_RPM - float(d["max_rpm"])) < 1e-9 and c.M == float(d["m"]) and c.G == float(d["g"])
+    np.testing.assert_allclose(np.asarray(c.J), d["J"], rtol=0, atol=0)
+    clipped = np.clip(d["rpm"], 0, c.MAX_RPM)
+    thrust, tau = O.rotor_wrench(clipped, c)
+    np.testing.assert_allclose(thrust, d["u"][:, 0], rtol=1e-13, atol=1e-16)
+    np.testing.assert_allclose(tau, d["u"][:, 1:], rtol=1e-12, atol=1e-18)
+    # continuous-time derivative used by the RK4 integrator
+    _, _, acc, wdot = O.dyn_derivative(d["pos"], d["quat"], d["vel"], d["rates"], clipped, c)
+    np.testing.assert_allclose(acc, d["v_dot"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(wdot, d["w_dot"], rtol=1e-12, atol=1e-9)
+    # one explicit-Euler substep: (v_new - v) / dt and (w_new - w) / dt are exactly those accelerations
+    for dt in (1 / 240, 1 / 100):
+        _, _, v1, w1, _ = O.dyn_step_euler(d["pos"], d["quat"], d["vel"], d["rates"], clipped, dt, c)
+        np.testing.assert_allclose((v1 - d["vel"]) / dt, d["v_dot"], rtol=0, atol=1e-10)
+        np.testing.assert_allclose((w1 - d["rates"]) / dt, d["w_dot"], rtol=1e-10, atol=1e-7)
+    # AviaryOracle.step clips like action_to_input(cap_rpm=True) does
+    ora = O.AviaryOracle(d["pos"], np.zeros_like(d["pos"]), c, 240, 240)
+    ora.quat, ora.vel, ora.rates = d["quat"].copy(), d["vel"].copy(), d["rates"].copy()
+    obs = ora.step(d["rpm"])
+    np.testing.assert_allclose((obs[:, 10:13] - d["vel"]) * 240, d["v_dot"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(obs[:, 16:20], clipped, rtol=0, atol=0)
