@@ -59,7 +59,11 @@ typedef enum mds_status {
 typedef enum mds_dtype { MDS_F32 = 0, MDS_F64 = 1, MDS_F16 = 2 } mds_dtype;
 /* DYN / DYN_DRAG: [UPSTREAM] Physics.DYN (+ _drag), every entry point.  DYN_GND / DYN_DW / DYN_GND_DRAG_DW add [UPSTREAM]
  * _groundEffect / _downwash (Physics.PYB_GND, PYB_DW, PYB_GND_DRAG_DW: Bullet external forces there, extra terms of the DYN wrench
- * here; spec-level): explicit Euler only, served by mds_step (the other step entry points return MDS_EUNSUPPORTED). */
+ * here; spec-level): explicit Euler, f32 / f64.  Upstream refreshes every drone's kinematics between physics substeps and the
+ * downwash couples the drones of an env, so these modes run ONE substep per launch on a double-buffered state: mds_step, and the
+ * controller paths (mds_step_geometric, mds_step_lqr, mds_step_cbf_geometric, mds_step_nominal: controller + first substep in one
+ * launch, the action replayed by the remaining substeps); the mds_rollout_* calls issue the same steps in a loop on the caller's
+ * stream (no two-chain split, no state-in-registers form).  Only mds_step_dslpid returns MDS_EUNSUPPORTED. */
 typedef enum mds_physics {
   MDS_PHYSICS_DYN = 0, MDS_PHYSICS_DYN_DRAG = 1, MDS_PHYSICS_DYN_GND = 2, MDS_PHYSICS_DYN_DW = 3, MDS_PHYSICS_DYN_GND_DRAG_DW = 4
 } mds_physics;

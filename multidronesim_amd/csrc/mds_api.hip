@@ -128,6 +128,7 @@ struct mds_handle {
   Lqr12Gain<float> lqr12_f;
   Lqr12Gain<double> lqr12_d;
   void* state_alt;     // second state buffer of the ground-effect / downwash step (double-buffered substeps)
+  void* act_scratch = nullptr;   // S [n,4]: the controller's action, replayed by the later substeps of a ground-effect / downwash step
   bool envfx;          // physics has ground effect and / or downwash
   EnvFx<float> fx_f;
   EnvFx<double> fx_d;
@@ -163,7 +164,7 @@ constexpr int kSplitMinSteps = MDS_SPLIT_MIN_STEPS;
 // between 2^18 and 2^19 it pays only once the chains have had ~1000 steps to drift out of phase); loop 1: the CBF loop
 // (2^15 drones 36.6 vs 36.4 us, 2^16 41.0 vs 39.4, 2^17 52.9 vs 44.7, 2^18 71.7 vs 60.3).
 static int rollout_streams_policy(const mds_handle* h, int loop, int n_steps) {
-  if (n_steps < 2 || !h->split_st) return 1;
+  if (n_steps < 2 || !h->split_st || h->envfx) return 1;     // ground effect / downwash: the substeps swap two state buffers, one chain
   if (h->rollout_streams) return h->rollout_streams;
   const size_t n = (size_t)h->n;
   const int min_steps = h->split_min_steps > 0 ? h->split_min_steps : kSplitMinSteps;
@@ -361,6 +362,7 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   hipError_t e = hipMalloc(&h->state, 13 * h->ld * es);
   if (e == hipSuccess && h->envfx) e = hipMalloc(&h->state_alt, 13 * h->ld * es);
   if (e == hipSuccess && h->envfx) e = hipMemset(h->state_alt, 0, 13 * h->ld * es);
+  if (e == hipSuccess && h->envfx) e = hipMalloc(&h->act_scratch, (size_t)h->n * 4 * es);
   if (e == hipSuccess) e = hipMalloc(&h->origin, 3 * h->ld * cs);
   if (e == hipSuccess) e = hipMalloc(&h->last_rpm, 4 * h->ld * cs);
   if (e == hipSuccess) e = hipMalloc(&h->lem, 7 * h->ld * cs);
@@ -405,6 +407,7 @@ int mds_destroy(mds_handle* h) {
   MDS_DEV(h);
   if (h->state) (void)hipFree(h->state);
   if (h->state_alt) (void)hipFree(h->state_alt);
+  if (h->act_scratch) (void)hipFree(h->act_scratch);
   if (h->origin) (void)hipFree(h->origin);
   if (h->last_rpm) (void)hipFree(h->last_rpm);
   if (h->lem) (void)hipFree(h->lem);
@@ -570,29 +573,73 @@ static void launch_step_plain(mds_handle* h, const void* action, void* obs, hipS
 #undef MDS_LAUNCH_STEP
 }
 
+// [UPSTREAM] BaseAviary.step under ground effect / downwash: one launch per physics substep on the double-buffered state
+// (k_step_env).  first_substep: substeps [first_substep, K) are run (a controller kernel has already done substep 0 and left its
+// action in `action`).
+static int step_env_plain(mds_handle* h, const void* action, void* obs, hipStream_t st, int first_substep) {
+  const dim3 grid = grid_for(h->n, kBlock);
+  const int K = h->cfg.pyb_freq / h->cfg.ctrl_freq, D = h->cfg.num_drones;
+  void* rpm = rpm_track(h);
+  for (int k = first_substep; k < K; ++k) {
+    void* ob = k == K - 1 ? obs : nullptr;
+    if (h->cfg.dtype == MDS_F64) {
+      if (has_drag(h)) k_step_env<double, double, true><<<grid, kBlock, 0, st>>>(h->cd, h->fx_d, h->n, h->ld, D, (const double*)h->state, (double*)h->state_alt, (const double*)h->origin, (double*)rpm, (const double*)action, (double*)ob, k > 0, k == K - 1);
+      else k_step_env<double, double, false><<<grid, kBlock, 0, st>>>(h->cd, h->fx_d, h->n, h->ld, D, (const double*)h->state, (double*)h->state_alt, (const double*)h->origin, (double*)rpm, (const double*)action, (double*)ob, k > 0, k == K - 1);
+    } else {
+      if (has_drag(h)) k_step_env<float, float, true><<<grid, kBlock, 0, st>>>(h->cf, h->fx_f, h->n, h->ld, D, (const float*)h->state, (float*)h->state_alt, (const float*)h->origin, (float*)rpm, (const float*)action, (float*)ob, k > 0, k == K - 1);
+      else k_step_env<float, float, false><<<grid, kBlock, 0, st>>>(h->cf, h->fx_f, h->n, h->ld, D, (const float*)h->state, (float*)h->state_alt, (const float*)h->origin, (float*)rpm, (const float*)action, (float*)ob, k > 0, k == K - 1);
+    }
+    void* t = h->state; h->state = h->state_alt; h->state_alt = t;
+  }
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+// One control step of a controller path under ground effect / downwash: k_step_ctrl_env (trajectory sample or given input ->
+// controller -> first substep), then the remaining substeps through k_step_env with the action it left in act_scratch.
+// ctrl 0 GeometricControl, 1 LQRController (12-state), 2 ThrustOmega low level on u_in, 3 YankOmega low level on u_in.
+static int step_env_ctrl(mds_handle* h, int ctrl, double t, const void* u_in, double thrust_offset, void* obs, void* act, hipStream_t st) {
+  const dim3 grid = grid_for(h->n, kBlock);
+  const int K = h->cfg.pyb_freq / h->cfg.ctrl_freq, D = h->cfg.num_drones;
+  void* rpm = rpm_track(h);
+  void* abuf = K > 1 ? h->act_scratch : nullptr;
+  const void* gain = ctrl == 1 ? h->gain_dev[0] : nullptr;
+  const bool drag = has_drag(h);
+#define MDS_CE(T, CC, FX, DRAG, CTRL)                                                                                              \
+  k_step_ctrl_env<T, T, DRAG, CTRL><<<grid, kBlock, 0, st>>>(CC, FX, gain, h->n, h->ld, D, t, h->traj_mode, (const T*)h->state, (T*)h->state_alt, \
+                                                             (const T*)h->origin, (const T*)h->lem, SegTable{h->segs, h->nseg_total}, h->tinfo, \
+                                                             (T*)rpm, (T*)h->ll, (const T*)u_in, (T)(1.0 / h->cfg.ctrl_freq), (T)thrust_offset,  \
+                                                             (T*)abuf, (T*)obs, (T*)act, K == 1)
+#define MDS_CE_D(T, CC, FX, CTRL)            \
+  do {                                       \
+    if (drag) MDS_CE(T, CC, FX, true, CTRL); \
+    else MDS_CE(T, CC, FX, false, CTRL);     \
+  } while (0)
+#define MDS_CE_C(T, CC, FX)                   \
+  do {                                        \
+    if (ctrl == 0) MDS_CE_D(T, CC, FX, 0);    \
+    else if (ctrl == 1) MDS_CE_D(T, CC, FX, 1); \
+    else if (ctrl == 2) MDS_CE_D(T, CC, FX, 2); \
+    else MDS_CE_D(T, CC, FX, 3);              \
+  } while (0)
+  if (h->cfg.dtype == MDS_F64) MDS_CE_C(double, h->cd, h->fx_d);
+  else MDS_CE_C(float, h->cf, h->fx_f);
+#undef MDS_CE_C
+#undef MDS_CE_D
+#undef MDS_CE
+  MDS_HIP(hipGetLastError());
+  void* tmp = h->state; h->state = h->state_alt; h->state_alt = tmp;
+  if (K > 1) return step_env_plain(h, h->act_scratch, obs, st, 1);
+  return MDS_OK;
+}
+
 int mds_step(mds_handle* h, const void* action, void* obs, void* stream) {
   MDS_DEV(h);
   if (!h || !action) return fail(MDS_EINVAL, "mds_step: null argument");
   if (!aligned16(action) || !aligned16(obs)) return fail(MDS_EALIGN, "mds_step: action_dev/obs_dev");
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid = grid_for(h->n, kBlock);
-  if (h->envfx) {   // one launch per physics substep, double-buffered state (k_step_env)
-    const int K = h->cfg.pyb_freq / h->cfg.ctrl_freq, D = h->cfg.num_drones;
-    void* rpm = rpm_track(h);
-    for (int k = 0; k < K; ++k) {
-      void* ob = k == K - 1 ? obs : nullptr;
-      if (h->cfg.dtype == MDS_F64) {
-        if (has_drag(h)) k_step_env<double, double, true><<<grid, kBlock, 0, st>>>(h->cd, h->fx_d, h->n, h->ld, D, (const double*)h->state, (double*)h->state_alt, (const double*)h->origin, (double*)rpm, (const double*)action, (double*)ob, k > 0, k == K - 1);
-        else k_step_env<double, double, false><<<grid, kBlock, 0, st>>>(h->cd, h->fx_d, h->n, h->ld, D, (const double*)h->state, (double*)h->state_alt, (const double*)h->origin, (double*)rpm, (const double*)action, (double*)ob, k > 0, k == K - 1);
-      } else {
-        if (has_drag(h)) k_step_env<float, float, true><<<grid, kBlock, 0, st>>>(h->cf, h->fx_f, h->n, h->ld, D, (const float*)h->state, (float*)h->state_alt, (const float*)h->origin, (float*)rpm, (const float*)action, (float*)ob, k > 0, k == K - 1);
-        else k_step_env<float, float, false><<<grid, kBlock, 0, st>>>(h->cf, h->fx_f, h->n, h->ld, D, (const float*)h->state, (float*)h->state_alt, (const float*)h->origin, (float*)rpm, (const float*)action, (float*)ob, k > 0, k == K - 1);
-      }
-      void* t = h->state; h->state = h->state_alt; h->state_alt = t;
-    }
-    MDS_HIP(hipGetLastError());
-    return MDS_OK;
-  }
+  if (h->envfx) return step_env_plain(h, action, obs, st, 0);
   launch_step_plain(h, action, obs, st);
   MDS_HIP(hipGetLastError());
   return MDS_OK;
@@ -812,10 +859,10 @@ static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, 
 
 int mds_step_geometric(mds_handle* h, double t, void* obs, void* act, void* stream) {
   MDS_DEV(h);
-  if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h) return fail(MDS_EINVAL, "mds_step_geometric: null handle");
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_step_geometric: call mds_set_lemniscate first");
   if (!aligned16(obs) || !aligned16(act)) return fail(MDS_EALIGN, "mds_step_geometric: obs_dev/action_dev");
+  if (h->envfx) return step_env_ctrl(h, 0, t, nullptr, 0.0, obs, act, (hipStream_t)stream);
   launch_step_geometric(h, t, obs, act, (hipStream_t)stream);
   MDS_HIP(hipGetLastError());
   return MDS_OK;
@@ -823,11 +870,18 @@ int mds_step_geometric(mds_handle* h, double t, void* obs, void* act, void* stre
 
 int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs, int obs_every_step, void* stream) {
   MDS_DEV(h);
-  if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h || n_steps < 0) return fail(MDS_EINVAL, "mds_rollout_geometric");
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_rollout_geometric: call mds_set_lemniscate first");
   if (!aligned16(obs)) return fail(MDS_EALIGN, "mds_rollout_geometric: obs_dev");
   const double dt = 1.0 / h->cfg.ctrl_freq;
+  if (h->envfx) {          // ground effect / downwash: every substep is its own launch on the double-buffered state
+    h->last_rollout_streams = 1;
+    for (int k = 0; k < n_steps; ++k) {
+      if (int rc = step_env_ctrl(h, 0, t0, nullptr, 0.0, (obs_every_step || k == n_steps - 1) ? obs : nullptr, nullptr, (hipStream_t)stream)) return rc;
+      t0 += dt;
+    }
+    return MDS_OK;
+  }
   const unsigned nbatch = (unsigned)((h->n + kBlock - 1) / kBlock);
   const int streams = rollout_streams_policy(h, 0, n_steps);
   if (streams == 2 && nbatch >= 2) {
@@ -875,11 +929,22 @@ int mds_rollout_step(mds_handle* h, const void* actions, int n_action_sets, int 
   if (!h || !actions || n_action_sets < 1 || first_step < 0 || n_steps < 0 || (obs_log && log_slots < 1) || episode_len < 0)
     return fail(MDS_EINVAL, "mds_rollout_step: arguments");
   if (episode_len > 0 && !h->init_pose) return fail(MDS_ESTATE, "mds_rollout_step: episode resets need an earlier mds_reset");
-  if (h->envfx) return fail(MDS_EUNSUPPORTED, "mds_rollout_step: ground effect / downwash physics is served by mds_step only");
   const size_t es = elem_size(h->cfg.dtype), act_bytes = (size_t)h->n * 4 * es, obs_bytes = (size_t)h->n * kObsDim * es;
   if (!aligned16(actions) || !aligned16(obs_log) || (n_action_sets > 1 && act_bytes % 16) || (obs_log && log_slots > 1 && obs_bytes % 16))
     return fail(MDS_EALIGN, "mds_rollout_step: actions_dev/obs_log_dev (every action set and log slot must start 16-byte aligned)");
   hipStream_t st = (hipStream_t)stream;
+  if (h->envfx) {          // ground effect / downwash: the env.step loop, one launch per substep
+    h->last_rollout_streams = 1;
+    for (int k = 0; k < n_steps; ++k) {
+      const long long j = (long long)first_step + k;
+      if (episode_len > 0 && j > 0 && j % episode_len == 0)
+        if (int rc = launch_reset_range(h, st, 0, h->n)) return rc;
+      const char* a = (const char*)actions + (size_t)(j % n_action_sets) * act_bytes;
+      char* o = obs_log ? (char*)obs_log + (size_t)(j % log_slots) * obs_bytes : nullptr;
+      if (int rc = step_env_plain(h, a, o, st, 0)) return rc;
+    }
+    return MDS_OK;
+  }
   const unsigned nbatch = (unsigned)((h->n + kBlock - 1) / kBlock);
   const bool split = rollout_streams_policy(h, 0, n_steps) == 2 && nbatch >= 2;
   const unsigned half = nbatch / 2;
@@ -920,7 +985,8 @@ int mds_rollout_step_fused(mds_handle* h, const void* actions, int n_action_sets
   if (!h || !actions || n_action_sets < 1 || first_step < 0 || n_steps < 0 || (obs_log && log_slots < 1) || episode_len < 0 ||
       steps_per_launch < 1)
     return fail(MDS_EINVAL, "mds_rollout_step_fused: arguments");
-  if (h->envfx) return fail(MDS_EUNSUPPORTED, "mds_rollout_step_fused: ground effect / downwash physics is served by mds_step only");
+  if (h->envfx)            // env-mates interact every substep: no state-in-registers form; the step-by-step loop serves it
+    return mds_rollout_step(h, actions, n_action_sets, first_step, n_steps, obs_log, log_slots, episode_len, stream);
   if (episode_len > 0 && !h->init_pose) return fail(MDS_ESTATE, "mds_rollout_step_fused: episode resets need an earlier mds_reset");
   const size_t es = elem_size(h->cfg.dtype), act_bytes = (size_t)h->n * 4 * es, obs_bytes = (size_t)h->n * kObsDim * es;
   if (!aligned16(actions) || !aligned16(obs_log) || (n_action_sets > 1 && act_bytes % 16) || (obs_log && log_slots > 1 && obs_bytes % 16))
@@ -973,10 +1039,38 @@ int mds_get_last_rollout_streams(const mds_handle* h) {
   return h->last_rollout_streams;
 }
 
+struct EnvRange;
+static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream, bool with_filter,
+                                 const char* who, const EnvRange* rg);
+
 // ctrl: 0 GeometricControl, 1 LQRController (12-state), 2 LQROmegaController + ThrustOmega, 3 LQRYankOmegaController + YankOmega
 static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream, int ctrl, const char* who) {
-  if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h || n_steps < 0) return fail(MDS_EINVAL, who);
+  if (h->envfx) {
+    // ground effect / downwash: env-mates interact every physics substep, so there is no state-in-registers form; the same loop
+    // runs step by step (one launch per substep), each step's observation written straight into its slot of the log
+    if (!h->has_traj) return fail(MDS_ESTATE, "mds_rollout_*_fused: call mds_set_lemniscate first");
+    if (ctrl == 1 && !h->has_lqr12) return fail(MDS_ESTATE, "mds_rollout_lqr_fused: call mds_set_lqr_gain first");
+    if (ctrl >= 2 && !obs_last) return fail(MDS_EINVAL, "mds_rollout_nominal_fused: obs_dev is required (in: current observation, out: last one)");
+    if (!aligned16(obs_log) || !aligned16(obs_last)) return fail(MDS_EALIGN, "mds_rollout_*_fused: obs buffers");
+    const size_t obs_bytes = (size_t)h->n * kObsDim * elem_size(h->cfg.dtype);
+    const double dt = 1.0 / h->cfg.ctrl_freq;
+    hipStream_t st = (hipStream_t)stream;
+    for (int k = 0; k < n_steps; ++k) {
+      char* slot = obs_log ? (char*)obs_log + (size_t)k * obs_bytes : nullptr;
+      const bool last = k == n_steps - 1;
+      if (ctrl <= 1) {
+        void* o = slot ? (void*)slot : (last ? obs_last : nullptr);
+        if (int rc = step_env_ctrl(h, ctrl, t0, nullptr, 0.0, o, nullptr, st)) return rc;
+        if (slot && last && obs_last) MDS_HIP(hipMemcpyAsync(obs_last, slot, obs_bytes, hipMemcpyDeviceToDevice, st));
+      } else {
+        if (int rc = step_nominal_lowlevel(h, t0, obs_last, nullptr, nullptr, stream, false, who, nullptr)) return rc;
+        if (slot) MDS_HIP(hipMemcpyAsync(slot, obs_last, obs_bytes, hipMemcpyDeviceToDevice, st));
+      }
+      t0 += dt;
+    }
+    return MDS_OK;
+  }
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_rollout_*_fused: call mds_set_lemniscate first");
   const bool lqr = ctrl == 1;
   if (lqr && !h->has_lqr12) return fail(MDS_ESTATE, "mds_rollout_lqr_fused: call mds_set_lqr_gain first");
@@ -1426,11 +1520,11 @@ int mds_lqr_compute(mds_handle* h, const void* obs, const void* des, void* u, vo
 
 int mds_step_lqr(mds_handle* h, double t, void* obs, void* act, void* stream) {
   MDS_DEV(h);
-  if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h) return fail(MDS_EINVAL, "mds_step_lqr: null handle");
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_step_lqr: call mds_set_lemniscate / mds_set_trajectory_segments first");
   if (!h->has_lqr12) return fail(MDS_ESTATE, "mds_step_lqr: call mds_set_lqr_gain first");
   if (!aligned16(obs) || !aligned16(act)) return fail(MDS_EALIGN, "mds_step_lqr: obs_dev/action_dev");
+  if (h->envfx) return step_env_ctrl(h, 1, t, nullptr, 0.0, obs, act, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid = grid_for(h->n, kBlock);
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
@@ -1532,8 +1626,8 @@ int mds_thrust_omega_from_rates(mds_handle* h, const void* u, const void* rates,
 // nominal controller -> [ECBF QP] -> low level -> env.step.  with_filter = false: the plain loops of
 // simulations/EnvGeometricOmega.py / EnvGeometricYankOmega.py (ctrl[j].compute(obs[j]) = LQR + low level, :314 / :319).
 static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream, bool with_filter,
-                                 const char* who, EnvRange rg = EnvRange{0, -1, 0}) {
-  if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
+                                 const char* who, const EnvRange* rgp = nullptr) {
+  EnvRange rg = rgp ? *rgp : EnvRange{0, -1, 0};
   if (!h->has_traj || h->traj_mode != 1) return fail(MDS_ESTATE, "mds_step_cbf_geometric / mds_step_nominal: call mds_set_lemniscate first");
   if (!aligned16(obs) || !aligned16(action)) return fail(MDS_EALIGN, "mds_step_cbf_geometric / mds_step_nominal: obs_dev/action_dev");
   const bool yank = h->cbf_nominal == 2;
@@ -1582,6 +1676,8 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
   // order 2: u_safe[0] += M G (CBFTest.py:346); order 3: the yank goes to the low level as it is (CBFTestOrd3.py:350)
   const double ll_offset = (with_filter && !yank) ? h->cfg.M * h->cfg.G : 0.0;
+  if (h->envfx)            // ground effect / downwash: low level + first substep, then the remaining substeps (whole batch, one stream)
+    return step_env_ctrl(h, yank ? 3 : 2, t, u_ll, ll_offset, obs, action, st);
 #define MDS_LL(RK4, DRAG, YANK)                                                                                                  \
   MDS_DISPATCH(h, (k_lowlevel_step<T, S, RK4, DRAG, YANK><<<grid, kBlock, 0, st>>>(C, n_end, h->ld, (T)(1.0 / h->cfg.ctrl_freq),  \
                                                                                    (T)ll_offset, (S*)h->state, (const T*)h->origin, \
@@ -1640,7 +1736,7 @@ int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs, 
       double t = t0 + dt;
       for (int k = 1; k < n_steps; ++k) {
         for (int s = 0; s < 2; ++s)
-          if (int rc = step_nominal_lowlevel(h, t, obs, status, nullptr, s == 0 ? st : h->split_st, true, "mds_rollout_cbf_geometric", half[s])) return rc;
+          if (int rc = step_nominal_lowlevel(h, t, obs, status, nullptr, s == 0 ? st : h->split_st, true, "mds_rollout_cbf_geometric", &half[s])) return rc;
         t += dt;
       }
       return MDS_OK;

@@ -224,6 +224,34 @@ __global__ __launch_bounds__(kBlock) void k_rollout_step(const Consts<T> c, cons
 // kinematic information of every drone between substeps; the downwash on a drone depends on its env-mates' positions), reading
 // state_in and writing state_out (double-buffered: env-mates are read while they are being updated).  Explicit Euler only.
 // drag_from_action: substeps after the first take the _drag term from this step's clipped action (as aviary_step does).
+// one explicit-Euler substep of drone i with the environment terms: rotor wrench of the clipped RPM, [UPSTREAM] _groundEffect on the
+// drone's own propellers, _downwash from every env-mate above (positions read from state_in: the state BEFORE this substep),
+// _drag from `prev`.  s holds drone i's state_in row on entry, the stepped state on return.
+template <typename T, typename S, bool DRAG>
+__device__ __forceinline__ void env_substep(const Consts<T>& c, const EnvFx<T>& fx, const int D, const size_t ld, const int i,
+                                            const S* __restrict__ state_in, const T* __restrict__ origin, const V3<T> org,
+                                            State<T>& s, const T clipped[4], const T prev[4]) {
+  T drag_s = T(0);
+  if (DRAG) drag_s = T(0.10471975511965977462) * ((prev[0] + prev[1]) + (prev[2] + prev[3]));
+  T thrust;
+  V3<T> tau;
+  rotor_wrench(c, clipped, &thrust, &tau);
+  if (fx.gnd) ground_effect(c, fx, s, s.p.z + org.z, clipped, &thrust, &tau);
+  if (fx.dw) {
+    const V3<T> me = {s.p.x + org.x, s.p.y + org.y, s.p.z + org.z};
+    const int e0 = (i / D) * D;
+    T f = T(0);
+    for (int j = e0; j < e0 + D; ++j) {
+      if (j == i) continue;
+      T a4[4];
+      load4<S, T>(state_in + 4 * (size_t)j, a4);                                // (px, py, pz, qx) of env-mate j, before this substep
+      f += downwash_pair(fx, me, V3<T>{a4[0] + origin[j], a4[1] + origin[ld + j], a4[2] + origin[2 * ld + j]});
+    }
+    thrust += f;
+  }
+  step_euler_wrench<T, DRAG>(c, s, thrust, tau, drag_s);
+}
+
 template <typename T, typename S, bool DRAG>
 __global__ __launch_bounds__(kBlock) void k_step_env(const Consts<T> c, const EnvFx<T> fx, const int n, const size_t ld, const int D,
                                                      const S* __restrict__ state_in, S* __restrict__ state_out,
@@ -238,38 +266,90 @@ __global__ __launch_bounds__(kBlock) void k_step_env(const Consts<T> c, const En
     State<T> s;
     load_state<S, T>(state_in, ld, i, s);
     const V3<T> org = {origin[i], origin[ld + i], origin[2 * ld + i]};
-    T act[4], clipped[4];
+    T act[4], clipped[4], prev[4] = {T(0), T(0), T(0), T(0)};
     load4<S, T>(action + (size_t)i * 4, act);
     for (int k = 0; k < 4; ++k) clipped[k] = m_clamp(act[k], T(0), c.max_rpm);
-    T drag_s = T(0);
-    if (DRAG) {
-      T prev[4];
+    if (DRAG)
       for (int k = 0; k < 4; ++k) prev[k] = drag_from_action ? clipped[k] : last_rpm[k * ld + i];
-      drag_s = T(0.10471975511965977462) * ((prev[0] + prev[1]) + (prev[2] + prev[3]));
-    }
-    T thrust;
-    V3<T> tau;
-    rotor_wrench(c, clipped, &thrust, &tau);
-    if (fx.gnd) ground_effect(c, fx, s, s.p.z + org.z, clipped, &thrust, &tau);
-    if (fx.dw) {
-      const V3<T> me = {s.p.x + org.x, s.p.y + org.y, s.p.z + org.z};
-      const int e0 = (i / D) * D;
-      T f = T(0);
-      for (int j = e0; j < e0 + D; ++j) {
-        if (j == i) continue;
-        T a4[4];
-        load4<S, T>(state_in + 4 * (size_t)j, a4);                                // (px, py, pz, qx) of env-mate j, before this substep
-        f += downwash_pair(fx, me, V3<T>{a4[0] + origin[j], a4[1] + origin[ld + j], a4[2] + origin[2 * ld + j]});
-      }
-      thrust += f;
-    }
-    step_euler_wrench<T, DRAG>(c, s, thrust, tau, drag_s);
+    env_substep<T, S, DRAG>(c, fx, D, ld, i, state_in, origin, org, s, clipped, prev);
     store_state<S, T>(state_out, ld, i, s);
     if (store_rpm && (DRAG || last_rpm))
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
     if (obs) pack_obs(s, org, clipped, o);
   }
   if (obs) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
+}
+
+// The controller kernels' first physics substep under ground effect / downwash: trajectory sample -> controller -> the substep
+// above, reading state_in and writing state_out like k_step_env (env-mates are read while they are being updated).  CTRL 0:
+// GeometricControl; 1: the 12-state LQRController (K read from its device copy); 2 / 3: a given input u_in [n,4] through the
+// ThrustOmega / YankOmega low level (the CBF loops: u_safe + thrust_offset).  The unclipped action goes to act_buf when further
+// substeps follow (k_step_env replays it); obs / action_out may be NULL.
+template <typename T, typename S, bool DRAG, int CTRL>
+__global__ __launch_bounds__(kBlock) void k_step_ctrl_env(const Consts<T> c, const EnvFx<T> fx, const void* __restrict__ Kp, const int n,
+                                                          const size_t ld, const int D, const double t, const int traj_mode,
+                                                          const S* __restrict__ state_in, S* __restrict__ state_out,
+                                                          const T* __restrict__ origin, const T* __restrict__ lem, const SegTable segs,
+                                                          const int* __restrict__ tinfo, T* __restrict__ last_rpm, T* __restrict__ ll,
+                                                          const S* __restrict__ u_in, const T ctrl_dt, const T thrust_offset,
+                                                          S* __restrict__ act_buf, S* __restrict__ obs, S* __restrict__ action_out,
+                                                          const int store_rpm) {
+  __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = i < n;
+  T o[kObsDim];
+  if (valid) {
+    State<T> s;
+    load_state<S, T>(state_in, ld, i, s);
+    const V3<T> org = {origin[i], origin[ld + i], origin[2 * ld + i]};
+    T act[4], clipped[4], prev[4] = {T(0), T(0), T(0), T(0)};
+    if (CTRL <= 1) {
+      Desired<T> des;
+      if (traj_mode == 1) {
+        const LemniscateParams<T> P = {lem[lidx(0, i, ld)], lem[lidx(1, i, ld)], lem[lidx(2, i, ld)], lem[lidx(3, i, ld)], lem[lidx(4, i, ld)],
+                                       lem[lidx(5, i, ld)], lem[lidx(6, i, ld)]};
+        des = lemniscate_local(P, t);               // local frame: mds_set_lemniscate made the origin the trajectory centre
+      } else {
+        des = TrajLocal<T>::eval(segs, traj_info(tinfo, i), t, org);
+      }
+      T u[4];
+      if (CTRL == 0) {
+        const M3<T> R = quat_to_rot(s.q);
+        geometric_control<T>(c, s.p - des.p, R, s.v, mul(R, s.w), des, u, nullptr);
+      } else {
+        lqr12_control<T>(c, *static_cast<const Lqr12Gain<T>*>(Kp), euler_from_quat(s.q), quat_rotate(s.q, s.w), s.v, s.p - des.p, des.v,
+                         des.yaw, des.yaw_rate, u);
+      }
+      input_to_action(c, u, act);
+    } else {
+      T u[4];
+      load4<S, T>(u_in + (size_t)i * 4, u);
+      u[0] += thrust_offset;
+      LowLevelState<T> L;
+      L.last_omega = {ll[0 * ld + i], ll[1 * ld + i], ll[2 * ld + i]};
+      L.integral = {ll[3 * ld + i], ll[4 * ld + i], ll[5 * ld + i]};
+      if (CTRL == 3) {   // obs still holds the previous step's row here (read and later rewritten by the same wave)
+        T rpm_prev[4];
+        load4<S, T>(obs + (size_t)i * kObsDim + 16, rpm_prev);
+        yank_omega_control(c, ctrl_dt, u, rpm_prev, s.w, L, act);
+      } else {
+        thrust_omega_control(c, ctrl_dt, u, s.w, L, act);
+      }
+      ll[0 * ld + i] = L.last_omega.x; ll[1 * ld + i] = L.last_omega.y; ll[2 * ld + i] = L.last_omega.z;
+      ll[3 * ld + i] = L.integral.x; ll[4 * ld + i] = L.integral.y; ll[5 * ld + i] = L.integral.z;
+    }
+    for (int k = 0; k < 4; ++k) clipped[k] = m_clamp(act[k], T(0), c.max_rpm);
+    if (DRAG)
+      for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
+    env_substep<T, S, DRAG>(c, fx, D, ld, i, state_in, origin, org, s, clipped, prev);
+    store_state<S, T>(state_out, ld, i, s);
+    if (store_rpm && (DRAG || last_rpm))
+      for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
+    if (act_buf) store4<S, T>(act_buf + (size_t)i * 4, act);
+    if (action_out) store4<S, T>(action_out + (size_t)i * 4, act);
+    if (obs && store_rpm) pack_obs(s, org, clipped, o);
+  }
+  if (obs && store_rpm) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
 }
 
 // ------------------------------------------------------------------------------------

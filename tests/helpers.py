@@ -72,7 +72,7 @@ def open_loop_setup(n, seed=1, tilt=0.02):
 
 
 def oracle_cbf_closed_loop(xyz, rpy, P, steps, Kcbf, umax, safety_radius, zscale, x_obs, obs_r, pyb_freq=100, ctrl_freq=100,
-                           consts=O.CF2P, nominal="geometric", order=2, Fmin=None, Fmax=None, first_rpm=0.0):
+                           consts=O.CF2P, nominal="geometric", order=2, Fmin=None, Fmax=None, first_rpm=0.0, physics="dyn"):
     """simulations/CBFTest.py:303-350 on the oracle, per env: geometric nominal (return_omegas) ->
     u_hat = (force - M G, w_des), xdes = [0,0,yaw, vel, pos] -> ECBF QP (fallback to nominal) ->
     + M G -> ThrustOmega low level -> env.step.  order 3 / nominal "lqr_yank_omega": the loop of
@@ -81,7 +81,7 @@ def oracle_cbf_closed_loop(xyz, rpy, P, steps, Kcbf, umax, safety_radius, zscale
     E, D = xyz.shape[0], xyz.shape[1]
     n = E * D
     Pf = P.reshape(-1, 7)
-    ora = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), consts, pyb_freq, ctrl_freq)
+    ora = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), consts, pyb_freq, ctrl_freq, physics=physics, drones_per_env=D)
     ll = O.YankOmegaOracle(n, consts) if order == 3 else O.ThrustOmegaOracle(n, consts)
     Klqr = O.lqr_omega_gain(consts) if nominal == "lqr_omega" else None
     Kyo = O.lqr_yank_omega_gain(consts, 1.0 / ctrl_freq) if nominal == "lqr_yank_omega" else None

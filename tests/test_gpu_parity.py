@@ -587,14 +587,113 @@ def test_ground_effect_and_downwash_match_oracle(mds, physics, name, dtype, tol)
         for k in range(40):
             pobs = plain.step(H.open_loop_rpm(k, 0.01, ph, hover=consts.HOVER_RPM))
         assert np.abs(pobs[:, 2] - oobs[:, 2]).max() > 0.01                     # the effects are doing something in this scene
-        env.set_trajectories(np.tile(np.array([1.0, 1.0, 0, 0, 1.0, 0, 0]), (E, D, 1)))
-        with pytest.raises(RuntimeError):                                       # served by env.step only
-            env.step_geometric(0.0)
         np.testing.assert_allclose(env.get_state()[..., 0:3].reshape(-1, 3), g[:, 0:3], atol=tol * 10)   # double-buffer bookkeeping
         env.close()
     with pytest.raises(RuntimeError):
         mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=2, initial_xyzs=np.zeros((2, 3)), initial_rpys=np.zeros((2, 3)),
                        physics=mds.Physics.PYB_DW, pyb_freq=100, ctrl_freq=100, integrator="rk4")
+
+
+def _stacked_near_ground(E, D, seed=9):
+    """envs of D drones stacked above each other just over the floor, each on its own small Lemniscate around its column"""
+    rng = np.random.default_rng(seed)
+    cen = np.zeros((E, D, 3))
+    cen[..., 0:2] = rng.uniform(-2, 2, size=(E, 1, 2)) + rng.normal(size=(E, D, 2)) * 0.03
+    cen[..., 2] = 0.06 + 0.3 * np.arange(D)
+    xyz = cen + np.concatenate([rng.normal(size=(E, D, 2)) * 0.05, rng.uniform(0, 0.02, size=(E, D, 1))], axis=-1)
+    rpy = rng.uniform(-0.2, 0.2, size=(E, D, 3))
+    P = np.zeros((E, D, 7))
+    P[..., 0], P[..., 1], P[..., 2:5], P[..., 5] = 0.25, 1.2, cen, 0.15
+    P[..., 6] = 2 * np.pi * np.arange(D) / (D + 0.25)
+    return xyz, rpy, P
+
+
+@pytest.mark.parametrize("physics,name", [("PYB_GND", "dyn_gnd"), ("PYB_DW", "dyn_dw"), ("PYB_GND_DRAG_DW", "dyn_gnd_drag_dw")])
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 3e-5)])
+def test_ground_effect_and_downwash_in_the_controller_paths(mds, physics, name, dtype, tol):
+    """[UPSTREAM] _groundEffect / _downwash under the fused controller paths (k_step_ctrl_env: trajectory sample -> GeometricControl
+    -> first substep, the action replayed by the second substep through k_step_env), stacked scene near the ground, 200 Hz physics /
+    100 Hz control, against the oracle's closed loop with the same physics; the C rollout loop and the whole-rollout entry point
+    issue the same steps (bitwise), the latter logging every observation."""
+    E, D, steps = 6, 5, 60
+    xyz, rpy, P = _stacked_near_ground(E, D)
+    Pf = P.reshape(-1, 7)
+    ora = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), O.CF2P, 200, 100, physics=name, drones_per_env=D)
+    plain = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), O.CF2P, 200, 100, physics="dyn")
+    oobs, pobs = ora.step(np.zeros((E * D, 4))), plain.step(np.zeros((E * D, 4)))
+    envs = [mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=getattr(mds.Physics, physics),
+                           pyb_freq=200, ctrl_freq=100, num_envs=E, dtype=dtype) for _ in range(3)]
+    for e in envs:
+        e.set_trajectories(P)
+        e.step(mds.torch.zeros((E, D, 4), dtype=e.dtype))
+    t, step_obs = 0.0, []
+    for k in range(steps):
+        pos, vel, acc, yaw, yd = O.lemniscate(t, Pf[:, 0], Pf[:, 1], Pf[:, 2:5], Pf[:, 5], Pf[:, 6])
+        oobs = ora.step(O.geometric_compute(oobs, pos, vel, acc, yaw, yd))
+        pobs = plain.step(O.geometric_compute(pobs, pos, vel, acc, yaw, yd))
+        gobs, act = envs[0].step_geometric(t, return_action=True)
+        step_obs.append(gobs.clone())
+        t += 0.01
+    g = np_obs(gobs)
+    assert np.abs(g[:, :16] - oobs[:, :16]).max() < tol * max(1.0, np.abs(oobs[:, :16]).max())
+    np.testing.assert_allclose(g[:, 16:], oobs[:, 16:], rtol=1e-5 if dtype == "float32" else 1e-10)
+    assert np.abs(pobs[:, :3] - oobs[:, :3]).max() > 1e-3                      # the effects are doing something in this closed loop
+    np.testing.assert_allclose(envs[0].get_state()[..., 0:3].reshape(-1, 3), g[:, 0:3], atol=tol * 10)   # double-buffer bookkeeping
+    r = envs[1].rollout_geometric(0.0, steps, obs_every_step=True)
+    assert envs[1].last_rollout_streams() == 1
+    np.testing.assert_array_equal(r.cpu().numpy(), gobs.cpu().numpy())
+    last, log = envs[2].rollout_geometric_fused(0.0, steps, log=True)
+    np.testing.assert_array_equal(log.cpu().numpy(), mds.torch.stack(step_obs).cpu().numpy())
+    np.testing.assert_array_equal(last.cpu().numpy(), gobs.cpu().numpy())
+    for e in envs:
+        e.close()
+
+
+def test_ground_effect_under_the_lqr_and_cbf_paths(mds):
+    """The same physics modes under mds_step_lqr (12-state LQRController) and under the CBF loop (nominal -> QP -> ThrustOmega low
+    level -> first substep + replay), float64, against the oracle loops."""
+    from multidronesim_amd.control import LQRController
+    from multidronesim_amd.model.linearized import LinearizedModel
+    from multidronesim_amd.cbf.cbf import DroneCBF
+    from multidronesim_amd.cbf.qptracker import DroneQPTracker
+    from multidronesim_amd.model.linear_omega import LinearizedOmegaModel
+    E, D, steps = 4, 5, 50
+    xyz, rpy, P = _stacked_near_ground(E, D, seed=3)
+    Pf = P.reshape(-1, 7)
+    env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.PYB_GND_DRAG_DW,
+                         pyb_freq=200, ctrl_freq=100, num_envs=E, dtype="float64")
+    env.set_trajectories(P)
+    LQRController(env, LinearizedModel(env))
+    ora = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), O.CF2P, 200, 100, physics="dyn_gnd_drag_dw", drones_per_env=D)
+    K = O.lqr12_gain(O.CF2P)
+    oobs = ora.step(np.zeros((E * D, 4)))
+    env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+    t = 0.0
+    for k in range(steps):
+        pos, vel, acc, yaw, yd = O.lemniscate(t, Pf[:, 0], Pf[:, 1], Pf[:, 2:5], Pf[:, 5], Pf[:, 6])
+        act, _ = O.lqr12_compute(oobs, pos, vel, yaw, yd, K)
+        oobs = ora.step(act)
+        gobs = env.step_lqr(t)
+        t += 0.01
+    assert np.abs(np_obs(gobs)[:, :16] - oobs[:, :16]).max() < 1e-7
+    env.close()
+    # CBF loop near the ground, one sphere beside the columns
+    x_obs, obs_r = [np.array([[0.4, 0.0, 0.4], [0, 0, 0]])], [0.05]
+    env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.PYB_GND,
+                         pyb_freq=200, ctrl_freq=100, num_envs=E, dtype="float64")
+    env.set_trajectories(P)
+    cbf = DroneCBF(env, [LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.05, zscale=1.0, order=2)
+    trk = DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+    oobs, ohist = H.oracle_cbf_closed_loop(xyz, rpy, P, 40, cbf.Kcbf.reshape(-1), cbf.umax, 0.05, 1.0, x_obs, obs_r, pyb_freq=200, ctrl_freq=100,
+                                           physics="dyn_gnd")
+    env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+    t = 0.0
+    for k in range(40):
+        gobs, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
+        np.testing.assert_array_equal(st.cpu().numpy(), ohist[k])
+        t += 0.01
+    assert np.abs(gobs.double().cpu().numpy()[..., :16] - oobs[..., :16]).max() < 1e-6
+    env.close()
 
 
 def test_set_origin_rebases_the_local_frame_without_moving_anything(mds):
