@@ -274,7 +274,7 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 20000 for c3/c5, 2000 for c2, 200 for c4, 50 for c3big)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: steps / 10)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
-    ap.add_argument("--dtype", default="float32", choices=["float32", "float64", "float16"])
+    ap.add_argument("--dtype", default="float32", choices=["float32", "float64", "float16", "float32c"])
     ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the contract's line: skip the secondary measurements (profiling runs)")
@@ -471,6 +471,8 @@ def main(argv=None):
     us_per_step = dev_ms * 1e3 / args.steps                  # HIP events on the launch stream / steps (launch period, not pure kernel time)
     es = {torch.float16: 2, torch.float32: 4, torch.float64: 8}[env.dtype]
     bytes_per = (BYTES_PER_DRONE_STEP_C4 if c4 else BYTES_PER_DRONE_STEP) * es // 4
+    if args.dtype == "float32c":
+        bytes_per += 104                                  # 13 residuals read and written
     if c5:
         bytes_per = 13 * es * 2 + 4 * es + 20 * es       # R state + W state + R action + W obs (origin read not counted)
     if fused_T and c5:
@@ -486,7 +488,8 @@ def main(argv=None):
         "metric": METRIC,
         "value": value, "unit": "drone-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"float32": "f32", "float64": "f64", "float16": "f16-storage/f32-math"}[args.dtype], "data": "synthetic",
+        "dtype": {"float32": "f32", "float64": "f64", "float16": "f16-storage/f32-math", "float32c": "f32 (compensated state accumulation)"}[args.dtype],
+        "data": "synthetic",
         "config": {"workload": desc, "envs_per_gpu": E, "drones_per_env": D, "pyb_freq": 100, "ctrl_freq": 100,
                    "physics": "DYN (explicit Euler)" if not rk4 else "DYN (RK4)",
                    "physics_note": "the reference's default Physics.PYB (Bullet multibody step + ground plane) is not reproduced: no PyBullet here, parity vs it is undemonstrated",
@@ -505,7 +508,7 @@ def main(argv=None):
                                  "launches": "two concurrent half-shard launches per control step, one per stream; "
                                              "achieved = 2 x bytes_per_launch / us_per_step"})
         line["config"]["launch"] = "C rollout loop, half shards on 2 streams"
-    if geo and args.dtype == "float32" and not fused_T and not rk4:
+    if geo and args.dtype == "float32" and not fused_T and not rk4:   # (float32c: different traffic, no committed counters)
         if args.workload == "c3big":
             line["roofline"]["residency"] = ("HBM-resident: 890 MB touched per control step (state 218 + parameters 117 + observations 335 MB written, "
                                              "state 218 MB rewritten), 3.5x the 256 MiB Infinity Cache")
@@ -643,12 +646,15 @@ def main(argv=None):
             except Exception as exc:
                 line["roofline"]["hbm_resident"] = {"error": str(exc)}
             torch.cuda.empty_cache()
-            for key, dty, integ, bpd in (("rk4", "float32", "rk4", BYTES_PER_DRONE_STEP), ("f64", "float64", "euler", 2 * BYTES_PER_DRONE_STEP)):
+            for key, dty, integ, bpd in (("rk4", "float32", "rk4", BYTES_PER_DRONE_STEP), ("f64", "float64", "euler", 2 * BYTES_PER_DRONE_STEP),
+                                         ("f32c", "float32c", "euler", BYTES_PER_DRONE_STEP + 104)):
                 try:
                     us, used, sane = extra_c3_variant(CtrlAviary, DroneModel, Physics, torch, local_rank, device, E, D, phase, 1000, dty, integ, 200, 0)
                     gb = bpd * n_local / (us * 1e-6) / 1e9
                     line[key] = {"what": {"rk4": "same C3 step with the classical RK4 integrator (north_star's), fp32",
-                                          "f64": "same C3 step in float64 (the reference's precision), explicit Euler"}[key],
+                                          "f64": "same C3 step in float64 (the reference's precision), explicit Euler",
+                                          "f32c": "same C3 step in fp32 with compensated state accumulation (MDS_F32C: 13 residuals read and written, "
+                                                  "open-loop 1000-step error 3e-6 instead of 1.4e-5)"}[key],
                                  "us_per_step": us, "value": n_local / (us * 1e-6), "unit": "drone-steps/s", "bytes_per_drone_step": bpd,
                                  "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBPS, "streams": used, "steps": 200, "state_sane": sane}
                 except Exception as exc:

@@ -12,7 +12,7 @@
  *   - n = num_envs * num_drones "drones"; drone d of env e has flat index e*num_drones + d.
  *   - "dev" pointers are device (HBM) pointers owned by the caller (e.g. PyTorch-ROCm
  *     tensors); their element type is the handle's storage dtype (mds_dtype): float for
- *     MDS_F32, double for MDS_F64, IEEE half for MDS_F16 (fp16 storage, fp32 arithmetic).
+ *     MDS_F32 and MDS_F32C, double for MDS_F64, IEEE half for MDS_F16 (fp16 storage, fp32 arithmetic).
  *   - "host" pointers are host double arrays (set-up / inspection only, never hot path).
  *   - `stream` is a hipStream_t (NULL = default stream).  Hot-path calls (mds_step*, mds_rollout*, the operators) only
  *     enqueue work on it and return; they never synchronise or copy, and they allocate only once: the first
@@ -56,7 +56,13 @@ typedef enum mds_status {
   MDS_EUNSUPPORTED = -6 /* combination not built (e.g. order-3 CBF with fp16 storage) */
 } mds_status;
 
-typedef enum mds_dtype { MDS_F32 = 0, MDS_F64 = 1, MDS_F16 = 2 } mds_dtype;
+/* MDS_F32C: fp32 buffers and fp32 arithmetic like MDS_F32, but every one of the 13 state components is kept as an fp32 value plus an
+ * fp32 residual and the integrators accumulate into the pair (two-sum): the storage rounding of an uncontrolled quadrotor (four
+ * chained integrators, ~t^2.5) goes away -- open-loop 240 Hz flight holds 3e-6 instead of 1.4e-5 after 1000 steps -- for 104 more
+ * bytes per drone-step (13 residuals read and written).  Served by mds_step, mds_step_geometric, mds_step_cbf_geometric,
+ * mds_step_nominal and the mds_rollout_* loops built on them (mds_rollout_geometric, mds_rollout_step[_fused], mds_rollout_cbf_geometric);
+ * DYN / DYN_DRAG physics, Euler and RK4.  Not built: the state-in-registers kernels (mds_rollout_*_fused), mds_step_lqr, mds_step_dslpid. */
+typedef enum mds_dtype { MDS_F32 = 0, MDS_F64 = 1, MDS_F16 = 2, MDS_F32C = 3 } mds_dtype;
 /* DYN / DYN_DRAG: [UPSTREAM] Physics.DYN (+ _drag), every entry point.  DYN_GND / DYN_DW / DYN_GND_DRAG_DW add [UPSTREAM]
  * _groundEffect / _downwash (Physics.PYB_GND, PYB_DW, PYB_GND_DRAG_DW: Bullet external forces there, extra terms of the DYN wrench
  * here; spec-level): explicit Euler, f32 / f64.  Upstream refreshes every drone's kinematics between physics substeps and the
@@ -128,7 +134,8 @@ int mds_reset(mds_handle* h, const double* xyz_host, const double* rpy_host, voi
  * four components per 16-byte group: stride 4 for k < 12, 1 for k = 12).  origin_dev[k] (may be NULL): the origin planes,
  * stride 1, float for MDS_F32 / MDS_F16 handles and double for MDS_F64; world position = state position + origin.  The
  * pointers stay valid until mds_destroy, except that the ground-effect / downwash physics modes swap their two state
- * buffers every substep (ask again after each mds_step there). */
+ * buffers every substep (ask again after each mds_step there).  MDS_F32C handles: these are the fp32 values; the residual planes
+ * stay private (mds_get_state returns value + residual). */
 int mds_state_ptrs(mds_handle* h, void* comp_dev[13], size_t stride_elems[13], void* origin_dev[3]);
 
 /* Test / checkpoint access to the 13-float state in the WORLD frame (host double [n,13]).

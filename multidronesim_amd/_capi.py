@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDS_LIB_PATH") or os.path.join(_HERE, "libmds.so")
 
 MDS_OK = 0
-MDS_F32, MDS_F64, MDS_F16 = 0, 1, 2
+MDS_F32, MDS_F64, MDS_F16, MDS_F32C = 0, 1, 2, 3
 MDS_PHYSICS_DYN, MDS_PHYSICS_DYN_DRAG, MDS_PHYSICS_DYN_GND, MDS_PHYSICS_DYN_DW, MDS_PHYSICS_DYN_GND_DRAG_DW = 0, 1, 2, 3, 4
 MDS_INTEGRATOR_EULER, MDS_INTEGRATOR_RK4 = 0, 1
 MDS_CF2X, MDS_CF2P = 0, 1

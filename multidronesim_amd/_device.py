@@ -6,9 +6,10 @@ import torch
 
 from . import _capi as capi
 
-TORCH_DTYPE = {capi.MDS_F32: torch.float32, capi.MDS_F64: torch.float64, capi.MDS_F16: torch.float16}
+TORCH_DTYPE = {capi.MDS_F32: torch.float32, capi.MDS_F64: torch.float64, capi.MDS_F16: torch.float16, capi.MDS_F32C: torch.float32}
 DTYPE_BY_NAME = {"float32": capi.MDS_F32, "fp32": capi.MDS_F32, "f32": capi.MDS_F32, torch.float32: capi.MDS_F32,
                  "float64": capi.MDS_F64, "fp64": capi.MDS_F64, "f64": capi.MDS_F64, torch.float64: capi.MDS_F64,
+                 "float32c": capi.MDS_F32C, "fp32c": capi.MDS_F32C, "f32c": capi.MDS_F32C,      # fp32 with compensated state accumulation
                  "float16": capi.MDS_F16, "fp16": capi.MDS_F16, "f16": capi.MDS_F16, torch.float16: capi.MDS_F16}
 
 

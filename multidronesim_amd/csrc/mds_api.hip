@@ -36,7 +36,7 @@ int fail(int code, const char* what) {
     if (e__ != hipSuccess) return fail_hip(e__, #call); \
   } while (0)
 
-size_t elem_size(int dtype) { return dtype == MDS_F64 ? 8 : (dtype == MDS_F16 ? 2 : 4); }
+size_t elem_size(int dtype) { return dtype == MDS_F64 ? 8 : (dtype == MDS_F16 ? 2 : 4); }   // MDS_F32C: fp32 buffers
 size_t comp_size(int dtype) { return dtype == MDS_F64 ? 8 : 4; }
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -74,6 +74,7 @@ struct mds_handle {
   int n;
   size_t ld;           // plane stride (elements)
   void* state;         // S [13][ld]
+  void* state_lo = nullptr;      // MDS_F32C: float [13][ld] residual planes (compensated accumulation), same packed layout
   void* origin;        // T [3][ld]
   void* last_rpm;      // T [4][ld]
   void* lem;           // T [7][ld]
@@ -211,7 +212,7 @@ static int split_join(mds_handle* h, hipStream_t st, int rc_body) {
 // dispatch on the handle dtype: F32 -> <float,float>, F64 -> <double,double>, F16 -> <float,half_t>
 #define MDS_DISPATCH(h, EXPR)                                               \
   do {                                                                      \
-    if ((h)->cfg.dtype == MDS_F32) {                                        \
+    if ((h)->cfg.dtype == MDS_F32 || (h)->cfg.dtype == MDS_F32C) {           \
       typedef float T; typedef float S; const Consts<T>& C = (h)->cf; (void)C; EXPR; \
     } else if ((h)->cfg.dtype == MDS_F64) {                                 \
       typedef double T; typedef double S; const Consts<T>& C = (h)->cd; (void)C; EXPR; \
@@ -221,6 +222,13 @@ static int split_join(mds_handle* h, hipStream_t st, int rc_body) {
   } while (0)
 
 static inline dim3 grid_for(int n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+static inline bool is_comp(const mds_handle* h) { return h->cfg.dtype == MDS_F32C; }
+static inline bool is_f32(const mds_handle* h) { return h->cfg.dtype == MDS_F32 || h->cfg.dtype == MDS_F32C; }   // fp32 buffers
+// entry points whose kernels keep the state in registers across steps or integrate it in place without the residual planes
+#define MDS_NO_COMP(h, who)                                                                                                          \
+  do {                                                                                                                               \
+    if ((h) && is_comp(h)) return fail(MDS_EUNSUPPORTED, who ": not built for MDS_F32C (compensated fp32) handles");                 \
+  } while (0)
 
 template <typename T> static void fill_cbf(const mds_handle* h, const mds_cbf_params& p, CbfParams<T>& o) {
   o.order = p.order;
@@ -308,9 +316,9 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   *out = nullptr;
   if (cfg->num_envs <= 0 || cfg->num_drones <= 0) return fail(MDS_EINVAL, "mds_create: num_envs/num_drones must be > 0");
   if ((long long)cfg->num_envs * cfg->num_drones > (1LL << 30)) return fail(MDS_EINVAL, "mds_create: too many drones");
-  if (cfg->dtype < MDS_F32 || cfg->dtype > MDS_F16) return fail(MDS_EINVAL, "mds_create: dtype");
+  if (cfg->dtype < MDS_F32 || cfg->dtype > MDS_F32C) return fail(MDS_EINVAL, "mds_create: dtype");
   if (cfg->physics < MDS_PHYSICS_DYN || cfg->physics > MDS_PHYSICS_DYN_GND_DRAG_DW) return fail(MDS_EINVAL, "mds_create: physics");
-  if (cfg->physics >= MDS_PHYSICS_DYN_GND && (cfg->integrator != MDS_INTEGRATOR_EULER || cfg->dtype == MDS_F16))
+  if (cfg->physics >= MDS_PHYSICS_DYN_GND && (cfg->integrator != MDS_INTEGRATOR_EULER || cfg->dtype == MDS_F16 || cfg->dtype == MDS_F32C))
     return fail(MDS_EINVAL, "mds_create: ground effect / downwash run with the explicit Euler integrator on f32 / f64 storage");
   if (cfg->integrator != MDS_INTEGRATOR_EULER && cfg->integrator != MDS_INTEGRATOR_RK4) return fail(MDS_EINVAL, "mds_create: integrator");
   if (cfg->drone_model != MDS_CF2X && cfg->drone_model != MDS_CF2P) return fail(MDS_EINVAL, "mds_create: drone_model");
@@ -360,6 +368,8 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
     mds_set_dslpid_gains(h, &dg);
   }
   hipError_t e = hipMalloc(&h->state, 13 * h->ld * es);
+  if (e == hipSuccess && is_comp(h)) e = hipMalloc(&h->state_lo, 13 * h->ld * es);
+  if (e == hipSuccess && is_comp(h)) e = hipMemset(h->state_lo, 0, 13 * h->ld * es);
   if (e == hipSuccess && h->envfx) e = hipMalloc(&h->state_alt, 13 * h->ld * es);
   if (e == hipSuccess && h->envfx) e = hipMemset(h->state_alt, 0, 13 * h->ld * es);
   if (e == hipSuccess && h->envfx) e = hipMalloc(&h->act_scratch, (size_t)h->n * 4 * es);
@@ -384,7 +394,7 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
     const size_t nbytes = (size_t)h->n * 6 * sizeof(double);
     MDS_HIP(hipMemset(h->scratch, 0, nbytes));
     MDS_DISPATCH(h, (k_reset<T, S><<<grid_for(h->n, 256), 256, 0, 0>>>(h->n, h->ld, h->scratch, h->scratch + (size_t)3 * h->n,
-                                                                         (const T*)h->origin, (S*)h->state, (T*)h->last_rpm, 0)));
+                                                                         (const T*)h->origin, (S*)h->state, (T*)h->last_rpm, 0, (S*)h->state_lo)));
     MDS_HIP(hipGetLastError());
     MDS_HIP(hipDeviceSynchronize());
   }
@@ -406,6 +416,7 @@ int mds_destroy(mds_handle* h) {
   if (!h) return MDS_OK;
   MDS_DEV(h);
   if (h->state) (void)hipFree(h->state);
+  if (h->state_lo) (void)hipFree(h->state_lo);
   if (h->state_alt) (void)hipFree(h->state_alt);
   if (h->act_scratch) (void)hipFree(h->act_scratch);
   if (h->origin) (void)hipFree(h->origin);
@@ -455,7 +466,7 @@ static int launch_reset_range(mds_handle* h, hipStream_t st, size_t i0, size_t i
   const double* xyz = h->init_pose;
   const double* rpy = h->init_pose + (size_t)3 * h->n;
   MDS_DISPATCH(h, (k_reset<T, S><<<grid_for(i1 - i0, 256), 256, 0, st>>>((int)i1, h->ld, xyz, rpy, (const T*)h->origin, (S*)h->state,
-                                                                          (T*)h->last_rpm, (int)i0)));
+                                                                          (T*)h->last_rpm, (int)i0, (S*)h->state_lo)));
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }
@@ -506,7 +517,7 @@ int mds_get_state(mds_handle* h, double* out, void* stream) {
   if (!h || !out) return fail(MDS_EINVAL, "mds_get_state: null argument");
   hipStream_t st = (hipStream_t)stream;
   MDS_DISPATCH(h, (k_get_state<T, S><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, h->ld, (const S*)h->state, (const T*)h->origin,
-                                                                            h->scratch)));
+                                                                            h->scratch, (const S*)h->state_lo)));
   MDS_HIP(hipGetLastError());
   MDS_HIP(hipMemcpyAsync(out, h->scratch, (size_t)h->n * 13 * sizeof(double), hipMemcpyDeviceToHost, st));
   MDS_HIP(hipStreamSynchronize(st));
@@ -519,7 +530,7 @@ int mds_set_state(mds_handle* h, const double* in, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   MDS_HIP(hipMemcpyAsync(h->scratch, in, (size_t)h->n * 13 * sizeof(double), hipMemcpyHostToDevice, st));
   MDS_DISPATCH(h, (k_set_state<T, S><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, h->ld, h->scratch, (const T*)h->origin,
-                                                                            (S*)h->state)));
+                                                                            (S*)h->state, (S*)h->state_lo)));
   MDS_HIP(hipGetLastError());
   MDS_HIP(hipStreamSynchronize(st));
   return MDS_OK;
@@ -530,7 +541,7 @@ int mds_set_origin(mds_handle* h, const double* origin, void* stream) {
   if (!h || !origin) return fail(MDS_EINVAL, "mds_set_origin: null argument");
   hipStream_t st = (hipStream_t)stream;
   MDS_HIP(hipMemcpyAsync(h->scratch, origin, (size_t)h->n * 3 * sizeof(double), hipMemcpyHostToDevice, st));
-  MDS_DISPATCH(h, (k_set_origin<T, S><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, h->ld, h->scratch, (T*)h->origin, (S*)h->state)));
+  MDS_DISPATCH(h, (k_set_origin<T, S><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, h->ld, h->scratch, (T*)h->origin, (S*)h->state, (S*)h->state_lo)));
   MDS_HIP(hipGetLastError());
   MDS_HIP(hipStreamSynchronize(st));
   return MDS_OK;
@@ -557,8 +568,14 @@ static void launch_step_plain(mds_handle* h, const void* action, void* obs, hipS
     pad = static_lds < 32768 ? 32768 - static_lds : 0;
   }
 #define MDS_LAUNCH_STEP(HAS_OBS, RK4, DRAG)                                                                          \
-  MDS_DISPATCH(h, (k_step<T, S, HAS_OBS, RK4, DRAG><<<grid, kBlock, pad, st>>>(C, h->n, h->ld, (S*)h->state, (const T*)h->origin, \
-                                                                               (T*)rpm_track(h), (const S*)action, (S*)obs, (int)batch0)))
+  do {                                                                                                               \
+    if (is_comp(h))                                                                                                  \
+      k_step<float, float, HAS_OBS, RK4, DRAG, true><<<grid, kBlock, pad, st>>>(h->cf, h->n, h->ld, (float*)h->state, (const float*)h->origin, \
+                                                                                (float*)rpm_track(h), (const float*)action, (float*)obs, (int)batch0, (float*)h->state_lo); \
+    else                                                                                                             \
+      MDS_DISPATCH(h, (k_step<T, S, HAS_OBS, RK4, DRAG><<<grid, kBlock, pad, st>>>(C, h->n, h->ld, (S*)h->state, (const T*)h->origin, \
+                                                                                   (T*)rpm_track(h), (const S*)action, (S*)obs, (int)batch0))); \
+  } while (0)
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
 #define MDS_STEP_OBS(HAS_OBS)                           \
   do {                                                  \
@@ -788,7 +805,7 @@ int mds_traj_eval(mds_handle* h, double t, void* des, void* stream) {
   if (h->traj_mode != 2) return fail(MDS_ESTATE, "mds_traj_eval: no trajectories set");
   hipStream_t st = (hipStream_t)stream;
   if (h->cfg.dtype == MDS_F64) k_traj_eval<double><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, t, SegTable{h->segs, h->nseg_total}, h->tinfo, (double*)des);
-  else if (h->cfg.dtype == MDS_F32) k_traj_eval<float><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, t, SegTable{h->segs, h->nseg_total}, h->tinfo, (float*)des);
+  else if (is_f32(h)) k_traj_eval<float><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, t, SegTable{h->segs, h->nseg_total}, h->tinfo, (float*)des);
   else k_traj_eval<half_t><<<grid_for(h->n, 256), 256, 0, st>>>(h->n, t, SegTable{h->segs, h->nseg_total}, h->tinfo, (half_t*)des);
   MDS_HIP(hipGetLastError());
   return MDS_OK;
@@ -826,8 +843,14 @@ static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, 
   if (h->traj_mode == 2) {      // general trajectories: segment tables
     const bool rk4_ = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag_ = has_drag(h);
 #define MDS_TRAJ(RK4, DRAG)                                                                                                   \
-  MDS_DISPATCH(h, (k_step_traj<T, S, RK4, DRAG><<<dim3(nbatch), kBlock, pad, st>>>(C, h->n, h->ld, t, (S*)h->state, (const T*)h->origin, \
-                                                                               SegTable{h->segs, h->nseg_total}, h->tinfo, (T*)rpm_track(h), (S*)obs, (S*)act, (int)batch0)))
+  do {                                                                                                                        \
+    if (is_comp(h))                                                                                                           \
+      k_step_traj<float, float, RK4, DRAG, true><<<dim3(nbatch), kBlock, pad, st>>>(h->cf, h->n, h->ld, t, (float*)h->state, (const float*)h->origin, \
+                                                                                    SegTable{h->segs, h->nseg_total}, h->tinfo, (float*)rpm_track(h), (float*)obs, (float*)act, (int)batch0, (float*)h->state_lo); \
+    else                                                                                                                      \
+      MDS_DISPATCH(h, (k_step_traj<T, S, RK4, DRAG><<<dim3(nbatch), kBlock, pad, st>>>(C, h->n, h->ld, t, (S*)h->state, (const T*)h->origin, \
+                                                                                   SegTable{h->segs, h->nseg_total}, h->tinfo, (T*)rpm_track(h), (S*)obs, (S*)act, (int)batch0))); \
+  } while (0)
     if (rk4_ && drag_) MDS_TRAJ(true, true);
     else if (rk4_) MDS_TRAJ(true, false);
     else if (drag_) MDS_TRAJ(false, true);
@@ -836,9 +859,16 @@ static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, 
     return MDS_OK;
   }
 #define MDS_LAUNCH_GEO2(HAS_OBS, HAS_ACT, RK4, DRAG)                                                                           \
-  MDS_DISPATCH(h, (k_step_geometric<T, S, HAS_OBS, HAS_ACT, RK4, DRAG><<<grid, kBlock, pad, st>>>(C, h->n, h->ld, t, (S*)h->state, \
-                                                                                                (const T*)h->lem, (T*)rpm_track(h), \
-                                                                                                (S*)obs, (S*)act, (int)batch0)))
+  do {                                                                                                                         \
+    if (is_comp(h))                                                                                                            \
+      k_step_geometric<float, float, HAS_OBS, HAS_ACT, RK4, DRAG, true><<<grid, kBlock, pad, st>>>(h->cf, h->n, h->ld, t, (float*)h->state, \
+                                                                                                   (const float*)h->lem, (float*)rpm_track(h), \
+                                                                                                   (float*)obs, (float*)act, (int)batch0, (float*)h->state_lo); \
+    else                                                                                                                       \
+      MDS_DISPATCH(h, (k_step_geometric<T, S, HAS_OBS, HAS_ACT, RK4, DRAG><<<grid, kBlock, pad, st>>>(C, h->n, h->ld, t, (S*)h->state, \
+                                                                                                    (const T*)h->lem, (T*)rpm_track(h), \
+                                                                                                    (S*)obs, (S*)act, (int)batch0))); \
+  } while (0)
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
   const dim3 grid(nbatch);
 #define MDS_LAUNCH_GEO(HAS_OBS, HAS_ACT)                         \
@@ -985,7 +1015,7 @@ int mds_rollout_step_fused(mds_handle* h, const void* actions, int n_action_sets
   if (!h || !actions || n_action_sets < 1 || first_step < 0 || n_steps < 0 || (obs_log && log_slots < 1) || episode_len < 0 ||
       steps_per_launch < 1)
     return fail(MDS_EINVAL, "mds_rollout_step_fused: arguments");
-  if (h->envfx)            // env-mates interact every substep: no state-in-registers form; the step-by-step loop serves it
+  if (h->envfx || is_comp(h))   // env-mates interact every substep / residual planes: no state-in-registers form; the step-by-step loop serves it
     return mds_rollout_step(h, actions, n_action_sets, first_step, n_steps, obs_log, log_slots, episode_len, stream);
   if (episode_len > 0 && !h->init_pose) return fail(MDS_ESTATE, "mds_rollout_step_fused: episode resets need an earlier mds_reset");
   const size_t es = elem_size(h->cfg.dtype), act_bytes = (size_t)h->n * 4 * es, obs_bytes = (size_t)h->n * kObsDim * es;
@@ -1046,6 +1076,7 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
 // ctrl: 0 GeometricControl, 1 LQRController (12-state), 2 LQROmegaController + ThrustOmega, 3 LQRYankOmegaController + YankOmega
 static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream, int ctrl, const char* who) {
   if (!h || n_steps < 0) return fail(MDS_EINVAL, who);
+  MDS_NO_COMP(h, "mds_rollout_*_fused");
   if (h->envfx) {
     // ground effect / downwash: env-mates interact every physics substep, so there is no state-in-registers form; the same loop
     // runs step by step (one launch per substep), each step's observation written straight into its slot of the log
@@ -1429,7 +1460,7 @@ int mds_dslpid_reset(mds_handle* h, void* stream) {
 #define MDS_PID_DTYPE(STEP, RK4, DRAG)                                                        \
   do {                                                                                        \
     if (h->cfg.dtype == MDS_F64) MDS_PID_LAUNCH(double, double, h->cd, h->pid_d, STEP, RK4, DRAG); \
-    else if (h->cfg.dtype == MDS_F32) MDS_PID_LAUNCH(float, float, h->cf, h->pid_f, STEP, RK4, DRAG); \
+    else if (is_f32(h)) MDS_PID_LAUNCH(float, float, h->cf, h->pid_f, STEP, RK4, DRAG); \
     else MDS_PID_LAUNCH(float, half_t, h->cf, h->pid_f, STEP, RK4, DRAG);                     \
   } while (0)
 
@@ -1448,6 +1479,7 @@ int mds_step_dslpid(mds_handle* h, const void* tpos, const void* trpy, void* obs
   MDS_DEV(h);
   if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h || !tpos || !trpy) return fail(MDS_EINVAL, "mds_step_dslpid: null argument");
+  MDS_NO_COMP(h, "mds_step_dslpid");
   if (!aligned16(obs) || !aligned16(act)) return fail(MDS_EALIGN, "mds_step_dslpid: obs_dev/action_dev");
   hipStream_t st = (hipStream_t)stream;
   const void* obs_in = nullptr;
@@ -1482,7 +1514,7 @@ int mds_lqr_omega_compute(mds_handle* h, const void* obs, const void* des, void*
   hipStream_t st = (hipStream_t)stream;
   if (h->cfg.dtype == MDS_F64)
     k_lqr_omega_compute<double, double><<<grid_for(h->n, 256), 256, 0, st>>>(h->cd, h->lqr_d, h->n, (const double*)obs, (const double*)des, (double*)u);
-  else if (h->cfg.dtype == MDS_F32)
+  else if (is_f32(h))
     k_lqr_omega_compute<float, float><<<grid_for(h->n, 256), 256, 0, st>>>(h->cf, h->lqr_f, h->n, (const float*)obs, (const float*)des, (float*)u);
   else
     k_lqr_omega_compute<float, half_t><<<grid_for(h->n, 256), 256, 0, st>>>(h->cf, h->lqr_f, h->n, (const half_t*)obs, (const half_t*)des, (half_t*)u);
@@ -1510,7 +1542,7 @@ int mds_lqr_compute(mds_handle* h, const void* obs, const void* des, void* u, vo
   hipStream_t st = (hipStream_t)stream;
   if (h->cfg.dtype == MDS_F64)
     k_lqr12_compute<double, double><<<grid_for(h->n, 256), 256, 0, st>>>(h->cd, h->lqr12_d, h->n, (const double*)obs, (const double*)des, (double*)u, (double*)action);
-  else if (h->cfg.dtype == MDS_F32)
+  else if (is_f32(h))
     k_lqr12_compute<float, float><<<grid_for(h->n, 256), 256, 0, st>>>(h->cf, h->lqr12_f, h->n, (const float*)obs, (const float*)des, (float*)u, (float*)action);
   else
     k_lqr12_compute<float, half_t><<<grid_for(h->n, 256), 256, 0, st>>>(h->cf, h->lqr12_f, h->n, (const half_t*)obs, (const half_t*)des, (half_t*)u, (half_t*)action);
@@ -1521,6 +1553,7 @@ int mds_lqr_compute(mds_handle* h, const void* obs, const void* des, void* u, vo
 int mds_step_lqr(mds_handle* h, double t, void* obs, void* act, void* stream) {
   MDS_DEV(h);
   if (!h) return fail(MDS_EINVAL, "mds_step_lqr: null handle");
+  MDS_NO_COMP(h, "mds_step_lqr");
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_step_lqr: call mds_set_lemniscate / mds_set_trajectory_segments first");
   if (!h->has_lqr12) return fail(MDS_ESTATE, "mds_step_lqr: call mds_set_lqr_gain first");
   if (!aligned16(obs) || !aligned16(act)) return fail(MDS_EALIGN, "mds_step_lqr: obs_dev/action_dev");
@@ -1534,7 +1567,7 @@ int mds_step_lqr(mds_handle* h, double t, void* obs, void* act, void* stream) {
 #define MDS_LQR(RK4, DRAG)                                                                    \
   do {                                                                                        \
     if (h->cfg.dtype == MDS_F64) MDS_LQR_T(double, double, h->cd, h->lqr12_d, RK4, DRAG);     \
-    else if (h->cfg.dtype == MDS_F32) MDS_LQR_T(float, float, h->cf, h->lqr12_f, RK4, DRAG);  \
+    else if (is_f32(h)) MDS_LQR_T(float, float, h->cf, h->lqr12_f, RK4, DRAG);  \
     else MDS_LQR_T(float, half_t, h->cf, h->lqr12_f, RK4, DRAG);                              \
   } while (0)
   if (rk4 && drag) MDS_LQR(true, true);
@@ -1567,7 +1600,7 @@ int mds_lqr_yank_omega_compute(mds_handle* h, const void* obs, const void* des, 
   hipStream_t st = (hipStream_t)stream;
   if (h->cfg.dtype == MDS_F64)
     k_lqr_yank_omega_compute<double, double><<<grid_for(h->n, 256), 256, 0, st>>>(h->cd, h->lqr_yo_d, h->n, (const double*)obs, (const double*)des, (double*)u);
-  else if (h->cfg.dtype == MDS_F32)
+  else if (is_f32(h))
     k_lqr_yank_omega_compute<float, float><<<grid_for(h->n, 256), 256, 0, st>>>(h->cf, h->lqr_yo_f, h->n, (const float*)obs, (const float*)des, (float*)u);
   else
     k_lqr_yank_omega_compute<float, half_t><<<grid_for(h->n, 256), 256, 0, st>>>(h->cf, h->lqr_yo_f, h->n, (const half_t*)obs, (const half_t*)des, (half_t*)u);
@@ -1679,10 +1712,18 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
   if (h->envfx)            // ground effect / downwash: low level + first substep, then the remaining substeps (whole batch, one stream)
     return step_env_ctrl(h, yank ? 3 : 2, t, u_ll, ll_offset, obs, action, st);
 #define MDS_LL(RK4, DRAG, YANK)                                                                                                  \
-  MDS_DISPATCH(h, (k_lowlevel_step<T, S, RK4, DRAG, YANK><<<grid, kBlock, 0, st>>>(C, n_end, h->ld, (T)(1.0 / h->cfg.ctrl_freq),  \
-                                                                                   (T)ll_offset, (S*)h->state, (const T*)h->origin, \
-                                                                                   (T*)rpm_track(h), (T*)h->ll, (const S*)u_ll,  \
-                                                                                   (S*)obs, (S*)action, batch0)))
+  do {                                                                                                                           \
+    if (is_comp(h))                                                                                                              \
+      k_lowlevel_step<float, float, RK4, DRAG, YANK, true><<<grid, kBlock, 0, st>>>(h->cf, n_end, h->ld, (float)(1.0 / h->cfg.ctrl_freq), \
+                                                                                    (float)ll_offset, (float*)h->state, (const float*)h->origin, \
+                                                                                    (float*)rpm_track(h), (float*)h->ll, (const float*)u_ll, \
+                                                                                    (float*)obs, (float*)action, batch0, (float*)h->state_lo); \
+    else                                                                                                                         \
+      MDS_DISPATCH(h, (k_lowlevel_step<T, S, RK4, DRAG, YANK><<<grid, kBlock, 0, st>>>(C, n_end, h->ld, (T)(1.0 / h->cfg.ctrl_freq),  \
+                                                                                     (T)ll_offset, (S*)h->state, (const T*)h->origin, \
+                                                                                     (T*)rpm_track(h), (T*)h->ll, (const S*)u_ll,  \
+                                                                                     (S*)obs, (S*)action, batch0)));              \
+  } while (0)
 #define MDS_LL_Y(YANK)                           \
   do {                                           \
     if (rk4 && drag) MDS_LL(true, true, YANK);   \
@@ -1759,7 +1800,7 @@ int mds_step_nominal(mds_handle* h, double t, void* obs, void* action, void* str
   if (h->cfg.dtype == MDS_F16) return fail(MDS_EUNSUPPORTED, "mds_step_nominal: fp16 storage");
   // no action wanted: the one-step instance of the whole-rollout kernel does LQR + low level + physics in one launch
   // (212 B per drone-step instead of 392 B over two launches: 34 / 48 us -> 18 us at C3)
-  if (!action && h->has_traj && h->traj_mode == 1 && !h->envfx)
+  if (!action && h->has_traj && h->traj_mode == 1 && !h->envfx && !is_comp(h))
     return rollout_fused(h, t, 1, nullptr, obs, stream, h->cbf_nominal == 2 ? 3 : 2, "mds_step_nominal");
   return step_nominal_lowlevel(h, t, obs, nullptr, action, stream, false, "mds_step_nominal");
 }

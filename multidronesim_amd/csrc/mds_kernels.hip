@@ -89,6 +89,26 @@ template <typename S, typename T> __device__ __forceinline__ void store_state(S*
   stp<S, T>(st + 12 * ld, i, s.w.z);
 }
 
+// residual planes of the compensated storage (MDS_F32C): same packed layout as the state
+template <typename S, typename T> __device__ __forceinline__ void load_resid(const S* __restrict__ lo, size_t ld, size_t i, Resid<T>& r) {
+  State<T> t;
+  load_state<S, T>(lo, ld, i, t);
+  r.p = t.p; r.v = t.v; r.w = t.w;
+  for (int k = 0; k < 4; ++k) r.q[k] = t.q[k];
+}
+template <typename S, typename T> __device__ __forceinline__ void store_resid(S* __restrict__ lo, size_t ld, size_t i, const Resid<T>& r) {
+  State<T> t;
+  t.p = r.p; t.v = r.v; t.w = r.w;
+  for (int k = 0; k < 4; ++k) t.q[k] = r.q[k];
+  store_state<S, T>(lo, ld, i, t);
+}
+// one control step of the rigid body, plain or with compensated accumulation
+template <typename T, bool RK4, bool DRAG, bool COMP>
+__device__ __forceinline__ void aviary_step_any(const Consts<T>& c, State<T>& s, Resid<T>& r, const T action[4], T rpm_prev[4], T clipped[4]) {
+  if (COMP) aviary_step_comp<T, RK4, DRAG>(c, s, r, action, rpm_prev, clipped);
+  else aviary_step<T, RK4, DRAG>(c, s, action, rpm_prev, clipped);
+}
+
 // Observation packing: each lane owns one 20-element row; the wave's rows form one
 // contiguous span of the caller's [n,20] array.  Rows go to LDS (ds_write_b128, conflict
 // free at the 80-byte fp32 row stride), then lane l stores 16-byte chunk (it*64 + l).
@@ -154,23 +174,27 @@ __device__ __forceinline__ void write_obs_rows(unsigned char* __restrict__ lds_b
 // ------------------------------------------------------------------------------------
 // [UPSTREAM] BaseAviary.step for every drone (a1-a4)
 // ------------------------------------------------------------------------------------
-template <typename T, typename S, bool HAS_OBS, bool RK4, bool DRAG>
-__global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && !RK4) ? MDS_STEP_MIN_WAVES : 1) void k_step(const Consts<T> c, const int n, const size_t ld, S* __restrict__ state,
+template <typename T, typename S, bool HAS_OBS, bool RK4, bool DRAG, bool COMP = false>
+__global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && !RK4 && !COMP) ? MDS_STEP_MIN_WAVES : 1) void k_step(const Consts<T> c, const int n, const size_t ld, S* __restrict__ state,
                                                  const T* __restrict__ origin, T* __restrict__ last_rpm,
-                                                 const S* __restrict__ action, S* __restrict__ obs, const int batch0) {
+                                                 const S* __restrict__ action, S* __restrict__ obs, const int batch0,
+                                                 S* __restrict__ state_lo = nullptr) {
   __shared__ __align__(16) unsigned char lds[HAS_OBS ? (kBlock * kObsDim * sizeof(S)) : 16];
   const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
   const bool valid = i < n;
   T o[kObsDim];
   if (valid) {
     State<T> s;
+    Resid<T> r;
     load_state<S, T>(state, ld, i, s);
+    if (COMP) load_resid<S, T>(state_lo, ld, i, r);
     T act[4], prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4];
     load4<S, T>(action + (size_t)i * 4, act);
     if (DRAG)
       for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
-    aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
+    aviary_step_any<T, RK4, DRAG, COMP>(c, s, r, act, prev, clipped);
     store_state<S, T>(state, ld, i, s);
+    if (COMP) store_resid<S, T>(state_lo, ld, i, r);
     if (DRAG || last_rpm)
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
     if (HAS_OBS) {
@@ -358,6 +382,7 @@ __global__ __launch_bounds__(kBlock) void k_step_ctrl_env(const Consts<T> c, con
 template <typename T> struct GeoIn {
   State<T> s;
   LemniscateParams<T> P;
+  Resid<T> r;          // compensated storage only
 };
 template <typename T, typename S>
 __device__ __forceinline__ void load_geo_in(const S* __restrict__ state, const T* __restrict__ lem, size_t ld, size_t i, GeoIn<T>& in) {
@@ -378,10 +403,11 @@ __device__ __forceinline__ void load_geo_in(const S* __restrict__ state, const T
 }
 
 // One batch row of the fused kernel: controller + physics on registers already loaded.
-template <typename T, typename S, bool HAS_OBS, bool HAS_ACT, bool RK4, bool DRAG>
+template <typename T, typename S, bool HAS_OBS, bool HAS_ACT, bool RK4, bool DRAG, bool COMP = false>
 __device__ __forceinline__ void geo_process(const Consts<T>& c, const int n, const size_t ld, const double t, const int i,
                                             GeoIn<T>& in, S* __restrict__ state, T* __restrict__ last_rpm,
-                                            S* __restrict__ obs, S* __restrict__ action_out, unsigned char* lds) {
+                                            S* __restrict__ obs, S* __restrict__ action_out, unsigned char* lds,
+                                            S* __restrict__ state_lo = nullptr) {
   const bool valid = i < n;
   T o[kObsDim];
   if (valid) {
@@ -402,7 +428,7 @@ __device__ __forceinline__ void geo_process(const Consts<T>& c, const int n, con
       geometric_control<T>(c, s.p - des.p, R, s.v, ang_v, des, u, nullptr);
       input_to_action(c, u, act);
     }
-    aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
+    aviary_step_any<T, RK4, DRAG, COMP>(c, s, in.r, act, prev, clipped);
 #endif
     if (DRAG || last_rpm)
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
@@ -419,7 +445,10 @@ __device__ __forceinline__ void geo_process(const Consts<T>& c, const int n, con
   }
   // observation rows go out first (their LDS round trip must not sit behind the state stores)
   if (HAS_OBS) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
-  if (valid) store_state<S, T>(state, ld, i, in.s);
+  if (valid) {
+    store_state<S, T>(state, ld, i, in.s);
+    if (COMP) store_resid<S, T>(state_lo, ld, i, in.r);
+  }
 }
 
 // One batch of 256 drones per workgroup, inputs loaded straight into registers; every dtype / integrator / physics
@@ -427,17 +456,21 @@ __device__ __forceinline__ void geo_process(const Consts<T>& c, const int n, con
 #ifndef MDS_GEOSIMPLE_MIN_WAVES
 #define MDS_GEOSIMPLE_MIN_WAVES 1
 #endif
-template <typename T, typename S, bool HAS_OBS, bool HAS_ACT, bool RK4, bool DRAG>
+template <typename T, typename S, bool HAS_OBS, bool HAS_ACT, bool RK4, bool DRAG, bool COMP = false>
 __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && !RK4) ? MDS_GEOSIMPLE_MIN_WAVES : 1) void k_step_geometric(const Consts<T> c, const int n, const size_t ld, const double t,
                                                            S* __restrict__ state, const T* __restrict__ lem,
                                                            T* __restrict__ last_rpm, S* __restrict__ obs,
-                                                           S* __restrict__ action_out, const int batch0) {
+                                                           S* __restrict__ action_out, const int batch0,
+                                                           S* __restrict__ state_lo = nullptr) {
   __shared__ __align__(16) unsigned char lds[HAS_OBS ? (kBlock * kObsDim * sizeof(S)) : 16];
   // batch0: first 256-drone batch of this launch (a rollout may step the two halves of the shard on two streams)
   const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
   GeoIn<T> in;
-  if (i < n) load_geo_in<T, S>(state, lem, ld, i, in);
-  geo_process<T, S, HAS_OBS, HAS_ACT, RK4, DRAG>(c, n, ld, t, i, in, state, last_rpm, obs, action_out, lds);
+  if (i < n) {
+    load_geo_in<T, S>(state, lem, ld, i, in);
+    if (COMP) load_resid<S, T>(state_lo, ld, i, in.r);
+  }
+  geo_process<T, S, HAS_OBS, HAS_ACT, RK4, DRAG, COMP>(c, n, ld, t, i, in, state, last_rpm, obs, action_out, lds, state_lo);
 }
 
 // ------------------------------------------------------------------------------------
@@ -445,19 +478,21 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 && !RK4) ? MDS_GEOSIMPLE_MI
 // table (mds_traj.hpp TrajLocal: phases and absolute positions in double, the rest in T), relative to the
 // drone's local-frame origin.  obs / action_out may be NULL.
 // ------------------------------------------------------------------------------------
-template <typename T, typename S, bool RK4, bool DRAG>
+template <typename T, typename S, bool RK4, bool DRAG, bool COMP = false>
 __global__ __launch_bounds__(kBlock) void k_step_traj(const Consts<T> c, const int n, const size_t ld, const double t,
                                                       S* __restrict__ state, const T* __restrict__ origin,
                                                       const SegTable segs, const int* __restrict__ tinfo,
                                                       T* __restrict__ last_rpm, S* __restrict__ obs, S* __restrict__ action_out,
-                                                      const int batch0) {
+                                                      const int batch0, S* __restrict__ state_lo = nullptr) {
   __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
   const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
   const bool valid = i < n;
   T o[kObsDim];
   State<T> s;
+  Resid<T> r;
   if (valid) {
     load_state<S, T>(state, ld, i, s);
+    if (COMP) load_resid<S, T>(state_lo, ld, i, r);
     const V3<T> org = {origin[i], origin[ld + i], origin[2 * ld + i]};
     const Desired<T> des = TrajLocal<T>::eval(segs, traj_info(tinfo, i), t, org);
     T prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4], act[4];
@@ -470,14 +505,17 @@ __global__ __launch_bounds__(kBlock) void k_step_traj(const Consts<T> c, const i
       geometric_control<T>(c, s.p - des.p, R, s.v, ang_v, des, u, nullptr);
       input_to_action(c, u, act);
     }
-    aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
+    aviary_step_any<T, RK4, DRAG, COMP>(c, s, r, act, prev, clipped);
     if (DRAG || last_rpm)
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
     if (action_out) store4<S, T>(action_out + (size_t)i * 4, act);
     if (obs) pack_obs(s, org, clipped, o);
   }
   if (obs) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
-  if (valid) store_state<S, T>(state, ld, i, s);
+  if (valid) {
+    store_state<S, T>(state, ld, i, s);
+    if (COMP) store_resid<S, T>(state_lo, ld, i, r);
+  }
 }
 
 // The same fused step with the reference's 12-state LQR (control/lqr/lqr_controller.py) as the controller: the default
@@ -783,19 +821,21 @@ __global__ void k_lqr_yank_omega_compute(const Consts<T> c, const LqrYoGain<T> K
   store4<S, T>(u_out + (size_t)i * 4, u);
 }
 
-template <typename T, typename S, bool RK4, bool DRAG, bool YANK>
+template <typename T, typename S, bool RK4, bool DRAG, bool YANK, bool COMP = false>
 __global__ __launch_bounds__(kBlock) void k_lowlevel_step(const Consts<T> c, const int n, const size_t ld, const T ctrl_dt,
                                                           const T thrust_offset, S* __restrict__ state,
                                                           const T* __restrict__ origin, T* __restrict__ last_rpm,
                                                           T* __restrict__ ll, const S* __restrict__ u_in, S* __restrict__ obs,
-                                                          S* __restrict__ action_out, const int batch0) {
+                                                          S* __restrict__ action_out, const int batch0, S* __restrict__ state_lo = nullptr) {
   __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
   const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
   const bool valid = i < n;
   T o[kObsDim];
   State<T> s;
+  Resid<T> r;
   if (valid) {
     load_state<S, T>(state, ld, i, s);
+    if (COMP) load_resid<S, T>(state_lo, ld, i, r);
     T u[4];
     load4<S, T>(u_in + (size_t)i * 4, u);
     u[0] += thrust_offset;
@@ -815,14 +855,17 @@ __global__ __launch_bounds__(kBlock) void k_lowlevel_step(const Consts<T> c, con
     ll[3 * ld + i] = L.integral.x; ll[4 * ld + i] = L.integral.y; ll[5 * ld + i] = L.integral.z;
     if (DRAG)
       for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
-    aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
+    aviary_step_any<T, RK4, DRAG, COMP>(c, s, r, act, prev, clipped);
     if (DRAG || last_rpm)
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
     if (action_out) store4<S, T>(action_out + (size_t)i * 4, act);
     pack_obs(s, V3<T>{origin[i], origin[ld + i], origin[2 * ld + i]}, clipped, o);
   }
   write_obs_rows<S, T>(lds, obs, n, i, valid, o);
-  if (valid) store_state<S, T>(state, ld, i, s);
+  if (valid) {
+    store_state<S, T>(state, ld, i, s);
+    if (COMP) store_resid<S, T>(state_lo, ld, i, r);
+  }
 }
 
 // ThrustOmegaController.computeControlFromInput through LQROmegaController.compute_low_level
@@ -937,39 +980,48 @@ __global__ __launch_bounds__(kBlock) void k_get_obs(const int n, const size_t ld
 // ------------------------------------------------------------------------------------
 // set-up kernels (double in, storage out; not on the hot path)
 // ------------------------------------------------------------------------------------
+// state_lo (compensated storage, else NULL): what the rounding to S dropped
 template <typename T, typename S>
 __global__ void k_reset(const int n, const size_t ld, const double* __restrict__ xyz, const double* __restrict__ rpy,
-                        const T* __restrict__ origin, S* __restrict__ state, T* __restrict__ last_rpm, const int i0) {
+                        const T* __restrict__ origin, S* __restrict__ state, T* __restrict__ last_rpm, const int i0,
+                        S* __restrict__ state_lo = nullptr) {
   const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double q[4];
   quat_from_euler<double>(rpy[3 * i], rpy[3 * i + 1], rpy[3 * i + 2], q);
-  for (int k = 0; k < 3; ++k) state[sidx(k, i, ld)] = (S)(xyz[3 * i + k] - (double)origin[k * ld + i]);
-  for (int k = 0; k < 4; ++k) state[sidx(3 + k, i, ld)] = (S)q[k];
-  for (int k = 7; k < 13; ++k) state[sidx(k, i, ld)] = (S)0;
+  for (int k = 0; k < 13; ++k) {
+    const double v = k < 3 ? xyz[3 * i + k] - (double)origin[k * ld + i] : (k < 7 ? q[k - 3] : 0.0);
+    const S hi = (S)v;
+    state[sidx(k, i, ld)] = hi;
+    if (state_lo) state_lo[sidx(k, i, ld)] = (S)(v - (double)hi);
+  }
   for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = T(0);
 }
 
 template <typename T, typename S>
 __global__ void k_set_origin(const int n, const size_t ld, const double* __restrict__ new_origin, T* __restrict__ origin,
-                             S* __restrict__ state) {
+                             S* __restrict__ state, S* __restrict__ state_lo = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   for (int k = 0; k < 3; ++k) {
-    const double world = (double)state[sidx(k, i, ld)] + (double)origin[k * ld + i];
+    const double world = (double)state[sidx(k, i, ld)] + (state_lo ? (double)state_lo[sidx(k, i, ld)] : 0.0) + (double)origin[k * ld + i];
     const T no = (T)new_origin[3 * i + k];
     origin[k * ld + i] = no;
-    state[sidx(k, i, ld)] = (S)(world - (double)no);
+    const double local = world - (double)no;
+    const S hi = (S)local;
+    state[sidx(k, i, ld)] = hi;
+    if (state_lo) state_lo[sidx(k, i, ld)] = (S)(local - (double)hi);
   }
 }
 
 template <typename T, typename S>
 __global__ void k_get_state(const int n, const size_t ld, const S* __restrict__ state, const T* __restrict__ origin,
-                            double* __restrict__ out) {
+                            double* __restrict__ out, const S* __restrict__ state_lo = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   for (int k = 0; k < 13; ++k) {
     double v = (double)state[sidx(k, i, ld)];
+    if (state_lo) v += (double)state_lo[sidx(k, i, ld)];
     if (k < 3) v += (double)origin[k * ld + i];
     out[13 * (size_t)i + k] = v;
   }
@@ -977,13 +1029,15 @@ __global__ void k_get_state(const int n, const size_t ld, const S* __restrict__ 
 
 template <typename T, typename S>
 __global__ void k_set_state(const int n, const size_t ld, const double* __restrict__ in, const T* __restrict__ origin,
-                            S* __restrict__ state) {
+                            S* __restrict__ state, S* __restrict__ state_lo = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   for (int k = 0; k < 13; ++k) {
     double v = in[13 * (size_t)i + k];
     if (k < 3) v -= (double)origin[k * ld + i];
-    state[sidx(k, i, ld)] = (S)v;
+    const S hi = (S)v;
+    state[sidx(k, i, ld)] = hi;
+    if (state_lo) state_lo[sidx(k, i, ld)] = (S)(v - (double)hi);
   }
 }
 
