@@ -287,10 +287,12 @@ def main(argv=None):
                     help="mds_set_rollout_streams: 0 auto (the library's policy for the timed call's length), 1 one stream, 2 split")
     ap.add_argument("--c4-scene", default="level", choices=["level", "far"],
                     help="c4 obstacles.  'level': SURVEY 8d's four spheres at (+-0.5, +-0.5, 0.5) -- about a third of the envs fall back to "
-                         "the nominal control like the reference (qptracker.py:30-34): with the omega linearisation the thrust reaches the "
-                         "barrier through e_z only, so an obstacle row of a drone flying towards a sphere's axis leaves the reach of the "
-                         "input box (profiles/tools/c4_scene.py).  'far': the same spheres at (+-12, +-12, 0.65), at least 7 m from every "
-                         "drone: r / v > 2.6 s keeps every obstacle row positive, the QP work is the 120 inter-agent rows per env")
+                         "the nominal control like the reference (qptracker.py:30-34).  Measured (profiles/tools/c4_scene.py): every fallback is "
+                         "an OBSTACLE row beyond the reach of the input box -- the rows are built on the tracking-error state and with the "
+                         "omega linearisation the thrust acts on the barrier through e_z only, so once the filter has pushed a drone ~1 m / "
+                         "4 m/s off its trajectory the row k0 h + k1 hdot + Lf2 h of a static sphere (x_des = x) turns hugely negative for "
+                         "1 < r / |v_err| < 2.6 s whatever the thrust.  'far': the same four spheres 100 m away (r / |v_err| > 15 s): the 64 "
+                         "obstacle rows are still built and scanned every step but stay positive; what remains is the 120 inter-agent rows")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU tests of the N>1 path")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # CPU test of the exit-code relay
     ap.add_argument("--gather-obs", action="store_true",
@@ -383,7 +385,7 @@ def main(argv=None):
         cbf = DroneCBF(env, [LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2,
                        cbf_poles=np.array([-2.2, -2.4]))                                    # CBFTest.py:419
         tracker = DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
-        c4_xy, c4_z = (0.5, 0.5) if args.c4_scene == "level" else (12.0, 0.65)
+        c4_xy, c4_z = (0.5, 0.5) if args.c4_scene == "level" else (100.0, 0.65)
         c4_obs = [np.array([[sx * c4_xy, sy * c4_xy, c4_z], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
         c4_r = [0.1] * 4
     env.set_trajectories(P)
@@ -448,8 +450,8 @@ def main(argv=None):
     barrier(world, local_rank)
     torch.cuda.synchronize(device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    wall0 = time.perf_counter()
     ev0.record(torch.cuda.current_stream(device))       # same stream the kernels are enqueued on
+    wall0 = time.perf_counter()                         # the K steps start here: the marker above is not one of them
     run(args.warmup * dt, args.steps)
     ev1.record(torch.cuda.current_stream(device))
     torch.cuda.synchronize(device)

@@ -65,6 +65,7 @@ struct DevGuard {
 
 __global__ void k_noop() {}
 
+
 }  // namespace
 
 struct mds_handle {

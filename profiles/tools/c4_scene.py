@@ -22,7 +22,7 @@ P[..., 4] = 0.5 + 0.3 * np.arange(D); xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
 env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN, pyb_freq=100, ctrl_freq=100, num_envs=E)
 cbf = DroneCBF(env, [LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2, cbf_poles=np.array([-2.2, -2.4]))
 tracker = DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
-xy, z = (0.5, 0.5) if scene == "level" else (12.0, 0.65)
+xy, z = (0.5, 0.5) if scene == "level" else (100.0, 0.65)
 x_obs = [np.array([[sx * xy, sy * xy, z], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
 r_obs = [0.1] * 4
 env.set_trajectories(P)
@@ -65,3 +65,14 @@ zc = obs_before.reshape(E, D, 20)[..., 2].double().cpu().numpy()
 print("  drone heights at that step: plane spacing check, min |z_i - z_j| over pairs per env: median %.3f min %.3f" % (
     np.median([np.abs(zc[e][:, None] - zc[e][None, :])[np.triu_indices(D, 1)].min() for e in range(0, E, 8)]),
     min(np.abs(zc[e][:, None] - zc[e][None, :])[np.triu_indices(D, 1)].min() for e in range(0, E, 8))))
+if os.environ.get("C4_SCENE_DEBUG"):
+    sl = rows["obstacle"]
+    bad_env = np.where(st != 0)[0][:3]
+    ob = obs_before.reshape(E, D, 20).double().cpu().numpy()
+    for e in bad_env:
+        hk = h[e, sl].reshape(D, 4)
+        Gk = G[e, sl, 0::4].reshape(D, 4, D)
+        d = np.unravel_index(np.argmin(hk), hk.shape)
+        print("env", e, "worst obstacle row: drone", d[0], "obstacle", d[1], "h", hk[d], "G", Gk[d[0], d[1], d[0]], "pos", ob[e, d[0], 0:3], "vel", ob[e, d[0], 10:13],
+              "rpy", ob[e, d[0], 7:10], "xdes vel", xdes[e, d[0], 3:6].cpu().numpy(), "xdes pos", xdes[e, d[0], 6:9].cpu().numpy())
+    print("speeds: max |v| %.2f, max |rpy| %.2f, z range %.2f..%.2f" % (np.abs(ob[..., 10:13]).max(), np.abs(ob[..., 7:9]).max(), ob[..., 2].min(), ob[..., 2].max()))
