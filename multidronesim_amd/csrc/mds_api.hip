@@ -111,6 +111,8 @@ struct mds_handle {
   int split_min_steps = 0;              // auto policy: calls shorter than this stay on one stream (MDS_TUNE_SPLIT_MIN_STEPS, tuning only)
   int last_rollout_streams = 0;         // what the last mds_rollout_* call did (mds_get_last_rollout_streams)
   bool cbf_hildreth = false;            // MDS_CBF_SOLVER=hildreth, read once by mds_cbf_configure
+  bool cbf_fused = false;               // MDS_CBF_FUSED=1 at configure time: the one-launch CBF step (k_cbf_step) where it applies; it wins only
+                                        // on scenes whose QPs need no iterations (see the kernel's header), so the default is the three launches
   void* cbf_unom;      // S [n,4]  scratch of mds_step_cbf_geometric
   void* cbf_xdes;      // S [n,9]
   void* cbf_usafe;     // S [n,4]
@@ -1285,6 +1287,8 @@ int mds_cbf_configure(mds_handle* h, const mds_cbf_params* p, const double* obst
   {
     const char* solver = getenv("MDS_CBF_SOLVER");
     h->cbf_hildreth = solver && solver[0] == 'h';
+    const char* fused = getenv("MDS_CBF_FUSED");
+    h->cbf_fused = fused && fused[0] == '1';
   }
   h->cbf = *p;
   fill_cbf(h, *p, h->cbf_f);
@@ -1668,6 +1672,43 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
   (void)who;
   hipStream_t st = (hipStream_t)stream;
   const size_t es = elem_size(h->cfg.dtype);
+  // One-launch form (k_cbf_step): order 2, whole envs per wave (D | 64, D <= 16), explicit Euler without drag, nominal 0 / 1, no
+  // action output.  Everything else takes the three launches below.
+  {
+    const int D = h->cfg.num_drones;
+    const int m2 = D * (D - 1) / 2 + D * h->cbf.n_obs + 2 * D;
+    if (rg.ne < 0) rg.ne = h->cfg.num_envs;
+    const size_t j0 = (size_t)rg.e0 * D, j1 = j0 + (size_t)rg.ne * D;
+    if (with_filter && h->cbf_fused && !action && h->cbf.order == 2 && !h->cbf_hildreth && D <= 16 && 64 % D == 0 && m2 <= 512 && !h->envfx &&
+        h->cfg.integrator == MDS_INTEGRATOR_EULER && !has_drag(h) && h->cbf_nominal <= 1 && j0 % 64 == 0 && h->cfg.dtype != MDS_F16) {
+      const dim3 grid64((unsigned)((j1 - j0 + 63) / 64));
+      const int batch0 = (int)(j0 / 64), max_iter = h->cbf.max_iter > 0 ? h->cbf.max_iter : 64 * m2;
+      const void* gain = h->cbf_nominal == 1 ? h->gain_dev[1] : nullptr;
+      void* rpm = rpm_track(h);
+#define MDS_CS(T, CC, CP, RR, NOM, COMP, TOL)                                                                                                \
+  k_cbf_step<T, RR, NOM, COMP><<<grid64, 64, 0, st>>>(CC, CP, gain, (int)j1, h->ld, h->cfg.num_envs, t, (T)(1.0 / h->cfg.ctrl_freq), (T*)h->state, \
+                                                      (T*)h->state_lo, (const T*)h->lem, (T*)rpm, (T*)h->ll, h->pair_ij, (const T*)h->obstacles,   \
+                                                      (T*)obs, (int*)status, h->cbf_cost, max_iter, (T)((TOL) * (TOL)), batch0)
+#define MDS_CS_N(T, CC, CP, RR, COMP, TOL)                         \
+  do {                                                             \
+    if (h->cbf_nominal == 1) MDS_CS(T, CC, CP, RR, 1, COMP, TOL);  \
+    else MDS_CS(T, CC, CP, RR, 0, COMP, TOL);                      \
+  } while (0)
+#define MDS_CS_R(T, CC, CP, COMP, TOL)                 \
+  do {                                                 \
+    if (m2 <= 256) MDS_CS_N(T, CC, CP, 4, COMP, TOL);  \
+    else MDS_CS_N(T, CC, CP, 8, COMP, TOL);            \
+  } while (0)
+      if (h->cfg.dtype == MDS_F64) MDS_CS_R(double, h->cd, h->cbf_d, false, (h->cbf.tol > 0 ? h->cbf.tol : 1e-12));
+      else if (is_comp(h)) MDS_CS_R(float, h->cf, h->cbf_f, true, (h->cbf.tol > 0 ? h->cbf.tol : 1e-6));
+      else MDS_CS_R(float, h->cf, h->cbf_f, false, (h->cbf.tol > 0 ? h->cbf.tol : 1e-6));
+#undef MDS_CS_R
+#undef MDS_CS_N
+#undef MDS_CS
+      MDS_HIP(hipGetLastError());
+      return MDS_OK;
+    }
+  }
   if (!h->cbf_unom) {
     MDS_HIP(hipMalloc(&h->cbf_unom, (size_t)h->n * 4 * es));
     MDS_HIP(hipMalloc(&h->cbf_xdes, (size_t)h->n * 10 * es));

@@ -26,6 +26,27 @@ template <typename T> struct CbfParams {
   T Fmin, Fmax;   // order 3 force box (:564-565)
 };
 
+// Order-2 row from the quantities it depends on: e = pos_i - pos_j (actual positions) and the differences of the tracking errors
+// d = (x_i - xdes_i) - (x_j - xdes_j) in roll, pitch and velocity.  Returns h_row and the thrust coefficient L_g L_f h (the omega
+// columns are zero with the omega linearisation).
+template <typename T>
+MDS_HD void cbf_row_o2(const CbfParams<T>& P, T ex, T ey, T ez, T dr, T dp, T dvx, T dvy, T dvz, T Ds, T* h_row, T* Lg0) {
+  const T s = m_fma(ex, ex, ey * ey);
+  const T ezc = ez * P.inv_zscale;
+  const T ezc2 = ezc * ezc;
+  const T Ds2 = Ds * Ds;
+  const T h = m_fma(s, s, m_fma(ezc2, ezc2, -(Ds2 * Ds2)));
+  const T gx = T(4) * ex * s, gy = T(4) * ey * s, gz = T(4) * ez * ez * ez * P.inv_c4;
+  const T Hxx = T(12) * ex * ex + T(4) * ey * ey, Hxy = T(8) * ex * ey, Hyy = T(4) * ex * ex + T(12) * ey * ey,
+          Hzz = T(12) * ez * ez * P.inv_c4;
+  const T dax = P.g * dp, day = -P.g * dr;
+  const T hdot = m_fma(gx, dvx, m_fma(gy, dvy, gz * dvz));
+  const T quad = Hxx * dvx * dvx + T(2) * Hxy * dvx * dvy + Hyy * dvy * dvy + Hzz * dvz * dvz;
+  const T Lf2 = m_fma(gx, dax, gy * day) + quad;
+  *h_row = m_fma(P.k[0], h, m_fma(P.k[1], hdot, Lf2));
+  *Lg0 = gz * P.inv_m;
+}
+
 // One ECBF row between agent i (state xi, desired xdi) and agent / obstacle j.
 //   h_row = Kcbf . hdots + L_f^r h,   Lg[4] with G[4i:4i+4] = -Lg, G[4j:4j+4] = +Lg.
 // e = pos_i - pos_j from the ACTUAL states; d = (xi - xdi) - (xj - xdj) (error states);
@@ -40,26 +61,20 @@ MDS_HD void cbf_pair_row(const CbfParams<T>& P, const T* xi, const T* xdi, const
 #pragma unroll
 #endif
   for (int k = 0; k < xd; ++k) d[k] = (xi[k] - xdi[k]) - (obstacle ? T(0) : (xj[k] - xdj[k]));
-  const T s = m_fma(ex, ex, ey * ey);
-  const T ezc = ez * P.inv_zscale;
-  const T ezc2 = ezc * ezc;
-  const T Ds2 = Ds * Ds;
-  const T h = m_fma(s, s, m_fma(ezc2, ezc2, -(Ds2 * Ds2)));
-  const T gx = T(4) * ex * s, gy = T(4) * ey * s, gz = T(4) * ez * ez * ez * P.inv_c4;
-  const T Hxx = T(12) * ex * ex + T(4) * ey * ey, Hxy = T(8) * ex * ey, Hyy = T(4) * ex * ex + T(12) * ey * ey,
-          Hzz = T(12) * ez * ez * P.inv_c4;
   if (ORDER == 2) {
-    const T dr = d[0], dp = d[1], dvx = d[3], dvy = d[4], dvz = d[5];
-    const T dax = P.g * dp, day = -P.g * dr;
-    const T hdot = m_fma(gx, dvx, m_fma(gy, dvy, gz * dvz));
-    const T quad = Hxx * dvx * dvx + T(2) * Hxy * dvx * dvy + Hyy * dvy * dvy + Hzz * dvz * dvz;
-    const T Lf2 = m_fma(gx, dax, gy * day) + quad;
-    *h_row = m_fma(P.k[0], h, m_fma(P.k[1], hdot, Lf2));
-    Lg[0] = gz * P.inv_m;
+    cbf_row_o2(P, ex, ey, ez, d[0], d[1], d[3], d[4], d[5], Ds, h_row, &Lg[0]);
     Lg[1] = T(0);
     Lg[2] = T(0);
     Lg[3] = T(0);
   } else {
+    const T s = m_fma(ex, ex, ey * ey);
+    const T ezc = ez * P.inv_zscale;
+    const T ezc2 = ezc * ezc;
+    const T Ds2 = Ds * Ds;
+    const T h = m_fma(s, s, m_fma(ezc2, ezc2, -(Ds2 * Ds2)));
+    const T gx = T(4) * ex * s, gy = T(4) * ey * s, gz = T(4) * ez * ez * ez * P.inv_c4;
+    const T Hxx = T(12) * ex * ex + T(4) * ey * ey, Hxy = T(8) * ex * ey, Hyy = T(4) * ex * ex + T(12) * ey * ey,
+            Hzz = T(12) * ez * ez * P.inv_c4;
     constexpr int o3 = ORDER == 2 ? 0 : 1;   // keeps the order-3 slots in range when instantiated for order 2
     const T dr = d[0], dp = d[1], dF = d[3], dvx = d[3 + o3], dvy = d[4 + o3], dvz = d[5 + o3];
     const T dax = P.g * dp, day = -P.g * dr, daz = dF * P.inv_m;

@@ -353,6 +353,249 @@ template <typename T, int NV> struct CbfRow {
   int ij;
 };
 
+// The active-set iterations of k_cbf_filter_gi on rows already built: R unit-norm rows per lane in registers (ca, cb, b, ia, ib,
+// valid), the QP point u in LDS (su, n = NV * D variables), the thin QR of the active normals and the multipliers in the wave's LDS
+// scratch.  ROWTAB: the selected row is fetched from an LDS copy of the rows (srow) by a uniform address; without it, from the owning
+// lane's registers (a select over its R rows + v_readlane) -- 16 bytes of LDS per row less.  Returns converged / iterations; su holds
+// the minimiser when converged.  Must be called with all 64 lanes active.
+template <typename T, int R, int NMAX, int NV, bool ROWTAB, int kQS>
+__device__ __forceinline__ void gi_solve(const int lane, const int n, const int max_iter, const T tol2, const bool infeasible0,
+                                         const T (&ca)[R][NV], const T (&cb)[R][NV], const T (&b)[R], const int (&ia)[R], const int (&ib)[R],
+                                         const bool (&valid)[R], bool (&act)[R], T* __restrict__ su, T* __restrict__ sd,
+                                         T* __restrict__ slam, T* __restrict__ sdi, T (*__restrict__ sQ)[kQS], T (*__restrict__ sR)[kQS],
+                                         int* __restrict__ sact, const CbfRow<T, NV>* __restrict__ srow, bool& converged_out, int& it_out,
+                                         int& q_out) {
+  constexpr bool PRE = NMAX * sizeof(T) <= 128;   // a lane's rows of Q and R fit in registers: one LDS round trip per step instead of 2q
+  static_assert(kQS == (PRE ? ((NMAX + 3) / 4 * 4 + 4) : NMAX + 1), "LDS row stride of Q and R");
+  bool converged = false;
+  bool infeasible = infeasible0;
+  int q = 0, it = 0;
+  while (!infeasible && it < max_iter) {
+    // ---- most violated row outside the active set (distance^2 to its half-space) ----
+    T best = T(0);
+    int best_k = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      T res = -b[k];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) res = m_fma(ca[k][v], su[NV * ia[k] + v], m_fma(cb[k][v], su[NV * ib[k] + v], res));
+      const T sc = (valid[k] && !act[k] && res > T(0)) ? res * res : T(0);
+      if (sc > best) {
+        best = sc;
+        best_k = k;
+      }
+    }
+    const T wbest = wv::allreduce(best, wv::Max());
+    if (!(wbest > tol2)) {
+      converged = true;
+      break;
+    }
+    const int owner = (int)__builtin_ctzll(__ballot(best == wbest));                         // ties: lowest lane, then its lowest row
+    const int kk = wv::get(best_k, owner), wrow = owner + 64 * kk;
+    T wca[NV], wcb[NV], wb;
+    int wia, wib;
+    if constexpr (ROWTAB) {
+      const CbfRow<T, NV> wr = srow[wrow];                                                 // uniform address: one broadcast read
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        wca[v] = wr.ca[v];
+        wcb[v] = wr.cb[v];
+      }
+      wb = wr.b;
+      wia = wr.ij & 255;
+      wib = wr.ij >> 8;
+    } else {                                                                               // no row table in LDS: the owner's registers, row kk
+      T sb_ = b[0];
+      int sia = ia[0], sib = ib[0];
+#pragma unroll
+      for (int k = 1; k < R; ++k) {
+        sb_ = kk == k ? b[k] : sb_;
+        sia = kk == k ? ia[k] : sia;
+        sib = kk == k ? ib[k] : sib;
+      }
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        T sa = ca[0][v], sc = cb[0][v];
+#pragma unroll
+        for (int k = 1; k < R; ++k) {
+          sa = kk == k ? ca[k][v] : sa;
+          sc = kk == k ? cb[k][v] : sc;
+        }
+        wca[v] = wv::get(sa, owner);
+        wcb[v] = wv::get(sc, owner);
+      }
+      wb = wv::get(sb_, owner);
+      wia = wv::get(sia, owner);
+      wib = wv::get(sib, owner);
+    }
+    const bool two = wib != wia;
+    T lam_new = T(0);
+    // ---- bring that row into the active set, dropping blocking rows on the way ----
+    while (true) {
+      if (++it > max_iter) {
+        infeasible = true;
+        break;
+      }
+      // ---- everything this step reads from LDS, in one round trip ----
+      T res = -wb;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) res = m_fma(wca[v], su[NV * wia + v], m_fma(two ? wcb[v] : T(0), su[NV * wib + v], res));
+      T dc = T(0);
+      if (lane < q) {                                                                    // d = Q^T a
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dc = m_fma(wca[v], sQ[NV * wia + v][lane], m_fma(two ? wcb[v] : T(0), sQ[NV * wib + v][lane], dc));
+      }
+      const int ln = lane < NMAX ? lane : NMAX - 1;                                      // lanes >= n hold no row: clamp the address only
+      const T my_lam = slam[ln], my_di = sdi[ln], my_u = su[ln];
+      T zv = T(0), rc = dc;
+      if constexpr (PRE) {
+        T qrow[NMAX], rrow[NMAX];
+#pragma unroll
+        for (int c = 0; c < NMAX; ++c) {
+          qrow[c] = sQ[ln][c];
+          rrow[c] = sR[ln][c];
+        }
+        if (lane < n) {                                                                  // z = a - Q d
+          const int ag = lane / NV, vv = lane - ag * NV;
+#pragma unroll
+          for (int v = 0; v < NV; ++v)
+            if (v == vv) zv = (ag == wia ? wca[v] : T(0)) + ((two && ag == wib) ? wcb[v] : T(0));
+        }
+#pragma unroll
+        for (int c = 0; c < NMAX; ++c) {                                                 // one exit test per column; the compiler keeps it a loop
+          if (c >= q) break;                                                             // with indexed VGPR reads of qrow (no scratch)
+          zv = m_fma(-qrow[c], wv::get(dc, c), zv);                                      // lanes >= n: garbage, masked below
+        }
+        if (lane >= n) zv = T(0);
+        // r = R^-1 d by back substitution on the row-scaled system (row l divided by its pivot, off the serial chain):
+        // per step one v_readlane and one fma -- lane k's entry is final when step k reads it
+#pragma unroll
+        for (int c = 0; c < NMAX; ++c) rrow[c] *= my_di;
+        rc *= my_di;
+#pragma unroll
+        for (int k = NMAX - 1; k >= 0; --k)
+          if (k < q) {
+            const T rk = wv::get(rc, k);
+            rc = lane < k ? m_fma(-rrow[k], rk, rc) : rc;
+          }
+      } else {
+        if (lane < n) sd[lane] = dc;
+        MDS_WAVE_SYNC();
+        if (lane < n) {
+          const int ag = lane / NV, vv = lane - ag * NV;
+#pragma unroll
+          for (int v = 0; v < NV; ++v)
+            if (v == vv) zv = (ag == wia ? wca[v] : T(0)) + ((two && ag == wib) ? wcb[v] : T(0));
+          for (int c = 0; c < q; ++c) zv = m_fma(-sQ[lane][c], sd[c], zv);
+        }
+        for (int k = q - 1; k >= 0; --k) {
+          const T rk = wv::get(rc, k) * sdi[k];
+          if (lane == k) rc = rk;
+          else if (lane < k) rc = m_fma(-sR[lane][k], rk, rc);
+        }
+      }
+      constexpr bool ROW0 = NMAX <= 16;                                                  // z, r, lambda live in lanes 0..n-1 only
+      const T zz = wv::allreduce_n<ROW0>(zv * zv, wv::Add());
+      const T rmax = wv::allreduce_n<ROW0>(lane < q ? m_abs(rc) : T(0), wv::Max());
+      T t1v = GiEps<T>::inf;
+      if (lane < q && rc > GiEps<T>::r * rmax && rc > T(0)) t1v = m_max(my_lam, T(0)) * m_rcp(rc);
+      const T t1 = wv::allreduce_n<ROW0>(t1v, wv::Min());
+      const int drop = t1 < GiEps<T>::inf ? (int)__builtin_ctzll(__ballot(t1v == t1)) : 0;  // ties: lowest column
+      const bool has_z = zz > GiEps<T>::z;
+      const T t2 = has_z ? res * m_rcp(zz) : GiEps<T>::inf;
+      const T t = m_min(t1, t2);
+      if (!(t < GiEps<T>::inf)) {
+        infeasible = true;                                                               // no step possible: rows inconsistent
+        break;
+      }
+      const bool full = has_z && t2 <= t1;
+      MDS_WAVE_SYNC();
+      if (has_z && lane < n) su[lane] = m_fma(-t, zv, my_u);
+      if (lane < q) slam[lane] = m_fma(-t, rc, my_lam);
+      lam_new += t;
+      if (!full) MDS_WAVE_SYNC();                                                        // the drop path reads slam / sact next; the add path only writes
+      if (full) {                                                                        // add: N <- [N a]
+        const T inz = m_rsqrt(zz), nz = zz * inz;
+        if (lane < n) sQ[lane][q] = zv * inz;
+        if (lane < q) sR[lane][q] = dc;
+        if (lane == 0) {
+          sR[q][q] = nz;
+          sdi[q] = inz;
+          slam[q] = lam_new;
+          sact[q] = wrow;
+        }
+        if (lane == owner) {
+#pragma unroll
+          for (int k = 0; k < R; ++k)
+            if (k == kk) act[k] = true;
+        }
+        ++q;
+        MDS_WAVE_SYNC();
+        break;
+      }
+      // ---- drop active column `drop` (its multiplier reached zero) ----
+      const int drow = sact[drop];
+      if (lane == (drow & 63)) {
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+          if (k == (drow >> 6)) act[k] = false;
+      }
+      T lnext = T(0);
+      int anext = 0;
+      if (lane >= drop && lane < q - 1) {
+        lnext = slam[lane + 1];
+        anext = sact[lane + 1];
+      }
+      MDS_WAVE_SYNC();
+      if (lane >= drop && lane < q - 1) {
+        slam[lane] = lnext;
+        sact[lane] = anext;
+      }
+      if (lane < q)                                                                      // each lane shifts its own row of R
+        for (int k = drop; k < q - 1; ++k) sR[lane][k] = sR[lane][k + 1];
+      MDS_WAVE_SYNC();
+      for (int l = drop; l < q - 1; ++l) {                                               // Givens on rows l, l+1
+        const T a = sR[l][l], bb = sR[l + 1][l];
+        const T rr = m_sqrt(m_fma(a, a, bb * bb));
+        const T cs = rr > T(0) ? a / rr : T(1), sn = rr > T(0) ? bb / rr : T(0);
+        MDS_WAVE_SYNC();
+        if (lane >= l && lane < q - 1) {
+          const T x = sR[l][lane], y = sR[l + 1][lane];
+          sR[l][lane] = m_fma(cs, x, sn * y);
+          sR[l + 1][lane] = m_fma(-sn, x, cs * y);
+        }
+        if (lane < n) {
+          const T x = sQ[lane][l], y = sQ[lane][l + 1];
+          sQ[lane][l] = m_fma(cs, x, sn * y);
+          sQ[lane][l + 1] = m_fma(-sn, x, cs * y);
+        }
+        MDS_WAVE_SYNC();
+      }
+      --q;
+      if (lane >= drop && lane < q) sdi[lane] = T(1) / sR[lane][lane];
+      MDS_WAVE_SYNC();
+    }
+  }
+  if (converged && it > 0) {
+    // final certificate: EVERY row (active ones included) holds at the returned point.  Guards the
+    // near-dependent / infeasible corner where a step along a numerically tiny z is taken.  (No iteration: the scan that
+    // declared convergence has just checked every row at the nominal point.)
+    T worst = T(0);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      T res = -b[k];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) res = m_fma(ca[k][v], su[NV * ia[k] + v], m_fma(cb[k][v], su[NV * ib[k] + v], res));
+      if (valid[k]) worst = m_max(worst, res);
+    }
+    worst = wv::allreduce(worst, wv::Max());
+    if (worst * worst > T(100) * tol2) converged = false;
+  }
+  converged_out = converged;
+  it_out = it;
+  q_out = q;
+}
+
 // NV = QP variables per agent (order 2: thrust only -> 1; order 3: yank, wx, wy -> 3, wz is box-only),
 // NMAX = compile-time bound on the number of QP variables n = NV * D (LDS footprint of Q, R ~ NMAX^2),
 // R = rows per lane.  One wavefront (= one env) per workgroup.
@@ -533,201 +776,9 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
   }
   MDS_WAVE_SYNC();
   bool converged = false;
-  bool infeasible = __any(bad);
   int q = 0, it = 0;
-  while (!infeasible && it < max_iter) {
-    // ---- most violated row outside the active set (distance^2 to its half-space) ----
-    T best = T(0);
-    int best_k = 0;
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-      T res = -b[k];
-#pragma unroll
-      for (int v = 0; v < NV; ++v) res = m_fma(ca[k][v], su[NV * ia[k] + v], m_fma(cb[k][v], su[NV * ib[k] + v], res));
-      const T sc = (valid[k] && !act[k] && res > T(0)) ? res * res : T(0);
-      if (sc > best) {
-        best = sc;
-        best_k = k;
-      }
-    }
-    const T wbest = wv::allreduce(best, wv::Max());
-    if (!(wbest > tol2)) {
-      converged = true;
-      break;
-    }
-    const int owner = (int)__builtin_ctzll(__ballot(best == wbest));                         // ties: lowest lane, then its lowest row
-    const int kk = wv::get(best_k, owner), wrow = owner + 64 * kk;
-    const CbfRow<T, NV> wr = srow[wrow];                                                   // uniform address: one broadcast read
-    T wca[NV], wcb[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      wca[v] = wr.ca[v];
-      wcb[v] = wr.cb[v];
-    }
-    const T wb = wr.b;
-    const int wia = wr.ij & 255, wib = wr.ij >> 8;
-    const bool two = wib != wia;
-    T lam_new = T(0);
-    // ---- bring that row into the active set, dropping blocking rows on the way ----
-    while (true) {
-      if (++it > max_iter) {
-        infeasible = true;
-        break;
-      }
-      // ---- everything this step reads from LDS, in one round trip ----
-      T res = -wb;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) res = m_fma(wca[v], su[NV * wia + v], m_fma(two ? wcb[v] : T(0), su[NV * wib + v], res));
-      T dc = T(0);
-      if (lane < q) {                                                                    // d = Q^T a
-#pragma unroll
-        for (int v = 0; v < NV; ++v) dc = m_fma(wca[v], sQ[NV * wia + v][lane], m_fma(two ? wcb[v] : T(0), sQ[NV * wib + v][lane], dc));
-      }
-      const int ln = lane < NMAX ? lane : NMAX - 1;                                      // lanes >= n hold no row: clamp the address only
-      const T my_lam = slam[ln], my_di = sdi[ln], my_u = su[ln];
-      T zv = T(0), rc = dc;
-      if constexpr (PRE) {
-        T qrow[NMAX], rrow[NMAX];
-#pragma unroll
-        for (int c = 0; c < NMAX; ++c) {
-          qrow[c] = sQ[ln][c];
-          rrow[c] = sR[ln][c];
-        }
-        if (lane < n) {                                                                  // z = a - Q d
-          const int ag = lane / NV, vv = lane - ag * NV;
-#pragma unroll
-          for (int v = 0; v < NV; ++v)
-            if (v == vv) zv = (ag == wia ? wca[v] : T(0)) + ((two && ag == wib) ? wcb[v] : T(0));
-        }
-#pragma unroll
-        for (int c = 0; c < NMAX; ++c) {                                                 // one exit test per column; the compiler keeps it a loop
-          if (c >= q) break;                                                             // with indexed VGPR reads of qrow (no scratch)
-          zv = m_fma(-qrow[c], wv::get(dc, c), zv);                                      // lanes >= n: garbage, masked below
-        }
-        if (lane >= n) zv = T(0);
-        // r = R^-1 d by back substitution on the row-scaled system (row l divided by its pivot, off the serial chain):
-        // per step one v_readlane and one fma -- lane k's entry is final when step k reads it
-#pragma unroll
-        for (int c = 0; c < NMAX; ++c) rrow[c] *= my_di;
-        rc *= my_di;
-#pragma unroll
-        for (int k = NMAX - 1; k >= 0; --k)
-          if (k < q) {
-            const T rk = wv::get(rc, k);
-            rc = lane < k ? m_fma(-rrow[k], rk, rc) : rc;
-          }
-      } else {
-        if (lane < n) sd[lane] = dc;
-        MDS_WAVE_SYNC();
-        if (lane < n) {
-          const int ag = lane / NV, vv = lane - ag * NV;
-#pragma unroll
-          for (int v = 0; v < NV; ++v)
-            if (v == vv) zv = (ag == wia ? wca[v] : T(0)) + ((two && ag == wib) ? wcb[v] : T(0));
-          for (int c = 0; c < q; ++c) zv = m_fma(-sQ[lane][c], sd[c], zv);
-        }
-        for (int k = q - 1; k >= 0; --k) {
-          const T rk = wv::get(rc, k) * sdi[k];
-          if (lane == k) rc = rk;
-          else if (lane < k) rc = m_fma(-sR[lane][k], rk, rc);
-        }
-      }
-      constexpr bool ROW0 = NMAX <= 16;                                                  // z, r, lambda live in lanes 0..n-1 only
-      const T zz = wv::allreduce_n<ROW0>(zv * zv, wv::Add());
-      const T rmax = wv::allreduce_n<ROW0>(lane < q ? m_abs(rc) : T(0), wv::Max());
-      T t1v = GiEps<T>::inf;
-      if (lane < q && rc > GiEps<T>::r * rmax && rc > T(0)) t1v = m_max(my_lam, T(0)) * m_rcp(rc);
-      const T t1 = wv::allreduce_n<ROW0>(t1v, wv::Min());
-      const int drop = t1 < GiEps<T>::inf ? (int)__builtin_ctzll(__ballot(t1v == t1)) : 0;  // ties: lowest column
-      const bool has_z = zz > GiEps<T>::z;
-      const T t2 = has_z ? res * m_rcp(zz) : GiEps<T>::inf;
-      const T t = m_min(t1, t2);
-      if (!(t < GiEps<T>::inf)) {
-        infeasible = true;                                                               // no step possible: rows inconsistent
-        break;
-      }
-      const bool full = has_z && t2 <= t1;
-      MDS_WAVE_SYNC();
-      if (has_z && lane < n) su[lane] = m_fma(-t, zv, my_u);
-      if (lane < q) slam[lane] = m_fma(-t, rc, my_lam);
-      lam_new += t;
-      if (!full) MDS_WAVE_SYNC();                                                        // the drop path reads slam / sact next; the add path only writes
-      if (full) {                                                                        // add: N <- [N a]
-        const T inz = m_rsqrt(zz), nz = zz * inz;
-        if (lane < n) sQ[lane][q] = zv * inz;
-        if (lane < q) sR[lane][q] = dc;
-        if (lane == 0) {
-          sR[q][q] = nz;
-          sdi[q] = inz;
-          slam[q] = lam_new;
-          sact[q] = wrow;
-        }
-        if (lane == owner) {
-#pragma unroll
-          for (int k = 0; k < R; ++k)
-            if (k == kk) act[k] = true;
-        }
-        ++q;
-        MDS_WAVE_SYNC();
-        break;
-      }
-      // ---- drop active column `drop` (its multiplier reached zero) ----
-      const int drow = sact[drop];
-      if (lane == (drow & 63)) {
-#pragma unroll
-        for (int k = 0; k < R; ++k)
-          if (k == (drow >> 6)) act[k] = false;
-      }
-      T lnext = T(0);
-      int anext = 0;
-      if (lane >= drop && lane < q - 1) {
-        lnext = slam[lane + 1];
-        anext = sact[lane + 1];
-      }
-      MDS_WAVE_SYNC();
-      if (lane >= drop && lane < q - 1) {
-        slam[lane] = lnext;
-        sact[lane] = anext;
-      }
-      if (lane < q)                                                                      // each lane shifts its own row of R
-        for (int k = drop; k < q - 1; ++k) sR[lane][k] = sR[lane][k + 1];
-      MDS_WAVE_SYNC();
-      for (int l = drop; l < q - 1; ++l) {                                               // Givens on rows l, l+1
-        const T a = sR[l][l], bb = sR[l + 1][l];
-        const T rr = m_sqrt(m_fma(a, a, bb * bb));
-        const T cs = rr > T(0) ? a / rr : T(1), sn = rr > T(0) ? bb / rr : T(0);
-        MDS_WAVE_SYNC();
-        if (lane >= l && lane < q - 1) {
-          const T x = sR[l][lane], y = sR[l + 1][lane];
-          sR[l][lane] = m_fma(cs, x, sn * y);
-          sR[l + 1][lane] = m_fma(-sn, x, cs * y);
-        }
-        if (lane < n) {
-          const T x = sQ[lane][l], y = sQ[lane][l + 1];
-          sQ[lane][l] = m_fma(cs, x, sn * y);
-          sQ[lane][l + 1] = m_fma(-sn, x, cs * y);
-        }
-        MDS_WAVE_SYNC();
-      }
-      --q;
-      if (lane >= drop && lane < q) sdi[lane] = T(1) / sR[lane][lane];
-      MDS_WAVE_SYNC();
-    }
-  }
-  if (converged) {
-    // final certificate: EVERY row (active ones included) holds at the returned point.  Guards the
-    // near-dependent / infeasible corner where a step along a numerically tiny z is taken.
-    T worst = T(0);
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-      T res = -b[k];
-#pragma unroll
-      for (int v = 0; v < NV; ++v) res = m_fma(ca[k][v], su[NV * ia[k] + v], m_fma(cb[k][v], su[NV * ib[k] + v], res));
-      if (valid[k]) worst = m_max(worst, res);
-    }
-    worst = wv::allreduce(worst, wv::Max());
-    if (worst * worst > T(100) * tol2) converged = false;
-  }
+  gi_solve<T, R, NMAX, NV, true, kQS>(lane, n, max_iter, tol2, __any(bad), ca, cb, b, ia, ib, valid, act, su, sd, slam, sdi, sQ, sR, sact, srow,
+                                      converged, it, q);
 #if defined(MDS_TUNE_ITERS)   // tuning build: iteration count and final active-set size in the high bits of status
   {
     const int nbox = __popcll(__ballot(lane < q && sact[lane < NMAX ? lane : 0] >= npairs + nobs_rows));
@@ -758,6 +809,215 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
       }
       usafe[base * 4 + k] = (S)u;
     }
+  }
+}
+
+// Row r of an order-2 env whose drones' world positions / tracking errors sit in LDS rows d0 .. d0 + D - 1 (k_cbf_step): the
+// unit-norm row  ca u[ia] + cb u[ib] <= b, whether it exists (vld), and whether it makes the QP infeasible by itself (bad: a
+// barrier row beyond the reach of the input box, or 0 * u <= h with h < 0).  Pair and obstacle rows are the same barrier with
+// different second operands: the operands are selected and the ~100-op row body runs once per slot, whatever kinds it straddles.
+template <typename T>
+__device__ __forceinline__ void cbf_o2_slot(const CbfParams<T>& P, const T (*__restrict__ pos)[3], const T (*__restrict__ de)[5],
+                                            const T* __restrict__ sob, const int d0, const int r, const int pair, const int npairs,
+                                            const int nobs_rows, const int m, const int n, T& ca, T& cb, T& b, int& ia, int& ib, bool& vld,
+                                            bool& bad) {
+  ca = cb = b = T(0);
+  ia = ib = 0;
+  vld = false;
+  const bool is_pair = r < npairs, is_obs = !is_pair && r < npairs + nobs_rows;
+  if (is_pair || is_obs) {
+    const int qo = r - npairs, ag = is_pair ? (pair & 255) : ((qo * P.obs_magic) >> 16);          // ag = q / n_obs, exact for q < 4096
+    const int oo = is_pair ? 0 : qo - ag * P.n_obs, bg = is_pair ? (pair >> 8) : ag;
+    const T* pi = pos[d0 + ag];
+    const T* di = de[d0 + ag];
+    const T* pj = is_pair ? pos[d0 + bg] : &sob[4 * oo];
+    const T* dj = de[d0 + bg];
+    const T z = T(0);
+    T hr, lg;
+    cbf_row_o2<T>(P, pi[0] - pj[0], pi[1] - pj[1], pi[2] - pj[2], di[0] - (is_pair ? dj[0] : z), di[1] - (is_pair ? dj[1] : z),
+                  di[2] - (is_pair ? dj[2] : z), di[3] - (is_pair ? dj[3] : z), di[4] - (is_pair ? dj[4] : z),
+                  is_pair ? P.Ds_pair : P.safety_radius + sob[4 * oo + 3], &hr, &lg);
+    ia = ag;
+    ib = bg;
+    ca = -lg;
+    cb = is_pair ? lg : T(0);
+    b = hr;
+  } else if (r < m) {                                          // +-u_var <= umax (cbf/cbf.py:400-412)
+    const int q = r - npairs - nobs_rows, var = q < n ? q : q - n;
+    ia = ib = var;
+    ca = q < n ? T(1) : T(-1);
+    b = P.umax[0];
+  }
+  if (r < m) {
+    const T n2 = m_fma(ca, ca, cb * cb);
+    if (n2 > T(0)) {
+      const T inv = m_rsqrt(n2);
+      ca *= inv;
+      cb *= inv;
+      b *= inv;
+      vld = true;
+      if (r < npairs + nobs_rows) {                            // beyond the reach of the input box: infeasible by itself (see k_cbf_filter_gi)
+        const T reach = (m_abs(ca) + m_abs(cb)) * P.umax[0];
+        if (b < -reach * (T(1) + T(sizeof(T) == 4 ? 1e-5 : 1e-10))) bad = true;
+      }
+    } else if (b < T(0)) {
+      bad = true;                                              // 0 * u <= h with h < 0
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// One CBF-filtered control step of simulations/CBFTest.py:303-350 in ONE launch (order 2, D | 64, D <= 16):
+//   stage A, one drone per lane : trajs[j](t), nominal controller (GeometricControl return_omegas, NOM 0, or LQROmegaController,
+//                                 NOM 1) -> u_hat = (force - M G, w), and what the rows need of obs_to_lin_model(obs) - xdes: the
+//                                 world position and the tracking errors in roll, pitch, velocity;
+//   stage B, one env at a time  : the wave's 64 / D envs in turn -- rows built R per lane from the LDS copy of stage A's outputs,
+//                                 most-violated-row scan, gi_solve (rows stay in registers: no row table);
+//   stage C, one drone per lane : u_safe (nominal if the env's QP has no solution, qptracker.py:30-34) + M G -> ThrustOmega low level
+//                                 -> physics step -> observation row -> state.
+// The three-launch path (k_cbf_nominal / k_cbf_filter_gi / k_lowlevel_step) moves u_hat, xdes, u_safe and the state through HBM
+// twice and runs the per-drone stages at full lane use but the QP kernel one env per wave; here the per-drone stages keep every lane
+// busy (a wave = 64 drones = 64 / D whole envs) and nothing but state, trajectory parameters and the observation crosses HBM.
+// Same arithmetic as the three kernels (shared device functions); x is formed from the state exactly as pack_obs would hand it over.
+// Measured at C4 (16 384 x 16, MI355X, profiles/r02_c4_fused.md): 32 us against 42 us per control step when no env needs an
+// iteration, but 74-80 us against 56 us on SURVEY 8d's scene, where a third of the envs iterate: 4096 waves is 4 per SIMD, each a
+// serial chain of four QPs (10.6 cycles per instruction per wave, VALU pipe 48 % busy), while the three-launch path gives the
+// latency-bound QP 16 384 waves and a longest-first dispatch.  Hence opt-in: MDS_CBF_FUSED=1 at mds_cbf_configure time.
+// ------------------------------------------------------------------------------------
+template <typename T, int R, int NOM, bool COMP>
+__global__ __launch_bounds__(64, (sizeof(T) == 4 && R == 4) ? 4 : 1) void k_cbf_step(const Consts<T> c, const CbfParams<T> P, const void* __restrict__ Kp, const int n_end,
+                                                 const size_t ld, const int E, const double t, const T ctrl_dt, T* __restrict__ state,
+                                                 T* __restrict__ state_lo, const T* __restrict__ lem, T* __restrict__ last_rpm,
+                                                 T* __restrict__ ll, const int* __restrict__ pair_ij, const T* __restrict__ obstacles,
+                                                 T* __restrict__ obs, int* __restrict__ status, int* __restrict__ cost_out,
+                                                 const int max_iter, const T tol2, const int batch0) {
+  constexpr int NMAX = 16, NV = 1;
+  constexpr int kQS = (NMAX + 3) / 4 * 4 + 4;
+  // LDS of the wave: [ solver scratch + stage A's per-drone outputs | aliased by the observation staging of stage C ] [ su | sconv ]
+  struct Work {
+    T pos[64][3], de[64][5];
+    T sd[NMAX], slam[NMAX], sdi[NMAX];
+    T sQ[NMAX][kQS], sR[NMAX][kQS];
+    int sact[NMAX];
+    T sob[kCbfMaxObs * 4];
+  };
+  constexpr size_t kObsBytes = (size_t)64 * kObsDim * sizeof(T);
+  constexpr size_t kWork = sizeof(Work) > kObsBytes ? sizeof(Work) : kObsBytes;
+  __shared__ __align__(16) unsigned char raw[(kWork + 15) / 16 * 16];
+  __shared__ T su_all[64];
+  __shared__ int sconv[64];
+  Work& W = *reinterpret_cast<Work*>(raw);
+  const int lane = threadIdx.x;
+  const int D = P.num_drones, G = 64 / D;
+  const int i = (batch0 + blockIdx.x) * 64 + lane;
+  const bool valid = i < n_end;
+  const int env0 = ((batch0 + blockIdx.x) * 64) / D;
+
+  // ---- stage A: nominal controller of drone i ----
+  GeoIn<T> in;
+  T un[4] = {T(0), T(0), T(0), T(0)};
+  int rpair[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) rpair[k] = lane + 64 * k < cbf_num_pairs(D) ? pair_ij[lane + 64 * k] : 0;
+  W.sob[lane] = lane < 4 * P.n_obs ? obstacles[lane] : T(0);
+  if (valid) {
+    load_geo_in<T, T>(state, lem, ld, i, in);
+    const Desired<T> des = lemniscate_local(in.P, t);
+    const V3<T> rpy = euler_from_quat(in.s.q);
+    if (NOM == 0) {
+      const M3<T> Rm = quat_to_rot(in.s.q);
+      const V3<T> ang_v = mul(Rm, in.s.w);
+      T u[4];
+      GeoAux<T> A;
+      geometric_control<T>(c, in.s.p - des.p, Rm, in.s.v, ang_v, des, u, &A);
+      un[0] = A.force - c.gravity;
+      un[1] = A.w_des.x; un[2] = A.w_des.y; un[3] = A.w_des.z;
+    } else {
+      T u[4];
+      lqr_omega_control<T>(c, *static_cast<const LqrGain<T>*>(Kp), rpy, in.s.v, in.s.p, des.p, des.v, des.yaw, u);
+      un[0] = u[0] - c.gravity;                                                    // CBFTest.py:339
+      un[1] = u[1]; un[2] = u[2]; un[3] = u[3];
+    }
+    // obs_to_lin_model(obs, 9) - xdes with obs = pack_obs(state): rpy, world velocity, world position; xdes = [0, 0, yaw, v_des, p_des]
+    W.pos[lane][0] = in.s.p.x + in.P.cx;
+    W.pos[lane][1] = in.s.p.y + in.P.cy;
+    W.pos[lane][2] = in.s.p.z + in.P.cz;
+    W.de[lane][0] = rpy.x - T(0);
+    W.de[lane][1] = rpy.y - T(0);
+    W.de[lane][2] = in.s.v.x - des.v.x;
+    W.de[lane][3] = in.s.v.y - des.v.y;
+    W.de[lane][4] = in.s.v.z - des.v.z;
+    su_all[lane] = un[0];
+  }
+  MDS_WAVE_SYNC();
+
+  // ---- stage B: the wave's envs, one after the other ----
+  const int n = D;                                             // QP variables per env (order 2: the thrusts)
+  const int npairs = cbf_num_pairs(D), nobs_rows = D * P.n_obs, m = npairs + nobs_rows + 2 * n;
+  for (int g = 0; g < G; ++g) {
+    const int env = env0 + g;
+    if (env >= E) break;                                       // wave-uniform
+    const int d0 = g * D;                                      // first lane / LDS row of this env's drones
+    T ca[R][NV], cb[R][NV], b[R];
+    int ia[R], ib[R];
+    bool vld[R], act[R];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      act[k] = false;
+      cbf_o2_slot<T>(P, W.pos, W.de, W.sob, d0, lane + 64 * k, rpair[k], npairs, nobs_rows, m, n, ca[k][0], cb[k][0], b[k], ia[k], ib[k], vld[k], bad);
+    }
+    bool converged = false;
+    int it = 0, q = 0;
+    gi_solve<T, R, NMAX, NV, false, kQS>(lane, n, max_iter, tol2, __any(bad), ca, cb, b, ia, ib, vld, act, &su_all[d0], W.sd, W.slam, W.sdi, W.sQ,
+                                         W.sR, W.sact, nullptr, converged, it, q);
+    if (lane == 0) {
+      status[env] = converged ? 0 : 1;
+      if (cost_out) cost_out[env] = it;
+    }
+    if (lane >= d0 && lane < d0 + D) sconv[lane] = converged ? 1 : 0;
+    MDS_WAVE_SYNC();
+  }
+
+  // ---- stage C: low level + physics of drone i ----
+  // The state and the trajectory centre are read again here rather than held in 20 registers across stage B (146 -> 4 waves per
+  // SIMD); the pointers go through an empty asm so that the compiler does not keep the first copies alive instead.
+  T o[kObsDim];
+  T safe = T(0);
+  int conv = 0;
+  if (valid) {
+    safe = su_all[lane];
+    conv = sconv[lane];
+  }
+  MDS_WAVE_SYNC();                                             // raw is the observation staging from here on
+  const T* state2 = state;
+  const T* lem2 = lem;
+  asm volatile("" : "+s"(state2), "+s"(lem2));
+  GeoIn<T> in2;
+  if (valid) {
+    load_geo_in<T, T>(state2, lem2, ld, i, in2);
+    if (COMP) load_resid<T, T>(state_lo, ld, i, in2.r);
+    T u[4];
+    u[0] = (conv ? safe : un[0]) + c.gravity;                                              // CBFTest.py:346
+    u[1] = conv ? m_clamp(un[1], -P.umax[1], P.umax[1]) : un[1];
+    u[2] = conv ? m_clamp(un[2], -P.umax[2], P.umax[2]) : un[2];
+    u[3] = conv ? m_clamp(un[3], -P.umax[3], P.umax[3]) : un[3];
+    LowLevelState<T> L;
+    L.last_omega = {ll[0 * ld + i], ll[1 * ld + i], ll[2 * ld + i]};
+    L.integral = {ll[3 * ld + i], ll[4 * ld + i], ll[5 * ld + i]};
+    T act4[4], prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4];
+    thrust_omega_control(c, ctrl_dt, u, in2.s.w, L, act4);
+    ll[0 * ld + i] = L.last_omega.x; ll[1 * ld + i] = L.last_omega.y; ll[2 * ld + i] = L.last_omega.z;
+    ll[3 * ld + i] = L.integral.x; ll[4 * ld + i] = L.integral.y; ll[5 * ld + i] = L.integral.z;
+    aviary_step_any<T, false, false, COMP>(c, in2.s, in2.r, act4, prev, clipped);
+    if (last_rpm)
+      for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
+    pack_obs(in2.s, V3<T>{in2.P.cx, in2.P.cy, in2.P.cz}, clipped, o);
+  }
+  write_obs_rows<T, T>(raw, obs, n_end, i, valid, o);
+  if (valid) {
+    store_state<T, T>(state, ld, i, in2.s);
+    if (COMP) store_resid<T, T>(state_lo, ld, i, in2.r);
   }
 }
 

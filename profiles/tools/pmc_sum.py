@@ -6,5 +6,5 @@ for d in sys.argv[1:]:
             k = r["Kernel_Name"][:60]
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
         for k in acc:
-            if "cbf" in k or "lowlevel" in k:
+            if "cbf" in k or "lowlevel" in k or "k_step_geometric" in k:
                 print(k, {c: round(acc[k][c] / cnt[k][c]) for c in acc[k]}, "launches", max(cnt[k].values()))

@@ -480,6 +480,65 @@ def test_c4_full_size_properties(mds):
     assert np.abs(g[..., :16] - oobs.reshape(g.shape)[..., :16]).max() < 1e-4
 
 
+@pytest.mark.parametrize("nominal", ["geometric", "lqr_omega"])
+def test_one_launch_cbf_step_matches_the_three_launch_path(mds, nominal, monkeypatch):
+    """k_cbf_step (MDS_CBF_FUSED=1: nominal controller, the wave's 64 / D QPs and the low level + physics step in one launch) against
+    the default three launches on the same scene: per-env statuses and iteration counts equal at every step, observations equal to
+    rounding (the stages share their device functions; the launches may contract FMAs differently), float64 and float32; the two-chain
+    rollout of the one-launch form equals its step-by-step loop bitwise.  D = 16 (4 envs per wave), a ragged last wave (E = 70 -> 1120
+    drones = 17 full waves + 32 lanes), obstacles among the drones so that rows go active and some envs fall back."""
+    from multidronesim_amd.control.lqr.lqr_omega_controller import LQROmegaController
+    E, D, steps = 70, 16, 60
+    xyz, rpy, P = H.c2_setup(E, D, phase="c3", offset=1.5)
+    P[..., 4] = 0.5 + 0.3 * np.arange(D)
+    xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    x_obs = [np.array([[sx * 0.5, sy * 0.5, 0.5], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
+    obs_r = [0.1] * 4
+    for dtype, tol in (("float64", 1e-9), ("float32", 2e-4)):
+        out = {}
+        for fused in ("0", "1"):
+            monkeypatch.setenv("MDS_CBF_FUSED", fused)
+            env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                                 pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype)
+            env.set_trajectories(P)
+            if nominal == "lqr_omega":
+                LQROmegaController(env, mds.LinearizedOmegaModel(env), None)
+                env.set_cbf_nominal("lqr_omega")
+            cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2,
+                               cbf_poles=np.array([-2.2, -2.4]))
+            trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+            env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+            t, hist, its = 0.0, [], []
+            for k in range(steps):
+                o, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
+                hist.append(st.cpu().numpy().copy())
+                its.append(cbf.last_iterations().cpu().numpy().copy())
+                t += env.CTRL_TIMESTEP
+            out[fused] = (o.double().cpu().numpy().copy(), np.array(hist), np.array(its), env.get_state())
+            if fused == "1":                                    # the C loop on two chains issues the same launches
+                b = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                                   pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype)
+                b.set_trajectories(P)
+                if nominal == "lqr_omega":
+                    LQROmegaController(b, mds.LinearizedOmegaModel(b), None)
+                    b.set_cbf_nominal("lqr_omega")
+                cb2 = mds.DroneCBF(b, [mds.LinearizedOmegaModel(b) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2,
+                                   cbf_poles=np.array([-2.2, -2.4]))
+                tb = mds.DroneQPTracker(cb2, num_robots=D, xdim=9, env=b)
+                b.set_rollout_streams(2)
+                b.step(mds.torch.zeros((E, D, 4), dtype=b.dtype))
+                ob, sb = b.rollout_cbf_geometric(0.0, steps, tb, x_obs, obs_r)
+                np.testing.assert_array_equal(ob.double().cpu().numpy(), out["1"][0])
+                np.testing.assert_array_equal(b.get_state(), out["1"][3])
+                b.close()
+            env.close()
+        np.testing.assert_array_equal(out["0"][1], out["1"][1])
+        np.testing.assert_array_equal(out["0"][2], out["1"][2])
+        assert 0.0 < out["0"][1].mean() < 1.0 and out["0"][2].max() >= 2        # fallbacks and real iterations both occur
+        assert np.abs(out["0"][0][..., :16] - out["1"][0][..., :16]).max() < tol
+        np.testing.assert_allclose(out["0"][3], out["1"][3], atol=tol)
+
+
 @pytest.mark.parametrize("streams", [1, 2])
 def test_cbf_rollout_equals_stepwise(mds, streams):
     """mds_rollout_cbf_geometric (C loop; with two streams the env halves run as independent chains with their own cost

@@ -32,8 +32,8 @@ def kernel_ops(isa, mangled):
 
 
 def test_hot_kernels_have_no_scratch_and_expected_occupancy(isa):
-    for name, max_vgpr in (("_ZN3mds16k_step_geometricIffLb1ELb0ELb0ELb0EEEvNS_6ConstsIT_EEimdPT0_PKS2_PS2_S5_S5_i", 64),
-                           ("_ZN3mds6k_stepIffLb1ELb0ELb0EEEvNS_6ConstsIT_EEimPT0_PKS2_PS2_PKS4_S5_i", 64)):
+    for name, max_vgpr in (("_ZN3mds16k_step_geometricIffLb1ELb0ELb0ELb0ELb0EEEvNS_6ConstsIT_EEimdPT0_PKS2_PS2_S5_S5_iS5_", 64),
+                           ("_ZN3mds6k_stepIffLb1ELb0ELb0ELb0EEEvNS_6ConstsIT_EEimPT0_PKS2_PS2_PKS4_S5_iS5_", 64)):
         meta = isa[isa.index("amdhsa.kernels:"):]
         blk = next(b for b in meta.split("\n  - ") if re.search(r"\.name:\s+" + re.escape(name) + r"\n", b))
         vg = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
@@ -43,7 +43,7 @@ def test_hot_kernels_have_no_scratch_and_expected_occupancy(isa):
 
 
 def test_no_mfma_and_no_barrier_in_hot_kernel(isa):
-    ops = kernel_ops(isa, "_ZN3mds16k_step_geometricIffLb1ELb0ELb0ELb0EEEvNS_6ConstsIT_EEimdPT0_PKS2_PS2_S5_S5_i")
+    ops = kernel_ops(isa, "_ZN3mds16k_step_geometricIffLb1ELb0ELb0ELb0ELb0EEEvNS_6ConstsIT_EEimdPT0_PKS2_PS2_S5_S5_iS5_")
     assert not [o for o in ops if "mfma" in o]
     assert not [o for o in ops if o.startswith("s_barrier")]          # wave-scope LDS staging only
     assert len([o for o in ops if o.startswith("global_store_dwordx4")]) == 5 + 3   # obs span 5 x 1 KiB per wave + 3 packed state groups
