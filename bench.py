@@ -340,11 +340,17 @@ def main(argv=None):
     all_cores = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and args.workload in ("c2", "c3"):
         all_cores = cpu_baseline_all_cores(D, phase, min(6.0, args.cpu_budget))      # forks: before anything touches the GPU
-    rank, local_rank, world = dist_init("nccl")
+    # MDS_BENCH_DIST_BACKEND=gloo + MDS_BENCH_SHARE_GPU=1: rehearsal of the N > 1 path on a one-GPU box (every rank on device 0, the
+    # timing reductions over gloo on host tensors); the real run is one rank per GPU over RCCL
+    backend = os.environ.get("MDS_BENCH_DIST_BACKEND", "nccl")
+    rank, local_rank, world = dist_init(backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("MDS_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    red_dev = device if backend == "nccl" else torch.device("cpu")        # where the timing reductions live
 
     import __graft_entry__
     if not os.path.exists(__graft_entry__.LIB):
@@ -459,10 +465,10 @@ def main(argv=None):
     barrier(world, local_rank)
     wall = time.perf_counter() - wall0
     dev_ms = ev0.elapsed_time(ev1)
-    elapsed = max_over_ranks(wall, world, device)
-    dev_ms_max = max_over_ranks(dev_ms, world, device)
-    dev_ms_ranks = gather_over_ranks(dev_ms, world, device)
-    wall_ranks = gather_over_ranks(wall_mine, world, device)
+    elapsed = max_over_ranks(wall, world, red_dev)
+    dev_ms_max = max_over_ranks(dev_ms, world, red_dev)
+    dev_ms_ranks = gather_over_ranks(dev_ms, world, red_dev)
+    wall_ranks = gather_over_ranks(wall_mine, world, red_dev)
     used_streams = env.last_rollout_streams() if c_loop else 1
 
     obs = c5_log[(c5_k[0] - 1) % c5_T] if c5 else env._obs
@@ -585,7 +591,7 @@ def main(argv=None):
         env.rollout_geometric_fused(0.0, T2, log=True, log_out=log2)
         reps = 10
         us = _timed_steps(device, lambda: [env.rollout_geometric_fused(r_ * T2 * dt, T2, log=True, log_out=log2) for r_ in range(reps)], reps * T2)
-        us = max_over_ranks(us, world, device)
+        us = max_over_ranks(us, world, red_dev)
         b2 = 20 * es + 53 * es / T2
         line["fused_rollout"] = {"steps_per_launch": T2, "us_per_step": us, "value": n_local * world / (us * 1e-6), "unit": "drone-steps/s",
                                  "bytes_per_drone_step": b2, "achieved_GBps": b2 * n_local / (us * 1e-6) / 1e9,
@@ -599,7 +605,7 @@ def main(argv=None):
         env.rollout_step(c5_act_tab, 0, C5_EPISODE, c5_log, episode_len=C5_EPISODE, steps_per_launch=T2)
         us = _timed_steps(device, lambda: env.rollout_step(c5_act_tab, C5_EPISODE, reps * C5_EPISODE, c5_log, episode_len=C5_EPISODE,
                                                            steps_per_launch=T2), reps * C5_EPISODE)
-        us = max_over_ranks(us, world, device)
+        us = max_over_ranks(us, world, red_dev)
         b2 = 24 * es + 26 * es / T2
         line["fused_rollout"] = {"steps_per_launch": T2, "us_per_step": us, "value": n_local * world / (us * 1e-6), "unit": "drone-steps/s",
                                  "bytes_per_drone_step": b2, "achieved_GBps": b2 * n_local / (us * 1e-6) / 1e9,
@@ -669,7 +675,7 @@ def main(argv=None):
         for _ in range(3):
             all_gather_observations(mine, buf)
         ms = _timed_steps(device, lambda: [all_gather_observations(mine, buf) for _ in range(20)], 20) * 1e-3
-        ms = max_over_ranks(ms, world, device)
+        ms = max_over_ranks(ms, world, red_dev)
         line["obs_allgather"] = {"ms": ms, "bytes_per_rank": mine.numel() * mine.element_size(), "backend": "nccl (RCCL)",
                                  "bus_GBps": mine.numel() * mine.element_size() * (world - 1) / (ms * 1e-3) / 1e9}
         del buf

@@ -63,7 +63,7 @@ def test_struct_layout_matches_header(lib):
     assert C.sizeof(capi.MdsGeometricGains) == 14 * 8
 
 
-@pytest.mark.parametrize("mut", [dict(num_envs=0), dict(num_drones=-1), dict(dtype=9), dict(physics=5), dict(integrator=2),
+@pytest.mark.parametrize("mut", [dict(num_envs=0), dict(num_drones=-1), dict(dtype=9), dict(dtype=4), dict(physics=5), dict(integrator=2),
                                  dict(drone_model=3), dict(pyb_freq=240, ctrl_freq=100), dict(ctrl_freq=0), dict(M=0.0),
                                  dict(KF=-1.0)])
 def test_create_rejects_bad_config_before_touching_the_device(lib, mut):
@@ -90,6 +90,34 @@ def test_null_handle_calls_return_einval(lib):
     assert lib.mds_yank_omega_compute(None, None, None, None, None) == -1
     assert lib.mds_set_lqr_gain(None, None) == -1
     assert lib.mds_destroy(None) == 0
+    # round-2 entry points
+    assert lib.mds_set_rollout_streams(None, 2) == -1
+    assert lib.mds_get_last_rollout_streams(None) == -1
+    assert lib.mds_rollout_streams_for(None, 0, 100) == -1
+    assert lib.mds_cbf_last_iterations(None, None, None) == -1
+    assert lib.mds_rollout_geometric(None, 0.0, 5, None, 1, None) == -1
+    assert lib.mds_rollout_cbf_geometric(None, 0.0, 5, None, None, None) == -1
+
+
+def test_compensated_dtype_is_a_valid_config_and_env_effects_reject_it(lib):
+    """MDS_F32C passes mds_create's validation (it then fails on the missing device here, not on the dtype); with ground effect /
+    downwash physics it is refused before the device is touched."""
+    cfg = capi.MdsConfig()
+    lib.mds_default_config(capi.MDS_CF2P, C.byref(cfg))
+    cfg.dtype = capi.MDS_F32C
+    h = C.c_void_p()
+    rc = lib.mds_create(C.byref(cfg), C.byref(h))
+    import torch
+    if torch.cuda.is_available():
+        assert rc == 0
+        lib.mds_destroy(h)
+    else:
+        assert rc in (-3, -2) and not h.value          # HIP error: no device -- not MDS_EINVAL
+    cfg.physics = capi.MDS_PHYSICS_DYN_GND
+    assert lib.mds_create(C.byref(cfg), C.byref(h)) == -1
+    cfg.dtype = 4
+    cfg.physics = capi.MDS_PHYSICS_DYN
+    assert lib.mds_create(C.byref(cfg), C.byref(h)) == -1
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
