@@ -264,6 +264,51 @@ def mint_dyn_wrench_accel(ref):
     print("dyn_wrench_accel", u.shape, "clipped rows:", int(((rpm < 0) | (rpm > env.MAX_RPM)).any(axis=1).sum()))
 
 
+def mint_closed_loop_reference_in_the_loop(ref):
+    """The do_control loop of simulations/EnvGeometric.py:431-473 with the REFERENCE's own objects in it: per drone a
+    trajectories/Lemniscate.py object sampled at t, a control/geometric.py GeometricControl.compute(obs) (through the reference's
+    obs_to_geo_model and input_to_action), t += CTRL_TIMESTEP.  Only env.step is not the reference's (it is [UPSTREAM] PyBullet
+    there): the explicit DYN step of oracle/np_oracle.py stands in, and the fixture says so.  8 drones (the C3 phase rule, per-drone
+    centres, one drone with a yawing trajectory), 100 Hz, 1000 control steps; observations every 50 steps."""
+    import os as _os
+    sys.path.insert(0, _os.path.dirname(_os.path.dirname(OUT)))
+    from oracle import np_oracle as O
+    env = make_env()
+    Lem = ref["lem"].Lemniscate
+    G = ref["geo"].GeometricControl
+    D, steps = 8, 1000
+    rng = np.random.default_rng(21)
+    cen = np.zeros((D, 3))
+    cen[:, :2] = rng.uniform(-5, 5, size=(D, 2))
+    cen[:, 2] = 0.5
+    ang = 2 * np.pi * np.arange(D) / D
+    xyz = cen + np.stack([np.sin(ang), np.cos(ang), np.zeros(D)], axis=1)
+    P = np.zeros((D, 7))
+    P[:, 0], P[:, 1], P[:, 2:5] = 1.0, 1.5, cen
+    P[:, 6] = 2 * np.pi * np.arange(D) / (D + 0.25)
+    P[3, 5] = 0.02                                  # one slowly yawing drone (yaw reaches 0.6 rad; the reference controller, with its no-op transpose, leaves its trajectory for good once |yaw| passes ~2 rad: yaw_rate 0.2 diverges after 3.5 s)
+    P[5, 0], P[5, 1] = 0.7, 1.1
+    trajs = [Lem(a=P[j, 0], omega=P[j, 1], center=P[j, 2:5].copy(), yaw_rate=P[j, 5], phase_shift=P[j, 6]) for j in range(D)]
+    ctrl = [G(env) for _ in range(D)]
+    ora = O.AviaryOracle(xyz, np.zeros((D, 3)), O.CF2P, 100, 100)
+    obs = ora.step(np.zeros((D, 4)))                # EnvGeometric.py:431
+    t, log, acts = 0.0, [obs.copy()], []
+    for i in range(steps):
+        action = np.zeros((D, 4))
+        for j in range(D):
+            pos, vel, acc, yaw, omega = trajs[j](t)
+            ctrl[j].set_desired_trajectory(j, pos, vel, acc, yaw, omega)
+            action[j] = ctrl[j].compute(obs[j].copy())
+        obs = ora.step(action)
+        t += 0.01
+        if (i + 1) % 50 == 0:
+            log.append(obs.copy())
+            acts.append(action.copy())
+    np.savez_compressed(OUT + "/closed_loop_ref_in_loop.npz", xyz=xyz, params=P, obs_log=np.array(log), action_log=np.array(acts), steps=steps,
+                        every=50, physics="oracle DYN step (np_oracle.AviaryOracle); trajectories and controller: reference objects", **META)
+    print("closed loop (reference in the loop)", np.array(log).shape, "final |pos - centre| max", np.abs(obs[:, :3] - cen).max())
+
+
 def mint_cbf(ref):
     env = make_env()
     cbf = ref["cbf"]
@@ -532,6 +577,7 @@ if __name__ == "__main__":
     mint_mixer(ref)
     mint_dynamics(ref)
     mint_dyn_wrench_accel(ref)
+    mint_closed_loop_reference_in_the_loop(ref)
     mint_cbf(ref)
     mint_thrust_omega()
     mint_lqr_omega(ref)

@@ -340,6 +340,31 @@ def test_fused_geometric_1000_steps(mds, E, D, phase, dtype, tol):
     env.close()
 
 
+@pytest.mark.parametrize("dtype,tol,rtol_rpm", [("float64", 1e-8, 1e-9), ("float32", 1e-5, 5e-6), ("float32c", 1e-5, 5e-6)])
+def test_fused_loop_against_the_reference_objects_in_the_loop(mds, dtype, tol, rtol_rpm):
+    """The fused kernel (trajectory -> GeometricControl -> mixer -> DYN step) over 1000 control steps against
+    tests/golden/closed_loop_ref_in_loop.npz, a rollout in which trajectory sampling and controller were the reference's OWN
+    Lemniscate / GeometricControl objects (only env.step was the oracle's): every 50th observation within north_star's 1e-5 (fp32)."""
+    d = np.load(os.path.join(G, "closed_loop_ref_in_loop.npz"))
+    P, every = d["params"], int(d["every"])
+    D = P.shape[0]
+    env = make_env(mds, 1, D, d["xyz"], np.zeros((D, 3)), dtype)
+    env.set_trajectories(P)
+    obs, *_ = env.step(mds.torch.zeros((1, D, 4), dtype=env.dtype, device=env.device))
+    np.testing.assert_allclose(np_obs(obs), d["obs_log"][0], rtol=0, atol=tol)
+    t = 0.0
+    for i in range(int(d["steps"])):
+        obs, act = env.step_geometric(t, return_action=True)
+        t += env.CTRL_TIMESTEP
+        if (i + 1) % every == 0:
+            k = (i + 1) // every
+            g = np_obs(obs)
+            assert np.abs(g[:, :16] - d["obs_log"][k][:, :16]).max() < tol, (i + 1)
+            np.testing.assert_allclose(g[:, 16:], d["obs_log"][k][:, 16:], rtol=rtol_rpm)
+            np.testing.assert_allclose(act.double().cpu().numpy().reshape(D, 4), d["action_log"][k - 1], rtol=rtol_rpm)
+    env.close()
+
+
 def test_fused_matches_unfused_operator_chain(mds):
     """step_geometric == lemniscate_eval -> geometric_compute -> step, operator by operator."""
     from multidronesim_amd.control.geometric import GeometricControl

@@ -233,3 +233,25 @@ def test_dyn_wrench_and_accelerations_match_the_reference_tree():
     obs = ora.step(d["rpm"])
     np.testing.assert_allclose((obs[:, 10:13] - d["vel"]) * 240, d["v_dot"], rtol=0, atol=1e-9)
     np.testing.assert_allclose(obs[:, 16:20], clipped, rtol=0, atol=0)
+
+
+def test_closed_loop_with_the_reference_objects_in_the_loop():
+    """tests/golden/closed_loop_ref_in_loop.npz: 1000 control steps of the EnvGeometric.py loop in which the trajectory sampling and
+    the controller are the REFERENCE's own Lemniscate / GeometricControl objects (per drone, reference call order) and only env.step is
+    the oracle's DYN step.  The oracle's vectorised loop -- its own lemniscate() and geometric_compute() -- must walk the same path."""
+    d = load("closed_loop_ref_in_loop.npz")
+    P, every = d["params"], int(d["every"])
+    D = P.shape[0]
+    ora = O.AviaryOracle(d["xyz"], np.zeros((D, 3)), O.CF2P, 100, 100)
+    obs = ora.step(np.zeros((D, 4)))
+    np.testing.assert_allclose(obs, d["obs_log"][0], rtol=0, atol=1e-14)
+    t = 0.0
+    for i in range(int(d["steps"])):
+        pos, vel, acc, yaw, yd = O.lemniscate(t, P[:, 0], P[:, 1], P[:, 2:5], P[:, 5], P[:, 6])
+        act = O.geometric_compute(obs, pos, vel, acc, yaw, yd)
+        obs = ora.step(act)
+        t += 0.01
+        if (i + 1) % every == 0:
+            k = (i + 1) // every
+            np.testing.assert_allclose(act, d["action_log"][k - 1], rtol=1e-9)
+            np.testing.assert_allclose(obs, d["obs_log"][k], rtol=0, atol=1e-8)
