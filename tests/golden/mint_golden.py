@@ -309,6 +309,47 @@ def mint_closed_loop_reference_in_the_loop(ref):
     print("closed loop (reference in the loop)", np.array(log).shape, "final |pos - centre| max", np.abs(obs[:, :3] - cen).max())
 
 
+def mint_closed_loop_lqr_reference_in_the_loop(ref):
+    """The same loop with the controller simulations/EnvGeometric.py runs by default: per drone a reference LQRController
+    (control/lqr/lqr_controller.py on model/linearized.py, gain from its own solve_continuous_are) fed by a reference Lemniscate,
+    wind 2.5e-4 N along x on every drone from the first control step on (EnvGeometric.py:34,463-467).  Only env.step is the oracle's
+    DYN step.  4 drones, 100 Hz, 600 control steps; observations every 50 steps."""
+    import contextlib
+    import io
+    import os as _os
+    sys.path.insert(0, _os.path.dirname(_os.path.dirname(OUT)))
+    from oracle import np_oracle as O
+    lin = load("model.linearized", REF + "/model/linearized.py")
+    mod = load("control.lqr.lqr_controller", REF + "/control/lqr/lqr_controller.py")
+    env = make_env()
+    Lem = ref["lem"].Lemniscate
+    D, steps = 4, 600
+    xyz = np.array([[np.sin(2 * np.pi * j / D), np.cos(2 * np.pi * j / D), 0.5] for j in range(D)])
+    P = np.array([[1.0, 1.5, 0.0, 0.0, 0.5, 0.0, (-np.pi / 4) * (j - 1)] for j in range(D)])         # EnvGeometric.py:540
+    trajs = [Lem(a=P[j, 0], omega=P[j, 1], center=P[j, 2:5].copy(), yaw_rate=P[j, 5], phase_shift=P[j, 6]) for j in range(D)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        ctrl = [mod.LQRController(env, lin.LinearizedModel(env)) for _ in range(D)]
+    ora = O.AviaryOracle(xyz, np.zeros((D, 3)), O.CF2P, 100, 100)
+    obs = ora.step(np.zeros((D, 4)))
+    ora.wind = np.array([2.5e-4, 0.0, 0.0])
+    t, log, acts = 0.0, [obs.copy()], []
+    for i in range(steps):
+        action = np.zeros((D, 4))
+        for j in range(D):
+            pos, vel, acc, yaw, omega = trajs[j](t)
+            ctrl[j].set_desired_trajectory(j, pos, vel, acc, yaw, omega)
+            action[j], _ = ctrl[j].compute(obs[j].copy())
+        obs = ora.step(action)
+        t += 0.01
+        if (i + 1) % 50 == 0:
+            log.append(obs.copy())
+            acts.append(action.copy())
+    np.savez_compressed(OUT + "/closed_loop_lqr_ref_in_loop.npz", xyz=xyz, params=P, K=ctrl[0].K, wind=ora.wind, obs_log=np.array(log),
+                        action_log=np.array(acts), steps=steps, every=50,
+                        physics="oracle DYN step (np_oracle.AviaryOracle); trajectories and controller: reference objects", **META)
+    print("closed loop lqr (reference in the loop)", np.array(log).shape, "final |pos - centre| max", np.abs(obs[:, :3] - P[:, 2:5]).max())
+
+
 def mint_cbf(ref):
     env = make_env()
     cbf = ref["cbf"]
@@ -578,6 +619,7 @@ if __name__ == "__main__":
     mint_dynamics(ref)
     mint_dyn_wrench_accel(ref)
     mint_closed_loop_reference_in_the_loop(ref)
+    mint_closed_loop_lqr_reference_in_the_loop(ref)
     mint_cbf(ref)
     mint_thrust_omega()
     mint_lqr_omega(ref)

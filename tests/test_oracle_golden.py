@@ -255,3 +255,26 @@ def test_closed_loop_with_the_reference_objects_in_the_loop():
             k = (i + 1) // every
             np.testing.assert_allclose(act, d["action_log"][k - 1], rtol=1e-9)
             np.testing.assert_allclose(obs, d["obs_log"][k], rtol=0, atol=1e-8)
+
+
+def test_closed_loop_lqr_with_the_reference_objects_in_the_loop():
+    """tests/golden/closed_loop_lqr_ref_in_loop.npz: the default 'lqr' loop of simulations/EnvGeometric.py (reference LQRController on
+    LinearizedModel, reference Lemniscate, wind on from the first control step), 600 steps; the oracle's lqr12 loop walks the same path."""
+    d = load("closed_loop_lqr_ref_in_loop.npz")
+    P, every = d["params"], int(d["every"])
+    D = P.shape[0]
+    K = O.lqr12_gain(O.CF2P)
+    np.testing.assert_allclose(K, d["K"], rtol=1e-8, atol=1e-10)
+    ora = O.AviaryOracle(d["xyz"], np.zeros((D, 3)), O.CF2P, 100, 100)
+    obs = ora.step(np.zeros((D, 4)))
+    ora.wind = d["wind"]
+    t = 0.0
+    for i in range(int(d["steps"])):
+        pos, vel, acc, yaw, yd = O.lemniscate(t, P[:, 0], P[:, 1], P[:, 2:5], P[:, 5], P[:, 6])
+        act, _ = O.lqr12_compute(obs, pos, vel, yaw, yd, K)
+        obs = ora.step(act)
+        t += 0.01
+        if (i + 1) % every == 0:
+            k = (i + 1) // every
+            np.testing.assert_allclose(act, d["action_log"][k - 1], rtol=1e-7)
+            np.testing.assert_allclose(obs, d["obs_log"][k], rtol=0, atol=1e-7)
