@@ -461,11 +461,10 @@ def main(argv=None):
     run(args.warmup * dt, args.steps)
     ev1.record(torch.cuda.current_stream(device))
     torch.cuda.synchronize(device)
-    wall_mine = time.perf_counter() - wall0
-    barrier(world, local_rank)
-    wall = time.perf_counter() - wall0
+    wall_mine = time.perf_counter() - wall0             # this rank's K steps: first enqueue .. its synchronize returns
+    barrier(world, local_rank)                          # closing bracket; its own latency (an RCCL barrier, ~100 us) is not part of the K steps
     dev_ms = ev0.elapsed_time(ev1)
-    elapsed = max_over_ranks(wall, world, red_dev)
+    elapsed = max_over_ranks(wall_mine, world, red_dev)  # the slowest rank's time
     dev_ms_max = max_over_ranks(dev_ms, world, red_dev)
     dev_ms_ranks = gather_over_ranks(dev_ms, world, red_dev)
     wall_ranks = gather_over_ranks(wall_mine, world, red_dev)
