@@ -154,10 +154,10 @@ static inline void* rpm_track(mds_handle* h) {
 
 // Shards at least this large step their two halves on two streams inside mds_rollout_geometric (0 = auto policy).
 constexpr size_t kSplitMinDrones = size_t(1) << 18;
-// Calls shorter than this stay on the caller's stream under the auto policy: the two chains cost a fork and a join (two
-// cross-stream dependencies, ~25 us per call) and start in lock step.  C3, us per control step by call length, one stream ->
-// two chains: 5 steps 17.9 -> 21.2, 20 steps 17.5 -> 17.6, 50 steps 17.3 -> 16.2, 100 steps 17.7 -> 15.7, 2000 steps 17.6 -> 15.4
-// (profiles/r02_short_calls.log).
+// Calls shorter than this stay on the caller's stream under the auto policy: a two-chain call costs a fork and a join (two
+// cross-stream dependencies) and its halves start in lock step -- ~35 us more than n x its steady-state step.  C3, us per
+// control step by call length, one stream -> two chains: 5 steps 18.0 -> 20.0, 20 steps 17.1-17.4 -> 17.0-17.1, 50 steps
+// 16.7 -> 15.5, 100 steps 17.4 -> 15.2, 2000 steps 17.4 -> 14.8 (profiles/r02_short_calls.log).
 #ifndef MDS_SPLIT_MIN_STEPS
 #define MDS_SPLIT_MIN_STEPS 32
 #endif
