@@ -293,6 +293,7 @@ def main(argv=None):
                          "4 m/s off its trajectory the row k0 h + k1 hdot + Lf2 h of a static sphere (x_des = x) turns hugely negative for "
                          "1 < r / |v_err| < 2.6 s whatever the thrust.  'far': the same four spheres 100 m away (r / |v_err| > 15 s): the 64 "
                          "obstacle rows are still built and scanned every step but stay positive; what remains is the 120 inter-agent rows")
+    ap.add_argument("--c5-log-gb", type=float, default=200.0, help="c5: size of the rollout log ring in GB (SURVEY 8d: sized for the 288 GB of HBM)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU tests of the N>1 path")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # CPU test of the exit-code relay
     ap.add_argument("--gather-obs", action="store_true",
@@ -377,7 +378,11 @@ def main(argv=None):
         g = torch.Generator(device=device).manual_seed(1234 + rank)
         c5_actions = [(env.HOVER_RPM * (1 + 0.05 * torch.randn((E, D, 4), device=device, generator=g))).clamp(0, env.MAX_RPM).to(env.dtype)
                       for _ in range(8)]
-        c5_T = 16
+        # rollout log [T, E, D, 20]: SURVEY 8d sizes it for the 288 GB of HBM ("T so that the buffer stays under ~250 GB"); --c5-log-gb
+        # (default 200, clamped to 70 % of what is free) -- the observation stream then really goes to HBM, slot after slot
+        slot_bytes = E * D * 20 * {torch.float16: 2, torch.float32: 4, torch.float64: 8}[env.dtype]
+        free_b = torch.cuda.mem_get_info(device)[0]
+        c5_T = max(16, int(min(args.c5_log_gb * 1e9, 0.7 * free_b) // slot_bytes))
         c5_log = torch.empty((c5_T, E, D, 20), dtype=env.dtype, device=device)
         c5_act_tab = torch.stack(c5_actions).contiguous()                       # [8,E,D,4]: the action table of the C loop
         c5_actions = [c5_act_tab[k] for k in range(8)]
@@ -558,7 +563,7 @@ def main(argv=None):
         line["roofline"]["traffic"] = None
         line["dtype"] = {"float16": "f16-storage/f32-math", "float32": "f32", "float64": "f64"}[str(env.dtype).split(".")[-1]]
         line["config"].update({"pyb_freq": 240, "ctrl_freq": 240,
-                               "episode_steps": C5_EPISODE,
+                               "episode_steps": C5_EPISODE, "rollout_log_slots": c5_T, "rollout_log_GB": c5_T * slot_bytes / 1e9,
                                "launch": "python ctypes loop, obs -> rollout log slot" if args.python_loop else
                                ("C loop (mds_rollout_step), half shards on 2 streams, obs -> rollout log slot" if split
                                 else "C loop (mds_rollout_step), one stream, obs -> rollout log slot")})
@@ -610,7 +615,7 @@ def main(argv=None):
                                  "bytes_per_drone_step": b2, "achieved_GBps": b2 * n_local / (us * 1e-6) / 1e9,
                                  "bound": "VALU (state in registers; the action table is read, the observation log written)",
                                  "kernel": "k_rollout_step<float,_Float16,false,false>",
-                                 "state_sane": bool(torch.isfinite(c5_log).all().item())}
+                                 "state_sane": bool(torch.isfinite(c5_log[:16]).all().item())}
     env.close()
     del env
     if args.workload == "c3" and world == 1 and not fused_T and not args.python_loop and extras and not rk4:
