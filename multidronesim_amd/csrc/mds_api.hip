@@ -111,6 +111,8 @@ struct mds_handle {
   int split_min_steps = 0;              // auto policy: calls shorter than this stay on one stream (MDS_TUNE_SPLIT_MIN_STEPS, tuning only)
   int last_rollout_streams = 0;         // what the last mds_rollout_* call did (mds_get_last_rollout_streams)
   bool cbf_hildreth = false;            // MDS_CBF_SOLVER=hildreth, read once by mds_cbf_configure
+  bool cbf_q4 = false;                  // MDS_CBF_Q4=1 at configure time: the four-envs-per-wave QP kernel (k_cbf_filter_q4) where it applies; measured
+                                        // no faster than one env per wave (see its header), so opt-in
   bool cbf_fused = false;               // MDS_CBF_FUSED=1 at configure time: the one-launch CBF step (k_cbf_step) where it applies; it wins only
                                         // on scenes whose QPs need no iterations (see the kernel's header), so the default is the three launches
   void* cbf_unom;      // S [n,4]  scratch of mds_step_cbf_geometric
@@ -1287,6 +1289,8 @@ int mds_cbf_configure(mds_handle* h, const mds_cbf_params* p, const double* obst
   {
     const char* solver = getenv("MDS_CBF_SOLVER");
     h->cbf_hildreth = solver && solver[0] == 'h';
+    const char* q4e = getenv("MDS_CBF_Q4");
+    h->cbf_q4 = q4e && q4e[0] == '1';
     const char* fused = getenv("MDS_CBF_FUSED");
     h->cbf_fused = fused && fused[0] == '1';
   }
@@ -1385,22 +1389,37 @@ static int cbf_filter_range(mds_handle* h, const void* obs_, const void* xdes_, 
     else if (R <= 8) MDS_HILD(T, CP, 8, TOL); \
     else MDS_HILD(T, CP, 17, TOL);          \
   } while (0)
+  // order 2 with at most 16 thrust variables and 224 rows: four envs per wavefront, one per 16-lane row (k_cbf_filter_q4)
+  const bool q4 = h->cbf_q4 && !hildreth && order == 2 && n <= 16 && m <= 224;
+#define MDS_Q4(T, CP, RL, TOL)                                                                                                    \
+  k_cbf_filter_q4<T, T, RL><<<dim3((unsigned)((E + 3) / 4)), 64, 0, st>>>(CP, E, h->pair_ij, (const T*)h->obstacles, (const T*)obs, \
+                                                                          (const T*)xdes, (const T*)unom, (T*)usafe, (int*)status,  \
+                                                                          max_iter, (T)((TOL) * (TOL)), cost_out)
+#define MDS_Q4_R(T, CP, TOL)               \
+  do {                                     \
+    if (m <= 128) MDS_Q4(T, CP, 8, TOL);   \
+    else MDS_Q4(T, CP, 14, TOL);           \
+  } while (0)
   if (h->cfg.dtype == MDS_F64) {
     const double tol = h->cbf.tol > 0 ? h->cbf.tol : 1e-12;
-    if (hildreth) MDS_HILD_R(double, h->cbf_d, tol);
+    if (q4) MDS_Q4_R(double, h->cbf_d, tol);
+    else if (hildreth) MDS_HILD_R(double, h->cbf_d, tol);
     else MDS_GI_ALL(double, h->cbf_d, tol);
   } else {
     const double tol = h->cbf.tol > 0 ? h->cbf.tol : 1e-6;
-    if (hildreth) MDS_HILD_R(float, h->cbf_f, tol);
+    if (q4) MDS_Q4_R(float, h->cbf_f, tol);
+    else if (hildreth) MDS_HILD_R(float, h->cbf_f, tol);
     else MDS_GI_ALL(float, h->cbf_f, tol);
   }
+#undef MDS_Q4_R
+#undef MDS_Q4
 #undef MDS_HILD_R
 #undef MDS_HILD
 #undef MDS_GI_ALL
 #undef MDS_GI_R
 #undef MDS_GI
   MDS_HIP(hipGetLastError());
-  if (!hildreth && E >= 1024) {                           // small batches have no tail to hide
+  if (!hildreth && !q4 && E >= 1024) {                    // small batches have no tail to hide
     if (calls < 0 || calls >= 7) {
       k_cbf_order<<<1, 1024, 0, st>>>(E, cost_tab, order_tab, count_tab);
       MDS_HIP(hipGetLastError());

@@ -1021,4 +1021,282 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 && R == 4) ? 4 : 1) void k_cbf_
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Order-2 filter, FOUR envs per wavefront: each 16-lane DPP row of the wave owns one env (D <= 16 thrust variables, RL rows of
+// G u <= h per lane).  Same Goldfarb-Idnani active-set iteration as gi_solve, with every "wave-uniform" quantity of that version
+// (violation maximum, selected row, step lengths, active-set size q, iteration count) uniform per ROW instead: reductions are the
+// four DPP steps of a row all-reduce (no v_readlane), a lane's value is handed to its row with ds_bpermute (__shfl, width 16),
+// first-set-lane comes from the row's 16 bits of a ballot.  The four envs run in lock step through a two-phase loop (scan for the
+// most violated row | one add-or-drop step); a row that is done idles under a predicate.  Control flow stays wave-uniform (DPP
+// needs every lane), per-row state is a predicate on stores.
+// Why: the one-env-per-wave kernel is latency-bound -- 11.5 cycles per instruction per wave, an env with nothing to do still costs
+// 15 k cycles, the vectors of the iteration are 16 long in a 64-lane wave (profiles/r02_pmc_c4_*).  Four envs per wave quarter the
+// waves, fill the lanes of every step of the iteration and amortise the latency of the global reads over four envs.
+// Measured at C4 (profiles/r02_c4_fused.md): exact (every parity test passes with it: statuses equal to the oracle's at every step),
+// but no faster -- per full-batch launch 31.4 us against 29.6 us when no env iterates, 71 us against 56 us on SURVEY 8d's scene.
+// 14 rows per lane cost 168-187 VGPRs (3 waves per SIMD at best, Q and R left in LDS), a wave lives as long as the slowest of its
+// four envs and pays scan + step in every pass.  Opt-in: MDS_CBF_Q4=1 at mds_cbf_configure time.
+// ------------------------------------------------------------------------------------
+namespace r16 {
+template <typename T, typename Op> __device__ __forceinline__ T allreduce(T v, Op op) {   // over each 16-lane row; all 64 lanes active
+  v = op(v, wv::mov<0xB1>(v));
+  v = op(v, wv::mov<0x4E>(v));
+  v = op(v, wv::mov<0x141>(v));
+  v = op(v, wv::mov<0x140>(v));
+  return v;
+}
+template <typename T> __device__ __forceinline__ T get(T v, int idx) { return __shfl(v, idx, 16); }   // lane idx of the caller's row
+__device__ __forceinline__ int first(bool pred, int lane) {       // lowest lane of the caller's row with pred, 0 if none
+  const unsigned long long m = __ballot(pred);
+  const unsigned f = (unsigned)(m >> (lane & 48)) & 0xffffu;
+  return f ? __ffs(f) - 1 : 0;
+}
+}  // namespace r16
+
+template <typename T, typename S, int RL>
+__global__ __launch_bounds__(64, sizeof(T) == 4 ? 3 : 1) void k_cbf_filter_q4(const CbfParams<T> P, const int E, const int* __restrict__ pair_ij,
+                                                      const T* __restrict__ obstacles, const S* __restrict__ obs,
+                                                      const S* __restrict__ xdes, const S* __restrict__ unom, S* __restrict__ usafe,
+                                                      int* __restrict__ status, const int max_iter, const T tol2,
+                                                      int* __restrict__ cost_out) {
+  constexpr int NMAX = 16, kQS = 20;
+  struct EnvLds {
+    T pos[NMAX][3], de[NMAX][5];
+    T u[NMAX], lam[NMAX], di[NMAX];
+    T Q[NMAX][kQS], R[NMAX][kQS];
+    int act[NMAX];
+  };
+  __shared__ __align__(16) EnvLds L4[4];
+  __shared__ T sob[kCbfMaxObs * 4];
+  const int lane = threadIdx.x, rl = lane & 15, r4 = lane >> 4;
+  const int env = blockIdx.x * 4 + r4;
+  const bool live = env < E;                                   // uniform per row
+  const int D = P.num_drones, n = D;
+  const int npairs = cbf_num_pairs(D), nobs_rows = D * P.n_obs, m = npairs + nobs_rows + 2 * n;
+  EnvLds& L = L4[r4];
+
+  // ---- inputs of the row's env: drone rl reads its own observation / xdes / nominal rows ----
+  int rpair[RL];
+#pragma unroll
+  for (int k = 0; k < RL; ++k) rpair[k] = rl + 16 * k < npairs ? pair_ij[rl + 16 * k] : 0;
+  sob[lane] = lane < 4 * P.n_obs ? obstacles[lane] : T(0);
+  T un[4] = {T(0), T(0), T(0), T(0)};
+  if (live && rl < D) {
+    const size_t i = (size_t)env * D + rl;
+    const S* o = obs + i * 20;
+    const S* xd = xdes + i * 9;
+    load4<S, T>(unom + i * 4, un);
+    T o0[4], o1[4], o2[4], o3[4];
+    load4<S, T>(o, o0);                                        // pos3, q0
+    load4<S, T>(o + 4, o1);                                    // q1..3, roll
+    load4<S, T>(o + 8, o2);                                    // pitch, yaw, vx, vy
+    load4<S, T>(o + 12, o3);                                   // vz, ...
+    L.pos[rl][0] = o0[0]; L.pos[rl][1] = o0[1]; L.pos[rl][2] = o0[2];
+    L.de[rl][0] = o1[3] - (T)xd[0];                            // obs_to_lin_model(obs, 9) - xdes: roll, pitch, velocity
+    L.de[rl][1] = o2[0] - (T)xd[1];
+    L.de[rl][2] = o2[2] - (T)xd[3];
+    L.de[rl][3] = o2[3] - (T)xd[4];
+    L.de[rl][4] = o3[0] - (T)xd[5];
+    L.u[rl] = un[0];
+  }
+  MDS_WAVE_SYNC();
+
+  // ---- rows: RL per lane, row index r = rl + 16 k ----
+  // a row is (ca, b, ia | ib << 8): a unit-norm pair row has cb = -ca on its second agent, every other row has one agent (cb = 0)
+  T ca[RL], b[RL];
+  int iab[RL];
+  unsigned vmask = 0, amask = 0;                               // bit k: row k of this lane exists / is in the active set
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < RL; ++k) {
+    bool vld;
+    T cbk;
+    int iak, ibk;
+    cbf_o2_slot<T>(P, L.pos, L.de, sob, 0, rl + 16 * k, rpair[k], npairs, nobs_rows, m, n, ca[k], cbk, b[k], iak, ibk, vld, bad);
+    iab[k] = iak | (ibk << 8);
+    vmask |= vld ? 1u << k : 0u;
+  }
+  const bool env_bad = r16::allreduce(bad ? 1 : 0, wv::Max()) != 0;
+
+  // ---- per-row solver state (uniform within a 16-lane row) ----
+  int phase = (!live || env_bad) ? 2 : 0;                      // 0 scan, 1 step, 2 done
+  bool converged = false;
+  int q = 0, it = 0;
+  T wca = T(0), wcb = T(0), wb = T(0), lam_new = T(0);
+  int wia = 0, wib = 0, wown = 0, wkk = 0;
+  for (int guard = 0; guard < max_iter + 2; ++guard) {
+    if (!__any(phase != 2)) break;
+    // ================= scan: most violated row outside the active set =================
+    {
+      T best = T(0);
+      int best_k = 0;
+#pragma unroll
+      for (int k = 0; k < RL; ++k) {
+        const int iak = iab[k] & 255, ibk = iab[k] >> 8;
+        const T res = m_fma(ca[k], L.u[iak] - (ibk != iak ? L.u[ibk] : T(0)), -b[k]);
+        const T sc = (((vmask & ~amask) >> k) & 1u) && res > T(0) ? res * res : T(0);
+        if (sc > best) {
+          best = sc;
+          best_k = k;
+        }
+      }
+      const T wbest = r16::allreduce(best, wv::Max());
+      const bool scan = phase == 0;
+      const bool conv_now = scan && !(wbest > tol2);
+      const bool sel = scan && !conv_now;
+      const int owner = r16::first(best == wbest, lane);
+      const int kk = r16::get(best_k, owner);
+      T sa = ca[0], sb_ = b[0];
+      int siab = iab[0];
+#pragma unroll
+      for (int k = 1; k < RL; ++k) {
+        sa = kk == k ? ca[k] : sa;
+        sb_ = kk == k ? b[k] : sb_;
+        siab = kk == k ? iab[k] : siab;
+      }
+      const T nca = r16::get(sa, owner), nb = r16::get(sb_, owner);
+      const int niab = r16::get(siab, owner);
+      const int nia = niab & 255, nib = niab >> 8;
+      const T ncb = nib != nia ? -nca : T(0);
+      if (conv_now) {
+        converged = true;
+        phase = 2;
+      }
+      if (sel) {
+        wca = nca; wcb = ncb; wb = nb; wia = nia; wib = nib; wown = owner; wkk = kk;
+        lam_new = T(0);
+        phase = 1;
+      }
+    }
+    // ================= one add-or-drop step for the rows in phase 1 =================
+    const bool step = phase == 1;
+    const bool over = step && it + 1 > max_iter;
+    if (step) ++it;
+    if (over) phase = 2;                                        // not converged: falls back
+    const bool stepping = step && !over;
+    const bool two = wib != wia;
+    const T wcb2 = two ? wcb : T(0);
+    const T res = m_fma(wca, L.u[wia], m_fma(wcb2, L.u[wib], -wb));
+    const T dc = rl < q ? m_fma(wca, L.Q[wia][rl], wcb2 * L.Q[wib][rl]) : T(0);                   // d = Q^T a
+    const T my_lam = L.lam[rl], my_di = L.di[rl], my_u = L.u[rl];
+    T zv = rl < n ? ((rl == wia ? wca : T(0)) + ((two && rl == wib) ? wcb : T(0))) : T(0);      // z = a - Q d
+    const int qmax = wv::allreduce(stepping ? q : 0, wv::Max());                                  // wave-uniform loop bound
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) {
+      if (c >= qmax) break;
+      const T dcc = r16::get(dc, c);
+      zv = c < q ? m_fma(-L.Q[rl][c], dcc, zv) : zv;
+    }
+    if (rl >= n) zv = T(0);
+    T rc = dc * my_di;                                                                            // r = R^-1 d on the row-scaled system
+#pragma unroll
+    for (int k = NMAX - 1; k >= 0; --k) {
+      if (k >= qmax) continue;
+      const T rk = r16::get(rc, k);
+      rc = (k < q && rl < k) ? m_fma(-(L.R[rl][k] * my_di), rk, rc) : rc;
+    }
+    const T zz = r16::allreduce(zv * zv, wv::Add());
+    const T rmax = r16::allreduce(rl < q ? m_abs(rc) : T(0), wv::Max());
+    T t1v = GiEps<T>::inf;
+    if (rl < q && rc > GiEps<T>::r * rmax && rc > T(0)) t1v = m_max(my_lam, T(0)) * m_rcp(rc);
+    const T t1 = r16::allreduce(t1v, wv::Min());
+    const int drop = t1 < GiEps<T>::inf ? r16::first(t1v == t1, lane) : 0;
+    const bool has_z = zz > GiEps<T>::z;
+    const T t2 = has_z ? res * m_rcp(zz) : GiEps<T>::inf;
+    const T t = m_min(t1, t2);
+    const bool nostep = stepping && !(t < GiEps<T>::inf);                                         // rows inconsistent: falls back
+    if (nostep) phase = 2;
+    const bool doing = stepping && !nostep;
+    const bool full = has_z && t2 <= t1;
+    MDS_WAVE_SYNC();
+    if (doing && has_z && rl < n) L.u[rl] = m_fma(-t, zv, my_u);
+    if (doing && rl < q) L.lam[rl] = m_fma(-t, rc, my_lam);
+    if (doing) lam_new += t;
+    MDS_WAVE_SYNC();
+    const bool adding = doing && full, dropping = doing && !full;
+    if (adding) {                                                                                 // N <- [N a]
+      const T inz = m_rsqrt(zz), nz = zz * inz;
+      if (rl < n) L.Q[rl][q] = zv * inz;
+      if (rl < q) L.R[rl][q] = dc;
+      if (rl == 0) {
+        L.R[q][q] = nz;
+        L.di[q] = inz;
+        L.lam[q] = lam_new;
+        L.act[q] = wown + 16 * wkk;
+      }
+      if (rl == wown) amask |= 1u << wkk;
+      ++q;
+      phase = 0;
+    }
+    MDS_WAVE_SYNC();
+    if (__any(dropping)) {                                                                        // drop active column `drop`
+      const int dcol = dropping ? drop : 0;
+      const int drow = L.act[dcol];
+      if (dropping && rl == (drow & 15)) amask &= ~(1u << (drow >> 4));
+      T lnext = T(0);
+      int anext = 0;
+      const bool shift = dropping && rl >= dcol && rl < q - 1;
+      if (shift) {
+        lnext = L.lam[rl + 1];
+        anext = L.act[rl + 1];
+      }
+      MDS_WAVE_SYNC();
+      if (shift) {
+        L.lam[rl] = lnext;
+        L.act[rl] = anext;
+      }
+      if (dropping && rl < q)                                                                     // each lane shifts its own row of R
+        for (int k = dcol; k < q - 1; ++k) L.R[rl][k] = L.R[rl][k + 1];
+      MDS_WAVE_SYNC();
+      const int lmax = wv::allreduce(dropping ? q - 1 : 0, wv::Max());
+      for (int l = 0; l < lmax; ++l) {                                                            // Givens on rows l, l+1 (rows with dcol <= l < q-1)
+        const bool lact = dropping && l >= dcol && l < q - 1;
+        const T a = L.R[l][l], bb = L.R[l + 1 < NMAX ? l + 1 : l][l];
+        const T rr = m_sqrt(m_fma(a, a, bb * bb));
+        const T cs = rr > T(0) ? a / rr : T(1), sn = rr > T(0) ? bb / rr : T(0);
+        MDS_WAVE_SYNC();
+        if (lact && rl >= l && rl < q - 1) {
+          const T x = L.R[l][rl], y = L.R[l + 1][rl];
+          L.R[l][rl] = m_fma(cs, x, sn * y);
+          L.R[l + 1][rl] = m_fma(-sn, x, cs * y);
+        }
+        if (lact && rl < n) {
+          const T x = L.Q[rl][l], y = L.Q[rl][l + 1];
+          L.Q[rl][l] = m_fma(cs, x, sn * y);
+          L.Q[rl][l + 1] = m_fma(-sn, x, cs * y);
+        }
+        MDS_WAVE_SYNC();
+      }
+      if (dropping) --q;
+      if (dropping && rl >= dcol && rl < q) L.di[rl] = T(1) / L.R[rl][rl];
+      MDS_WAVE_SYNC();
+    }
+  }
+  if (phase != 2) converged = false;                                                              // guard ran out
+  // final certificate for rows that iterated: EVERY row holds at the returned point (see gi_solve)
+  {
+    T worst = T(0);
+#pragma unroll
+    for (int k = 0; k < RL; ++k) {
+      const int iak = iab[k] & 255, ibk = iab[k] >> 8;
+      const T res = m_fma(ca[k], L.u[iak] - (ibk != iak ? L.u[ibk] : T(0)), -b[k]);
+      if ((vmask >> k) & 1u) worst = m_max(worst, res);
+    }
+    worst = r16::allreduce(worst, wv::Max());
+    if (converged && it > 0 && worst * worst > T(100) * tol2) converged = false;
+  }
+  if (live && rl == 0) {
+    status[env] = converged ? 0 : 1;
+    if (cost_out) cost_out[env] = it;
+  }
+  if (live && rl < D) {
+    T u[4] = {un[0], un[1], un[2], un[3]};
+    if (converged) {
+      u[0] = L.u[rl];
+      for (int k = 1; k < 4; ++k) u[k] = m_clamp(un[k], -P.umax[k], P.umax[k]);
+    }
+    store4<S, T>(usafe + ((size_t)env * D + rl) * 4, u);
+  }
+}
+
 }  // namespace mds

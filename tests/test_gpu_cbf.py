@@ -539,6 +539,63 @@ def test_one_launch_cbf_step_matches_the_three_launch_path(mds, nominal, monkeyp
         np.testing.assert_allclose(out["0"][3], out["1"][3], atol=tol)
 
 
+def test_four_envs_per_wave_qp_kernel_matches_the_default(mds, monkeypatch):
+    """k_cbf_filter_q4 (MDS_CBF_Q4=1: one env per 16-lane DPP row, four per wavefront, the same active-set iteration with per-row
+    reductions) against the one-env-per-wave kernel on the same closed loop: statuses equal at every step, observations equal to
+    rounding (a tie between equally violated rows may be broken differently: the minimiser is the same), E = 70 (two envs of the last
+    wave unused), D = 16 and D = 8, float64 and float32; and against the oracle's statuses for D = 6 (lanes 6..15 of a row idle)."""
+    from tests import helpers as H2
+    for D, E, steps in ((16, 70, 50), (8, 37, 50)):
+        xyz, rpy, P = H2.c2_setup(E, D, phase="c3", offset=1.5)
+        P[..., 4] = 0.5 + 0.3 * np.arange(D)
+        xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+        x_obs = [np.array([[sx * 0.5, sy * 0.5, 0.5], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
+        obs_r = [0.1] * 4
+        for dtype, tol in (("float64", 1e-9), ("float32", 2e-4)):
+            out = {}
+            for q4 in ("0", "1"):
+                monkeypatch.setenv("MDS_CBF_Q4", q4)
+                env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                                     pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype)
+                env.set_trajectories(P)
+                cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2,
+                                   cbf_poles=np.array([-2.2, -2.4]))
+                trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+                env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+                t, hist = 0.0, []
+                for k in range(steps):
+                    o, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
+                    hist.append(st.cpu().numpy().copy())
+                    t += env.CTRL_TIMESTEP
+                out[q4] = (o.double().cpu().numpy().copy(), np.array(hist), int(cbf.last_iterations().max().item()))
+                env.close()
+            np.testing.assert_array_equal(out["0"][1], out["1"][1])
+            assert np.abs(out["0"][0][..., :16] - out["1"][0][..., :16]).max() < tol
+            if D == 16:
+                assert 0.0 < out["1"][1].mean() < 1.0 and out["1"][2] >= 2           # fallbacks and real iterations both occur
+    monkeypatch.setenv("MDS_CBF_Q4", "1")
+    E, D, steps = 8, 6, 150
+    xyz, rpy, P = H2.c2_setup(E, D, phase="c3", offset=0.0, omega=1.0)
+    xyz[..., 2] = 0.5 + 0.25 * np.arange(D)
+    P[..., 4] = 0.5 + 0.12 * np.arange(D)
+    x_obs = [np.array([[sx * 0.5, sy * 0.5, 0.5], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
+    obs_r = [0.1] * 4
+    env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                         pyb_freq=100, ctrl_freq=100, num_envs=E, dtype="float64")
+    env.set_trajectories(P)
+    cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2)
+    trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+    oobs, ohist = H2.oracle_cbf_closed_loop(xyz, rpy, P, steps, cbf.Kcbf.reshape(-1), cbf.umax, 0.1, 1.0, x_obs, obs_r)
+    env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+    t = 0.0
+    for k in range(steps):
+        gobs, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
+        np.testing.assert_array_equal(st.cpu().numpy(), ohist[k])
+        t += env.CTRL_TIMESTEP
+    assert np.abs(gobs.double().cpu().numpy()[..., :16] - oobs[..., :16]).max() < 1e-9
+    env.close()
+
+
 @pytest.mark.parametrize("streams", [1, 2])
 def test_cbf_rollout_equals_stepwise(mds, streams):
     """mds_rollout_cbf_geometric (C loop; with two streams the env halves run as independent chains with their own cost
