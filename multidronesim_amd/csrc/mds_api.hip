@@ -110,9 +110,12 @@ struct mds_handle {
                                         // fork's own latency already starts chain 1 about half a kernel late: 20-step calls 17.3 vs 17.6 us)
   int split_min_steps = 0;              // auto policy: calls shorter than this stay on one stream (MDS_TUNE_SPLIT_MIN_STEPS, tuning only)
   int last_rollout_streams = 0;         // what the last mds_rollout_* call did (mds_get_last_rollout_streams)
+  bool next_nom_ok[3] = {false, false, false};   // per env-range slot: the last low-level launch also left the nominal input of ...
+  double next_nom_t[3] = {0.0, 0.0, 0.0};        // ... the control step at this time in the scratch (C rollout loops chain on it)
   bool cbf_hildreth = false;            // MDS_CBF_SOLVER=hildreth, read once by mds_cbf_configure
   bool cbf_q4 = false;                  // MDS_CBF_Q4=1 at configure time: the four-envs-per-wave QP kernel (k_cbf_filter_q4) where it applies; measured
                                         // no faster than one env per wave (see its header), so opt-in
+  bool cbf_chain_nominal = true;        // MDS_CBF_CHAIN=0 at configure time: the C rollout loops launch the nominal kernel every step (A/B)
   bool cbf_fused = false;               // MDS_CBF_FUSED=1 at configure time: the one-launch CBF step (k_cbf_step) where it applies; it wins only
                                         // on scenes whose QPs need no iterations (see the kernel's header), so the default is the three launches
   void* cbf_unom;      // S [n,4]  scratch of mds_step_cbf_geometric
@@ -1076,7 +1079,7 @@ int mds_get_last_rollout_streams(const mds_handle* h) {
 
 struct EnvRange;
 static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream, bool with_filter,
-                                 const char* who, const EnvRange* rg);
+                                 const char* who, const EnvRange* rg, bool have_nominal, bool want_next, double t_next);
 
 // ctrl: 0 GeometricControl, 1 LQRController (12-state), 2 LQROmegaController + ThrustOmega, 3 LQRYankOmegaController + YankOmega
 static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream, int ctrl, const char* who) {
@@ -1100,7 +1103,7 @@ static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, v
         if (int rc = step_env_ctrl(h, ctrl, t0, nullptr, 0.0, o, nullptr, st)) return rc;
         if (slot && last && obs_last) MDS_HIP(hipMemcpyAsync(obs_last, slot, obs_bytes, hipMemcpyDeviceToDevice, st));
       } else {
-        if (int rc = step_nominal_lowlevel(h, t0, obs_last, nullptr, nullptr, stream, false, who, nullptr)) return rc;
+        if (int rc = step_nominal_lowlevel(h, t0, obs_last, nullptr, nullptr, stream, false, who, nullptr, false, false, 0.0)) return rc;
         if (slot) MDS_HIP(hipMemcpyAsync(slot, obs_last, obs_bytes, hipMemcpyDeviceToDevice, st));
       }
       t0 += dt;
@@ -1291,6 +1294,8 @@ int mds_cbf_configure(mds_handle* h, const mds_cbf_params* p, const double* obst
     h->cbf_hildreth = solver && solver[0] == 'h';
     const char* q4e = getenv("MDS_CBF_Q4");
     h->cbf_q4 = q4e && q4e[0] == '1';
+    const char* chain = getenv("MDS_CBF_CHAIN");
+    h->cbf_chain_nominal = !(chain && chain[0] == '0');
     const char* fused = getenv("MDS_CBF_FUSED");
     h->cbf_fused = fused && fused[0] == '1';
   }
@@ -1682,8 +1687,11 @@ int mds_thrust_omega_from_rates(mds_handle* h, const void* u, const void* rates,
 
 // nominal controller -> [ECBF QP] -> low level -> env.step.  with_filter = false: the plain loops of
 // simulations/EnvGeometricOmega.py / EnvGeometricYankOmega.py (ctrl[j].compute(obs[j]) = LQR + low level, :314 / :319).
+// have_nominal: the previous step's low-level launch has already left this step's u_hat / xdes in the scratch (want_next of that call);
+// want_next: this step's low-level launch also computes the nominal input of the step at t_next (C rollout loops; nominal 0 / 1 only).
 static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream, bool with_filter,
-                                 const char* who, const EnvRange* rgp = nullptr) {
+                                 const char* who, const EnvRange* rgp = nullptr, bool have_nominal = false, bool want_next = false,
+                                 double t_next = 0.0) {
   EnvRange rg = rgp ? *rgp : EnvRange{0, -1, 0};
   if (!h->has_traj || h->traj_mode != 1) return fail(MDS_ESTATE, "mds_step_cbf_geometric / mds_step_nominal: call mds_set_lemniscate first");
   if (!aligned16(obs) || !aligned16(action)) return fail(MDS_EALIGN, "mds_step_cbf_geometric / mds_step_nominal: obs_dev/action_dev");
@@ -1740,7 +1748,39 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
   const dim3 grid = grid_for(i1 - i0, kBlock);
   // the hover force is subtracted from the nominal input only on the way into the filter (CBFTest.py:339, CBFTestOrd3.py:341)
   const double hover_sub = with_filter ? h->cfg.M * h->cfg.G : 0.0;
-  if (h->cbf_nominal == 2) {
+  const bool skip_nominal = have_nominal && h->next_nom_ok[rg.slot] && h->next_nom_t[rg.slot] == t;
+  h->next_nom_ok[rg.slot] = false;
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
+  const void* nom_K = h->cbf_nominal == 1 ? h->gain_dev[1] : nullptr;
+  // k_lowlevel_step: (a) `only` mode = the nominal controller of this step (GeometricControl / LQR-omega: the ONE compiled copy of
+  // cbf_nominal_of, see there); (b) low level + physics + observation, optionally followed by the nominal input of the next step
+#define MDS_NX(T, S, ON, TT, ONLY) NextNominal<T, S>{(ON) ? (const T*)h->lem : nullptr, nom_K, (ON) ? (S*)h->cbf_unom : nullptr, (S*)h->cbf_xdes, TT, \
+                                                     (T)hover_sub, h->cbf_nominal, ONLY}
+#define MDS_LL(RK4, DRAG, YANK, ULL, OFFS, ON, TT, ONLY)                                                                         \
+  do {                                                                                                                           \
+    if (is_comp(h))                                                                                                              \
+      k_lowlevel_step<float, float, RK4, DRAG, YANK, true><<<grid, kBlock, 0, st>>>(h->cf, n_end, h->ld, (float)(1.0 / h->cfg.ctrl_freq), \
+                                                                                    (float)(OFFS), (float*)h->state, (const float*)h->origin, \
+                                                                                    (float*)rpm_track(h), (float*)h->ll, (const float*)(ULL), \
+                                                                                    (float*)obs, (float*)action, batch0, (float*)h->state_lo, \
+                                                                                    MDS_NX(float, float, ON, TT, ONLY));         \
+    else                                                                                                                         \
+      MDS_DISPATCH(h, (k_lowlevel_step<T, S, RK4, DRAG, YANK><<<grid, kBlock, 0, st>>>(C, n_end, h->ld, (T)(1.0 / h->cfg.ctrl_freq),  \
+                                                                                     (T)(OFFS), (S*)h->state, (const T*)h->origin, \
+                                                                                     (T*)rpm_track(h), (T*)h->ll, (const S*)(ULL), \
+                                                                                     (S*)obs, (S*)action, batch0, (S*)nullptr,    \
+                                                                                     MDS_NX(T, S, ON, TT, ONLY))));               \
+  } while (0)
+#define MDS_LL_Y(YANK, ULL, OFFS, ON, TT, ONLY)                         \
+  do {                                                                  \
+    if (rk4 && drag) MDS_LL(true, true, YANK, ULL, OFFS, ON, TT, ONLY); \
+    else if (rk4) MDS_LL(true, false, YANK, ULL, OFFS, ON, TT, ONLY);   \
+    else if (drag) MDS_LL(false, true, YANK, ULL, OFFS, ON, TT, ONLY);  \
+    else MDS_LL(false, false, YANK, ULL, OFFS, ON, TT, ONLY);           \
+  } while (0)
+  if (skip_nominal) {
+    // u_hat / xdes of this step came out of the previous step's low-level launch
+  } else if (h->cbf_nominal == 2) {
     if (h->cfg.dtype == MDS_F64)
       k_cbf_nominal_lqr_yo<double, double><<<grid, kBlock, 0, st>>>(h->cd, h->lqr_yo_d, n_end, h->ld, t, hover_sub, (const double*)h->state,
                                                                     (const double*)h->lem, (const double*)obs, (double*)h->cbf_unom,
@@ -1749,16 +1789,8 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
       k_cbf_nominal_lqr_yo<float, float><<<grid, kBlock, 0, st>>>(h->cf, h->lqr_yo_f, n_end, h->ld, t, (float)hover_sub, (const float*)h->state,
                                                                   (const float*)h->lem, (const float*)obs, (float*)h->cbf_unom,
                                                                   (float*)h->cbf_xdes, batch0);
-  } else if (h->cbf_nominal == 1) {
-    if (h->cfg.dtype == MDS_F64)
-      k_cbf_nominal_lqr<double, double><<<grid, kBlock, 0, st>>>(h->cd, h->lqr_d, n_end, h->ld, t, hover_sub, (const double*)h->state,
-                                                                 (const double*)h->lem, (double*)h->cbf_unom, (double*)h->cbf_xdes, batch0);
-    else
-      k_cbf_nominal_lqr<float, float><<<grid, kBlock, 0, st>>>(h->cf, h->lqr_f, n_end, h->ld, t, (float)hover_sub, (const float*)h->state,
-                                                               (const float*)h->lem, (float*)h->cbf_unom, (float*)h->cbf_xdes, batch0);
   } else {
-    MDS_DISPATCH(h, (k_cbf_nominal<T, S><<<grid, kBlock, 0, st>>>(C, n_end, h->ld, t, (const S*)h->state, (const T*)h->lem,
-                                                                  (S*)h->cbf_unom, (S*)h->cbf_xdes, batch0)));
+    MDS_LL_Y(false, nullptr, 0.0, true, t, 1);
   }
   MDS_HIP(hipGetLastError());
   const void* u_ll = h->cbf_unom;
@@ -1767,35 +1799,18 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
     if (rc != MDS_OK) return rc;
     u_ll = h->cbf_usafe;
   }
-  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
   // order 2: u_safe[0] += M G (CBFTest.py:346); order 3: the yank goes to the low level as it is (CBFTestOrd3.py:350)
   const double ll_offset = (with_filter && !yank) ? h->cfg.M * h->cfg.G : 0.0;
   if (h->envfx)            // ground effect / downwash: low level + first substep, then the remaining substeps (whole batch, one stream)
     return step_env_ctrl(h, yank ? 3 : 2, t, u_ll, ll_offset, obs, action, st);
-#define MDS_LL(RK4, DRAG, YANK)                                                                                                  \
-  do {                                                                                                                           \
-    if (is_comp(h))                                                                                                              \
-      k_lowlevel_step<float, float, RK4, DRAG, YANK, true><<<grid, kBlock, 0, st>>>(h->cf, n_end, h->ld, (float)(1.0 / h->cfg.ctrl_freq), \
-                                                                                    (float)ll_offset, (float*)h->state, (const float*)h->origin, \
-                                                                                    (float*)rpm_track(h), (float*)h->ll, (const float*)u_ll, \
-                                                                                    (float*)obs, (float*)action, batch0, (float*)h->state_lo); \
-    else                                                                                                                         \
-      MDS_DISPATCH(h, (k_lowlevel_step<T, S, RK4, DRAG, YANK><<<grid, kBlock, 0, st>>>(C, n_end, h->ld, (T)(1.0 / h->cfg.ctrl_freq),  \
-                                                                                     (T)ll_offset, (S*)h->state, (const T*)h->origin, \
-                                                                                     (T*)rpm_track(h), (T*)h->ll, (const S*)u_ll,  \
-                                                                                     (S*)obs, (S*)action, batch0)));              \
-  } while (0)
-#define MDS_LL_Y(YANK)                           \
-  do {                                           \
-    if (rk4 && drag) MDS_LL(true, true, YANK);   \
-    else if (rk4) MDS_LL(true, false, YANK);     \
-    else if (drag) MDS_LL(false, true, YANK);    \
-    else MDS_LL(false, false, YANK);             \
-  } while (0)
-  if (yank) MDS_LL_Y(true);
-  else MDS_LL_Y(false);
+  const bool next_on = want_next && !yank && h->cbf_nominal <= 1 && !action;
+  h->next_nom_ok[rg.slot] = next_on;
+  h->next_nom_t[rg.slot] = t_next;
+  if (yank) MDS_LL_Y(true, u_ll, ll_offset, false, t_next, 0);
+  else MDS_LL_Y(false, u_ll, ll_offset, next_on, t_next, 0);
 #undef MDS_LL_Y
 #undef MDS_LL
+#undef MDS_NX
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }
@@ -1837,8 +1852,12 @@ int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs, 
     auto body = [&]() -> int {
       double t = t0 + dt;
       for (int k = 1; k < n_steps; ++k) {
+        // each chain's low-level launch of step k also computes the nominal input of its step k + 1 (next_nominal), so that
+        // from its second step on a chain is two launches per step: QP, low level
         for (int s = 0; s < 2; ++s)
-          if (int rc = step_nominal_lowlevel(h, t, obs, status, nullptr, s == 0 ? st : h->split_st, true, "mds_rollout_cbf_geometric", &half[s])) return rc;
+          if (int rc = step_nominal_lowlevel(h, t, obs, status, nullptr, s == 0 ? st : h->split_st, true, "mds_rollout_cbf_geometric", &half[s],
+                                             k > 1, h->cbf_chain_nominal && k < n_steps - 1, t + dt))
+            return rc;
         t += dt;
       }
       return MDS_OK;
@@ -1847,7 +1866,12 @@ int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs, 
   }
   h->last_rollout_streams = 1;
   for (int k = 0; k < n_steps; ++k) {
-    if (int rc = mds_step_cbf_geometric(h, t0, obs, status, nullptr, stream)) return rc;
+    if (k == 0) {
+      if (int rc = mds_step_cbf_geometric(h, t0, obs, status, nullptr, stream)) return rc;   // validation; plain first step
+    } else if (int rc = step_nominal_lowlevel(h, t0, obs, status, nullptr, stream, true, "mds_rollout_cbf_geometric", nullptr, k > 1,
+                                              h->cbf_chain_nominal && k < n_steps - 1, t0 + dt)) {
+      return rc;
+    }
     t0 += dt;
   }
   return MDS_OK;

@@ -89,6 +89,16 @@ template <typename S, typename T> __device__ __forceinline__ void store_state(S*
   stp<S, T>(st + 12 * ld, i, s.w.z);
 }
 
+// the state as the next kernel will load it: every component through the storage type (a no-op unless S is narrower than T)
+template <typename T, typename S> __device__ __forceinline__ State<T> state_as_stored(const State<T>& s) {
+  State<T> o;
+  o.p = {(T)(S)s.p.x, (T)(S)s.p.y, (T)(S)s.p.z};
+  for (int k = 0; k < 4; ++k) o.q[k] = (T)(S)s.q[k];
+  o.v = {(T)(S)s.v.x, (T)(S)s.v.y, (T)(S)s.v.z};
+  o.w = {(T)(S)s.w.x, (T)(S)s.w.y, (T)(S)s.w.z};
+  return o;
+}
+
 // residual planes of the compensated storage (MDS_F32C): same packed layout as the state
 template <typename S, typename T> __device__ __forceinline__ void load_resid(const S* __restrict__ lo, size_t ld, size_t i, Resid<T>& r) {
   State<T> t;
@@ -714,55 +724,60 @@ __global__ __launch_bounds__(kBlock) void k_rollout_traj(const Consts<T> c, cons
 
 // ------------------------------------------------------------------------------------
 // CBF-filtered control step (simulations/CBFTest.py:303-350) = three launches:
-//   k_cbf_nominal    per drone : trajs[j](t), GeometricControl.compute(return_omegas) ->
+//   nominal          per drone : (k_lowlevel_step in its `only` mode, or the tail of the previous step's launch) trajs[j](t), GeometricControl.compute(return_omegas) ->
 //                                u_hat = (force - M G, w_des), xdes = [0,0,yaw, vel, pos]   (:339-343)
 //   k_cbf_filter_o2* per env   : DroneQPTracker.compute_control                             (:345)
 //   k_lowlevel_step  per drone : u_safe[0] += M G (:346), ThrustOmegaController (:348),
 //                                env.step(action) (:350)
 // ------------------------------------------------------------------------------------
-template <typename T, typename S>
-__global__ __launch_bounds__(kBlock) void k_cbf_nominal(const Consts<T> c, const int n, const size_t ld, const double t,
-                                                        const S* __restrict__ state, const T* __restrict__ lem,
-                                                        S* __restrict__ unom, S* __restrict__ xdes, const int batch0) {
-  const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
-  if (i >= n) return;
-  GeoIn<T> in;
-  load_geo_in<T, S>(state, lem, ld, i, in);
-  const Desired<T> des = lemniscate_local(in.P, t);
-  const M3<T> R = quat_to_rot(in.s.q);
-  const V3<T> ang_v = mul(R, in.s.w);
-  T u[4];
-  GeoAux<T> A;
-  geometric_control<T>(c, in.s.p - des.p, R, in.s.v, ang_v, des, u, &A);
-  const T un[4] = {A.force - c.gravity, A.w_des.x, A.w_des.y, A.w_des.z};
-  store4<S, T>(unom + (size_t)i * 4, un);
-  S* xd = xdes + (size_t)i * 9;
-  xd[0] = (S)0; xd[1] = (S)0; xd[2] = (S)des.yaw;
-  xd[3] = (S)des.v.x; xd[4] = (S)des.v.y; xd[5] = (S)des.v.z;
-  xd[6] = (S)(des.p.x + in.P.cx); xd[7] = (S)(des.p.y + in.P.cy); xd[8] = (S)(des.p.z + in.P.cz);
-}
+// Optional tail of k_lowlevel_step: the NEXT control step's nominal controller, on the state the kernel has just produced and still
+// holds in registers (the C loop knows t_{k+1}): unom / xdes of step k+1 come out of step k's launch, one launch and one read of the
+// state less per step.  kind 0: GeometricControl (return_omegas), 1: LQROmegaController (K points at its LqrGain).  unom == NULL: off.
+template <typename T, typename S> struct NextNominal {
+  const T* lem;
+  const void* K;
+  S* unom;
+  S* xdes;
+  double t;
+  T hover_sub;
+  int kind;
+  int only;      // 1: the launch is ONLY this tail (the stand-alone nominal controller of the step-by-step loop): no low level, no physics
+};
 
-// Same role with the LQR-omega nominal controller the reference's CBFTest actually instantiates
-// (simulations/CBFTest.py:290-293, control/lqr/lqr_omega_controller.py:90-119).
+// The nominal controller of the CBF loops for drone i (simulations/CBFTest.py:303-343): trajectory sample, GeometricControl
+// (return_omegas) or LQROmegaController, u_hat = (force - M G, w) and xdes = [0, 0, yaw, v_des, p_des] into the scratch.
+// The step-by-step loop and the C rollout (which chains the nominal input of step k+1 onto the low-level launch of step k) must stay
+// bitwise equal.  Inlined into two different kernels this body does NOT compile to the same arithmetic (1-ulp differences in 1 % of
+// the RPMs after three steps, also with its inputs made opaque; a __noinline__ body is equal but costs 50 % of the C4 step), so it has
+// exactly ONE call site: the tail of k_lowlevel_step, which the step-by-step loop launches in its `only` mode as its nominal kernel.
 template <typename T, typename S>
-__global__ __launch_bounds__(kBlock) void k_cbf_nominal_lqr(const Consts<T> c, const LqrGain<T> K, const int n, const size_t ld,
-                                                            const double t, const T hover_sub, const S* __restrict__ state,
-                                                            const T* __restrict__ lem, S* __restrict__ unom,
-                                                            S* __restrict__ xdes, const int batch0) {
-  const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
-  if (i >= n) return;
-  GeoIn<T> in;
-  load_geo_in<T, S>(state, lem, ld, i, in);
-  const Desired<T> des = lemniscate_local(in.P, t);
-  const V3<T> rpy = euler_from_quat(in.s.q);
-  T u[4];
-  lqr_omega_control<T>(c, K, rpy, in.s.v, in.s.p, des.p, des.v, des.yaw, u);      // local frame: the centre cancels in p - p_des
-  const T un[4] = {u[0] - hover_sub, u[1], u[2], u[3]};                            // CBFTest.py:339 (hover_sub = M G; 0 without a filter)
-  store4<S, T>(unom + (size_t)i * 4, un);
-  S* xd = xdes + (size_t)i * 9;
+__device__ __forceinline__ void cbf_nominal_of(const Consts<T>* cp, const NextNominal<T, S>* nxp, const State<T>* sp, const int i, const size_t ld) {
+  const Consts<T>& c = *cp;
+  const NextNominal<T, S>& nx = *nxp;
+  const State<T>& sn = *sp;
+  const LemniscateParams<T> P = {nx.lem[lidx(0, i, ld)], nx.lem[lidx(1, i, ld)], nx.lem[lidx(2, i, ld)], nx.lem[lidx(3, i, ld)],
+                                 nx.lem[lidx(4, i, ld)], nx.lem[lidx(5, i, ld)], nx.lem[lidx(6, i, ld)]};
+  const Desired<T> des = lemniscate_local(P, nx.t);
+  T un[4];
+  if (nx.kind == 0) {
+    const M3<T> Rm = quat_to_rot(sn.q);
+    const V3<T> ang_v = mul(Rm, sn.w);
+    T uu[4];
+    GeoAux<T> A;
+    geometric_control<T>(c, sn.p - des.p, Rm, sn.v, ang_v, des, uu, &A);
+    un[0] = A.force - nx.hover_sub;
+    un[1] = A.w_des.x; un[2] = A.w_des.y; un[3] = A.w_des.z;
+  } else {
+    T uu[4];
+    lqr_omega_control<T>(c, *static_cast<const LqrGain<T>*>(nx.K), euler_from_quat(sn.q), sn.v, sn.p, des.p, des.v, des.yaw, uu);
+    un[0] = uu[0] - nx.hover_sub;
+    un[1] = uu[1]; un[2] = uu[2]; un[3] = uu[3];
+  }
+  store4<S, T>(nx.unom + (size_t)i * 4, un);
+  S* xd = nx.xdes + (size_t)i * 9;
   xd[0] = (S)0; xd[1] = (S)0; xd[2] = (S)des.yaw;
   xd[3] = (S)des.v.x; xd[4] = (S)des.v.y; xd[5] = (S)des.v.z;
-  xd[6] = (S)(des.p.x + in.P.cx); xd[7] = (S)(des.p.y + in.P.cy); xd[8] = (S)(des.p.z + in.P.cz);
+  xd[6] = (S)(des.p.x + P.cx); xd[7] = (S)(des.p.y + P.cy); xd[8] = (S)(des.p.z + P.cz);
 }
 
 // LQROmegaController.compute(obs, skip_low_level=True): obs [n,20], des [n,11] -> u [n,4]
@@ -826,45 +841,55 @@ __global__ __launch_bounds__(kBlock) void k_lowlevel_step(const Consts<T> c, con
                                                           const T thrust_offset, S* __restrict__ state,
                                                           const T* __restrict__ origin, T* __restrict__ last_rpm,
                                                           T* __restrict__ ll, const S* __restrict__ u_in, S* __restrict__ obs,
-                                                          S* __restrict__ action_out, const int batch0, S* __restrict__ state_lo = nullptr) {
+                                                          S* __restrict__ action_out, const int batch0, S* __restrict__ state_lo = nullptr,
+                                                          const NextNominal<T, S> nx = NextNominal<T, S>{nullptr, nullptr, nullptr, nullptr, 0.0, T(0), 0, 0}) {
   __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
   const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
   const bool valid = i < n;
+  const bool do_step = !(!YANK && nx.only != 0);               // wave-uniform
   T o[kObsDim];
   State<T> s;
   Resid<T> r;
   if (valid) {
     load_state<S, T>(state, ld, i, s);
-    if (COMP) load_resid<S, T>(state_lo, ld, i, r);
-    T u[4];
-    load4<S, T>(u_in + (size_t)i * 4, u);
-    u[0] += thrust_offset;
-    LowLevelState<T> L;
-    L.last_omega = {ll[0 * ld + i], ll[1 * ld + i], ll[2 * ld + i]};
-    L.integral = {ll[3 * ld + i], ll[4 * ld + i], ll[5 * ld + i]};
-    T act[4], prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4];
-    // compute_low_level rotates obs[13:16] (= R w) back with R^T: the body rate is the state's w
-    if (YANK) {   // obs still holds the previous step's row here: every row is read and later rewritten by the same wave
-      T rpm_prev[4];
-      load4<S, T>(obs + (size_t)i * kObsDim + 16, rpm_prev);
-      yank_omega_control(c, ctrl_dt, u, rpm_prev, s.w, L, act);
-    } else {
-      thrust_omega_control(c, ctrl_dt, u, s.w, L, act);
+    if (do_step) {
+      if (COMP) load_resid<S, T>(state_lo, ld, i, r);
+      T u[4];
+      load4<S, T>(u_in + (size_t)i * 4, u);
+      u[0] += thrust_offset;
+      LowLevelState<T> L;
+      L.last_omega = {ll[0 * ld + i], ll[1 * ld + i], ll[2 * ld + i]};
+      L.integral = {ll[3 * ld + i], ll[4 * ld + i], ll[5 * ld + i]};
+      T act[4], prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4];
+      // compute_low_level rotates obs[13:16] (= R w) back with R^T: the body rate is the state's w
+      if (YANK) {   // obs still holds the previous step's row here: every row is read and later rewritten by the same wave
+        T rpm_prev[4];
+        load4<S, T>(obs + (size_t)i * kObsDim + 16, rpm_prev);
+        yank_omega_control(c, ctrl_dt, u, rpm_prev, s.w, L, act);
+      } else {
+        thrust_omega_control(c, ctrl_dt, u, s.w, L, act);
+      }
+      ll[0 * ld + i] = L.last_omega.x; ll[1 * ld + i] = L.last_omega.y; ll[2 * ld + i] = L.last_omega.z;
+      ll[3 * ld + i] = L.integral.x; ll[4 * ld + i] = L.integral.y; ll[5 * ld + i] = L.integral.z;
+      if (DRAG)
+        for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
+      aviary_step_any<T, RK4, DRAG, COMP>(c, s, r, act, prev, clipped);
+      if (DRAG || last_rpm)
+        for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
+      if (action_out) store4<S, T>(action_out + (size_t)i * 4, act);
+      pack_obs(s, V3<T>{origin[i], origin[ld + i], origin[2 * ld + i]}, clipped, o);
     }
-    ll[0 * ld + i] = L.last_omega.x; ll[1 * ld + i] = L.last_omega.y; ll[2 * ld + i] = L.last_omega.z;
-    ll[3 * ld + i] = L.integral.x; ll[4 * ld + i] = L.integral.y; ll[5 * ld + i] = L.integral.z;
-    if (DRAG)
-      for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
-    aviary_step_any<T, RK4, DRAG, COMP>(c, s, r, act, prev, clipped);
-    if (DRAG || last_rpm)
-      for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
-    if (action_out) store4<S, T>(action_out + (size_t)i * 4, act);
-    pack_obs(s, V3<T>{origin[i], origin[ld + i], origin[2 * ld + i]}, clipped, o);
   }
-  write_obs_rows<S, T>(lds, obs, n, i, valid, o);
+  if (do_step) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
   if (valid) {
-    store_state<S, T>(state, ld, i, s);
-    if (COMP) store_resid<S, T>(state_lo, ld, i, r);
+    if (do_step) {
+      store_state<S, T>(state, ld, i, s);
+      if (COMP) store_resid<S, T>(state_lo, ld, i, r);
+    }
+    if (!YANK && nx.unom != nullptr) {        // the nominal controller on the state just stored (only: on the state just loaded)
+      const State<T> sn = state_as_stored<T, S>(s);
+      cbf_nominal_of<T, S>(&c, &nx, &sn, i, ld);
+    }
   }
 }
 
