@@ -875,7 +875,7 @@ __device__ __forceinline__ void cbf_o2_slot(const CbfParams<T>& P, const T (*__r
 //                                 most-violated-row scan, gi_solve (rows stay in registers: no row table);
 //   stage C, one drone per lane : u_safe (nominal if the env's QP has no solution, qptracker.py:30-34) + M G -> ThrustOmega low level
 //                                 -> physics step -> observation row -> state.
-// The three-launch path (k_cbf_nominal / k_cbf_filter_gi / k_lowlevel_step) moves u_hat, xdes, u_safe and the state through HBM
+// The three-launch path (nominal / k_cbf_filter_gi / k_lowlevel_step) moves u_hat, xdes, u_safe and the state through HBM
 // twice and runs the per-drone stages at full lane use but the QP kernel one env per wave; here the per-drone stages keep every lane
 // busy (a wave = 64 drones = 64 / D whole envs) and nothing but state, trajectory parameters and the observation crosses HBM.
 // Same arithmetic as the three kernels (shared device functions); x is formed from the state exactly as pack_obs would hand it over.
