@@ -591,17 +591,21 @@ def main(argv=None):
     # the whole-rollout kernel, 50 control steps per launch with every step's observation streamed to a [50,n,20] log
     if args.workload in ("c2", "c3") and not fused_T and not args.python_loop and extras and not rk4:
         T2 = 50
-        log2 = torch.empty((T2, E, D, 20), dtype=env.dtype, device=device)
-        env.rollout_geometric_fused(0.0, T2, log=True, log_out=log2)
-        reps = 10
-        us = _timed_steps(device, lambda: [env.rollout_geometric_fused(r_ * T2 * dt, T2, log=True, log_out=log2) for r_ in range(reps)], reps * T2)
+        try:                      # (every rank takes the same path: the reduction below is a collective)
+            log2 = torch.empty((T2, E, D, 20), dtype=env.dtype, device=device)
+            env.rollout_geometric_fused(0.0, T2, log=True, log_out=log2)
+            reps = 10
+            us = _timed_steps(device, lambda: [env.rollout_geometric_fused(r_ * T2 * dt, T2, log=True, log_out=log2) for r_ in range(reps)], reps * T2)
+            del log2
+        except Exception as exc:
+            us = float("nan")
+            line["fused_rollout_error"] = str(exc)
         us = max_over_ranks(us, world, red_dev)
         b2 = 20 * es + 53 * es / T2
         line["fused_rollout"] = {"steps_per_launch": T2, "us_per_step": us, "value": n_local * world / (us * 1e-6), "unit": "drone-steps/s",
                                  "bytes_per_drone_step": b2, "achieved_GBps": b2 * n_local / (us * 1e-6) / 1e9,
                                  "bound": "VALU (state in registers; only the obs log leaves the chip)",
                                  "kernel": f"k_rollout_geometric<{cname},{tname},false,false>"}
-        del log2
     if c5 and not fused_T and not args.python_loop and extras:
         # the same loop with 40 env.step per launch (mds_rollout_step_fused), one 1000-step episode per repetition
         T2, reps = 40, 4
