@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 200 /* 0.2.0 */
+#define MDS_VERSION 201 /* 0.2.1 */
 #define MDS_OBS_DIM 20  /* [UPSTREAM] _getDroneStateVector */
 #define MDS_ACT_DIM 4
 #define MDS_STATE_DIM 13 /* pos3 | quat4 xyzw | vel3 (world) | body rates3 */
@@ -69,7 +69,8 @@ typedef enum mds_dtype { MDS_F32 = 0, MDS_F64 = 1, MDS_F16 = 2, MDS_F32C = 3 } m
  * downwash couples the drones of an env, so these modes run ONE substep per launch on a double-buffered state: mds_step, and the
  * controller paths (mds_step_geometric, mds_step_lqr, mds_step_cbf_geometric, mds_step_nominal: controller + first substep in one
  * launch, the action replayed by the remaining substeps); the mds_rollout_* calls issue the same steps in a loop on the caller's
- * stream (no two-chain split, no state-in-registers form).  Only mds_step_dslpid returns MDS_EUNSUPPORTED. */
+ * stream (no two-chain split, no state-in-registers form).  mds_step_dslpid / mds_rollout_dslpid run the controller from the state as
+ * its own launch, then the substeps. */
 typedef enum mds_physics {
   MDS_PHYSICS_DYN = 0, MDS_PHYSICS_DYN_DRAG = 1, MDS_PHYSICS_DYN_GND = 2, MDS_PHYSICS_DYN_DW = 3, MDS_PHYSICS_DYN_GND_DRAG_DW = 4
 } mds_physics;
@@ -227,10 +228,10 @@ int mds_reset_async(mds_handle* h, void* stream);
  * (events on entry and exit -- the exit events are recorded even when a launch in between failed), so the usual stream
  * semantics hold. */
 int mds_set_rollout_streams(mds_handle* h, int n_streams);
-/* What the most recent mds_rollout_geometric / mds_rollout_step / mds_rollout_cbf_geometric of this handle did: 1 = the
+/* What the most recent mds_rollout_geometric / mds_rollout_step / mds_rollout_dslpid / mds_rollout_cbf_geometric of this handle did: 1 = the
  * caller's stream only, 2 = two chains on the internal streams, 0 = no rollout yet. */
 int mds_get_last_rollout_streams(const mds_handle* h);
-/* What a call of n_steps would do under the current setting: loop 0 = mds_rollout_geometric / mds_rollout_step, loop 1 =
+/* What a call of n_steps would do under the current setting: loop 0 = mds_rollout_geometric / mds_rollout_step / mds_rollout_dslpid, loop 1 =
  * mds_rollout_cbf_geometric.  Returns 1 or 2.  (A caller that warms a path up asks this for the length it is going to time.) */
 int mds_rollout_streams_for(const mds_handle* h, int loop, int n_steps);
 
@@ -337,6 +338,12 @@ int mds_dslpid_compute(mds_handle* h, const void* obs_dev, const void* target_po
 /* MultiDroneEnv.sim_step (PIDEnv.py:161-176): the same controller on the handle's own state, fused with
  * env.step(action).  obs_dev [n,20] / action_dev [n,4] optional. */
 int mds_step_dslpid(mds_handle* h, const void* target_pos_dev, const void* target_rpy_dev, void* obs_dev, void* action_dev, void* stream);
+/* n_steps of that sim_step as a C loop (PIDEnv.py:201-207, `for i in range(...): env.sim_step()`): step first_step + k uses target
+ * set (first_step + k) % n_target_sets of target_pos_dev / target_rpy_dev [n_target_sets, n, 3] (1 = the fixed TARGET_POSITIONS of
+ * PIDEnv; more = a waypoint table).  obs_dev [n,20] receives every step's observation (obs_every_step) or the last one only.
+ * Bit-identical to n_steps calls of mds_step_dslpid; follows the stream policy of mds_set_rollout_streams (loop 0). */
+int mds_rollout_dslpid(mds_handle* h, const void* target_pos_dev, const void* target_rpy_dev, int n_target_sets, int first_step,
+                       int n_steps, void* obs_dev, int obs_every_step, void* stream);
 
 /* LQROmegaController (control/lqr/lqr_omega_controller.py): K [4,9] row-major is the gain its
  * compute_gain_matrix() obtains from solve_continuous_are on the host (:53-57). */

@@ -87,11 +87,13 @@ def do_control(args, env, target_positions, target_rpys):
     shape = (args.num_drones, 4) if args.num_envs == 1 else (args.num_envs, args.num_drones, 4)
     obs, _, _, _, _ = env.step(np.zeros(shape))
     ctrl_steps = int(args.duration_sec * env.CTRL_FREQ)
-    for i in range(ctrl_steps):
-        obs = env.step_dslpid(target_positions, target_rpys)      # per-drone computeControlFromState + env.step, fused
-        if args.realtime:
+    if args.realtime:
+        for i in range(ctrl_steps):
+            obs = env.step_dslpid(target_positions, target_rpys)  # per-drone computeControlFromState + env.step, fused
             env.render()
             sync(i, start, env.CTRL_TIMESTEP)
+    elif ctrl_steps > 0:
+        obs = env.rollout_dslpid(target_positions, target_rpys, ctrl_steps)   # the same loop, issued by one C call
     final = obs.double().cpu().numpy()
     env.close()
     return final

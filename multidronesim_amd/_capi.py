@@ -100,6 +100,7 @@ PROTOTYPES = {
     "mds_dslpid_reset": (C.c_int, [_P, _P]),
     "mds_dslpid_compute": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "mds_step_dslpid": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "mds_rollout_dslpid": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "mds_set_lqr_omega_gain": (C.c_int, [_P, _PD]),
     "mds_lqr_omega_compute": (C.c_int, [_P, _P, _P, _P, _P]),
     "mds_set_lqr_gain": (C.c_int, [_P, _PD]),

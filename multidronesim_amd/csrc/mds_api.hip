@@ -1481,11 +1481,12 @@ int mds_dslpid_reset(mds_handle* h, void* stream) {
   return MDS_OK;
 }
 
+// PID_GRID / PID_B0: the launch's batches (all of them, or one half of the shard in a two-chain rollout)
 #define MDS_PID_LAUNCH(T, S, C, G, STEP, RK4, DRAG)                                                                           \
-  k_dslpid<T, S, STEP, RK4, DRAG><<<grid_for(h->n, kBlock), kBlock, 0, st>>>(C, G, h->n, h->ld, (T)(1.0 / h->cfg.ctrl_freq), (S*)h->state, \
-                                                                             (const T*)h->origin, (T*)rpm_track(h), (T*)h->pid,             \
-                                                                             (const S*)obs_in, (const S*)tpos, (const S*)trpy, (S*)obs,    \
-                                                                             (S*)act)
+  k_dslpid<T, S, STEP, RK4, DRAG><<<PID_GRID, kBlock, 0, st>>>(C, G, h->n, h->ld, (T)(1.0 / h->cfg.ctrl_freq), (S*)h->state, \
+                                                               (const T*)h->origin, (T*)rpm_track(h), (T*)h->pid,            \
+                                                               (const S*)obs_in, (const S*)tpos, (const S*)trpy, (S*)obs,   \
+                                                               (S*)act, PID_B0)
 #define MDS_PID_DTYPE(STEP, RK4, DRAG)                                                        \
   do {                                                                                        \
     if (h->cfg.dtype == MDS_F64) MDS_PID_LAUNCH(double, double, h->cd, h->pid_d, STEP, RK4, DRAG); \
@@ -1493,12 +1494,41 @@ int mds_dslpid_reset(mds_handle* h, void* stream) {
     else MDS_PID_LAUNCH(float, half_t, h->cf, h->pid_f, STEP, RK4, DRAG);                     \
   } while (0)
 
+// one MultiDroneEnv.sim_step for the batches [batch0, batch0 + nb) (nb == 0: the whole shard)
+static void launch_step_dslpid(mds_handle* h, const void* tpos, const void* trpy, void* obs, void* act, hipStream_t st, unsigned batch0 = 0,
+                               unsigned nb = 0) {
+  const dim3 PID_GRID = nb ? dim3(nb) : grid_for(h->n, kBlock);
+  const int PID_B0 = (int)batch0;
+  const void* obs_in = nullptr;
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
+  if (rk4 && drag) MDS_PID_DTYPE(true, true, true);
+  else if (rk4) MDS_PID_DTYPE(true, true, false);
+  else if (drag) MDS_PID_DTYPE(true, false, true);
+  else MDS_PID_DTYPE(true, false, false);
+}
+
+// the same step under ground effect / downwash: the controller reads the handle's state and leaves the action in act_scratch (or the
+// caller's buffer), then env.step runs it one substep per launch
+static int step_env_dslpid(mds_handle* h, const void* tpos, const void* trpy, void* obs, void* act_out, hipStream_t st) {
+  const dim3 PID_GRID = grid_for(h->n, kBlock);
+  const int PID_B0 = 0;
+  const void* obs_in = nullptr;
+  void* act = act_out ? act_out : h->act_scratch;
+  {
+    void* obs = nullptr;
+    MDS_PID_DTYPE(false, false, false);
+  }
+  return step_env_plain(h, act, obs, st, 0);
+}
+
 int mds_dslpid_compute(mds_handle* h, const void* obs_in, const void* tpos, const void* trpy, void* act, void* stream) {
   MDS_DEV(h);
   if (!h || !obs_in || !tpos || !trpy || !act) return fail(MDS_EINVAL, "mds_dslpid_compute: null argument");
   if (!aligned16(act)) return fail(MDS_EALIGN, "mds_dslpid_compute: rpm_dev");
   hipStream_t st = (hipStream_t)stream;
   void* obs = nullptr;
+  const dim3 PID_GRID = grid_for(h->n, kBlock);
+  const int PID_B0 = 0;
   MDS_PID_DTYPE(false, false, false);
   MDS_HIP(hipGetLastError());
   return MDS_OK;
@@ -1506,17 +1536,61 @@ int mds_dslpid_compute(mds_handle* h, const void* obs_in, const void* tpos, cons
 
 int mds_step_dslpid(mds_handle* h, const void* tpos, const void* trpy, void* obs, void* act, void* stream) {
   MDS_DEV(h);
-  if (h && h->envfx) return fail(MDS_EUNSUPPORTED, "ground effect / downwash physics is served by mds_step only");
   if (!h || !tpos || !trpy) return fail(MDS_EINVAL, "mds_step_dslpid: null argument");
   MDS_NO_COMP(h, "mds_step_dslpid");
   if (!aligned16(obs) || !aligned16(act)) return fail(MDS_EALIGN, "mds_step_dslpid: obs_dev/action_dev");
+  if (h->envfx) return step_env_dslpid(h, tpos, trpy, obs, act, (hipStream_t)stream);
+  launch_step_dslpid(h, tpos, trpy, obs, act, (hipStream_t)stream);
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_rollout_dslpid(mds_handle* h, const void* tpos, const void* trpy, int n_target_sets, int first_step, int n_steps, void* obs,
+                       int obs_every_step, void* stream) {
+  MDS_DEV(h);
+  if (!h || !tpos || !trpy || n_target_sets < 1 || first_step < 0 || n_steps < 0) return fail(MDS_EINVAL, "mds_rollout_dslpid: arguments");
+  MDS_NO_COMP(h, "mds_rollout_dslpid");
+  if (!aligned16(obs)) return fail(MDS_EALIGN, "mds_rollout_dslpid: obs_dev");
   hipStream_t st = (hipStream_t)stream;
-  const void* obs_in = nullptr;
-  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
-  if (rk4 && drag) MDS_PID_DTYPE(true, true, true);
-  else if (rk4) MDS_PID_DTYPE(true, true, false);
-  else if (drag) MDS_PID_DTYPE(true, false, true);
-  else MDS_PID_DTYPE(true, false, false);
+  const size_t set_bytes = (size_t)h->n * 3 * elem_size(h->cfg.dtype);
+  auto targets = [&](int k, const void** p, const void** r) {
+    const size_t off = (size_t)(((long long)first_step + k) % n_target_sets) * set_bytes;
+    *p = (const char*)tpos + off;
+    *r = (const char*)trpy + off;
+  };
+  const void *p, *r;
+  if (h->envfx) {
+    h->last_rollout_streams = 1;
+    for (int k = 0; k < n_steps; ++k) {
+      targets(k, &p, &r);
+      if (int rc = step_env_dslpid(h, p, r, (obs_every_step || k == n_steps - 1) ? obs : nullptr, nullptr, st)) return rc;
+    }
+    return MDS_OK;
+  }
+  const unsigned nbatch = (unsigned)((h->n + kBlock - 1) / kBlock);
+  if (rollout_streams_policy(h, 0, n_steps) == 2 && nbatch >= 2) {   // the PID memory is per drone too: two independent chains
+    hipStream_t sb = h->split_st;
+    h->last_rollout_streams = 2;
+    const unsigned half = nbatch / 2;
+    auto body = [&]() -> int {
+      for (int k = 0; k < n_steps; ++k) {
+        void* o = (obs_every_step || k == n_steps - 1) ? obs : nullptr;
+        targets(k, &p, &r);
+        if (k == 0)
+          if (int rc = split_fork(h, st)) return rc;
+        launch_step_dslpid(h, p, r, o, nullptr, st, 0, half);
+        launch_step_dslpid(h, p, r, o, nullptr, sb, half, nbatch - half);
+      }
+      MDS_HIP(hipGetLastError());
+      return MDS_OK;
+    };
+    return split_join(h, st, body());
+  }
+  h->last_rollout_streams = 1;
+  for (int k = 0; k < n_steps; ++k) {
+    targets(k, &p, &r);
+    launch_step_dslpid(h, p, r, (obs_every_step || k == n_steps - 1) ? obs : nullptr, nullptr, st);
+  }
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }

@@ -929,21 +929,23 @@ __global__ void k_thrust_omega(const Consts<T> c, const int n, const size_t ld, 
 // ------------------------------------------------------------------------------------
 // PIDEnv.MultiDroneEnv.sim_step (PIDEnv.py:161-176) for every drone: [UPSTREAM] DSLPIDControl
 // towards TARGET_POSITIONS / TARGET_RPYS, then env.step(action).  pid = 9 planes:
-// last_rpy3 | integral_pos_e3 | integral_rpy_e3.  STEP = false: controller only, from an obs array.
+// last_rpy3 | integral_pos_e3 | integral_rpy_e3.  STEP = false: controller only, from an obs array (or the state, obs_in NULL).
 // ------------------------------------------------------------------------------------
 template <typename T, typename S, bool STEP, bool RK4, bool DRAG>
 __global__ __launch_bounds__(kBlock) void k_dslpid(const Consts<T> c, const DslPidGains<T> g, const int n, const size_t ld, const T ctrl_dt,
                                                    S* __restrict__ state, const T* __restrict__ origin, T* __restrict__ last_rpm,
                                                    T* __restrict__ pid, const S* __restrict__ obs_in, const S* __restrict__ tpos,
-                                                   const S* __restrict__ trpy, S* __restrict__ obs, S* __restrict__ action_out) {
+                                                   const S* __restrict__ trpy, S* __restrict__ obs, S* __restrict__ action_out,
+                                                   const int batch0) {
   __shared__ __align__(16) unsigned char lds[STEP ? (kBlock * kObsDim * sizeof(S)) : 16];
-  const int i = blockIdx.x * kBlock + threadIdx.x;
+  // batch0: first 256-drone batch of this launch (mds_rollout_dslpid may step the two halves of the shard on two streams)
+  const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
   const bool valid = i < n;
   T o[kObsDim];
   State<T> s;
   if (valid) {
     V3<T> org = {T(0), T(0), T(0)};
-    if (STEP) {
+    if (STEP || !obs_in) {      // controller only with obs_in == NULL: from the handle's own state (ground effect / downwash steps)
       load_state<S, T>(state, ld, i, s);
       org = {origin[i], origin[ld + i], origin[2 * ld + i]};
     } else {

@@ -430,6 +430,27 @@ class BaseAviary:
         self.step_counter += self.PYB_STEPS_PER_CTRL
         return (self._obs, self._act) if return_action else self._obs
 
+    def rollout_dslpid(self, target_pos, target_rpy, n_steps: int, first_step: int = 0, obs_every_step: bool = False):
+        """``for i in range(n_steps): env.sim_step()`` of PIDEnv.py:201-207 as one C call (``mds_rollout_dslpid``).  Targets:
+        [D,3] / [E,D,3] (fixed, PIDEnv's TARGET_POSITIONS) or a waypoint table [W,E,D,3] used cyclically from ``first_step``.
+        Returns the last observation."""
+        self._require_open()
+        def prep(a):
+            if not isinstance(a, torch.Tensor):
+                a = np.asarray(a, dtype=np.float64)
+                if a.shape == (self.NUM_DRONES, 3):
+                    a = np.broadcast_to(a, (self.NUM_ENVS, self.NUM_DRONES, 3))
+            a = to_device(a, self.device, self.dtype)
+            return a.reshape(-1, self.n, 3).contiguous()
+        tp, tr = prep(target_pos), prep(target_rpy)
+        if tp.shape != tr.shape:
+            raise ValueError(f"target_pos {tuple(tp.shape)} and target_rpy {tuple(tr.shape)} must hold the same number of sets")
+        capi.check(self._lib.mds_rollout_dslpid(self._h, C.c_void_p(tp.data_ptr()), C.c_void_p(tr.data_ptr()), C.c_int(tp.shape[0]),
+                                                C.c_int(first_step), C.c_int(n_steps), C.c_void_p(self._obs.data_ptr()),
+                                                C.c_int(1 if obs_every_step else 0), self._stream()), "mds_rollout_dslpid")
+        self.step_counter += n_steps * self.PYB_STEPS_PER_CTRL
+        return self._obs
+
     def set_cbf_nominal(self, which: str):
         """Nominal controller of ``step_cbf_geometric``: "geometric" (GeometricControl return_omegas),
         "lqr_omega" (LQROmegaController) or "lqr_yank_omega" (LQRYankOmegaController, the order-3 loop of
