@@ -525,9 +525,10 @@ def main(argv=None):
             line["roofline"]["residency"] = ("HBM-resident: 890 MB touched per control step (state 218 + parameters 117 + observations 335 MB written, "
                                              "state 218 MB rewritten), 3.5x the 256 MiB Infinity Cache")
         else:
-            line["roofline"]["residency"] = ("Infinity-Cache-assisted: the step's 111 MB (84 MB working set, rewritten in place every step) fit the 256 MiB "
-                                             "Infinity Cache, so `frac` is an effective bandwidth fraction, not an HBM one; `frac_hbm_resident` "
-                                             "is the same kernel on a 4 M-drone shard (890 MB per step)")
+            step_mb, ws_mb = bytes_per * n_local / 1e6, (bytes_per - 52) * n_local / 1e6      # state is read and rewritten in place: counted once
+            line["roofline"]["residency"] = (f"Infinity-Cache-assisted: the step's {step_mb:.3g} MB ({ws_mb:.3g} MB working set, rewritten in place every step) "
+                                             "fit the 256 MiB Infinity Cache, so `frac` is an effective bandwidth fraction, not an HBM one"
+                                             + ("; `frac_hbm_resident` is the same kernel on a 4 M-drone shard (890 MB per step)" if args.workload == "c3" else ""))
         # HBM traffic from the PMC counters cannot be read inside this process; the committed summary of the
         # separate rocprofv3 --pmc passes (profiles/, same kernel) is reported, scaled to this run's launch shape.
         per_launch = n_local // 2 if split else n_local
