@@ -223,7 +223,7 @@ int mds_reset_async(mds_handle* h, void* stream);
  * gaps between dependent launches disappear (C3: 17.5 -> 15.0-15.7 us per step; half-shard launches also carry unused
  * LDS so that 5 instead of 8 workgroups share a CU and the chains interleave from the first step).
  * 0 = auto (geometric / plain step: two streams from 2^19 drones, from 2^18 for calls of 1000+ steps; CBF loop: from
- * 2^16 drones), 1 = the caller's stream only, 2 = always split (a set-up call then: it creates the internal streams of a
+ * 2^16 drones; calls of fewer than 16 steps always stay on the caller's stream -- a two-chain call costs ~35 us), 1 = the caller's stream only, 2 = always split (a set-up call then: it creates the internal streams of a
  * handle that mds_create gave none).  Results are bit-identical either way; the caller's stream orders the whole call
  * (events on entry and exit -- the exit events are recorded even when a launch in between failed), so the usual stream
  * semantics hold. */

@@ -160,11 +160,12 @@ static inline void* rpm_track(mds_handle* h) {
 // Shards at least this large step their two halves on two streams inside mds_rollout_geometric (0 = auto policy).
 constexpr size_t kSplitMinDrones = size_t(1) << 18;
 // Calls shorter than this stay on the caller's stream under the auto policy: a two-chain call costs a fork and a join (two
-// cross-stream dependencies) and its halves start in lock step -- ~35 us more than n x its steady-state step.  C3, us per
-// control step by call length, one stream -> two chains: 5 steps 18.0 -> 20.0, 20 steps 17.1-17.4 -> 17.0-17.1, 50 steps
-// 16.7 -> 15.5, 100 steps 17.4 -> 15.2, 2000 steps 17.4 -> 14.8 (profiles/r02_short_calls.log).
+// cross-stream dependencies) and its halves start in lock step -- ~35 us more than n x its steady-state step.  C3, wall-clock us
+// per control step (enqueue .. synchronize, median of 21 calls) by call length, one stream -> two chains: 8 steps 20.3 -> 20.8,
+// 12 steps 19.0 -> 19.0, 16 steps 19.0 -> 18.1, 20 steps 18.7 -> 17.7, 32 steps 18.2 -> 16.9, 48 steps 18.0 -> 16.5; by HIP events
+// 100 steps 17.4 -> 15.2, 2000 steps 17.4 -> 14.8 (profiles/r02_short_calls.log).
 #ifndef MDS_SPLIT_MIN_STEPS
-#define MDS_SPLIT_MIN_STEPS 32
+#define MDS_SPLIT_MIN_STEPS 16
 #endif
 constexpr int kSplitMinSteps = MDS_SPLIT_MIN_STEPS;
 

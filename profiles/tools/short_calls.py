@@ -1,7 +1,7 @@
 """How long must one mds_rollout_geometric call be for the two-chain issue to beat the caller's stream alone?
 C3 shard (65 536 x 8), obs every step.  For each (streams, steps per call): one untimed call of the same length through the
 same branch, then `reps` timed calls; prints HIP-event and wall-clock (enqueue .. synchronize) microseconds per control step.
-Run on the GPU box from the repo root:  python3 profiles/tools/short_calls.py [reps]"""
+Run on the GPU box from the repo root:  python3 profiles/tools/short_calls.py [reps [steps,steps,...]]"""
 import os
 import sys
 import time
@@ -14,6 +14,7 @@ import bench
 from multidronesim_amd.envs.CtrlAviary import CtrlAviary, DroneModel, Physics
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+step_list = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (5, 20, 50, 100, 200, 500, 2000)
 E, D = 65536, 8
 xyz, rpy, P = bench.make_inputs(E, D, "c3", 1000)
 env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN,
@@ -23,7 +24,7 @@ env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=env.device))
 dev = env.device
 st = torch.cuda.current_stream(dev)
 print("steps streams used  ev_us_min ev_us_med  wall_us_min wall_us_med", flush=True)
-for steps in (5, 20, 50, 100, 200, 500, 2000):
+for steps in step_list:
     for streams in (1, 2):
         env.set_rollout_streams(streams)
         env.rollout_geometric(0.0, steps, want_obs=True, obs_every_step=True)
