@@ -47,20 +47,11 @@ MDS_HD void cbf_row_o2(const CbfParams<T>& P, T ex, T ey, T ez, T dr, T dp, T dv
   *Lg0 = gz * P.inv_m;
 }
 
-// One ECBF row between agent i (state xi, desired xdi) and agent / obstacle j.
+// One ECBF row from e = pos_i - pos_j (ACTUAL positions) and d = (x_i - xdes_i) - (x_j - xdes_j), the difference of the two
+// tracking errors in the model's state layout (d = x_i - xdes_i against an obstacle, cbf/cbf.py:380-392):
 //   h_row = Kcbf . hdots + L_f^r h,   Lg[4] with G[4i:4i+4] = -Lg, G[4j:4j+4] = +Lg.
-// e = pos_i - pos_j from the ACTUAL states; d = (xi - xdi) - (xj - xdj) (error states);
-// for an obstacle the caller passes dj = 0 (cbf/cbf.py:380-392).
 template <typename T, int ORDER>
-MDS_HD void cbf_pair_row(const CbfParams<T>& P, const T* xi, const T* xdi, const T* xj, const T* xdj, bool obstacle, T Ds,
-                         T* h_row, T Lg[4]) {
-  constexpr int xd = ORDER == 2 ? 9 : 10;
-  const T ex = xi[xd - 3] - xj[xd - 3], ey = xi[xd - 2] - xj[xd - 2], ez = xi[xd - 1] - xj[xd - 1];
-  T d[xd];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-  for (int k = 0; k < xd; ++k) d[k] = (xi[k] - xdi[k]) - (obstacle ? T(0) : (xj[k] - xdj[k]));
+MDS_HD void cbf_row_core(const CbfParams<T>& P, T ex, T ey, T ez, const T* d, T Ds, T* h_row, T Lg[4]) {
   if (ORDER == 2) {
     cbf_row_o2(P, ex, ey, ez, d[0], d[1], d[3], d[4], d[5], Ds, h_row, &Lg[0]);
     Lg[1] = T(0);
@@ -92,6 +83,21 @@ MDS_HD void cbf_pair_row(const CbfParams<T>& P, const T* xi, const T* xdi, const
     Lg[2] = P.g * gx;
     Lg[3] = T(0);
   }
+}
+
+// The same row between agent i (state xi, desired xdi) and agent / obstacle j from the states themselves; for an obstacle the
+// caller passes xj = xdj = (0.., position) and obstacle = true.
+template <typename T, int ORDER>
+MDS_HD void cbf_pair_row(const CbfParams<T>& P, const T* xi, const T* xdi, const T* xj, const T* xdj, bool obstacle, T Ds,
+                         T* h_row, T Lg[4]) {
+  constexpr int xd = ORDER == 2 ? 9 : 10;
+  const T ex = xi[xd - 3] - xj[xd - 3], ey = xi[xd - 2] - xj[xd - 2], ez = xi[xd - 1] - xj[xd - 1];
+  T d[xd];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < xd; ++k) d[k] = (xi[k] - xdi[k]) - (obstacle ? T(0) : (xj[k] - xdj[k]));
+  cbf_row_core<T, ORDER>(P, ex, ey, ez, d, Ds, h_row, Lg);
 }
 
 // utils/model_conversions.py:20-58 obs_to_lin_model(obs, dim = 9 | 10) for one drone

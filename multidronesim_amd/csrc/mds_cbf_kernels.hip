@@ -686,6 +686,10 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
     x[XD - 3] = (T)o[0]; x[XD - 2] = (T)o[1]; x[XD - 1] = (T)o[2];
     swz[0][lane] = wz_lo;
     swz[1][lane] = wz_hi;
+    // every row needs the agents' tracking errors x - xdes, never xdes itself: formed once per agent, in place
+    T* xe = &sxd[lane * XD];
+#pragma unroll
+    for (int v = 0; v < XD - 3; ++v) xe[v] = x[v] - xe[v];
   }
   MDS_WAVE_SYNC();                            // sraw is dead from here on: srow may overwrite it
 
@@ -702,30 +706,34 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
     ia[k] = ib[k] = 0;
     valid[k] = false;
     act[k] = false;
-    if (r < npairs) {
-      ia[k] = rpair[k] & 255;
-      ib[k] = rpair[k] >> 8;
-      T hr, Lg[4];
-      cbf_pair_row<T, ORDER>(P, &sx[ia[k] * XD], &sxd[ia[k] * XD], &sx[ib[k] * XD], &sxd[ib[k] * XD], false, P.Ds_pair, &hr, Lg);
+    if (r < npairs + nobs_rows) {
+      // agent-agent and agent-obstacle rows through ONE instance of the row arithmetic (a wave whose lanes straddle the two
+      // kinds would otherwise run it twice): only the operands are selected
+      const bool ob = r >= npairs;
+      int i = rpair[k] & 255, j = rpair[k] >> 8;
+      const T* pj = &sx[j * XD + XD - 3];
+      T Ds = P.Ds_pair;
+      if (ob) {
+        const int q = r - npairs;
+        i = (q * P.obs_magic) >> 16;                       // q / n_obs, exact for q < 4096
+        const int o = q - i * P.n_obs;
+        j = i;
+        pj = &sob[4 * o];
+        Ds = P.safety_radius + sob[4 * o + 3];
+      }
+      const T* xi = &sx[i * XD];
+      const T *ei = &sxd[i * XD], *ej = &sxd[j * XD];
+      T d[XD], hr, Lg[4];
+#pragma unroll
+      for (int v = 0; v < XD - 3; ++v) d[v] = ei[v] - (ob ? T(0) : ej[v]);
+      cbf_row_core<T, ORDER>(P, xi[XD - 3] - pj[0], xi[XD - 2] - pj[1], xi[XD - 1] - pj[2], d, Ds, &hr, Lg);
+      ia[k] = i;
+      ib[k] = j;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         ca[k][v] = -Lg[v];
-        cb[k][v] = Lg[v];
+        cb[k][v] = ob ? T(0) : Lg[v];
       }
-      b[k] = hr;
-    } else if (r < npairs + nobs_rows) {
-      const int q = r - npairs, i = (q * P.obs_magic) >> 16, o = q - i * P.n_obs;         // i = q / n_obs, exact for q < 4096
-      T xo[XD];
-#pragma unroll
-      for (int v = 0; v < XD - 3; ++v) xo[v] = T(0);
-      xo[XD - 3] = sob[4 * o];
-      xo[XD - 2] = sob[4 * o + 1];
-      xo[XD - 1] = sob[4 * o + 2];
-      T hr, Lg[4];
-      cbf_pair_row<T, ORDER>(P, &sx[i * XD], &sxd[i * XD], xo, xo, true, P.safety_radius + sob[4 * o + 3], &hr, Lg);
-      ia[k] = ib[k] = i;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) ca[k][v] = -Lg[v];
       b[k] = hr;
     } else if (r < m) {                                    // +-u_var <= umax (cbf/cbf.py:400-412)
       const int q = r - npairs - nobs_rows, var = q < n ? q : q - n;
