@@ -264,6 +264,26 @@ def mint_dyn_wrench_accel(ref):
     print("dyn_wrench_accel", u.shape, "clipped rows:", int(((rpm < 0) | (rpm > env.MAX_RPM)).any(axis=1).sum()))
 
 
+def mint_attitude_flow(ref):
+    """The attitude kinematics the reference tree states: body-frame angular velocity, R_dot = R hat(w)
+    (model/dynamics.py:62-66 hat_map, :102 R_dot).  For a constant body rate its flow over dt is R(dt) = R expm(hat(w) dt): the
+    reference's own hat_map through scipy's expm, for random attitudes / rates / step sizes (incl. |w| = 0 and |w| dt > pi).
+    [UPSTREAM] _integrateQ has to produce that rotation."""
+    from scipy.linalg import expm
+    q = ref["dyn"].QuadrotorDynamics(sim_freq=240)
+    rng = np.random.default_rng(31)
+    n = 256
+    quat = Rotation.from_euler("xyz", rng.uniform(-3.1, 3.1, size=(n, 3))).as_quat()
+    w = rng.normal(size=(n, 3)) * np.concatenate([np.full(64, 0.3), np.full(64, 3.0), np.full(64, 30.0), np.full(64, 300.0)])[:, None]
+    w[::37] = 0.0
+    dt = np.tile(np.array([1 / 240, 1 / 100, 1 / 48, 0.05]), n // 4)
+    R = Rotation.from_quat(quat).as_matrix()
+    R_next = np.array([np.matmul(Ri, expm(q.hat_map(wi) * di)) for Ri, wi, di in zip(R, w, dt)])
+    R_dot = np.array([np.matmul(Ri, q.hat_map(wi)) for Ri, wi in zip(R, w)])           # dynamics.py:102
+    np.savez_compressed(OUT + "/attitude_flow.npz", quat=quat, w=w, dt=dt, R_next=R_next, R_dot=R_dot, **META)
+    print("attitude_flow", R_next.shape, "max |w| dt", float(np.max(np.linalg.norm(w, axis=1) * dt)))
+
+
 def mint_closed_loop_reference_in_the_loop(ref):
     """The do_control loop of simulations/EnvGeometric.py:431-473 with the REFERENCE's own objects in it: per drone a
     trajectories/Lemniscate.py object sampled at t, a control/geometric.py GeometricControl.compute(obs) (through the reference's
@@ -618,6 +638,7 @@ if __name__ == "__main__":
     mint_mixer(ref)
     mint_dynamics(ref)
     mint_dyn_wrench_accel(ref)
+    mint_attitude_flow(ref)
     mint_closed_loop_reference_in_the_loop(ref)
     mint_closed_loop_lqr_reference_in_the_loop(ref)
     mint_cbf(ref)

@@ -208,8 +208,9 @@ def test_oracle_reproduces_its_own_1000_step_rollouts():
 def test_dyn_wrench_and_accelerations_match_the_reference_tree():
     """a3 pinned where the reference tree restates it: RPM -> (thrust, torques) against utils/model_conversions.py:69-83
     (action_to_input) and (v_dot, w_dot) against model/dynamics.py:83-106 with the env's m, g, J.  What stays spec-level
-    ([UPSTREAM]-only) in a1-a4 after this: the update ORDER (v, w first; p with the new v, q with the new w), _integrateQ
-    and the pybullet euler / quaternion conversions."""
+    ([UPSTREAM]-only) in a1-a4 after this and test_integrate_q_is_the_flow_...: the update ORDER (v, w first; p with the new v,
+    q with the new w) and the pybullet euler / quaternion conversions (checked against scipy's, which the reference's
+    controllers apply to the same observation: test_oracle_physics.py)."""
     d = load("dyn_wrench_accel.npz")
     c = O.CF2P
     assert abs(c.MAX_RPM - float(d["max_rpm"])) < 1e-9 and c.M == float(d["m"]) and c.G == float(d["g"])
@@ -233,6 +234,25 @@ def test_dyn_wrench_and_accelerations_match_the_reference_tree():
     obs = ora.step(d["rpm"])
     np.testing.assert_allclose((obs[:, 10:13] - d["vel"]) * 240, d["v_dot"], rtol=0, atol=1e-9)
     np.testing.assert_allclose(obs[:, 16:20], clipped, rtol=0, atol=0)
+
+
+def test_integrate_q_is_the_flow_of_the_reference_attitude_kinematics():
+    """[UPSTREAM] _integrateQ pinned where the reference tree states the kinematics: body-frame rates, R_dot = R hat(w)
+    (model/dynamics.py:62-66, :102).  tests/golden/attitude_flow.npz holds R expm(hat(w) dt) built from the reference's own hat_map
+    for 256 random (q, w, dt), |w| dt from 0 to 44 rad; the oracle's quaternion update must land on that rotation, and its
+    finite difference on the reference's R_dot."""
+    d = load("attitude_flow.npz")
+    qn = O.integrate_q(d["quat"], d["w"], d["dt"])
+    np.testing.assert_allclose(np.linalg.norm(qn, axis=1), 1.0, atol=1e-14)
+    np.testing.assert_allclose(O.quat_to_rotmat_scipy(qn), d["R_next"], rtol=0, atol=2e-13)
+    still = np.linalg.norm(d["w"], axis=1) == 0
+    assert still.sum() >= 5 and np.array_equal(qn[still], d["quat"][still])
+    slow = np.linalg.norm(d["w"], axis=1) < 40.0             # central difference: error ~ h^2 |w|^3 / 6
+    h = 1e-6
+    q0, w0 = d["quat"][slow], d["w"][slow]
+    dR = (O.quat_to_rotmat_scipy(O.integrate_q(q0, w0, h)) - O.quat_to_rotmat_scipy(O.integrate_q(q0, w0, -h))) / (2 * h)
+    assert slow.sum() >= 128
+    np.testing.assert_allclose(dR, d["R_dot"][slow], rtol=0, atol=1e-6)
 
 
 def test_closed_loop_with_the_reference_objects_in_the_loop():
