@@ -154,6 +154,29 @@ def test_step_accelerations_match_the_reference_tree(mds, dtype, atol_v, rtol_w)
     env.close()
 
 
+@pytest.mark.parametrize("dtype,atol", [("float64", 1e-12), ("float32", 2e-6)])
+def test_step_attitude_update_is_the_flow_of_the_reference_kinematics(mds, dtype, atol):
+    """[UPSTREAM] _integrateQ in k_step against the kinematics the reference tree states (model/dynamics.py:62-66, :102: body-frame
+    rates, R_dot = R hat(w)): after one 240 Hz substep from the attitudes and rates of tests/golden/attitude_flow.npz (|w| up to
+    ~900 rad/s), R(q') = R(q) expm(hat(w') dt) with w' the kernel's own NEW body rate (the update order: q moves with the new
+    omega), and q' stays a unit quaternion."""
+    from scipy.linalg import expm
+    d = np.load(os.path.join(G, "attitude_flow.npz"))
+    n = d["quat"].shape[0]
+    pos = np.zeros((n, 3))
+    env = make_env(mds, 1, n, pos, np.zeros((n, 3)), dtype, 240, 240)
+    env.set_state(np.hstack([pos, d["quat"], np.zeros((n, 3)), d["w"]]))
+    s0 = env.get_state().reshape(n, 13)
+    env.step(mds.torch.full((1, n, 4), float(O.CF2P.HOVER_RPM), dtype=env.dtype, device=env.device))
+    s1 = env.get_state().reshape(n, 13)
+    hat = lambda w: np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    want = np.array([O.quat_to_rotmat_scipy(q) @ expm(hat(w) / 240) for q, w in zip(s0[:, 3:7], s1[:, 10:13])])
+    np.testing.assert_allclose(O.quat_to_rotmat_scipy(s1[:, 3:7]), want, rtol=0, atol=atol)
+    np.testing.assert_allclose(np.linalg.norm(s1[:, 3:7], axis=1), 1.0, atol=atol)
+    assert np.abs(s1[:, 10:13] - s0[:, 10:13]).max() > 1e-3      # w x Jw moved the rates: w' is not the fixture's w
+    env.close()
+
+
 def test_step_clips_action_and_reference_shapes(mds):
     """E=1 with NumPy in -> reference shapes: obs [D,20]; RPM clipped to [0, MAX_RPM] lands in obs[16:20]."""
     D = 3
