@@ -106,6 +106,7 @@ struct mds_handle {
   // stream, ev[1] joins it back.  Created (and primed) by mds_create for shards that can split, else by mds_set_rollout_streams(h, 2).
   hipStream_t split_st = nullptr;
   hipEvent_t split_ev[2] = {nullptr, nullptr};
+  int split_lds = 32768;                // LDS bytes a half-shard workgroup occupies in a two-chain rollout (MDS_TUNE_SPLIT_LDS, tuning only)
   int split_offset = 0;                 // 1: the fork event sits half way through chain 0's first step (MDS_TUNE_SPLIT_OFFSET, tuning only; the
                                         // fork's own latency already starts chain 1 about half a kernel late: 20-step calls 17.3 vs 17.6 us)
   int split_min_steps = 0;              // auto policy: calls shorter than this stay on one stream (MDS_TUNE_SPLIT_MIN_STEPS, tuning only)
@@ -410,6 +411,7 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   // shards large enough for the auto policy of the two-chain rollouts get their streams and events now (smallest auto
   // threshold: the CBF loop, 2^16 drones); smaller ones only if mds_set_rollout_streams(h, 2) asks for them
   if (const char* v = getenv("MDS_TUNE_SPLIT_OFFSET")) h->split_offset = atoi(v);
+  if (const char* v = getenv("MDS_TUNE_SPLIT_LDS")) h->split_lds = atoi(v);
   if (const char* v = getenv("MDS_TUNE_SPLIT_MIN_STEPS")) h->split_min_steps = atoi(v);
   if ((size_t)h->n >= kSplitMinDrones / 4) {
     if (int rc = split_streams_ready(h)) {
@@ -574,7 +576,7 @@ static void launch_step_plain(mds_handle* h, const void* action, void* obs, hipS
   size_t pad = 0;
   if (nb) {
     const size_t static_lds = obs ? (size_t)kBlock * kObsDim * elem_size(h->cfg.dtype) : 16;
-    pad = static_lds < 32768 ? 32768 - static_lds : 0;
+    pad = static_lds < (size_t)h->split_lds ? (size_t)h->split_lds - static_lds : 0;
   }
 #define MDS_LAUNCH_STEP(HAS_OBS, RK4, DRAG)                                                                          \
   do {                                                                                                               \
@@ -847,7 +849,7 @@ static int launch_step_geometric(mds_handle* h, double t, void* obs, void* act, 
   size_t pad = 0;
   if (nb) {
     const size_t static_lds = (h->traj_mode == 2 || obs) ? (size_t)kBlock * kObsDim * elem_size(h->cfg.dtype) : 16;
-    pad = static_lds < 32768 ? 32768 - static_lds : 0;
+    pad = static_lds < (size_t)h->split_lds ? (size_t)h->split_lds - static_lds : 0;
   }
   if (h->traj_mode == 2) {      // general trajectories: segment tables
     const bool rk4_ = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag_ = has_drag(h);
