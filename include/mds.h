@@ -20,6 +20,10 @@
  *     the two-chain rollouts are created and primed by mds_create (shards of 2^16 drones and more) or by
  *     mds_set_rollout_streams(h, 2), never by a rollout.  Set-up calls (mds_create, mds_reset,
  *     mds_set_*, mds_cbf_configure, mds_get/set_state) may allocate, copy from host memory and synchronise.
+ *     Because they only enqueue, the mds_step* / mds_rollout* calls can be recorded by a stream capture on `stream`
+ *     (hipStreamBeginCapture, torch.cuda.graph) and replayed as a hipGraph; a two-chain rollout forks from and joins back into
+ *     the capturing stream through its event pair, which is the capture-legal pattern.  (Scalar arguments such as t are baked into
+ *     the graph; replay buys nothing at these kernel sizes)
  *   - Every call taking a handle runs on the handle's device (mds_config.device) and leaves the calling thread's current
  *     HIP device as it found it; device pointers passed in must belong to that device.
  *   - Every call returns MDS_OK (0) or a negative mds_status; nothing throws or aborts

@@ -900,6 +900,41 @@ def test_rollout_step_equals_env_step_loop(mds, dtype, streams):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("streams", [1, 2])
+def test_rollout_calls_can_be_captured_into_a_hip_graph(mds, streams):
+    """The rollout entry points only enqueue (kernel launches, and for two chains event record / wait pairs that fork from and
+    join back into the caller's stream), so a caller may capture them into a hipGraph (here through torch.cuda.graph) and replay
+    it: 3 replays of a captured 6-step mds_rollout_step == 18 eager steps, bit for bit, one chain and two."""
+    torch = mds.torch
+    E, D, A, T = 199, 7, 3, 6
+    xyz, rpy, _ = H.c2_setup(E, D)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    envs = [make_env(mds, E, D, xyz, rpy, "float32", 240, 240) for _ in range(2)]
+    acts = (envs[0].HOVER_RPM * (1 + 0.05 * torch.randn((A, E, D, 4), device="cuda", generator=gen))).to(envs[0].dtype)
+    logs = [torch.zeros((T, E, D, 20), dtype=envs[0].dtype, device="cuda") for _ in range(2)]
+    for e in envs:
+        e.set_rollout_streams(streams)
+    for r in range(3):
+        envs[0].rollout_step(acts, 0, 6, logs[0])                      # first_step 0 every time: what a replayed graph does
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            envs[1].rollout_step(acts, 0, 6, logs[1])
+    torch.cuda.current_stream().wait_stream(side)
+    assert envs[1].last_rollout_streams() == streams
+    state_after_capture = envs[1].get_state()
+    np.testing.assert_allclose(state_after_capture[..., 0:3], xyz, atol=1e-6)   # capturing ran nothing (fp32 storage of the initial poses)
+    for r in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(logs[0].cpu().numpy(), logs[1].cpu().numpy())
+    np.testing.assert_array_equal(envs[0].get_state(), envs[1].get_state())
+    for e in envs:
+        e.close()
+
+
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-12), ("float32", 2e-5), ("float16", 5e-2)])
 def test_fused_rollout_step_equals_stepwise(mds, dtype, tol):
     """mds_rollout_step_fused (several env.step per launch, state in registers, launches cut at episode boundaries) against
