@@ -390,6 +390,11 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
       converged = true;
       break;
     }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)
+    // an env that iterates is on the launch's critical path (a serial chain of ~4 000-cycle steps, the envs that do not iterate
+    // are throughput work): its wave takes the SIMD's issue slots first from here on
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const int owner = (int)__builtin_ctzll(__ballot(best == wbest));                         // ties: lowest lane, then its lowest row
     const int kk = wv::get(best_k, owner), wrow = owner + 64 * kk;
     T wca[NV], wcb[NV], wb;
@@ -631,6 +636,11 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
     const int c0 = count_in[0], c1 = count_in[1];
     const int b = blockIdx.x;
     env = b < c0 ? order_in[b] : (b < c0 + c1 ? order_in[E + b - c0] : order_in[2 * E + b - c0 - c1]);
+#if !defined(MDS_TUNE_NO_SETPRIO)
+    // the envs that iterated last time: on the critical path from their first instruction
+    if (b < c0) __builtin_amdgcn_s_setprio(3);
+    else if (b < c0 + c1) __builtin_amdgcn_s_setprio(2);
+#endif
   }
   if (env >= E) return;
 #if defined(MDS_TUNE_ITERS)
