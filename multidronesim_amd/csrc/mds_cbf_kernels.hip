@@ -244,6 +244,9 @@ __global__ __launch_bounds__(256) void k_cbf_filter_o2(const CbfParams<T> P, con
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
 
+// keeps two loaded values live at this point (an empty asm the optimiser cannot look through): used to stop it from sinking LDS
+// reads into the conditional code that consumes them
+#define MDS_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 namespace wv {
 // DPP controls (gfx9): quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140.
 // Must be called with all 64 lanes active (wave-uniform control flow): a disabled source lane leaves `old`.
@@ -292,6 +295,33 @@ template <bool ROW0, typename T, typename Op> __device__ __forceinline__ T allre
   if (ROW0) return allreduce_row0(v, op);
   return allreduce(v, op);
 }
+// Max / min of NON-NEGATIVE values (squared residuals, |r|, step lengths; never -0, never NaN): fp32 of that kind order like their
+// bit patterns, so the reduction runs on v_max_i32 / v_min_i32 with the DPP read as the instruction's own operand (old = 0 with
+// bound_ctrl, the form the compiler folds) -- two instructions per step instead of copy, DPP move, compare, select.  double keeps
+// the generic path.
+template <int CTRL> __device__ __forceinline__ int dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+struct IMax {
+  __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; }
+};
+struct IMin {
+  __device__ __forceinline__ int operator()(int a, int b) const { return a < b ? a : b; }
+};
+template <bool ROW0, typename Op> __device__ __forceinline__ int allreduce_bits(int v, Op op) {
+  v = op(v, dpp0<0xB1>(v));
+  v = op(v, dpp0<0x4E>(v));
+  v = op(v, dpp0<0x141>(v));
+  v = op(v, dpp0<0x140>(v));
+  if (ROW0) return get(v, 0);
+  return op(op(get(v, 0), get(v, 16)), op(get(v, 32), get(v, 48)));
+}
+template <bool ROW0> __device__ __forceinline__ float max_nonneg(float v) {
+  return __builtin_bit_cast(float, allreduce_bits<ROW0>(__builtin_bit_cast(int, v), IMax()));
+}
+template <bool ROW0> __device__ __forceinline__ float min_nonneg(float v) {
+  return __builtin_bit_cast(float, allreduce_bits<ROW0>(__builtin_bit_cast(int, v), IMin()));
+}
+template <bool ROW0> __device__ __forceinline__ double max_nonneg(double v) { return allreduce_n<ROW0>(v, Max()); }
+template <bool ROW0> __device__ __forceinline__ double min_nonneg(double v) { return allreduce_n<ROW0>(v, Min()); }
 }  // namespace wv
 
 // 3-way partition of the envs by last step's solve cost: order[c*E + k] = k-th env of class c, count[c].
@@ -374,18 +404,30 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
     // ---- most violated row outside the active set (distance^2 to its half-space) ----
     T best = T(0);
     int best_k = 0;
+    T ua[R][NV], ub[R][NV];
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        ua[k][v] = su[NV * ia[k] + v];
+        ub[k][v] = su[NV * ib[k] + v];
+      }
+#pragma unroll
+    for (int k = 0; k < R; ++k)                            // every row's operands in ONE LDS round trip: left to itself the compiler sinks each
+#pragma unroll
+      for (int v = 0; v < NV; ++v) MDS_PIN2(ua[k][v], ub[k][v]);     // pair of reads under its row's `valid` test, R round trips in a row
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       T res = -b[k];
 #pragma unroll
-      for (int v = 0; v < NV; ++v) res = m_fma(ca[k][v], su[NV * ia[k] + v], m_fma(cb[k][v], su[NV * ib[k] + v], res));
+      for (int v = 0; v < NV; ++v) res = m_fma(ca[k][v], ua[k][v], m_fma(cb[k][v], ub[k][v], res));
       const T sc = (valid[k] && !act[k] && res > T(0)) ? res * res : T(0);
       if (sc > best) {
         best = sc;
         best_k = k;
       }
     }
-    const T wbest = wv::allreduce(best, wv::Max());
+    const T wbest = wv::max_nonneg<false>(best);
     if (!(wbest > tol2)) {
       converged = true;
       break;
@@ -501,10 +543,10 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
       }
       constexpr bool ROW0 = NMAX <= 16;                                                  // z, r, lambda live in lanes 0..n-1 only
       const T zz = wv::allreduce_n<ROW0>(zv * zv, wv::Add());
-      const T rmax = wv::allreduce_n<ROW0>(lane < q ? m_abs(rc) : T(0), wv::Max());
+      const T rmax = wv::max_nonneg<ROW0>(lane < q ? m_abs(rc) : T(0));
       T t1v = GiEps<T>::inf;
       if (lane < q && rc > GiEps<T>::r * rmax && rc > T(0)) t1v = m_max(my_lam, T(0)) * m_rcp(rc);
-      const T t1 = wv::allreduce_n<ROW0>(t1v, wv::Min());
+      const T t1 = wv::min_nonneg<ROW0>(t1v);
       const int drop = t1 < GiEps<T>::inf ? (int)__builtin_ctzll(__ballot(t1v == t1)) : 0;  // ties: lowest column
       const bool has_z = zz > GiEps<T>::z;
       const T t2 = has_z ? res * m_rcp(zz) : GiEps<T>::inf;
