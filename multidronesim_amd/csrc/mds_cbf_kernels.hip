@@ -322,6 +322,32 @@ template <bool ROW0> __device__ __forceinline__ float min_nonneg(float v) {
 }
 template <bool ROW0> __device__ __forceinline__ double max_nonneg(double v) { return allreduce_n<ROW0>(v, Max()); }
 template <bool ROW0> __device__ __forceinline__ double min_nonneg(double v) { return allreduce_n<ROW0>(v, Min()); }
+
+// f(c) for c = min(q, HI) - 1 down to LO with c a compile-time constant inside f (static register indices), q wave-uniform: a
+// binary search on q (log2 tests) and then straight-line steps, instead of one guarded step -- scalar compare + branch -- per
+// possible c.  f takes std::integral_constant-like tags.
+template <int C> struct Ic {
+  static constexpr int value = C;
+};
+template <int LO, int HI, typename F> __device__ __forceinline__ void desc_all(F&& f) {
+  if constexpr (HI > LO) {
+    f(Ic<HI - 1>{});
+    desc_all<LO, HI - 1>(f);
+  }
+}
+template <int LO, int HI, typename F> __device__ __forceinline__ void desc_upto(const int q, F&& f) {
+  if constexpr (HI - LO == 1) {
+    if (q > LO) f(Ic<LO>{});
+  } else if constexpr (HI > LO) {
+    constexpr int MID = (LO + HI) / 2;
+    if (q > MID) {
+      desc_upto<MID, HI>(q, f);
+      desc_all<LO, MID>(f);
+    } else {
+      desc_upto<LO, MID>(q, f);
+    }
+  }
+}
 }  // namespace wv
 
 // 3-way partition of the envs by last step's solve cost: order[c*E + k] = k-th env of class c, count[c].
@@ -487,12 +513,21 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
       T res = -wb;
 #pragma unroll
       for (int v = 0; v < NV; ++v) res = m_fma(wca[v], su[NV * wia + v], m_fma(two ? wcb[v] : T(0), su[NV * wib + v], res));
-      T dc = T(0);
-      if (lane < q) {                                                                    // d = Q^T a
-#pragma unroll
-        for (int v = 0; v < NV; ++v) dc = m_fma(wca[v], sQ[NV * wia + v][lane], m_fma(two ? wcb[v] : T(0), sQ[NV * wib + v][lane], dc));
-      }
       const int ln = lane < NMAX ? lane : NMAX - 1;                                      // lanes >= n hold no row: clamp the address only
+      T dc = T(0);
+      {                                                                                  // d = Q^T a: read by every lane (clamped column) so that the
+        T qa[NV], qb[NV];                                                                // reads join the step's one round trip, kept by lanes < q
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          qa[v] = sQ[NV * wia + v][ln];
+          qb[v] = sQ[NV * wib + v][ln];
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) MDS_PIN2(qa[v], qb[v]);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dc = m_fma(wca[v], qa[v], m_fma(two ? wcb[v] : T(0), qb[v], dc));
+        dc = lane < q ? dc : T(0);
+      }
       const T my_lam = slam[ln], my_di = sdi[ln], my_u = su[ln];
       T zv = T(0), rc = dc;
       if constexpr (PRE) {
@@ -508,23 +543,17 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
           for (int v = 0; v < NV; ++v)
             if (v == vv) zv = (ag == wia ? wca[v] : T(0)) + ((two && ag == wib) ? wcb[v] : T(0));
         }
-#pragma unroll
-        for (int c = 0; c < NMAX; ++c) {                                                 // one exit test per column; the compiler keeps it a loop
-          if (c >= q) break;                                                             // with indexed VGPR reads of qrow (no scratch)
-          zv = m_fma(-qrow[c], wv::get(dc, c), zv);                                      // lanes >= n: garbage, masked below
-        }
+        // columns q-1 .. 0, each a v_readlane + fma on a statically indexed register (lanes >= n: garbage, masked below)
+        wv::desc_upto<0, NMAX>(q, [&](auto c) { zv = m_fma(-qrow[decltype(c)::value], wv::get(dc, decltype(c)::value), zv); });
         if (lane >= n) zv = T(0);
         // r = R^-1 d by back substitution on the row-scaled system (row l divided by its pivot, off the serial chain):
         // per step one v_readlane and one fma -- lane k's entry is final when step k reads it
-#pragma unroll
-        for (int c = 0; c < NMAX; ++c) rrow[c] *= my_di;
         rc *= my_di;
-#pragma unroll
-        for (int k = NMAX - 1; k >= 0; --k)
-          if (k < q) {
-            const T rk = wv::get(rc, k);
-            rc = lane < k ? m_fma(-rrow[k], rk, rc) : rc;
-          }
+        wv::desc_upto<0, NMAX>(q, [&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          const T rk = wv::get(rc, k);
+          rc = lane < k ? m_fma(-(rrow[k] * my_di), rk, rc) : rc;
+        });
       } else {
         if (lane < n) sd[lane] = dc;
         MDS_WAVE_SYNC();
