@@ -675,8 +675,14 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
 // NV = QP variables per agent (order 2: thrust only -> 1; order 3: yank, wx, wy -> 3, wz is box-only),
 // NMAX = compile-time bound on the number of QP variables n = NV * D (LDS footprint of Q, R ~ NMAX^2),
 // R = rows per lane.  One wavefront (= one env) per workgroup.
+#ifndef MDS_GI_ROWTAB
+#define MDS_GI_ROWTAB 1
+#endif
+#ifndef MDS_GI_MINWAVES
+#define MDS_GI_MINWAVES 1
+#endif
 template <typename T, typename S, int R, int NMAX, int ORDER>
-__global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, const int E, const T kf, const int* __restrict__ pair_ij,
+__global__ __launch_bounds__(64, MDS_GI_MINWAVES) void k_cbf_filter_gi(const CbfParams<T> P, const int E, const T kf, const int* __restrict__ pair_ij,
                                                       const T* __restrict__ obstacles, const S* __restrict__ obs,
                                                       const S* __restrict__ xdes, const S* __restrict__ unom,
                                                       S* __restrict__ usafe, int* __restrict__ status, const int max_iter,
@@ -688,14 +694,18 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
   constexpr int kQS = PRE ? ((NMAX + 3) / 4 * 4 + 4) : NMAX + 1;   // LDS row stride: 16-byte rows (4 mod 16 dwords) / odd, both conflict-free column walks
   constexpr int DMAX = NMAX / NV;
   constexpr int NOBS_L = (DMAX * 20 + 63) / 64, NXD_L = (DMAX * XD + 63) / 64, NUN_L = (DMAX * 4 + 63) / 64;
-  static_assert(sizeof(CbfRow<T, NV>) * R * 64 >= sizeof(S) * DMAX * 20, "raw obs staging aliases the row table");
+  static_assert(!MDS_GI_ROWTAB || sizeof(CbfRow<T, NV>) * R * 64 >= sizeof(S) * DMAX * 20, "raw obs staging aliases the row table");
   __shared__ T sx[DMAX * XD], sxd[DMAX * XD];
   __shared__ T su[NMAX], sd[NMAX], slam[NMAX], sdi[NMAX];
   __shared__ T sQ[NMAX][kQS], sR[NMAX][kQS];
   __shared__ int sact[NMAX];
   __shared__ T sob[kCbfMaxObs * 4];
   __shared__ T swz[2][DMAX];
+#if MDS_GI_ROWTAB
   __shared__ __align__(16) CbfRow<T, NV> srow[R * 64];
+#else   // tuning build: no LDS copy of the rows (the selected row comes from its owner's registers); only the observation staging remains
+  __shared__ __align__(16) CbfRow<T, NV> srow[(sizeof(S) * DMAX * 20 + sizeof(CbfRow<T, NV>) - 1) / sizeof(CbfRow<T, NV>)];
+#endif
   S* sraw = reinterpret_cast<S*>(srow);                     // the env's observation rows, staged before the rows are built
   const int lane = threadIdx.x;
   // Longest-first dispatch: the solve time of an env is ~ its number of active rows, which changes slowly from one
@@ -860,13 +870,15 @@ __global__ __launch_bounds__(64) void k_cbf_filter_gi(const CbfParams<T> P, cons
       }
       w.b = b[k];
       w.ij = ia[k] | (ib[k] << 8);
+#if MDS_GI_ROWTAB
       srow[r] = w;
+#endif
     }
   }
   MDS_WAVE_SYNC();
   bool converged = false;
   int q = 0, it = 0;
-  gi_solve<T, R, NMAX, NV, true, kQS>(lane, n, max_iter, tol2, __any(bad), ca, cb, b, ia, ib, valid, act, su, sd, slam, sdi, sQ, sR, sact, srow,
+  gi_solve<T, R, NMAX, NV, MDS_GI_ROWTAB != 0, kQS>(lane, n, max_iter, tol2, __any(bad), ca, cb, b, ia, ib, valid, act, su, sd, slam, sdi, sQ, sR, sact, srow,
                                       converged, it, q);
 #if defined(MDS_TUNE_ITERS)   // tuning build: iteration count and final active-set size in the high bits of status
   {
