@@ -293,6 +293,9 @@ def main(argv=None):
                          "4 m/s off its trajectory the row k0 h + k1 hdot + Lf2 h of a static sphere (x_des = x) turns hugely negative for "
                          "1 < r / |v_err| < 2.6 s whatever the thrust.  'far': the same four spheres 100 m away (r / |v_err| > 15 s): the 64 "
                          "obstacle rows are still built and scanned every step but stay positive; what remains is the 120 inter-agent rows")
+    ap.add_argument("--c4-one-launch", action="store_true",
+                    help="c4: mds_cbf_set_step_kernel(h, 1) -- nominal controller, QPs and low level + physics in ONE launch per control step "
+                         "(the faster form when few envs iterate: the 'far' scene; slower on SURVEY 8d's)")
     ap.add_argument("--c5-log-gb", type=float, default=200.0, help="c5: size of the rollout log ring in GB (SURVEY 8d: sized for the 288 GB of HBM)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU tests of the N>1 path")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # CPU test of the exit-code relay
@@ -399,6 +402,8 @@ def main(argv=None):
         c4_xy, c4_z = (0.5, 0.5) if args.c4_scene == "level" else (100.0, 0.65)
         c4_obs = [np.array([[sx * c4_xy, sy * c4_xy, c4_z], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
         c4_r = [0.1] * 4
+        if args.c4_one_launch:
+            env.set_cbf_step_kernel(True)
     env.set_trajectories(P)
     del xyz, rpy, P
     env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=device))     # EnvGeometric.py:431
@@ -574,8 +579,10 @@ def main(argv=None):
             line["config"]["launch"] = f"C loop (mds_rollout_step_fused), {fused_T} steps per launch, obs -> rollout log slot"
     if c4:
         st = env._cbf_status
-        line["roofline"]["kernel"] = "k_cbf_nominal + k_cbf_filter_gi + k_lowlevel_step (3 launches per step and env half; QP is latency/ALU bound)"
+        line["roofline"]["kernel"] = ("k_cbf_step (one launch per step and env half: nominal controller, 4 QPs per wave, low level + physics)" if env.cbf_last_step_kernel() == 1 else
+                                      "k_cbf_filter_gi + k_lowlevel_step (2 launches per step and env half from the second step on; the QP is issue/latency bound)")
         line["config"]["scene"] = args.c4_scene
+        line["config"]["step_kernel"] = "one launch" if env.cbf_last_step_kernel() == 1 else "QP launch + low-level launch"   # what the library did
         if not args.python_loop:
             line["config"]["launch"] = "C rollout loop, env halves on 2 streams" if split else "C rollout loop, one stream"
         line["cbf_fallback_frac_last_step"] = float((st != 0).float().mean().item())

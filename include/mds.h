@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MDS_VERSION 201 /* 0.2.1 */
+#define MDS_VERSION 202 /* 0.2.2 */
 #define MDS_OBS_DIM 20  /* [UPSTREAM] _getDroneStateVector */
 #define MDS_ACT_DIM 4
 #define MDS_STATE_DIM 13 /* pos3 | quat4 xyzw | vel3 (world) | body rates3 */
@@ -381,6 +381,18 @@ int mds_yank_omega_compute(mds_handle* h, const void* u_dev, const void* obs_dev
 /* nominal controller of mds_step_cbf_geometric: 0 = GeometricControl(return_omegas), 1 = LQROmegaController,
  * 2 = LQRYankOmegaController (the only one valid with an order-3 CBF, and only with it) */
 int mds_cbf_set_nominal(mds_handle* h, int which);
+/* How mds_step_cbf_geometric / mds_rollout_cbf_geometric issue a control step.  0 (default): the QP of every env in its own
+ * wavefront (k_cbf_filter_gi), then low level + physics + the next step's nominal input per drone (k_lowlevel_step) -- the faster
+ * form when a sizeable share of the envs iterate (C4, SURVEY 8d scene: 49 us against 60 us per control step).  1: ONE launch per
+ * step (k_cbf_step: nominal controller, the wavefront's 64 / D QPs, low level + physics) where it applies -- order 2, D a divisor
+ * of 64 up to 16, Euler, DYN, geometric or LQR-omega nominal, f32 / f32c / f64, no action output; three launches otherwise --
+ * the faster form when few envs iterate (obstacles far away: 29 us against 40 us).  Same QP, same statuses and iteration
+ * counts; observations equal to rounding (the two forms contract FMAs differently), so pick one per handle: each form's rollout
+ * is bitwise its own step-by-step loop.  MDS_CBF_FUSED=1 in the environment selects 1 at mds_cbf_configure. */
+int mds_cbf_set_step_kernel(mds_handle* h, int one_launch);
+/* What the most recent mds_step_cbf_geometric / mds_rollout_cbf_geometric of this handle launched: 1 the one-launch kernel, 0 the QP
+ * launch + the low-level launch, -1 no CBF-filtered step yet (negative mds_status for a null handle is -1 as well: check the handle). */
+int mds_cbf_last_step_kernel(const mds_handle* h);
 
 /* One CBF-filtered control step for every env.
  * Order 2 (simulations/CBFTest.py:303-350): nominal (force - M G, w_des) from the geometric controller or the

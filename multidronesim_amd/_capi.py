@@ -111,6 +111,8 @@ PROTOTYPES = {
     "mds_lqr_yank_omega_compute": (C.c_int, [_P, _P, _P, _P, _P]),
     "mds_yank_omega_compute": (C.c_int, [_P, _P, _P, _P, _P]),
     "mds_cbf_set_nominal": (C.c_int, [_P, C.c_int]),
+    "mds_cbf_set_step_kernel": (C.c_int, [_P, C.c_int]),
+    "mds_cbf_last_step_kernel": (C.c_int, [_P]),
     "mds_step_cbf_geometric": (C.c_int, [_P, C.c_double, _P, _P, _P, _P]),
     "mds_rollout_cbf_geometric": (C.c_int, [_P, C.c_double, C.c_int, _P, _P, _P]),
     "mds_step_nominal": (C.c_int, [_P, C.c_double, _P, _P, _P]),

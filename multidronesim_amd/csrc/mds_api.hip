@@ -117,7 +117,8 @@ struct mds_handle {
   bool cbf_q4 = false;                  // MDS_CBF_Q4=1 at configure time: the four-envs-per-wave QP kernel (k_cbf_filter_q4) where it applies; measured
                                         // no faster than one env per wave (see its header), so opt-in
   bool cbf_chain_nominal = true;        // MDS_CBF_CHAIN=0 at configure time: the C rollout loops launch the nominal kernel every step (A/B)
-  bool cbf_fused = false;               // MDS_CBF_FUSED=1 at configure time: the one-launch CBF step (k_cbf_step) where it applies; it wins only
+  int cbf_last_step_kernel = -1;        // what the most recent CBF-filtered step launched: 1 the one-launch kernel, 0 QP + low level
+  bool cbf_fused = false;               // mds_cbf_set_step_kernel / MDS_CBF_FUSED=1 at configure time: the one-launch CBF step (k_cbf_step) where it applies; it wins only
                                         // on scenes whose QPs need no iterations (see the kernel's header), so the default is the three launches
   void* cbf_unom;      // S [n,4]  scratch of mds_step_cbf_geometric
   void* cbf_xdes;      // S [n,9]
@@ -1299,8 +1300,7 @@ int mds_cbf_configure(mds_handle* h, const mds_cbf_params* p, const double* obst
     h->cbf_q4 = q4e && q4e[0] == '1';
     const char* chain = getenv("MDS_CBF_CHAIN");
     h->cbf_chain_nominal = !(chain && chain[0] == '0');
-    const char* fused = getenv("MDS_CBF_FUSED");
-    h->cbf_fused = fused && fused[0] == '1';
+    if (const char* fused = getenv("MDS_CBF_FUSED")) h->cbf_fused = fused[0] == '1';       // unset: what mds_cbf_set_step_kernel chose
   }
   h->cbf = *p;
   fill_cbf(h, *p, h->cbf_f);
@@ -1722,6 +1722,18 @@ int mds_cbf_set_nominal(mds_handle* h, int which) {
   return MDS_OK;
 }
 
+int mds_cbf_set_step_kernel(mds_handle* h, int one_launch) {
+  if (!h || one_launch < 0 || one_launch > 1) return fail(MDS_EINVAL, "mds_cbf_set_step_kernel");
+  h->cbf_fused = one_launch != 0;
+  for (int k = 0; k < 3; ++k) h->next_nom_ok[k] = false;
+  return MDS_OK;
+}
+
+int mds_cbf_last_step_kernel(const mds_handle* h) {
+  if (!h) return fail(MDS_EINVAL, "mds_cbf_last_step_kernel: null handle");
+  return h->cbf_last_step_kernel;
+}
+
 int mds_lowlevel_reset(mds_handle* h, void* stream) {
   MDS_DEV(h);
   if (!h) return fail(MDS_EINVAL, "mds_lowlevel_reset: null handle");
@@ -1787,6 +1799,7 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
         h->cfg.integrator == MDS_INTEGRATOR_EULER && !has_drag(h) && h->cbf_nominal <= 1 && j0 % 64 == 0 && h->cfg.dtype != MDS_F16) {
       const dim3 grid64((unsigned)((j1 - j0 + 63) / 64));
       const int batch0 = (int)(j0 / 64), max_iter = h->cbf.max_iter > 0 ? h->cbf.max_iter : 64 * m2;
+      h->cbf_last_step_kernel = 1;
       const void* gain = h->cbf_nominal == 1 ? h->gain_dev[1] : nullptr;
       void* rpm = rpm_track(h);
 #define MDS_CS(T, CC, CP, RR, NOM, COMP, TOL)                                                                                                \
@@ -1813,6 +1826,7 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
       return MDS_OK;
     }
   }
+  if (with_filter) h->cbf_last_step_kernel = 0;
   if (!h->cbf_unom) {
     MDS_HIP(hipMalloc(&h->cbf_unom, (size_t)h->n * 4 * es));
     MDS_HIP(hipMalloc(&h->cbf_xdes, (size_t)h->n * 10 * es));

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.mds_version() == 201
+    assert lib.mds_version() == 202
     assert lib.mds_strerror(0) == b"ok"
     assert b"aligned" in lib.mds_strerror(-4)
     assert lib.mds_strerror(-99) == b"unknown status"
@@ -98,6 +98,8 @@ def test_null_handle_calls_return_einval(lib):
     assert lib.mds_rollout_geometric(None, 0.0, 5, None, 1, None) == -1
     assert lib.mds_rollout_cbf_geometric(None, 0.0, 5, None, None, None) == -1
     assert lib.mds_rollout_dslpid(None, None, None, 1, 0, 5, None, 0, None) == -1
+    assert lib.mds_cbf_set_step_kernel(None, 1) == -1
+    assert lib.mds_cbf_last_step_kernel(None) == -1
 
 
 def test_compensated_dtype_is_a_valid_config_and_env_effects_reject_it(lib):

@@ -497,7 +497,8 @@ def test_one_launch_cbf_step_matches_the_three_launch_path(mds, nominal, monkeyp
     for dtype, tol in (("float64", 1e-9), ("float32", 2e-4)):
         out = {}
         for fused in ("0", "1"):
-            monkeypatch.setenv("MDS_CBF_FUSED", fused)
+            if nominal == "lqr_omega":
+                monkeypatch.setenv("MDS_CBF_FUSED", fused)       # the environment switch (read at mds_cbf_configure) ...
             env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
                                  pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype)
             env.set_trajectories(P)
@@ -507,6 +508,8 @@ def test_one_launch_cbf_step_matches_the_three_launch_path(mds, nominal, monkeyp
             cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2,
                                cbf_poles=np.array([-2.2, -2.4]))
             trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+            if nominal != "lqr_omega":
+                env.set_cbf_step_kernel(fused == "1")           # ... and the API call (mds_cbf_set_step_kernel)
             env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
             t, hist, its = 0.0, [], []
             for k in range(steps):
@@ -514,6 +517,7 @@ def test_one_launch_cbf_step_matches_the_three_launch_path(mds, nominal, monkeyp
                 hist.append(st.cpu().numpy().copy())
                 its.append(cbf.last_iterations().cpu().numpy().copy())
                 t += env.CTRL_TIMESTEP
+            assert env.cbf_last_step_kernel() == int(fused)       # the library reports which form it launched
             out[fused] = (o.double().cpu().numpy().copy(), np.array(hist), np.array(its), env.get_state())
             if fused == "1":                                    # the C loop on two chains issues the same launches
                 b = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
@@ -525,9 +529,12 @@ def test_one_launch_cbf_step_matches_the_three_launch_path(mds, nominal, monkeyp
                 cb2 = mds.DroneCBF(b, [mds.LinearizedOmegaModel(b) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2,
                                    cbf_poles=np.array([-2.2, -2.4]))
                 tb = mds.DroneQPTracker(cb2, num_robots=D, xdim=9, env=b)
+                if nominal != "lqr_omega":
+                    b.set_cbf_step_kernel(True)
                 b.set_rollout_streams(2)
                 b.step(mds.torch.zeros((E, D, 4), dtype=b.dtype))
                 ob, sb = b.rollout_cbf_geometric(0.0, steps, tb, x_obs, obs_r)
+                assert b.cbf_last_step_kernel() == 1
                 np.testing.assert_array_equal(ob.double().cpu().numpy(), out["1"][0])
                 np.testing.assert_array_equal(b.get_state(), out["1"][3])
                 b.close()
