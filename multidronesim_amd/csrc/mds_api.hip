@@ -1429,7 +1429,7 @@ static int cbf_filter_range(mds_handle* h, const void* obs_, const void* xdes_, 
   MDS_HIP(hipGetLastError());
   if (!hildreth && !q4 && E >= 1024) {                    // small batches have no tail to hide
     if (calls < 0 || calls >= 7) {
-      k_cbf_order<<<1, 1024, 0, st>>>(E, cost_tab, order_tab, count_tab);
+      k_cbf_order<<<1, kOrderThreads, 0, st>>>(E, cost_tab, order_tab, count_tab);
       MDS_HIP(hipGetLastError());
       calls = 0;
     } else {

@@ -351,14 +351,18 @@ template <int LO, int HI, typename F> __device__ __forceinline__ void desc_upto(
 }  // namespace wv
 
 // 3-way partition of the envs by last step's solve cost: order[c*E + k] = k-th env of class c, count[c].
-// One workgroup, coalesced strided passes (thread t owns envs t, t + 1024, ...).
-__global__ __launch_bounds__(1024) void k_cbf_order(const int E, const int* __restrict__ cost, int* __restrict__ order,
+// One workgroup, coalesced strided passes (thread t owns envs t, t + kOrderThreads, ...).
+#ifndef MDS_ORDER_THREADS
+#define MDS_ORDER_THREADS 256
+#endif
+constexpr int kOrderThreads = MDS_ORDER_THREADS;   // one small workgroup: it has to find room on a CU beside the other chain's QP waves
+__global__ __launch_bounds__(kOrderThreads) void k_cbf_order(const int E, const int* __restrict__ cost, int* __restrict__ order,
                                                     int* __restrict__ count) {
-  __shared__ int wtot[3][16];
+  __shared__ int wtot[3][kOrderThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int c[3] = {0, 0, 0};
 #pragma unroll 8
-  for (int e = tid; e < E; e += 1024) {
+  for (int e = tid; e < E; e += kOrderThreads) {
     const int it = cost[e];
     c[0] += it >= kCbfHeavyIters;
     c[1] += it >= kCbfMediumIters && it < kCbfHeavyIters;
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(1024) void k_cbf_order(const int E, const int* __re
   }
   int off[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {                            // exclusive scan over the 1024 threads
+  for (int k = 0; k < 3; ++k) {                            // exclusive scan over the workgroup's threads
     int v = c[k];
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(1024) void k_cbf_order(const int E, const int* __re
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     int base = 0, total = 0;
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < kOrderThreads / 64; ++w) {
       if (w < wave) base += wtot[k][w];
       total += wtot[k][w];
     }
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(1024) void k_cbf_order(const int E, const int* __re
     if (tid == 0) count[k] = total;
   }
 #pragma unroll 8
-  for (int e = tid; e < E; e += 1024) {
+  for (int e = tid; e < E; e += kOrderThreads) {
     const int it = cost[e], cls = it >= kCbfHeavyIters ? 0 : (it >= kCbfMediumIters ? 1 : 2);
     const int pos = cls == 0 ? off[0]++ : (cls == 1 ? off[1]++ : off[2]++);
     order[cls * E + pos] = e;
