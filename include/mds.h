@@ -230,7 +230,10 @@ int mds_reset_async(mds_handle* h, void* stream);
  * 2^16 drones; calls of fewer than 16 steps always stay on the caller's stream -- a two-chain call costs ~35 us), 1 = the caller's stream only, 2 = always split (a set-up call then: it creates the internal streams of a
  * handle that mds_create gave none).  Results are bit-identical either way; the caller's stream orders the whole call
  * (events on entry and exit -- the exit events are recorded even when a launch in between failed), so the usual stream
- * semantics hold. */
+ * semantics hold.  ROCm maps a process's streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues: in a process with more than
+ * two or three other ACTIVE streams the internal stream may share a queue with the caller's and the chains then run one after the
+ * other (results unchanged, time lost).  Raise GPU_MAX_HW_QUEUES, or set MDS_SPLIT_STREAM_PRIORITY=high (or low) before the handle's
+ * streams are created: a stream of another priority level has hardware queues of its own. */
 int mds_set_rollout_streams(mds_handle* h, int n_streams);
 /* What the most recent mds_rollout_geometric / mds_rollout_step / mds_rollout_dslpid / mds_rollout_cbf_geometric of this handle did: 1 = the
  * caller's stream only, 2 = two chains on the internal streams, 0 = no rollout yet. */

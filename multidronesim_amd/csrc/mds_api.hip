@@ -191,7 +191,20 @@ static int rollout_streams_policy(const mds_handle* h, int loop, int n_steps) {
 static int split_streams_ready(mds_handle* h) {
   if (h->split_st && h->split_ev[0] && h->split_ev[1]) return MDS_OK;
   if (!h->split_st) {
-    MDS_HIP(hipStreamCreateWithFlags(&h->split_st, hipStreamNonBlocking));
+    // ROCm multiplexes a process's streams onto GPU_MAX_HW_QUEUES (4 by default) hardware queues; when the caller's stream and this one share
+    // a queue the two chains serialise (C4 with 8 other active streams in the process: 49 -> 87 us per step).  A stream of another priority
+    // level lives on queues of its own: MDS_SPLIT_STREAM_PRIORITY=high|low is for such applications (no measurable cost or gain otherwise).
+    static const int prio_mode = [] {
+      const char* e = getenv("MDS_SPLIT_STREAM_PRIORITY");
+      return !e ? 0 : (e[0] == 'h' || e[0] == '1') ? 1 : (e[0] == 'l' || e[0] == '2') ? 2 : 0;
+    }();
+    if (prio_mode) {
+      int lo = 0, hi = 0;
+      MDS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      MDS_HIP(hipStreamCreateWithPriority(&h->split_st, hipStreamNonBlocking, prio_mode == 1 ? hi : lo));
+    } else {
+      MDS_HIP(hipStreamCreateWithFlags(&h->split_st, hipStreamNonBlocking));
+    }
     k_noop<<<1, 64, 0, h->split_st>>>();
     MDS_HIP(hipGetLastError());
   }

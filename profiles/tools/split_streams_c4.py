@@ -1,5 +1,6 @@
-"""C4 (geometric nominal -> ECBF QP -> ThrustOmega -> DYN): do two half-size env shards stepping on two streams beat one
-full shard on one stream?  The QP kernel is latency/ALU bound, the other two kernels are memory bound."""
+"""C4 (geometric nominal -> ECBF QP -> ThrustOmega -> DYN, SURVEY 8d scene): N equal env shards, each its own env / tracker stepping through
+its own C rollout loop on its own stream (one chain each), against the library's own two-chain split of one 16 384-env shard.  bench.py's
+window: 20 warm-up steps, 200 timed.  python3 profiles/tools/split_streams_c4.py"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -8,11 +9,11 @@ from multidronesim_amd.envs.CtrlAviary import CtrlAviary, DroneModel, Physics
 from multidronesim_amd.cbf.cbf import DroneCBF
 from multidronesim_amd.cbf.qptracker import DroneQPTracker
 from multidronesim_amd.model.linear_omega import LinearizedOmegaModel
-D, K = 16, 1000
+D, W, K = 16, 20, 200
 dev = torch.device("cuda:0")
 c4_obs = [np.array([[sx * 0.5, sy * 0.5, 0.5], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
 c4_r = [0.1] * 4
-def mk(E, seed):
+def mk(E, seed, streams):
     xyz, rpy, P = bench.make_inputs(E, D, "c3", seed)
     P[..., 4] = 0.5 + 0.3 * np.arange(D); xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
     env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN,
@@ -20,26 +21,28 @@ def mk(E, seed):
     cbf = DroneCBF(env, [LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2, cbf_poles=np.array([-2.2, -2.4]))
     tr = DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
     env.set_trajectories(P)
+    env.set_rollout_streams(streams)
     env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=dev))
     return env, tr
-full = mk(16384, 1000)
-halves = [mk(8192, 2000 + k) for k in range(2)]
-streams = [torch.cuda.Stream() for _ in range(2)]
-clock = {"full": 0.0, "split": 0.0}
-def run_full(k):
-    env, tr = full
-    for _ in range(k):
-        env.step_cbf_geometric(clock["full"], tr, c4_obs, c4_r); clock["full"] += 0.01
-def run_split(k, lag=0):
-    for j in range(k):
-        for s, (env, tr) in enumerate(halves):
-            with torch.cuda.stream(streams[s]):
-                env.step_cbf_geometric(clock["split"], tr, c4_obs, c4_r)
-        clock["split"] += 0.01
-def timeit(fn, k):
-    torch.cuda.synchronize()
-    t0 = time.perf_counter(); fn(k); torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / k * 1e6
-run_full(200); run_split(200)
-for _ in range(3):
-    print("one shard 16384 envs: %.2f us/step | 2 shards x 8192 on 2 streams: %.2f" % (timeit(run_full, K), timeit(run_split, K)), flush=True)
+streams = [torch.cuda.Stream() for _ in range(8)]
+def run(parts, t0, k):
+    for s, (env, tr) in enumerate(parts):
+        with torch.cuda.stream(streams[s]):
+            env.rollout_cbf_geometric(t0, k, tr, c4_obs, c4_r)
+def lib_case():
+    lib = [mk(16384, 1000, 2)]
+    run(lib, 0.0, W); torch.cuda.synchronize()
+    t0 = time.perf_counter(); run(lib, W * 0.01, K); torch.cuda.synchronize()
+    print("library two-chain split of one 16384-env shard: %.2f us per step (streams used: %d)" % ((time.perf_counter() - t0) / K * 1e6, lib[0][0].last_rollout_streams()), flush=True)
+    lib[0][0].close()
+lib_case()
+for n in (1, 2, 3, 4, 6, 8):
+    E = 16384 // n // 16 * 16                       # whole 256-drone batches per shard
+    parts = [mk(E, 1000 + 17 * k, 1) for k in range(n)]
+    run(parts, 0.0, W); torch.cuda.synchronize()
+    t0 = time.perf_counter(); run(parts, W * 0.01, K); torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / K * 1e6
+    print("%d shard(s) x %d envs, one chain each: %.2f us per step (%.2f per 16384 envs)" % (n, E, us, us * 16384 / (E * n)), flush=True)
+    for env, tr in parts:
+        env.close()
+lib_case()
