@@ -41,7 +41,20 @@ WORKLOADS = {
 }
     # c5 is appended below (physics-only, fp16 storage)
 C5_EPISODE = 1000              # control steps per open-loop episode of the c5 rollout
-BYTES_PER_DRONE_STEP_C4 = 132 + 148 + 260   # three launches: nominal (R 80, W 52) + filter (R 132, W 16) + low-level step (R 104, W 156)
+# the CBF step's ALGORITHMIC bytes = the fused step's 212 + R u_hat 16 + R xdes 36 + W u_safe 16 (+ W status 4 / D) = 280 B per
+# drone-step.  What the launches of a split step move on top of that (u_hat / xdes / obs intermediates re-read by the next launch) is
+# wasted traffic, reported beside it from the counters (`roofline.traffic`), never counted as achieved.
+BYTES_PER_DRONE_STEP_C4 = 280
+# C4 obstacle scenes: four static spheres r = 0.1 m at (+-xy, +-xy, z) in world coordinates ((+-0.5, +-0.5, 0.5))
+C4_SCENES = {
+    "under": (0.5, -2.5, "four spheres on the floor 3 m under the lowest flight plane, (+-0.5, +-0.5, -2.5): every env's QP stays FEASIBLE over "
+                         "the window (status 0 everywhere: the exact, unique minimiser -- the branch on which the solver is faithful to the "
+                         "reference's cvxopt up to cvxopt's tolerances) and a third of the envs need active-set iterations"),
+    "level": (0.5, 0.5, "SURVEY 8d's spheres at (+-0.5, +-0.5, 0.5), level with the lowest flight plane: about a third of the envs become "
+                        "INFEASIBLE (obstacle rows beyond the reach of the input box) and keep the nominal input -- a modelled fallback, "
+                        "not the reference's behaviour there (cvxopt returns status 'unknown' + its last iterate; include/mds.h)"),
+    "far": (100.0, 0.65, "the same spheres 100 m away: their 64 rows are built and scanned but never bind; what iterates is the 120 inter-agent rows"),
+}
 BYTES_PER_DRONE_STEP = 212          # R state 52 + R traj params 28 + W state 52 + W obs 80
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -267,6 +280,247 @@ def extra_c3_variant(CtrlAviary, DroneModel, Physics, torch, local_rank, device,
     return us, used, sane
 
 
+def c4_spheres(scene, z_override=None):
+    """x_obs_list / obs_r_list as simulations/CBFTest.py:421-425 passes them: one (order, 3) state per sphere, radius 0.1."""
+    xy, z, _ = C4_SCENES[scene]
+    if z_override is not None:
+        z = z_override
+    return [np.array([[sx * xy, sy * xy, z], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)], [0.1] * 4
+
+
+def c4_inputs(E, D, seed):
+    """SURVEY 8d's C4 generator: the C3 swarm with trajectories / start heights stacked 0.3 m apart (with the omega linearisation the
+    barrier acts through e_z only)."""
+    xyz, rpy, P = make_inputs(E, D, "c3", seed)
+    P[..., 4] = 0.5 + 0.3 * np.arange(D)
+    xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    return xyz, rpy, P
+
+
+def c4_make(CtrlAviary, DroneModel, Physics, E, D, seed, dtype, local_rank):
+    from multidronesim_amd.cbf.cbf import DroneCBF
+    from multidronesim_amd.cbf.qptracker import DroneQPTracker
+    from multidronesim_amd.model.linear_omega import LinearizedOmegaModel
+    xyz, rpy, P = c4_inputs(E, D, seed)
+    env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN,
+                     pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype, device=local_rank)
+    cbf = DroneCBF(env, [LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2,
+                   cbf_poles=np.array([-2.2, -2.4]))                                    # CBFTest.py:419
+    tracker = DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+    env.set_trajectories(P)
+    return env, tracker
+
+
+ITER_EDGES = [0, 1, 2, 4, 8, 16, 32, 64, 1 << 30]
+ITER_BINS = ["0", "1", "2-3", "4-7", "8-15", "16-31", "32-63", "64+"]
+
+
+def c4_window_stats(torch, env, tracker, c4_obs, c4_r, first, steps):
+    """UNTIMED second pass over the same window, step by step from a fresh reset: what the solver did at EVERY step of it -- share of envs
+    with status 1 (infeasible: modelled fallback) and share that needed active-set iterations; the histogram is of the window's last step."""
+    env.reset()
+    env.step(torch.zeros((env.NUM_ENVS, env.NUM_DRONES, 4), dtype=env.dtype, device=env.device))
+    dt = env.CTRL_TIMESTEP
+    fb, it_share, it_mean = [], [], []
+    t = 0.0
+    it = None
+    for k in range(first + steps):
+        _, st = env.step_cbf_geometric(t, tracker, c4_obs, c4_r)
+        t += dt
+        if k >= first:
+            it = tracker.cbf.last_iterations()
+            fb.append((st != 0).float().mean())
+            it_share.append((it > 0).float().mean())
+            it_mean.append(it.float().mean())
+    fb, it_share, it_mean = (torch.stack(v).cpu() for v in (fb, it_share, it_mean))
+    hist = torch.histogram(it.float().cpu(), bins=torch.tensor([float(e) for e in ITER_EDGES]))[0]
+    return {"steps": [first, first + steps], "fallback_frac": {"mean": float(fb.mean()), "max": float(fb.max()), "last": float(fb[-1])},
+            "iterating_env_frac": {"mean": float(it_share.mean()), "max": float(it_share.max()), "last": float(it_share[-1])},
+            "iterations_per_env_mean": float(it_mean.mean()),
+            "iterations_last_step": {"bins": ITER_BINS, "envs": [int(v) for v in hist.tolist()], "mean": float(it.float().mean().item()),
+                                     "max": int(it.max().item())}}
+
+
+def c4_pmc_traffic(scene, n_local):
+    """Counter traffic of ONE control step (all its launches), from the committed summary of the separate rocprofv3 --pmc passes."""
+    path = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_c4_{scene}.json")
+    try:
+        rec = json.load(open(path))
+        per = rec["traffic_bytes_per_step"] / rec["drones_per_step_counted"]
+        return per * n_local, f"profiles/{os.path.basename(path)} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE summed over the launches of a control step, separate --pmc passes)"
+    except Exception:
+        return None, None
+
+
+def measure_c4(CtrlAviary, DroneModel, Physics, torch, local_rank, device, scene, dtype="float32", steps=200, warmup=20, fused_T=0,
+               one_launch=False, stats=True, seed=1000):
+    """BASELINE configs[3] on its own env: `warmup` untimed + `steps` timed control steps of the CBFTest.py:303-350 loop through the C
+    rollout (or the K-steps-per-launch kernel), HIP events on the launch stream; then the untimed per-step census of the same window."""
+    E, D, _, desc = WORKLOADS["c4"]
+    env, tracker = c4_make(CtrlAviary, DroneModel, Physics, E, D, seed, dtype, local_rank)
+    c4_obs, c4_r = c4_spheres(scene)
+    env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=device))
+    dt = env.CTRL_TIMESTEP
+    if one_launch:
+        env.set_cbf_step_kernel(True)
+
+    def roll(t0, k):
+        if fused_T:
+            env.rollout_cbf_geometric_fused(t0, k, tracker, c4_obs, c4_r, steps_per_launch=fused_T)
+        else:
+            env.rollout_cbf_geometric(t0, k, tracker, c4_obs, c4_r)
+    env.set_rollout_streams(0)
+    roll(0.0, warmup)
+    us = _timed_steps(device, lambda: roll(warmup * dt, steps), steps)
+    used = env.last_rollout_streams() if not fused_T else 1
+    obs = env._obs
+    sane = bool(torch.isfinite(obs).all().item()) and abs(float(obs[..., 3:7].norm(dim=-1).mean().item()) - 1.0) < 1e-3
+    n_local = E * D
+    gb = BYTES_PER_DRONE_STEP_C4 * n_local / (us * 1e-6) / 1e9
+    out = {"workload": desc, "scene": scene, "scene_what": C4_SCENES[scene][2], "us_per_step": us, "value": n_local / (us * 1e-6),
+           "unit": "drone-steps/s", "steps": steps, "warmup": warmup, "streams": used, "state_sane": sane,
+           "step_kernel": (f"k_cbf_rollout ({fused_T} control steps per launch, state in registers)" if fused_T else
+                           ("k_cbf_step (one launch per step)" if env.cbf_last_step_kernel() == 1 else "k_cbf_filter_gi + k_lowlevel_step (two launches per step and env half)")),
+           "roofline": {"bound": "hbm", "bytes_per_drone_step": BYTES_PER_DRONE_STEP_C4, "achieved": gb, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": gb / HBM_PEAK_GBPS,
+                        "note": "algorithmic bytes of SURVEY 8d (280 B per drone-step); the path is VALU / latency bound, not HBM bound"}}
+    tr, src = c4_pmc_traffic(scene, n_local)
+    if tr is not None:
+        out["roofline"].update({"traffic": tr, "traffic_source": src, "wasted_traffic_ratio": tr / (BYTES_PER_DRONE_STEP_C4 * n_local)})
+    if stats:
+        try:
+            out["window"] = c4_window_stats(torch, env, tracker, c4_obs, c4_r, warmup, steps)
+        except Exception as exc:
+            out["window"] = {"error": str(exc)}
+    env.close()
+    return out
+
+
+def measure_c5(CtrlAviary, DroneModel, Physics, torch, local_rank, device, steps=2000, slots=16, fused_T=40, seed=1000):
+    """BASELINE configs[4] on its own env: fp16 state storage, env.step() with random RPM around hover through the C loop
+    (mds_rollout_step), every step's observation streamed into a ring of `slots` log slots; and the several-steps-per-launch form."""
+    E, D, phase, desc = WORKLOADS["c5"]
+    xyz, rpy, _ = make_inputs(E, D, phase, seed)
+    env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN,
+                     pyb_freq=240, ctrl_freq=240, num_envs=E, dtype="float16", device=local_rank)
+    g = torch.Generator(device=device).manual_seed(1234)
+    act = torch.stack([(env.HOVER_RPM * (1 + 0.05 * torch.randn((E, D, 4), device=device, generator=g))).clamp(0, env.MAX_RPM).to(env.dtype)
+                       for _ in range(8)]).contiguous()
+    log = torch.empty((slots, E, D, 20), dtype=env.dtype, device=device)
+    env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=device))
+    env.set_rollout_streams(0)
+    n_local = E * D
+    env.rollout_step(act, 0, 200, log, episode_len=C5_EPISODE)
+    us = _timed_steps(device, lambda: env.rollout_step(act, 200, steps, log, episode_len=C5_EPISODE), steps)
+    used = env.last_rollout_streams()
+    last = log[(200 + steps - 1) % slots]
+    sane = bool(torch.isfinite(last).all().item()) and abs(float(last[..., 3:7].float().norm(dim=-1).mean().item()) - 1.0) < 1e-2
+    bpd = 100                                   # fp16 storage: R state 26 + R action 8 + W state 26 + W obs 40 (SURVEY 8d)
+    gb = bpd * n_local / (us * 1e-6) / 1e9
+    out = {"workload": desc, "us_per_step": us, "value": n_local / (us * 1e-6), "unit": "drone-steps/s", "steps": steps, "streams": used,
+           "rollout_log_slots": slots, "rollout_log_GB": log.numel() * log.element_size() / 1e9, "state_sane": sane,
+           "log_note": "a small ring (allocated in well under a second); `bench.py --workload c5` streams into a 200 GB log",
+           "roofline": {"bound": "hbm", "bytes_per_drone_step": bpd, "achieved": gb, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBPS,
+                        "kernel": "k_step<float,_Float16,true,false,false>"}}
+    try:
+        env.reset()
+        env.rollout_step(act, 0, C5_EPISODE, log, episode_len=C5_EPISODE, steps_per_launch=fused_T)
+        reps = 2
+        usf = _timed_steps(device, lambda: env.rollout_step(act, C5_EPISODE, reps * C5_EPISODE, log, episode_len=C5_EPISODE,
+                                                            steps_per_launch=fused_T), reps * C5_EPISODE)
+        b2 = 48 + 52 / fused_T
+        lastf = log[(C5_EPISODE * (reps + 1) - 1) % slots]
+        out["fused_rollout"] = {"steps_per_launch": fused_T, "us_per_step": usf, "value": n_local / (usf * 1e-6), "bytes_per_drone_step": b2,
+                                "achieved_GBps": b2 * n_local / (usf * 1e-6) / 1e9, "bound": "VALU (state in registers)",
+                                "kernel": "k_rollout_step<float,_Float16,false,false>", "state_sane": bool(torch.isfinite(lastf).all().item())}
+    except Exception as exc:
+        out["fused_rollout"] = {"error": str(exc)}
+    env.close()
+    return out
+
+
+def cpu_baseline_c4(budget_s=8.0, E=2, D=16, scene="under"):
+    """The oracle's C4 loop (geometric nominal -> cbf_filter: dense rows + exact QP per env -> ThrustOmega -> DYN step) on a bounded
+    sample, one core."""
+    from oracle import np_oracle as O
+    c = O.CF2P
+    xyz, rpy, P = c4_inputs(E, D, 123)
+    x_obs, obs_r = c4_spheres(scene)
+    n = E * D
+    Pf = P.reshape(-1, 7)
+    Kcbf = O.place_poles_chain([-2.2, -2.4])
+    umax = np.array([c.MAX_THRUST, 10.0, 10.0, 10.0])
+    ora = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), c, 100, 100, drones_per_env=D)
+    ll = O.ThrustOmegaOracle(n, c)
+    obs = ora.step(np.zeros((n, 4)))
+    t, steps, nfb = 0.0, 0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and steps < 400:
+        pos, vel, acc, yaw, yd = O.lemniscate(t, Pf[:, 0], Pf[:, 1], Pf[:, 2:5], Pf[:, 5], Pf[:, 6])
+        force, w_des, _ = O.geometric_compute(obs, pos, vel, acc, yaw, yd, c, return_omegas=True)
+        unom = np.concatenate([(force - c.M * c.G)[:, None], w_des], axis=1)
+        xdes = np.concatenate([np.zeros((n, 2)), yaw[:, None], vel, pos], axis=1)
+        x = O.obs_to_lin_model(obs, 9)
+        usafe = np.zeros((n, 4))
+        for e in range(E):
+            sl = slice(e * D, (e + 1) * D)
+            usafe[sl], st = O.cbf_filter(x[sl], xdes[sl], unom[sl], 2, Kcbf, umax, 0.1, 1.0, c, np.array(x_obs), obs_r)
+            nfb += st
+        usafe[:, 0] += c.M * c.G
+        obs = ora.step(ll.compute_low_level(usafe, obs, ora.CTRL_TIMESTEP))
+        t += ora.CTRL_TIMESTEP
+        steps += 1
+    el = time.perf_counter() - t0
+    return {"value": n * steps / el, "unit": "drone-steps/s", "cores": 1, "kind": "port",
+            "sample": f"float64 NumPy oracle, C4 loop ('{scene}' scene): {E} envs x {D} drones x {steps} control steps in {el:.1f} s "
+                      f"(dense 216-row G per env + exact active-set QP), {nfb} infeasible env-steps"}
+
+
+def cpu_baseline_c1(budget_s=6.0):
+    """SURVEY 8d's CPU shape for BASELINE configs[0]: 2 drones hovering (MultiDroneExample.py), pyb = ctrl = 240 Hz x 10 s = 2400 control
+    steps, the oracle's DSLPID + DYN step in the reference's per-drone loop shape, one core."""
+    from oracle import np_oracle as O
+    D = 2
+    ang = 2 * np.pi * np.arange(D) / D
+    xyz = np.stack([np.cos(ang), np.sin(ang), np.zeros(D)], axis=1)          # MultiDroneExample.py:133-138, circle r = 1
+    tgt = xyz + np.array([0.0, 0.0, 1.0])
+    ora = [O.AviaryOracle(xyz[j:j + 1], np.zeros((1, 3)), O.CF2P, 240, 240) for j in range(D)]
+    pid = [O.DSLPIDOracle(1, O.CF2P) for _ in range(D)]
+    obs = [o.step(np.zeros((1, 4))) for o in ora]
+    steps = 0
+    t0 = time.perf_counter()
+    while steps < 2400 and time.perf_counter() - t0 < budget_s:
+        for j in range(D):
+            rpm = pid[j].compute_from_state(1.0 / 240, obs[j], tgt[j:j + 1], np.zeros((1, 3)))
+            obs[j] = ora[j].step(rpm)
+        steps += 1
+    el = time.perf_counter() - t0
+    return {"value": D * steps / el, "unit": "drone-steps/s", "cores": 1, "kind": "port",
+            "sample": f"C1: 2 drones hover, DSLPID + DYN at 240 Hz, {steps} of 2400 control steps in {el:.1f} s, one Python call chain per drone "
+                      "(PyBullet Physics.PYB itself: not measurable, package unavailable)"}
+
+
+def cpu_baseline_c2_e64(budget_s=6.0):
+    """SURVEY 8d's CPU shape for BASELINE configs[1]: C2 scaled to E = 64 (64 x 4 drones), vectorised oracle, one core."""
+    from oracle import np_oracle as O
+    E, D = 64, 4
+    xyz, rpy, P = make_inputs(E, D, "c2", 123)
+    n = E * D
+    Pf = P.reshape(-1, 7)
+    ora = O.AviaryOracle(xyz.reshape(-1, 3), rpy.reshape(-1, 3), pyb_freq=100, ctrl_freq=100)
+    obs = ora.step(np.zeros((n, 4)))
+    t, steps = 0.0, 0
+    t0 = time.perf_counter()
+    while steps < 1000 and time.perf_counter() - t0 < budget_s:
+        pos, vel, acc, yaw, yd = O.lemniscate(t, Pf[:, 0], Pf[:, 1], Pf[:, 2:5], Pf[:, 5], Pf[:, 6])
+        obs = ora.step(O.geometric_compute(obs, pos, vel, acc, yaw, yd))
+        t += ora.CTRL_TIMESTEP
+        steps += 1
+    el = time.perf_counter() - t0
+    return {"value": n * steps / el, "unit": "drone-steps/s", "cores": 1, "kind": "port",
+            "sample": f"C2 at E = 64: 64 envs x 4 drones x {steps} control steps (T = 1000) in {el:.1f} s, vectorised float64 NumPy oracle"}
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
@@ -285,14 +539,17 @@ def main(argv=None):
     ap.add_argument("--python-loop", action="store_true", help="issue each step from Python (env.step_geometric) instead of the C rollout loop")
     ap.add_argument("--rollout-streams", type=int, default=0, choices=[0, 1, 2],
                     help="mds_set_rollout_streams: 0 auto (the library's policy for the timed call's length), 1 one stream, 2 split")
-    ap.add_argument("--c4-scene", default="level", choices=["level", "far"],
-                    help="c4 obstacles.  'level': SURVEY 8d's four spheres at (+-0.5, +-0.5, 0.5) -- about a third of the envs fall back to "
-                         "the nominal control like the reference (qptracker.py:30-34).  Measured (profiles/tools/c4_scene.py): every fallback is "
-                         "an OBSTACLE row beyond the reach of the input box -- the rows are built on the tracking-error state and with the "
+    ap.add_argument("--c4-scene", default="under", choices=sorted(C4_SCENES),
+                    help="c4 obstacles (C4_SCENES).  'under' (headline): spheres 3 m under the lowest plane -- no env is ever infeasible, a third "
+                         "iterate.  'level': SURVEY 8d's four spheres at (+-0.5, +-0.5, 0.5) -- about a third of the envs are infeasible and keep "
+                         "the nominal control (a MODELLED fallback: the reference falls back only when cvxopt raises, and cvxopt returns status "
+                         "'unknown' + an iterate on infeasible rows).  Measured (profiles/tools/c4_scene.py): every such env has an OBSTACLE row "
+                         "beyond the reach of the input box -- the rows are built on the tracking-error state and with the "
                          "omega linearisation the thrust acts on the barrier through e_z only, so once the filter has pushed a drone ~1 m / "
                          "4 m/s off its trajectory the row k0 h + k1 hdot + Lf2 h of a static sphere (x_des = x) turns hugely negative for "
                          "1 < r / |v_err| < 2.6 s whatever the thrust.  'far': the same four spheres 100 m away (r / |v_err| > 15 s): the 64 "
                          "obstacle rows are still built and scanned every step but stay positive; what remains is the 120 inter-agent rows")
+    ap.add_argument("--c4-z", type=float, default=None, help="c4: override the scene's sphere height (scene exploration)")
     ap.add_argument("--c4-one-launch", action="store_true",
                     help="c4: mds_cbf_set_step_kernel(h, 1) -- nominal controller, QPs and low level + physics in ONE launch per control step "
                          "(the faster form when few envs iterate: the 'far' scene; slower on SURVEY 8d's)")
@@ -399,9 +656,7 @@ def main(argv=None):
         cbf = DroneCBF(env, [LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2,
                        cbf_poles=np.array([-2.2, -2.4]))                                    # CBFTest.py:419
         tracker = DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
-        c4_xy, c4_z = (0.5, 0.5) if args.c4_scene == "level" else (100.0, 0.65)
-        c4_obs = [np.array([[sx * c4_xy, sy * c4_xy, c4_z], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
-        c4_r = [0.1] * 4
+        c4_obs, c4_r = c4_spheres(args.c4_scene, args.c4_z)
         if args.c4_one_launch:
             env.set_cbf_step_kernel(True)
     env.set_trajectories(P)
@@ -441,11 +696,13 @@ def main(argv=None):
                 if rc != 0:
                     raise RuntimeError(f"mds_step failed: {rc}")
                 c5_k[0] = j + 1
-        elif fused_T:
+        elif fused_T and tracker is None:
             t = t0
             for _ in range(k // fused_T):
                 env.rollout_geometric_fused(t, fused_T, log=True, log_out=log_buf)
                 t += fused_T * dt
+        elif tracker is not None and fused_T:
+            env.rollout_cbf_geometric_fused(t0, k, tracker, c4_obs, c4_r, steps_per_launch=fused_T)
         elif tracker is not None and args.python_loop:
             t = t0
             for _ in range(k):
@@ -494,7 +751,7 @@ def main(argv=None):
         bytes_per = 13 * es * 2 + 4 * es + 20 * es       # R state + W state + R action + W obs (origin read not counted)
     if fused_T and c5:
         bytes_per = 24 * es + 26 * es / fused_T   # action row + obs row per step, state R/W once per launch
-    elif fused_T:
+    elif fused_T and not c4:
         bytes_per = 20 * es + (33 * es + 20 * es) / fused_T     # obs row per step + (state R/W, params, final obs) once per launch
     achieved = bytes_per * n_local / (us_per_step * 1e-6) / 1e9
     split = used_streams == 2
@@ -513,7 +770,8 @@ def main(argv=None):
                    "parallelism": f"env-shard x{world}, no collective",
                    "launch": "python" if args.python_loop else "C rollout loop, one stream"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "kernel": f"k_step_geometric<{cname},{tname},true,false,{'true' if rk4 else 'false'},false>",
+                     "traffic": None,
+                     "kernel": f"k_step_geometric<{cname}, {tname}, true, false, {'true' if rk4 else 'false'}, false, {'true' if args.dtype in ('float32c', 'float32q') else 'false'}>",
                      "us_per_step": us_per_step, "bytes_per_launch": bytes_per * n_local, "streams": used_streams},
         "device_ms_per_step_max_rank": dev_ms_max / args.steps, "ranks_seen": len(dev_ms_ranks),
         "device_ms_per_rank": dev_ms_ranks, "value_per_rank": [n_local * args.steps / w for w in wall_ranks], "state_sane": ok,
@@ -558,7 +816,7 @@ def main(argv=None):
             del src_t, dst_t
         except Exception as exc:                                       # never let the calibration break the bench line
             line["roofline"]["copy_ceiling"] = {"error": str(exc)}
-    if fused_T:
+    if fused_T and not c4:
         line["roofline"]["kernel"] = f"k_rollout_geometric<float,float,false,false> ({fused_T} control steps per launch)"
         line["roofline"]["us_per_launch"] = us_per_step * fused_T
         line["roofline"]["bytes_per_launch"] = bytes_per * n_local * fused_T
@@ -581,7 +839,23 @@ def main(argv=None):
         st = env._cbf_status
         line["roofline"]["kernel"] = ("k_cbf_step (one launch per step and env half: nominal controller, 4 QPs per wave, low level + physics)" if env.cbf_last_step_kernel() == 1 else
                                       "k_cbf_filter_gi + k_lowlevel_step (2 launches per step and env half from the second step on; the QP is issue/latency bound)")
+        if fused_T:
+            line["roofline"]["kernel"] = f"k_cbf_rollout ({fused_T} control steps per launch: nominal controller, 4 QPs per wave, low level + physics, state in registers)"
+        line["roofline"]["bytes_per_drone_step"] = BYTES_PER_DRONE_STEP_C4
+        line["roofline"]["note"] = ("algorithmic bytes of SURVEY 8d (280 B per drone-step: the fused step's 212 + u_hat 16 + xdes 36 + u_safe 16); the path is "
+                                    "VALU / latency bound, `frac` says how far from the HBM roofline that leaves it")
+        tr, src = c4_pmc_traffic(args.c4_scene, n_local)
+        if tr is not None:
+            line["roofline"].update({"traffic": tr, "traffic_source": src, "wasted_traffic_ratio": tr / (BYTES_PER_DRONE_STEP_C4 * n_local)})
         line["config"]["scene"] = args.c4_scene
+        line["config"]["scene_what"] = C4_SCENES[args.c4_scene][2]
+        line["config"]["parity_note"] = ("fp32 vs the float64 oracle on this loop: see tests/test_gpu_cbf.py (status equality and state error over "
+                                         "the bench window and 1000 steps)")
+        if extras and world == 1:
+            try:
+                line["cbf_window"] = c4_window_stats(torch, env, tracker, c4_obs, c4_r, args.warmup, args.steps)
+            except Exception as exc:
+                line["cbf_window"] = {"error": str(exc)}
         line["config"]["step_kernel"] = "one launch" if env.cbf_last_step_kernel() == 1 else "QP launch + low-level launch"   # what the library did
         if not args.python_loop:
             line["config"]["launch"] = "C rollout loop, env halves on 2 streams" if split else "C rollout loop, one stream"
@@ -655,6 +929,27 @@ def main(argv=None):
         except Exception as exc:
             line["configs_1_c2"] = {"error": str(exc)}
         if args.dtype == "float32":
+            # BASELINE configs[3] (C4) and configs[4] (C5) beside the headline, same process, each on its own env: C4 on the scene where every
+            # QP is feasible (the headline C4 figure) and on SURVEY 8d's own spheres; C5 with a small log ring + its fused form
+            c4x = {"baseline_config_index": 3}
+            for key, scene in (("feasible_active", "under"), ("survey_8d", "level")):
+                try:
+                    c4x[key] = measure_c4(CtrlAviary, DroneModel, Physics, torch, local_rank, device, scene)
+                except Exception as exc:
+                    c4x[key] = {"error": str(exc)}
+                torch.cuda.empty_cache()
+            if hasattr(CtrlAviary, "rollout_cbf_geometric_fused"):
+                try:
+                    c4x["feasible_active_fused"] = measure_c4(CtrlAviary, DroneModel, Physics, torch, local_rank, device, "under", fused_T=20, stats=False)
+                except Exception as exc:
+                    c4x["feasible_active_fused"] = {"error": str(exc)}
+                torch.cuda.empty_cache()
+            line["configs_4_c4"] = c4x
+            try:
+                line["configs_5_c5"] = dict(measure_c5(CtrlAviary, DroneModel, Physics, torch, local_rank, device), baseline_config_index=4)
+            except Exception as exc:
+                line["configs_5_c5"] = {"error": str(exc)}
+            torch.cuda.empty_cache()
             # the same kernel beyond the Infinity Cache, north_star's integrator, and the reference's own precision, each on its own env
             try:
                 EB, DB, phB, _ = WORKLOADS["c3big"]
@@ -698,6 +993,19 @@ def main(argv=None):
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("c2", "c3"):
         line["cpu_baseline"] = cpu_baseline(D, phase, args.cpu_budget)
         line["cpu_baseline"]["all_cores"] = all_cores
+        # SURVEY 8d's own CPU shapes, and the C4 loop, beside the C3-shaped sample (each bounded to a few seconds, one core)
+        for key, fn in (("c1_two_drones_240hz", cpu_baseline_c1), ("c2_e64", cpu_baseline_c2_e64), ("c4", cpu_baseline_c4)):
+            try:
+                line["cpu_baseline"][key] = fn(min(8.0, args.cpu_budget / 2))
+            except Exception as exc:
+                line["cpu_baseline"][key] = {"error": str(exc)}
+        if isinstance(line.get("configs_4_c4"), dict):
+            line["configs_4_c4"]["cpu_baseline"] = line["cpu_baseline"]["c4"]
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline and c4:
+        try:
+            line["cpu_baseline"] = cpu_baseline_c4(args.cpu_budget, scene=args.c4_scene)
+        except Exception as exc:
+            line["cpu_baseline"] = {"error": str(exc)}
     elif rank == 0:
         line["cpu_baseline"] = None
     if rank == 0:

@@ -305,9 +305,19 @@ int mds_cbf_rows(mds_handle* h, const void* x_dev, const void* xdes_dev, void* G
 
 /* DroneQPTracker.compute_control (cbf/qptracker.py:22-34) for every env:
  * obs_dev [n,20], xdes_dev [n,xdim], u_nominal_dev [n,4] (thrust already offset by -M*G,
- * simulations/CBFTest.py:339) -> u_safe_dev [n,4]; status_dev [E] int32: 0 = QP solved,
- * 1 = no solution within the cap -> that env's u_safe is u_nominal unchanged
- * (qptracker.py:30-34).  Order 2: D coupled thrust variables, omega box-clipped.  Order 3: 3D coupled
+ * simulations/CBFTest.py:339) -> u_safe_dev [n,4]; status_dev [E] int32: 0 = QP solved (the unique
+ * minimiser), 1 = infeasible (MODELLED FALLBACK): the rows of that env admit no point (or the
+ * iteration cap ran out) and its u_safe is u_nominal unchanged.
+ * What status 1 is and is not: the reference takes its `return u_nominal` exit (qptracker.py:30-34)
+ * only when cvxopt.solvers.qp RAISES (qptracker.py:103-112: success = True as soon as the call
+ * returns).  cvxopt 1.3.2's coneqp does not certify infeasibility of a QP: on such rows it returns
+ * status 'unknown' with its last iterates (iteration limit / singular KKT system) and raises only
+ * the rank ValueError that P = I rules out -- so the reference most likely applies that last
+ * iterate to all drones of the env.  cvxopt is not available to this build; "infeasible -> u_nominal"
+ * is therefore this library's own, modelled, policy: parity with the reference on status-1 envs is
+ * UNPINNED and probably different.  On status-0 envs the minimiser is unique, so any exact solver
+ * agrees with cvxopt up to cvxopt's own tolerances (feastol / abstol 1e-7, reltol 1e-6).
+ * Order 2: D coupled thrust variables, omega box-clipped.  Order 3: 3D coupled
  * (yank, wx, wy) variables (<= 63), omega_z clipped to its box / force-box interval. */
 int mds_cbf_filter(mds_handle* h, const void* obs_dev, const void* xdes_dev, const void* u_nominal_dev, void* u_safe_dev,
                    int32_t* status_dev, void* stream);

@@ -1,8 +1,13 @@
 """cbf/qptracker.py of the reference: ``DroneQPTracker.compute_control`` -- minimally change
 the nominal input so that the ECBF rows hold (min 1/2|u - u_hat|^2 s.t. G u <= h, :86-114).
 
-The QP runs on the GPU, one wavefront per env (``mds_cbf_filter``).  An env whose QP finds no
-solution falls back to its nominal control, like the reference when cvxopt raises (:30-34)."""
+The QP runs on the GPU, one wavefront per env (``mds_cbf_filter``) and returns the exact, unique
+minimiser (status 0).  An env whose rows are infeasible keeps its nominal control with status 1:
+a MODELLED fallback.  The reference takes its ``return u_nominal`` exit (:30-34) only when
+``cvxopt.solvers.qp`` raises (:103-112), and cvxopt's ``coneqp`` answers an infeasible QP with
+``status 'unknown'`` and its last iterate rather than an exception, so on such envs the reference most
+likely applies that iterate; cvxopt is not available here, parity on status-1 envs is unpinned
+(include/mds.h, ``mds_cbf_filter``)."""
 from __future__ import annotations
 
 import ctypes as C

@@ -83,8 +83,10 @@ __global__ __launch_bounds__(256) void k_cbf_rows(const CbfParams<T> P, const in
 // rows are feasible.  Infeasibility is certified by weak duality: every update raises the dual
 // value by score/2, and for a feasible problem the dual never exceeds the primal optimum, which
 // the thrust box bounds by 1/2 sum_i (|F_hat_i| + umax_0)^2 -- once the accumulated dual value
-// passes that bound the rows are infeasible and the env falls back to u_hat with status 1 (the
-// reference falls back when cvxopt raises, qptracker.py:30-34).  The iteration cap is a backstop.
+// passes that bound the rows are infeasible and the env keeps u_hat with status 1.  That exit is this
+// library's MODELLED policy, not a restatement: the reference returns u_hat only when cvxopt.solvers.qp
+// raises (qptracker.py:30-34, :103-112), and cvxopt's coneqp returns status 'unknown' + its last iterate
+// on an infeasible QP instead of raising (include/mds.h, mds_cbf_filter).  The iteration cap is a backstop.
 // ------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ void wave_argmax(T& score, int& row) {
 #pragma unroll
@@ -978,7 +980,7 @@ __device__ __forceinline__ void cbf_o2_slot(const CbfParams<T>& P, const T (*__r
 //                                 world position and the tracking errors in roll, pitch, velocity;
 //   stage B, one env at a time  : the wave's 64 / D envs in turn -- rows built R per lane from the LDS copy of stage A's outputs,
 //                                 most-violated-row scan, gi_solve (rows stay in registers: no row table);
-//   stage C, one drone per lane : u_safe (nominal if the env's QP has no solution, qptracker.py:30-34) + M G -> ThrustOmega low level
+//   stage C, one drone per lane : u_safe (nominal if the env's QP has no solution: the modelled fallback of mds_cbf_filter) + M G -> ThrustOmega low level
 //                                 -> physics step -> observation row -> state.
 // The three-launch path (nominal / k_cbf_filter_gi / k_lowlevel_step) moves u_hat, xdes, u_safe and the state through HBM
 // twice and runs the per-drone stages at full lane use but the QP kernel one env per wave; here the per-drone stages keep every lane

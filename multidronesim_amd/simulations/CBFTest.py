@@ -77,7 +77,7 @@ class GeometricEnv(_base.GeometricEnv):
         o = log.double().cpu().numpy()
         self.observations.extend(list(o[:, 0] if env.NUM_ENVS == 1 else o))
         self.obs = self.observations[-1]
-        self.statuses = st_log.cpu().numpy()          # 1 where the QP failed and the nominal control was applied (qptracker.py:30-34)
+        self.statuses = st_log.cpu().numpy()          # 1 where the QP was infeasible and the nominal control was kept (modelled fallback: cbf/qptracker.py docstring)
         env.close()
 
 

@@ -931,10 +931,19 @@ def cbf_rows(x, xdes, order, Kcbf, umax, safety_radius, zscale, c: DroneConsts =
 
 # --------------------------------------------------------------------------------------
 # a15: cbf/qptracker.py:86-114 -- min 1/2|u|^2 - uhat^T u  s.t. G u <= h
-# cvxopt (interior point) is absent here: QP *solution* parity is UNPINNED against cvxopt;
-# the problem is strictly convex so the minimiser is unique and this exact active-set
-# solver is the oracle.  Infeasible / failure -> (False, None) -> caller keeps uhat
-# (qptracker.py:30-34).
+# cvxopt 1.3.2 (environment.yaml:52; interior point, coneqp) is absent here: QP *solution* parity
+# is UNPINNED against cvxopt.
+#  * Feasible rows: the problem is strictly convex, the minimiser is unique, and this exact
+#    active-set solver is the oracle; cvxopt returns the same point up to its own tolerances
+#    (feastol = abstol = 1e-7, reltol = 1e-6).
+#  * Infeasible rows: (False, None) -> the caller keeps uhat (status 1).  This is a MODELLED
+#    policy, NOT what the reference does: _rectify sets success = True as soon as
+#    solvers.qp returns (qptracker.py:103-112) and falls back (:30-34) only when it RAISES.
+#    cvxopt's coneqp does not certify QP infeasibility -- it returns status 'unknown' with its
+#    last iterates (iteration limit, or a singular KKT system after iteration 0) and raises only
+#    the rank ValueError that P = I excludes -- so on such an env the reference most likely
+#    applies cvxopt's last iterate to all of its drones.  Parity on that branch: unpinned and
+#    probably different.
 # --------------------------------------------------------------------------------------
 
 
@@ -1017,7 +1026,8 @@ def qp_project(uhat, G, h, tol=1e-10, max_iter=None):
 def cbf_filter(x, xdes, u_nominal, order, Kcbf, umax, safety_radius, zscale, c: DroneConsts = CF2P, x_obs=None,
                obs_r=None, Fmin=None, Fmax=None):
     """DroneQPTracker.compute_control (qptracker.py:22-34) for ONE env, given linear-model
-    states x [N, xdim].  Returns (u [N,4], status) with status 0 = ok, 1 = fallback."""
+    states x [N, xdim].  Returns (u [N,4], status) with status 0 = solved, 1 = infeasible (modelled
+    fallback to u_nominal -- see the note above qp_project: the reference falls back only when cvxopt raises)."""
     G, h = cbf_rows(x, xdes, order, Kcbf, umax, safety_radius, zscale, c, x_obs, obs_r, Fmin, Fmax)
     u_nominal = np.asarray(u_nominal, dtype=np.float64)
     ok, u, _ = qp_project(u_nominal.reshape(-1), G, h)
