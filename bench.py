@@ -47,7 +47,7 @@ C5_EPISODE = 1000              # control steps per open-loop episode of the c5 r
 BYTES_PER_DRONE_STEP_C4 = 280
 # C4 obstacle scenes: four static spheres r = 0.1 m at (+-xy, +-xy, z) in world coordinates ((+-0.5, +-0.5, 0.5))
 C4_SCENES = {
-    "under": (0.5, -2.5, "four spheres on the floor 3 m under the lowest flight plane, (+-0.5, +-0.5, -2.5): every env's QP stays FEASIBLE over "
+    "under": (0.5, -3.0, "four spheres 3.5 m under the lowest flight plane, (+-0.5, +-0.5, -3.0): every env's QP stays FEASIBLE over "
                          "the window (status 0 everywhere: the exact, unique minimiser -- the branch on which the solver is faithful to the "
                          "reference's cvxopt up to cvxopt's tolerances) and a third of the envs need active-set iterations"),
     "level": (0.5, 0.5, "SURVEY 8d's spheres at (+-0.5, +-0.5, 0.5), level with the lowest flight plane: about a third of the envs become "

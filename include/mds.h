@@ -403,8 +403,8 @@ int mds_cbf_set_nominal(mds_handle* h, int which);
  * counts; observations equal to rounding (the two forms contract FMAs differently), so pick one per handle: each form's rollout
  * is bitwise its own step-by-step loop.  MDS_CBF_FUSED=1 in the environment selects 1 at mds_cbf_configure. */
 int mds_cbf_set_step_kernel(mds_handle* h, int one_launch);
-/* What the most recent mds_step_cbf_geometric / mds_rollout_cbf_geometric of this handle launched: 1 the one-launch kernel, 0 the QP
- * launch + the low-level launch, -1 no CBF-filtered step yet (negative mds_status for a null handle is -1 as well: check the handle). */
+/* What the most recent mds_step_cbf_geometric / mds_rollout_cbf_geometric[_fused] of this handle launched: 2 the several-steps-per-launch
+ * kernel, 1 the one-launch kernel, 0 the QP launch + the low-level launch, -1 no CBF-filtered step yet (negative mds_status for a null handle is -1 as well: check the handle). */
 int mds_cbf_last_step_kernel(const mds_handle* h);
 
 /* One CBF-filtered control step for every env.
@@ -423,6 +423,19 @@ int mds_step_cbf_geometric(mds_handle* h, double t, void* obs_dev, int32_t* stat
  * policy: auto from 2^16 drones and 16 steps): a barrier couples drones of one env only, so the halves are independent step
  * chains and one half's QP kernel overlaps the other's memory-bound kernels.  Results are those of the step-by-step loop. */
 int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs_dev, int32_t* status_dev, void* stream);
+
+/* n_steps of mds_step_cbf_geometric with steps_per_launch control steps PER LAUNCH (the persistent form of the loop
+ * simulations/CBFTest.py:303-350: k_cbf_rollout).  A workgroup owns whole envs for the launch; state, u_hat, xdes and u_safe stay on the
+ * chip between steps, the QPs of a workgroup's envs are handed out to its wavefronts heaviest first, and there is no chip-wide step
+ * boundary inside a launch.  obs_log_dev: NULL, or a ring [log_slots, n, 20] -- step k of this call writes its observation (the
+ * reference's observations.append(obs), CBFTest.py:351) into slot (first_slot + k) % log_slots; without a log only the last step's
+ * observation is materialised.  obs_dev [n,20]: the last step's observation (out).  status_dev [E]: the last step's statuses as
+ * mds_cbf_filter; status_log_dev: NULL or [n_steps, E], every step's.  Covers order 2, D in {4, 8, 16}, <= 256 rows per env,
+ * explicit Euler at pyb_freq == ctrl_freq, DYN, geometric or LQR-omega nominal, f32 / f32c / f64; MDS_EUNSUPPORTED otherwise (use
+ * mds_rollout_cbf_geometric).  Same QP, statuses and iteration counts as the step-by-step loop; observations equal to rounding (the
+ * kernels contract FMAs differently, as the one-launch step does: mds_cbf_set_step_kernel). */
+int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int steps_per_launch, void* obs_log_dev, int log_slots,
+                                    int first_slot, void* obs_dev, int32_t* status_dev, int32_t* status_log_dev, void* stream);
 
 /* The same step without the filter: nominal LQR (mds_cbf_set_nominal 1 or 2) -> its low level -> env.step, i.e.
  * ctrl[j].compute(obs[j]) + env.step(action) of simulations/EnvGeometricOmega.py:314,327 (LQROmegaController +

@@ -115,6 +115,7 @@ PROTOTYPES = {
     "mds_cbf_last_step_kernel": (C.c_int, [_P]),
     "mds_step_cbf_geometric": (C.c_int, [_P, C.c_double, _P, _P, _P, _P]),
     "mds_rollout_cbf_geometric": (C.c_int, [_P, C.c_double, C.c_int, _P, _P, _P]),
+    "mds_rollout_cbf_geometric_fused": (C.c_int, [_P, C.c_double, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "mds_step_nominal": (C.c_int, [_P, C.c_double, _P, _P, _P]),
     "mds_rollout_nominal_fused": (C.c_int, [_P, C.c_double, C.c_int, _P, _P, _P]),
 }

@@ -1981,6 +1981,64 @@ int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs, 
   return MDS_OK;
 }
 
+int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int steps_per_launch, void* obs_log, int log_slots, int first_slot,
+                                    void* obs, int32_t* status, int32_t* status_log, void* stream) {
+  MDS_DEV(h);
+  if (!h || !obs || !status || n_steps < 0 || steps_per_launch < 1 || log_slots < 0 || first_slot < 0 || (obs_log && first_slot >= log_slots) ||
+      (obs_log && log_slots < 1))
+    return fail(MDS_EINVAL, "mds_rollout_cbf_geometric_fused: null or out-of-range argument");
+  if (!h->has_cbf) return fail(MDS_ESTATE, "mds_rollout_cbf_geometric_fused: call mds_cbf_configure first");
+  if (!h->has_traj || h->traj_mode != 1) return fail(MDS_ESTATE, "mds_rollout_cbf_geometric_fused: call mds_set_lemniscate first");
+  if (!aligned16(obs) || !aligned16(obs_log)) return fail(MDS_EALIGN, "mds_rollout_cbf_geometric_fused: obs buffers");
+  const int D = h->cfg.num_drones;
+  const int m2 = D * (D - 1) / 2 + D * h->cbf.n_obs + 2 * D;
+  // what the persistent kernel covers (everything else: mds_rollout_cbf_geometric, one or two launches per step)
+  if (h->cbf.order != 2 || h->cbf_hildreth || D < 4 || D > 16 || 64 % D != 0 || m2 > 256 || h->envfx || h->cfg.integrator != MDS_INTEGRATOR_EULER ||
+      has_drag(h) || h->cbf_nominal > 1 || h->cfg.dtype == MDS_F16 || h->cfg.pyb_freq != h->cfg.ctrl_freq)
+    return fail(MDS_EUNSUPPORTED, "mds_rollout_cbf_geometric_fused: order-2 CBF, D in {4, 8, 16}, <= 256 rows per env, explicit Euler at "
+                                  "pyb_freq == ctrl_freq without drag / ground effect / downwash, geometric or LQR-omega nominal, f32 / f32c / f64");
+  if (n_steps == 0) return MDS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  // wavefronts per workgroup: 8 in fp32 (two workgroups per CU at <= 128 VGPRs); 4 in double (one wavefront per SIMD: the double
+  // instantiation needs more than the 256 registers two wavefronts per SIMD would leave it)
+  constexpr int NWF = MDS_CBF_ROLL_NW, NWD = 4;
+  const int nw = h->cfg.dtype == MDS_F64 ? NWD : NWF;
+  const dim3 grid((unsigned)((h->n + 64 * nw - 1) / (64 * nw)));
+  const int max_iter = h->cbf.max_iter > 0 ? h->cbf.max_iter : 64 * m2;
+  const void* gain = h->cbf_nominal == 1 ? h->gain_dev[1] : nullptr;
+  const double dt = 1.0 / h->cfg.ctrl_freq;
+  void* rpm = rpm_track(h);
+  const size_t es = elem_size(h->cfg.dtype);
+  h->cbf_last_step_kernel = 2;
+  int slot = first_slot;
+  double t = t0;
+  for (int k0 = 0; k0 < n_steps; k0 += steps_per_launch) {
+    const int ks = n_steps - k0 < steps_per_launch ? n_steps - k0 : steps_per_launch;
+    int32_t* slog = status_log ? status_log + (size_t)k0 * h->cfg.num_envs : nullptr;
+#define MDS_CR(T, CC, CP, NOM, COMP, TOL)                                                                                                      \
+  k_cbf_rollout<T, 4, NOM, COMP, (sizeof(T) == 8 ? NWD : NWF)><<<grid, 64 * nw, 0, st>>>(CC, CP, gain, h->n, h->ld, h->cfg.num_envs, t, dt, ks, (T*)h->state, (T*)h->state_lo,  \
+                                                               (const T*)h->lem, (T*)rpm, (T*)h->ll, h->pair_ij, (const T*)h->obstacles,        \
+                                                               (T*)obs_log, slot, log_slots > 0 ? log_slots : 1, (T*)obs, (int*)status, (int*)slog, \
+                                                               h->cbf_cost, max_iter, (T)((TOL) * (TOL)))
+#define MDS_CR_N(T, CC, CP, COMP, TOL)                        \
+  do {                                                        \
+    if (h->cbf_nominal == 1) MDS_CR(T, CC, CP, 1, COMP, TOL); \
+    else MDS_CR(T, CC, CP, 0, COMP, TOL);                     \
+  } while (0)
+    if (h->cfg.dtype == MDS_F64) MDS_CR_N(double, h->cd, h->cbf_d, false, (h->cbf.tol > 0 ? h->cbf.tol : 1e-12));
+    else if (is_comp(h)) MDS_CR_N(float, h->cf, h->cbf_f, true, (h->cbf.tol > 0 ? h->cbf.tol : 1e-6));
+    else MDS_CR_N(float, h->cf, h->cbf_f, false, (h->cbf.tol > 0 ? h->cbf.tol : 1e-6));
+#undef MDS_CR_N
+#undef MDS_CR
+    MDS_HIP(hipGetLastError());
+    // t advances on the host exactly as inside the kernel (one += per step), so that consecutive launches continue the same sequence
+    for (int j = 0; j < ks; ++j) t += dt;
+    if (obs_log) slot = (slot + ks) % log_slots;
+  }
+  (void)es;
+  return MDS_OK;
+}
+
 int mds_step_nominal(mds_handle* h, double t, void* obs, void* action, void* stream) {
   MDS_DEV(h);
   if (!h || !obs) return fail(MDS_EINVAL, "mds_step_nominal: null argument");

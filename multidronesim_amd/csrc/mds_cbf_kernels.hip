@@ -1129,6 +1129,245 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 && R == 4) ? 4 : 1) void k_cbf_
 }
 
 // ------------------------------------------------------------------------------------
+// n_steps CBF-filtered control steps of simulations/CBFTest.py:303-350 in ONE launch (order 2, D | 64, D <= 16): the persistent form of
+// k_cbf_step.  A workgroup of NW wavefronts owns 64 NW drones = 64 NW / D whole envs for the whole launch and walks them through
+//   stage A, one drone per lane : trajs[j](t), nominal controller -> u_hat; position and tracking errors of the drone into LDS;
+//   stage B, one env per wave   : the workgroup's envs handed out through an LDS ticket counter, heaviest (by their last step's
+//                                 iteration count) first -- rows built R per lane, violation scan, gi_solve;
+//   stage C, one drone per lane : u_safe + M G -> ThrustOmega low level -> physics step -> observation row (every step, into
+//                                 slot (slot0 + k) % n_slots of the log ring or over obs_last) -> state,
+// with a workgroup barrier between the stages.  Between steps the 13-value state lives in LDS (registers in stages A and C), the
+// trajectory parameters in registers, the low level's PID memory in its global planes (read and written by the same lane only).
+// What this buys over one launch per step: (1) no step boundary across the chip -- workgroups drift apart, a CU whose envs iterate
+// at step k runs beside CUs already at step k + 1, and the launch ends with the slowest WORKGROUP's sum over all steps instead of
+// every step ending with its slowest wave; (2) an env that needs 10 iterations delays NW / (envs per workgroup) of a wave's time, not
+// the three other envs of its wave (k_cbf_step) -- stage B is balanced over the workgroup's waves; (3) u_hat, xdes, u_safe and the
+// state never cross HBM between steps.  Arithmetic: the same device functions as k_cbf_step / the three-launch path.
+// t advances in double exactly like the host loop (t += CTRL_TIMESTEP, CBFTest.py:352).
+// ------------------------------------------------------------------------------------
+#ifndef MDS_CBF_ROLL_NW
+#define MDS_CBF_ROLL_NW 8
+#endif
+// No per-drone value stays in registers from one stage to the next: the state, u_hat and the solver's output wait in LDS, the
+// trajectory parameters and the low level's memory are re-read from their global planes (L2 / Infinity-Cache hits: nobody else touches
+// them) -- each stage's register allocation is its own, and the kernel fits the 128 VGPRs that let 16 wavefronts share a CU (at C4 the
+// whole batch is then resident: 4096 wavefronts = 4 per SIMD).
+template <typename T, int R, int NOM, bool COMP, int NW>
+__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout(const Consts<T> c, const CbfParams<T> P, const void* __restrict__ Kp, const int n,
+                                                        const size_t ld, const int E, double t, const double ctrl_dt, const int n_steps,
+                                                        T* __restrict__ state, T* __restrict__ state_lo, const T* __restrict__ lem,
+                                                        T* __restrict__ last_rpm, T* __restrict__ ll, const int* __restrict__ pair_ij,
+                                                        const T* __restrict__ obstacles, T* __restrict__ obs_log, int slot,
+                                                        const int n_slots, T* __restrict__ obs_last, int* __restrict__ status,
+                                                        int* __restrict__ status_log, int* __restrict__ cost_io, const int max_iter,
+                                                        const T tol2) {
+  constexpr int NT = 64 * NW;
+  constexpr int NMAX = 16, NV = 1;
+  constexpr int kQS = (NMAX + 3) / 4 * 4 + 4;
+  constexpr int GBMAX = NT / 4;                                // envs per workgroup (D >= 4)
+  struct Scratch {                                             // one wave's active-set solver
+    T sd[NMAX], slam[NMAX], sdi[NMAX];
+    T sQ[NMAX][kQS], sR[NMAX][kQS];
+    int sact[NMAX];
+  };
+  struct Work {                                                // stages A -> B
+    T pos[NT][3], de[NT][5];
+    Scratch sc[NW];
+  };
+  constexpr size_t kObsBytes = (size_t)NT * kObsDim * sizeof(T);   // stage C's observation staging aliases Work
+  constexpr size_t kWork = sizeof(Work) > kObsBytes ? sizeof(Work) : kObsBytes;
+  __shared__ __align__(16) unsigned char raw[(kWork + 15) / 16 * 16];
+  __shared__ T st[13][NT];                                     // the state between steps (lane-contiguous planes: conflict-free)
+  __shared__ T sun[4][NT];                                     // u_hat of every drone (stage A -> stage C)
+  __shared__ T su_all[NT];                                     // thrust variable of every drone: u_hat[0] in, QP minimiser out
+  __shared__ int sconv[GBMAX], scost[GBMAX], sorder[GBMAX];    // per env of the workgroup: QP solved; iterations of its last solve; hand-out order
+  __shared__ int sticket;
+  __shared__ T sob[kCbfMaxObs * 4];
+  Work& W = *reinterpret_cast<Work*>(raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int D = P.num_drones, GB = NT / D;                     // envs per workgroup
+  const int i = blockIdx.x * NT + tid;
+  const bool valid = i < n;
+  const int env0 = (blockIdx.x * NT) / D;
+  const int nenv = min(GB, E - env0);                          // envs this workgroup really owns (>= 1: the grid covers n)
+  const int npairs = cbf_num_pairs(D), nobs_rows = D * P.n_obs, nq = D, m = npairs + nobs_rows + 2 * nq;
+
+  // ---- once per launch ----
+  int rpair[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) rpair[k] = lane + 64 * k < npairs ? pair_ij[lane + 64 * k] : 0;
+  if (tid < kCbfMaxObs * 4) sob[tid] = tid < 4 * P.n_obs ? obstacles[tid] : T(0);
+  if (tid < GB) scost[tid] = (tid < nenv && cost_io) ? cost_io[env0 + tid] : 0;
+  if (valid) {
+    State<T> s0;
+    load_state<T, T>(state, ld, i, s0);
+    st[0][tid] = s0.p.x; st[1][tid] = s0.p.y; st[2][tid] = s0.p.z;
+    st[3][tid] = s0.q[0]; st[4][tid] = s0.q[1]; st[5][tid] = s0.q[2]; st[6][tid] = s0.q[3];
+    st[7][tid] = s0.v.x; st[8][tid] = s0.v.y; st[9][tid] = s0.v.z;
+    st[10][tid] = s0.w.x; st[11][tid] = s0.w.y; st[12][tid] = s0.w.z;
+  }
+  __syncthreads();
+
+  for (int k = 0; k < n_steps; ++k) {
+    // ---- stage A: nominal controller of drone i ----
+    if (valid) {
+      GeoIn<T> in;
+      {
+        T a4[4];
+        load4<T, T>(lem + 4 * (size_t)i, a4);
+        struct alignas(2 * sizeof(T)) V2 {
+          T v[2];
+        };
+        const V2 c2 = *reinterpret_cast<const V2*>(lem + 4 * ld + 2 * (size_t)i);
+        in.P.a = a4[0]; in.P.omega = a4[1]; in.P.yaw_rate = a4[2]; in.P.phase_shift = a4[3];
+        in.P.cx = c2.v[0]; in.P.cy = c2.v[1]; in.P.cz = lem[6 * ld + i];
+      }
+      in.s.p = {st[0][tid], st[1][tid], st[2][tid]};
+      in.s.q[0] = st[3][tid]; in.s.q[1] = st[4][tid]; in.s.q[2] = st[5][tid]; in.s.q[3] = st[6][tid];
+      in.s.v = {st[7][tid], st[8][tid], st[9][tid]};
+      in.s.w = {st[10][tid], st[11][tid], st[12][tid]};
+      T un[4];
+      const Desired<T> des = lemniscate_local(in.P, t);
+      const V3<T> rpy = euler_from_quat(in.s.q);
+      if (NOM == 0) {
+        const M3<T> Rm = quat_to_rot(in.s.q);
+        const V3<T> ang_v = mul(Rm, in.s.w);
+        T u[4];
+        GeoAux<T> A;
+        geometric_control<T>(c, in.s.p - des.p, Rm, in.s.v, ang_v, des, u, &A);
+        un[0] = A.force - c.gravity;
+        un[1] = A.w_des.x; un[2] = A.w_des.y; un[3] = A.w_des.z;
+      } else {
+        T u[4];
+        lqr_omega_control<T>(c, *static_cast<const LqrGain<T>*>(Kp), rpy, in.s.v, in.s.p, des.p, des.v, des.yaw, u);
+        un[0] = u[0] - c.gravity;                                                    // CBFTest.py:339
+        un[1] = u[1]; un[2] = u[2]; un[3] = u[3];
+      }
+      W.pos[tid][0] = in.s.p.x + in.P.cx;
+      W.pos[tid][1] = in.s.p.y + in.P.cy;
+      W.pos[tid][2] = in.s.p.z + in.P.cz;
+      W.de[tid][0] = rpy.x - T(0);
+      W.de[tid][1] = rpy.y - T(0);
+      W.de[tid][2] = in.s.v.x - des.v.x;
+      W.de[tid][3] = in.s.v.y - des.v.y;
+      W.de[tid][4] = in.s.v.z - des.v.z;
+      su_all[tid] = un[0];
+      sun[0][tid] = un[0]; sun[1][tid] = un[1]; sun[2][tid] = un[2]; sun[3][tid] = un[3];
+    }
+    if (wave == 0) {
+      // hand-out order of this step's QPs: envs that iterated last step first (their solves are the long ones), stable within a class
+      if (GB <= 64) {
+        const bool has = lane < nenv;
+        const bool heavy = has && scost[has ? lane : 0] >= kCbfMediumIters;
+        const unsigned long long mh = __ballot(heavy), ml = __ballot(has && !heavy);
+        const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        const int pos = heavy ? __popcll(mh & below) : __popcll(mh) + __popcll(ml & below);
+        if (has) sorder[pos] = lane;
+      } else {
+        for (int e = lane; e < nenv; e += 64) sorder[e] = e;
+      }
+      if (lane == 0) sticket = 0;
+    }
+    __syncthreads();
+
+    // ---- stage B: the workgroup's envs, one per wave at a time ----
+    {
+      Scratch& S = W.sc[wave];
+      while (true) {
+        int tk = 0;
+        if (lane == 0) tk = atomicAdd(&sticket, 1);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (tk >= nenv) break;                                     // wave-uniform
+        const int el = sorder[tk];                                 // env of the workgroup (uniform)
+        const int d0 = el * D;
+        T ca[R][NV], cb[R][NV], b[R];
+        int ia[R], ib[R];
+        bool vld[R], act[R];
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          act[r] = false;
+          cbf_o2_slot<T>(P, W.pos, W.de, sob, d0, lane + 64 * r, rpair[r], npairs, nobs_rows, m, nq, ca[r][0], cb[r][0], b[r], ia[r], ib[r], vld[r], bad);
+        }
+        bool converged = false;
+        int it = 0, q = 0;
+        gi_solve<T, R, NMAX, NV, false, kQS>(lane, nq, max_iter, tol2, __any(bad), ca, cb, b, ia, ib, vld, act, &su_all[d0], S.sd, S.slam, S.sdi,
+                                             S.sQ, S.sR, S.sact, nullptr, converged, it, q);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        if (lane == 0) {
+          sconv[el] = converged ? 1 : 0;
+          scost[el] = it;
+          if (status_log) status_log[(size_t)k * E + env0 + el] = converged ? 0 : 1;
+          if (k == n_steps - 1) {
+            status[env0 + el] = converged ? 0 : 1;
+            if (cost_io) cost_io[env0 + el] = it;
+          }
+        }
+        MDS_WAVE_SYNC();
+      }
+    }
+    __syncthreads();
+
+    // ---- stage C: low level + physics of drone i ----
+    T o[kObsDim];
+    State<T> s;
+    Resid<T> rs;
+    T u[4] = {T(0), T(0), T(0), T(0)};
+    if (valid) {
+      const int conv = sconv[tid / D];
+      const T safe = su_all[tid];
+      const T un0 = sun[0][tid], un1 = sun[1][tid], un2 = sun[2][tid], un3 = sun[3][tid];
+      u[0] = (conv ? safe : un0) + c.gravity;                                                // CBFTest.py:346
+      u[1] = conv ? m_clamp(un1, -P.umax[1], P.umax[1]) : un1;
+      u[2] = conv ? m_clamp(un2, -P.umax[2], P.umax[2]) : un2;
+      u[3] = conv ? m_clamp(un3, -P.umax[3], P.umax[3]) : un3;
+      s.p = {st[0][tid], st[1][tid], st[2][tid]};
+      s.q[0] = st[3][tid]; s.q[1] = st[4][tid]; s.q[2] = st[5][tid]; s.q[3] = st[6][tid];
+      s.v = {st[7][tid], st[8][tid], st[9][tid]};
+      s.w = {st[10][tid], st[11][tid], st[12][tid]};
+    }
+    __syncthreads();                                             // raw is the observation staging from here on
+    const bool want = obs_log != nullptr || k == n_steps - 1;
+    if (valid) {
+      if (COMP) load_resid<T, T>(state_lo, ld, i, rs);
+      LowLevelState<T> L;
+      L.last_omega = {ll[0 * ld + i], ll[1 * ld + i], ll[2 * ld + i]};
+      L.integral = {ll[3 * ld + i], ll[4 * ld + i], ll[5 * ld + i]};
+      T act4[4], prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4];
+      thrust_omega_control(c, (T)ctrl_dt, u, s.w, L, act4);
+      ll[0 * ld + i] = L.last_omega.x; ll[1 * ld + i] = L.last_omega.y; ll[2 * ld + i] = L.last_omega.z;
+      ll[3 * ld + i] = L.integral.x; ll[4 * ld + i] = L.integral.y; ll[5 * ld + i] = L.integral.z;
+      aviary_step_any<T, false, false, COMP>(c, s, rs, act4, prev, clipped);
+      if (COMP) store_resid<T, T>(state_lo, ld, i, rs);
+      if (last_rpm && k == n_steps - 1)
+        for (int j = 0; j < 4; ++j) last_rpm[j * ld + i] = clipped[j];
+      st[0][tid] = s.p.x; st[1][tid] = s.p.y; st[2][tid] = s.p.z;
+      st[3][tid] = s.q[0]; st[4][tid] = s.q[1]; st[5][tid] = s.q[2]; st[6][tid] = s.q[3];
+      st[7][tid] = s.v.x; st[8][tid] = s.v.y; st[9][tid] = s.v.z;
+      st[10][tid] = s.w.x; st[11][tid] = s.w.y; st[12][tid] = s.w.z;
+      if (want) {
+        struct alignas(2 * sizeof(T)) V2 {
+          T v[2];
+        };
+        const V2 c2 = *reinterpret_cast<const V2*>(lem + 4 * ld + 2 * (size_t)i);
+        pack_obs(s, V3<T>{c2.v[0], c2.v[1], lem[6 * ld + i]}, clipped, o);
+      }
+      if (k == n_steps - 1) store_state<T, T>(state, ld, i, s);
+    }
+    if (want) {
+      T* dst = obs_log != nullptr ? obs_log + (size_t)slot * n * kObsDim : obs_last;
+      write_obs_rows<T, T>(raw, dst, n, i, valid, o);
+      if (obs_log != nullptr && obs_last != nullptr && k == n_steps - 1) write_obs_rows<T, T>(raw, obs_last, n, i, valid, o);
+    }
+    slot = slot + 1 == n_slots ? 0 : slot + 1;
+    t += ctrl_dt;
+    __syncthreads();                                             // staging drained before stage A overwrites Work
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // Order-2 filter, FOUR envs per wavefront: each 16-lane DPP row of the wave owns one env (D <= 16 thrust variables, RL rows of
 // G u <= h per lane).  Same Goldfarb-Idnani active-set iteration as gi_solve, with every "wave-uniform" quantity of that version
 // (violation maximum, selected row, step lengths, active-set size q, iteration count) uniform per ROW instead: reductions are the

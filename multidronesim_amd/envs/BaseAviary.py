@@ -496,6 +496,32 @@ class BaseAviary:
         self.step_counter += n_steps * self.PYB_STEPS_PER_CTRL
         return self._obs, self._cbf_status
 
+    def rollout_cbf_geometric_fused(self, t0: float, n_steps: int, tracker, x_obs=None, obs_r_list=None, steps_per_launch: int = 20,
+                                    obs_log: torch.Tensor | None = None, first_slot: int = 0, status_log: torch.Tensor | None = None):
+        """``n_steps`` of ``step_cbf_geometric`` with ``steps_per_launch`` control steps per launch (mds_rollout_cbf_geometric_fused: the
+        persistent kernel -- state, nominal input and QP results stay on the chip between steps).  ``obs_log``: optional ring
+        ``[slots, E, D, 20]``, step k writes slot ``(first_slot + k) % slots``; ``status_log``: optional int32 ``[n_steps, E]``.
+        Returns (obs, status) of the last step."""
+        self._require_open()
+        tracker.cbf.configure(x_obs, obs_r_list)
+        if getattr(self, "_cbf_status", None) is None:
+            self._cbf_status = torch.zeros((self.NUM_ENVS,), dtype=torch.int32, device=self.device)
+        slots = 0
+        if obs_log is not None:
+            if obs_log.dtype != self.dtype or obs_log.device != self.device or not obs_log.is_contiguous() or obs_log[0].numel() != self.n * capi.OBS_DIM:
+                raise ValueError("obs_log must be a contiguous [slots, E, D, 20] tensor of the env's dtype on its device")
+            slots = int(obs_log.shape[0])
+        if status_log is not None and (status_log.dtype != torch.int32 or status_log.device != self.device or not status_log.is_contiguous()
+                                       or status_log.numel() < n_steps * self.NUM_ENVS):
+            raise ValueError("status_log must be a contiguous int32 [n_steps, E] tensor on the env's device")
+        capi.check(self._lib.mds_rollout_cbf_geometric_fused(
+            self._h, C.c_double(t0), C.c_int(n_steps), C.c_int(steps_per_launch),
+            C.c_void_p(obs_log.data_ptr() if obs_log is not None else None), C.c_int(slots), C.c_int(first_slot),
+            C.c_void_p(self._obs.data_ptr()), C.c_void_p(self._cbf_status.data_ptr()),
+            C.c_void_p(status_log.data_ptr() if status_log is not None else None), self._stream()), "mds_rollout_cbf_geometric_fused")
+        self.step_counter += n_steps * self.PYB_STEPS_PER_CTRL
+        return self._obs, self._cbf_status
+
     def step_nominal(self, t: float, return_action: bool = False):
         """``ctrl[j].compute(obs[j])`` + ``env.step(action)`` of simulations/EnvGeometricOmega.py / EnvGeometricYankOmega.py for every
         drone: the LQR selected with ``set_cbf_nominal`` ("lqr_omega" | "lqr_yank_omega"), its low-level controller, the physics step.

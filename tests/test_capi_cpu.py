@@ -100,6 +100,8 @@ def test_null_handle_calls_return_einval(lib):
     assert lib.mds_rollout_dslpid(None, None, None, 1, 0, 5, None, 0, None) == -1
     assert lib.mds_cbf_set_step_kernel(None, 1) == -1
     assert lib.mds_cbf_last_step_kernel(None) == -1
+    # round-3 entry points
+    assert lib.mds_rollout_cbf_geometric_fused(None, 0.0, 5, 5, None, 0, 0, None, None, None, None) == -1
 
 
 def test_compensated_dtype_is_a_valid_config_and_env_effects_reject_it(lib):

@@ -682,3 +682,91 @@ def test_cbf_rollout_order3_two_chains_equals_stepwise(mds):
     assert np.isfinite(out[0][0]).all()
     for a, b in zip(*out):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("nominal", ["geometric", "lqr_omega"])
+def test_cbf_persistent_rollout_matches_the_stepwise_loop(mds, nominal):
+    """k_cbf_rollout (mds_rollout_cbf_geometric_fused: several control steps per launch, a workgroup owns whole envs, state and nominal
+    input stay on the chip, the workgroup's QPs handed out heaviest first) against the step-by-step loop on the same scene: per-env
+    statuses equal at EVERY step (status_log), last-step iteration counts equal, the logged observations of the last steps and the
+    final state equal to rounding (shared device functions; the kernels contract FMAs differently), float64, float32 and compensated
+    fp32.  D = 16, a ragged last workgroup (E = 70 -> 1120 drones = 2 full 512-drone workgroups + 96 lanes), launches of 25 + 25 + 10
+    steps, a 7-slot observation ring that wraps, obstacles among the drones so that rows go active and some envs are infeasible."""
+    from multidronesim_amd.control.lqr.lqr_omega_controller import LQROmegaController
+    E, D, steps, spl, slots = 70, 16, 60, 25, 7
+    xyz, rpy, P = H.c2_setup(E, D, phase="c3", offset=1.5)
+    P[..., 4] = 0.5 + 0.3 * np.arange(D)
+    xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    x_obs = [np.array([[sx * 0.5, sy * 0.5, 0.5], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
+    obs_r = [0.1] * 4
+
+    def make(dtype):
+        env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                             pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype)
+        env.set_trajectories(P)
+        if nominal == "lqr_omega":
+            LQROmegaController(env, mds.LinearizedOmegaModel(env), None)
+            env.set_cbf_nominal("lqr_omega")
+        cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2,
+                           cbf_poles=np.array([-2.2, -2.4]))
+        trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+        env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+        return env, cbf, trk
+
+    for dtype, tol in (("float64", 1e-9), ("float32", 2e-4), ("float32c", 2e-4)):
+        env, cbf, trk = make(dtype)
+        t, hist, olog = 0.0, [], []
+        for k in range(steps):
+            o, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
+            hist.append(st.cpu().numpy().copy())
+            olog.append(o.double().cpu().numpy().copy())
+            t += env.CTRL_TIMESTEP
+        its = cbf.last_iterations().cpu().numpy().copy()
+        ref_state = env.get_state()
+        env.close()
+        hist = np.array(hist)
+        assert 0.0 < hist.mean() < 1.0 and its.max() >= 2          # infeasible envs and real iterations both occur
+
+        b, cb2, tb = make(dtype)
+        ring = mds.torch.full((slots, E, D, 20), float("nan"), dtype=b.dtype, device=b.device)
+        slog = mds.torch.full((steps, E), -1, dtype=mds.torch.int32, device=b.device)
+        ob, sb = b.rollout_cbf_geometric_fused(0.0, steps, tb, x_obs, obs_r, steps_per_launch=spl, obs_log=ring, first_slot=3, status_log=slog)
+        assert b.cbf_last_step_kernel() == 2
+        np.testing.assert_array_equal(slog.cpu().numpy(), hist)                          # statuses at every step
+        np.testing.assert_array_equal(sb.cpu().numpy(), hist[-1])
+        np.testing.assert_array_equal(cb2.last_iterations().cpu().numpy(), its)
+        r = ring.double().cpu().numpy()
+        for k in range(steps - slots, steps):                                            # the ring holds the last `slots` steps
+            np.testing.assert_allclose(r[(3 + k) % slots][..., :16], olog[k][..., :16], rtol=0, atol=tol, err_msg=f"{dtype} step {k}")
+            np.testing.assert_allclose(r[(3 + k) % slots][..., 16:], olog[k][..., 16:], rtol=tol, atol=0)
+        np.testing.assert_array_equal(ob.double().cpu().numpy(), r[(3 + steps - 1) % slots])
+        np.testing.assert_allclose(b.get_state(), ref_state, rtol=0, atol=tol)
+        # without a log only the last observation is written; a second call continues the same loop
+        b2, _, tb2 = make(dtype)
+        b2.rollout_cbf_geometric_fused(0.0, 35, tb2, x_obs, obs_r, steps_per_launch=spl)
+        t35 = 0.0
+        for _ in range(35):
+            t35 += b2.CTRL_TIMESTEP                   # the loop's own clock: t += CTRL_TIMESTEP per step (not 35 * dt)
+        o2, s2 = b2.rollout_cbf_geometric_fused(t35, steps - 35, tb2, x_obs, obs_r, steps_per_launch=spl)
+        np.testing.assert_array_equal(o2.double().cpu().numpy(), ob.double().cpu().numpy())
+        np.testing.assert_array_equal(s2.cpu().numpy(), sb.cpu().numpy())
+        b.close()
+        b2.close()
+
+
+def test_cbf_persistent_rollout_rejects_what_it_does_not_cover(mds):
+    """Order 3, RK4 and drone counts outside {4, 8, 16} return MDS_EUNSUPPORTED (the caller uses mds_rollout_cbf_geometric)."""
+    E, D = 4, 6
+    xyz, rpy, P = H.c2_setup(E, D, phase="c3", offset=1.5)
+    env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                         pyb_freq=100, ctrl_freq=100, num_envs=E, dtype="float32")
+    env.set_trajectories(P)
+    cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2)
+    trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+    env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+    from multidronesim_amd import MdsError
+    with pytest.raises(MdsError) as ei:
+        env.rollout_cbf_geometric_fused(0.0, 5, trk)
+    assert ei.value.status == -6                    # MDS_EUNSUPPORTED
+    env.rollout_cbf_geometric(0.0, 5, trk)          # the general loop serves it
+    env.close()
