@@ -364,9 +364,11 @@ def measure_c4(CtrlAviary, DroneModel, Physics, torch, local_rank, device, scene
     if one_launch:
         env.set_cbf_step_kernel(True)
 
+    ring = torch.empty((fused_T, E, D, 20), dtype=env.dtype, device=device) if fused_T else None
+
     def roll(t0, k):
-        if fused_T:
-            env.rollout_cbf_geometric_fused(t0, k, tracker, c4_obs, c4_r, steps_per_launch=fused_T)
+        if fused_T:      # every step's observation is materialised, as in the step-by-step loop: a ring of fused_T slots
+            env.rollout_cbf_geometric_fused(t0, k, tracker, c4_obs, c4_r, steps_per_launch=fused_T, obs_log=ring)
         else:
             env.rollout_cbf_geometric(t0, k, tracker, c4_obs, c4_r)
     env.set_rollout_streams(0)
@@ -673,7 +675,7 @@ def main(argv=None):
     planned = env.rollout_streams_for(args.steps, cbf=c4) if c_loop else 1
     env.set_rollout_streams(planned if c_loop else args.rollout_streams)
     if fused_T:
-        if args.steps % fused_T or args.warmup % fused_T:
+        if (args.steps % fused_T or args.warmup % fused_T) and not c4:
             raise SystemExit("--steps and --warmup must be multiples of --fused-rollout")
         log_buf = torch.empty((fused_T, E, D, 20), dtype=env.dtype, device=device)
 
@@ -702,7 +704,8 @@ def main(argv=None):
                 env.rollout_geometric_fused(t, fused_T, log=True, log_out=log_buf)
                 t += fused_T * dt
         elif tracker is not None and fused_T:
-            env.rollout_cbf_geometric_fused(t0, k, tracker, c4_obs, c4_r, steps_per_launch=fused_T)
+            # every step's observation is materialised, as in the step-by-step loop (the reference appends it): a ring of fused_T slots
+            env.rollout_cbf_geometric_fused(t0, k, tracker, c4_obs, c4_r, steps_per_launch=fused_T, obs_log=log_buf)
         elif tracker is not None and args.python_loop:
             t = t0
             for _ in range(k):

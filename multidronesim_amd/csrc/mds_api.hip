@@ -2016,7 +2016,7 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
     const int ks = n_steps - k0 < steps_per_launch ? n_steps - k0 : steps_per_launch;
     int32_t* slog = status_log ? status_log + (size_t)k0 * h->cfg.num_envs : nullptr;
 #define MDS_CR(T, CC, CP, NOM, COMP, TOL)                                                                                                      \
-  k_cbf_rollout<T, 4, NOM, COMP, (sizeof(T) == 8 ? NWD : NWF)><<<grid, 64 * nw, 0, st>>>(CC, CP, gain, h->n, h->ld, h->cfg.num_envs, t, dt, ks, (T*)h->state, (T*)h->state_lo,  \
+  k_cbf_rollout<T, NOM, COMP, (sizeof(T) == 8 ? NWD : NWF)><<<grid, 64 * nw, 0, st>>>(CC, CP, gain, h->n, h->ld, h->cfg.num_envs, t, dt, ks, (T*)h->state, (T*)h->state_lo,  \
                                                                (const T*)h->lem, (T*)rpm, (T*)h->ll, h->pair_ij, (const T*)h->obstacles,        \
                                                                (T*)obs_log, slot, log_slots > 0 ? log_slots : 1, (T*)obs, (int*)status, (int*)slog, \
                                                                h->cbf_cost, max_iter, (T)((TOL) * (TOL)))
@@ -2035,7 +2035,11 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
     for (int j = 0; j < ks; ++j) t += dt;
     if (obs_log) slot = (slot + ks) % log_slots;
   }
-  (void)es;
+  if (obs_log) {       // the kernel materialises each step's observation once, in its log slot: obs_dev gets a copy of the last one
+    const size_t row = (size_t)h->n * kObsDim * es;
+    const int last = (first_slot + n_steps - 1) % log_slots;
+    MDS_HIP(hipMemcpyAsync(obs, (const char*)obs_log + (size_t)last * row, row, hipMemcpyDeviceToDevice, st));
+  }
   return MDS_OK;
 }
 

@@ -1129,31 +1129,80 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 && R == 4) ? 4 : 1) void k_cbf_
 }
 
 // ------------------------------------------------------------------------------------
-// n_steps CBF-filtered control steps of simulations/CBFTest.py:303-350 in ONE launch (order 2, D | 64, D <= 16): the persistent form of
+// n_steps CBF-filtered control steps of simulations/CBFTest.py:303-350 in ONE launch (order 2, D in {4, 8, 16}): the persistent form of
 // k_cbf_step.  A workgroup of NW wavefronts owns 64 NW drones = 64 NW / D whole envs for the whole launch and walks them through
-//   stage A, one drone per lane : trajs[j](t), nominal controller -> u_hat; position and tracking errors of the drone into LDS;
+//   stage A, one drone per lane : trajs[j](t), nominal controller -> u_hat; the drone's record (world position, tracking errors in
+//                                 roll, pitch, velocity: what the rows need of obs_to_lin_model(obs) - xdes) into LDS;
 //   stage B, one env per wave   : the workgroup's envs handed out through an LDS ticket counter, heaviest (by their last step's
 //                                 iteration count) first -- rows built R per lane, violation scan, gi_solve;
-//   stage C, one drone per lane : u_safe + M G -> ThrustOmega low level -> physics step -> observation row (every step, into
-//                                 slot (slot0 + k) % n_slots of the log ring or over obs_last) -> state,
-// with a workgroup barrier between the stages.  Between steps the 13-value state lives in LDS (registers in stages A and C), the
-// trajectory parameters in registers, the low level's PID memory in its global planes (read and written by the same lane only).
-// What this buys over one launch per step: (1) no step boundary across the chip -- workgroups drift apart, a CU whose envs iterate
-// at step k runs beside CUs already at step k + 1, and the launch ends with the slowest WORKGROUP's sum over all steps instead of
-// every step ending with its slowest wave; (2) an env that needs 10 iterations delays NW / (envs per workgroup) of a wave's time, not
-// the three other envs of its wave (k_cbf_step) -- stage B is balanced over the workgroup's waves; (3) u_hat, xdes, u_safe and the
-// state never cross HBM between steps.  Arithmetic: the same device functions as k_cbf_step / the three-launch path.
+//   stage C, one drone per lane : u_safe + M G -> ThrustOmega low level -> physics step -> observation row (every step into
+//                                 slot (slot0 + k) % n_slots of the log ring, or only the last one) -> stage A of the next step,
+// with a workgroup barrier before and after stage B only.  Stage C of step k and stage A of step k + 1 are one straight piece of
+// per-lane code with the state in registers (rotation matrix and Euler angles of the new state are formed once); across stage B the
+// state waits in LDS, u_hat in registers; the trajectory parameters and the low level's PID memory are re-read from their global
+// planes each step (L2 / Infinity-Cache hits: only this lane touches them).
+// LDS: every wave has a 5 KiB slice = [its 64 drones' records | its solver scratch], which is also its observation staging in stage
+// C -- a wave's staging overwrites nothing another wave still needs once stage B is over, so stage C needs no barrier of its own.
+// Row slots: row r = lane + 64 k of every env has the same kind, agents and obstacle for a given (lane, k): a 16-byte entry of a
+// table built once per launch replaces the per-env index decoding; an agent's record is two 16-byte LDS reads, an obstacle is a
+// record with zero tracking errors, so pair and obstacle rows run one branch-free body; box rows are constants.
+// What this buys over one launch per step: no chip-wide step boundary (workgroups drift apart: the launch ends with the slowest
+// WORKGROUP's sum over all steps instead of every step ending with its slowest wave); an env that needs 10 iterations delays one
+// wave of its workgroup while the other waves take the remaining envs (k_cbf_step: the three other envs of its wave wait);
+// u_hat, xdes, u_safe and the state never cross HBM between steps.  Arithmetic: the device functions of the other CBF kernels
+// (cbf_row_o2, the normalisation and reach test of cbf_o2_slot, gi_solve, the controller / physics templates).
 // t advances in double exactly like the host loop (t += CTRL_TIMESTEP, CBFTest.py:352).
 // ------------------------------------------------------------------------------------
 #ifndef MDS_CBF_ROLL_NW
 #define MDS_CBF_ROLL_NW 8
 #endif
-// No per-drone value stays in registers from one stage to the next: the state, u_hat and the solver's output wait in LDS, the
-// trajectory parameters and the low level's memory are re-read from their global planes (L2 / Infinity-Cache hits: nobody else touches
-// them) -- each stage's register allocation is its own, and the kernel fits the 128 VGPRs that let 16 wavefronts share a CU (at C4 the
-// whole batch is then resident: 4096 wavefronts = 4 per SIMD).
-template <typename T, int R, int NOM, bool COMP, int NW>
-__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout(const Consts<T> c, const CbfParams<T> P, const void* __restrict__ Kp, const int n,
+struct RollSlot {       // row r = lane + 64 k of any env: what it is (built once per launch by roll_slot_of)
+  int offA;             // byte offset of agent i's record from the env's first record; box rows: the variable index
+  int offB;             // pair rows: agent j's record (same base); obstacle rows: byte offset of the obstacle's record in sobrec
+  int ds;               // index into sDs: 0 = pair distance 2 safety_radius, 1 + o = safety_radius + r_o
+  int kind;             // 0 none, 1 pair, 2 obstacle, 3 box row +u <= umax, 4 box row -u <= umax;  | agent i << 8 | agent j << 16
+};
+
+template <typename T> __device__ __forceinline__ RollSlot roll_slot_of(const CbfParams<T>& P, const int* __restrict__ pair_ij, const int r) {
+  const int D = P.num_drones, npairs = cbf_num_pairs(D), nobs_rows = D * P.n_obs, m = npairs + nobs_rows + 2 * D;
+  constexpr int kRec = 9 * (int)sizeof(T);                     // record stride: 8 values + 1 pad (see k_cbf_rollout)
+  RollSlot sl = {0, 0, 0, 0};
+  if (r < npairs) {
+    const int ij = pair_ij[r], ia = ij & 255, ib = ij >> 8;
+    sl = {ia * kRec, ib * kRec, 0, 1 | (ia << 8) | (ib << 16)};
+  } else if (r < npairs + nobs_rows) {
+    const int q = r - npairs, ag = (q * P.obs_magic) >> 16, oo = q - ag * P.n_obs;       // as cbf_o2_slot
+    sl = {ag * kRec, oo * kRec, 1 + oo, 2 | (ag << 8) | (ag << 16)};
+  } else if (r < m) {
+    const int q = r - npairs - nobs_rows, var = q < D ? q : q - D;
+    sl = {var, 0, 0, (q < D ? 3 : 4) | (var << 8) | (var << 16)};
+  }
+  return sl;
+}
+
+// Kernel arguments are loop invariants of a kernel that never leaves its step loop: left alone, the compiler hoists every VGPR copy
+// a VALU instruction with two scalar operands needs (and every address it can form) out of the loop, keeps them live across all
+// three stages and spills them.  These make a local copy's fields "redefined here" (an empty asm per scalar register, no
+// instruction): whatever is derived from them is formed inside the stage that uses it.
+template <typename V> __device__ __forceinline__ void sfresh(V& v) { asm volatile("" : "+s"(v)); }
+template <typename T> __device__ __forceinline__ Consts<T> fresh(Consts<T> c) {
+  sfresh(c.kf); sfresh(c.km); sfresh(c.arm); sfresh(c.mass); sfresh(c.inv_mass); sfresh(c.gravity); sfresh(c.max_rpm); sfresh(c.hover_rpm);
+  sfresh(c.thrust_corr); sfresh(c.dt); sfresh(c.g_ctrl); sfresh(c.cos_max_tilt); sfresh(c.tan_max_tilt); sfresh(c.min_motor_thrust);
+  sfresh(c.max_motor_thrust); sfresh(c.inv_2L); sfresh(c.inv_4r); sfresh(c.inv_kf);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    sfresh(c.J[k]); sfresh(c.invJ[k]); sfresh(c.drag[k]); sfresh(c.wind[k]); sfresh(c.kp[k]); sfresh(c.kv[k]); sfresh(c.kR[k]); sfresh(c.kw[k]);
+  }
+  return c;
+}
+template <typename T> __device__ __forceinline__ CbfParams<T> fresh(CbfParams<T> P) {
+  sfresh(P.k[0]); sfresh(P.k[1]); sfresh(P.k[2]); sfresh(P.umax[0]); sfresh(P.umax[1]); sfresh(P.umax[2]); sfresh(P.umax[3]); sfresh(P.Ds_pair);
+  sfresh(P.safety_radius); sfresh(P.zscale); sfresh(P.inv_zscale); sfresh(P.inv_c4); sfresh(P.inv_m); sfresh(P.g); sfresh(P.Fmin); sfresh(P.Fmax);
+  return P;
+}
+
+template <typename T, int NOM, bool COMP, int NW>
+__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout(const Consts<T> c0, const CbfParams<T> P0, const void* __restrict__ Kp, const int n,
                                                         const size_t ld, const int E, double t, const double ctrl_dt, const int n_steps,
                                                         T* __restrict__ state, T* __restrict__ state_lo, const T* __restrict__ lem,
                                                         T* __restrict__ last_rpm, T* __restrict__ ll, const int* __restrict__ pair_ij,
@@ -1162,98 +1211,112 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
                                                         int* __restrict__ status_log, int* __restrict__ cost_io, const int max_iter,
                                                         const T tol2) {
   constexpr int NT = 64 * NW;
-  constexpr int NMAX = 16, NV = 1;
+  constexpr int R = 4, NMAX = 16, NV = 1;
   constexpr int kQS = (NMAX + 3) / 4 * 4 + 4;
   constexpr int GBMAX = NT / 4;                                // envs per workgroup (D >= 4)
+  // one drone's record: px py pz e_roll e_pitch e_vx e_vy e_vz + 1 pad -- at a 9-word stride the 16 agents' records start in 16 different
+  // LDS banks (at 8 words agents a and a + 4 collide on every field: 124 M conflict cycles against 81 M LDS-instruction cycles per launch)
+  constexpr int kRec = 9 * (int)sizeof(T);
   struct Scratch {                                             // one wave's active-set solver
     T sd[NMAX], slam[NMAX], sdi[NMAX];
     T sQ[NMAX][kQS], sR[NMAX][kQS];
     int sact[NMAX];
   };
-  struct Work {                                                // stages A -> B
-    T pos[NT][3], de[NT][5];
-    Scratch sc[NW];
+  struct alignas(16) Slice {                                   // one wave: stage A -> B data, aliased by its stage C observation staging
+    T rec[64][9];
+    Scratch sc;
   };
-  constexpr size_t kObsBytes = (size_t)NT * kObsDim * sizeof(T);   // stage C's observation staging aliases Work
-  constexpr size_t kWork = sizeof(Work) > kObsBytes ? sizeof(Work) : kObsBytes;
-  __shared__ __align__(16) unsigned char raw[(kWork + 15) / 16 * 16];
-  __shared__ T st[13][NT];                                     // the state between steps (lane-contiguous planes: conflict-free)
-  __shared__ T sun[4][NT];                                     // u_hat of every drone (stage A -> stage C)
+  constexpr int kObsWave = 64 * kObsDim * (int)sizeof(T);      // write_obs_rows' slice per wave
+  static_assert(sizeof(Slice) <= (size_t)kObsWave, "a wave's records + solver scratch must fit in its observation staging slice");
+  __shared__ __align__(16) unsigned char raw[NW * kObsWave];
+  __shared__ T st[13][NT];                                     // the state across stage B (lane-contiguous planes: conflict-free)
   __shared__ T su_all[NT];                                     // thrust variable of every drone: u_hat[0] in, QP minimiser out
+  __shared__ __align__(16) RollSlot stab[R][64];               // row slot table
+  __shared__ __align__(16) T sobrec[kCbfMaxObs][9];            // obstacles as records with zero tracking errors
+  __shared__ T sDs[kCbfMaxObs + 1];
   __shared__ int sconv[GBMAX], scost[GBMAX], sorder[GBMAX];    // per env of the workgroup: QP solved; iterations of its last solve; hand-out order
   __shared__ int sticket;
-  __shared__ T sob[kCbfMaxObs * 4];
-  Work& W = *reinterpret_cast<Work*>(raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int D = P.num_drones, GB = NT / D;                     // envs per workgroup
+  const int D = P0.num_drones, GB = NT / D;                    // envs per workgroup
   const int i = blockIdx.x * NT + tid;
   const bool valid = i < n;
   const int env0 = (blockIdx.x * NT) / D;
   const int nenv = min(GB, E - env0);                          // envs this workgroup really owns (>= 1: the grid covers n)
-  const int npairs = cbf_num_pairs(D), nobs_rows = D * P.n_obs, nq = D, m = npairs + nobs_rows + 2 * nq;
+  auto slice_of = [&](int w) -> Slice& { return *reinterpret_cast<Slice*>(raw + (size_t)w * kObsWave); };
 
   // ---- once per launch ----
-  int rpair[R];
-#pragma unroll
-  for (int k = 0; k < R; ++k) rpair[k] = lane + 64 * k < npairs ? pair_ij[lane + 64 * k] : 0;
-  if (tid < kCbfMaxObs * 4) sob[tid] = tid < 4 * P.n_obs ? obstacles[tid] : T(0);
-  if (tid < GB) scost[tid] = (tid < nenv && cost_io) ? cost_io[env0 + tid] : 0;
-  if (valid) {
-    State<T> s0;
-    load_state<T, T>(state, ld, i, s0);
-    st[0][tid] = s0.p.x; st[1][tid] = s0.p.y; st[2][tid] = s0.p.z;
-    st[3][tid] = s0.q[0]; st[4][tid] = s0.q[1]; st[5][tid] = s0.q[2]; st[6][tid] = s0.q[3];
-    st[7][tid] = s0.v.x; st[8][tid] = s0.v.y; st[9][tid] = s0.v.z;
-    st[10][tid] = s0.w.x; st[11][tid] = s0.w.y; st[12][tid] = s0.w.z;
+  {
+    const CbfParams<T>& P = P0;
+  if (tid < R * 64) stab[tid >> 6][tid & 63] = roll_slot_of<T>(P, pair_ij, (tid & 63) + 64 * (tid >> 6));
+  if (tid < kCbfMaxObs) {
+    const bool on = tid < P.n_obs;
+    sobrec[tid][0] = on ? obstacles[4 * tid] : T(0);
+    sobrec[tid][1] = on ? obstacles[4 * tid + 1] : T(0);
+    sobrec[tid][2] = on ? obstacles[4 * tid + 2] : T(0);
+    for (int k = 3; k < 9; ++k) sobrec[tid][k] = T(0);
+    sDs[1 + tid] = on ? P.safety_radius + obstacles[4 * tid + 3] : T(1);
   }
-  __syncthreads();
+  if (tid == 0) sDs[0] = P.Ds_pair;
+  }
+  if (tid < GB) scost[tid] = (tid < nenv && cost_io) ? cost_io[env0 + tid] : 0;
+  State<T> s;
+  s.p = s.v = s.w = {T(0), T(0), T(0)};
+  s.q[0] = s.q[1] = s.q[2] = T(0);
+  s.q[3] = T(1);
+  if (valid) load_state<T, T>(state, ld, i, s);
+  T un0 = T(0), un1 = T(0), un2 = T(0), un3 = T(0);            // u_hat of this step (stage A -> stage C, in registers across stage B)
+
+  // stage A of drone i on the state in registers at time ta: u_hat, the record, the stash of the state
+  auto stage_a = [&](const Consts<T>& c, const LemniscateParams<T>& Pl, const double ta, const int tq) {
+    const int lq = tq & 63, wq = tq >> 6;
+    const Desired<T> des = lemniscate_local(Pl, ta);
+    const V3<T> rpy = euler_from_quat(s.q);
+    if (NOM == 0) {
+      const M3<T> Rm = quat_to_rot(s.q);
+      const V3<T> ang_v = mul(Rm, s.w);
+      T u[4];
+      GeoAux<T> A;
+      geometric_control<T>(c, s.p - des.p, Rm, s.v, ang_v, des, u, &A);
+      un0 = A.force - c.gravity;
+      un1 = A.w_des.x; un2 = A.w_des.y; un3 = A.w_des.z;
+    } else {
+      T u[4];
+      lqr_omega_control<T>(c, *static_cast<const LqrGain<T>*>(Kp), rpy, s.v, s.p, des.p, des.v, des.yaw, u);
+      un0 = u[0] - c.gravity;                                                      // CBFTest.py:339
+      un1 = u[1]; un2 = u[2]; un3 = u[3];
+    }
+    // obs_to_lin_model(obs, 9) - xdes with obs = pack_obs(state): world position, roll, pitch, world velocity; xdes = [0, 0, yaw, v_des, p_des]
+    T* rc = slice_of(wq).rec[lq];
+    rc[0] = s.p.x + Pl.cx;
+    rc[1] = s.p.y + Pl.cy;
+    rc[2] = s.p.z + Pl.cz;
+    rc[3] = rpy.x - T(0);
+    rc[4] = rpy.y - T(0);
+    rc[5] = s.v.x - des.v.x;
+    rc[6] = s.v.y - des.v.y;
+    rc[7] = s.v.z - des.v.z;
+    su_all[tq] = un0;
+    st[0][tq] = s.p.x; st[1][tq] = s.p.y; st[2][tq] = s.p.z;
+    st[3][tq] = s.q[0]; st[4][tq] = s.q[1]; st[5][tq] = s.q[2]; st[6][tq] = s.q[3];
+    st[7][tq] = s.v.x; st[8][tq] = s.v.y; st[9][tq] = s.v.z;
+    st[10][tq] = s.w.x; st[11][tq] = s.w.y; st[12][tq] = s.w.z;
+  };
+  auto load_params = [&](unsigned iu) {
+    LemniscateParams<T> Pl;
+    T a4[4];
+    load4<T, T>(lem + 4 * (size_t)iu, a4);
+    struct alignas(2 * sizeof(T)) V2 {
+      T v[2];
+    };
+    const V2 c2 = *reinterpret_cast<const V2*>(lem + 4 * ld + 2 * (size_t)iu);
+    Pl.a = a4[0]; Pl.omega = a4[1]; Pl.yaw_rate = a4[2]; Pl.phase_shift = a4[3];
+    Pl.cx = c2.v[0]; Pl.cy = c2.v[1]; Pl.cz = lem[6 * ld + iu];
+    return Pl;
+  };
+  if (valid && n_steps > 0) stage_a(c0, load_params((unsigned)i), t, tid);
+  const int log2D = 31 - __clz(D);                             // D is 4, 8 or 16
 
   for (int k = 0; k < n_steps; ++k) {
-    // ---- stage A: nominal controller of drone i ----
-    if (valid) {
-      GeoIn<T> in;
-      {
-        T a4[4];
-        load4<T, T>(lem + 4 * (size_t)i, a4);
-        struct alignas(2 * sizeof(T)) V2 {
-          T v[2];
-        };
-        const V2 c2 = *reinterpret_cast<const V2*>(lem + 4 * ld + 2 * (size_t)i);
-        in.P.a = a4[0]; in.P.omega = a4[1]; in.P.yaw_rate = a4[2]; in.P.phase_shift = a4[3];
-        in.P.cx = c2.v[0]; in.P.cy = c2.v[1]; in.P.cz = lem[6 * ld + i];
-      }
-      in.s.p = {st[0][tid], st[1][tid], st[2][tid]};
-      in.s.q[0] = st[3][tid]; in.s.q[1] = st[4][tid]; in.s.q[2] = st[5][tid]; in.s.q[3] = st[6][tid];
-      in.s.v = {st[7][tid], st[8][tid], st[9][tid]};
-      in.s.w = {st[10][tid], st[11][tid], st[12][tid]};
-      T un[4];
-      const Desired<T> des = lemniscate_local(in.P, t);
-      const V3<T> rpy = euler_from_quat(in.s.q);
-      if (NOM == 0) {
-        const M3<T> Rm = quat_to_rot(in.s.q);
-        const V3<T> ang_v = mul(Rm, in.s.w);
-        T u[4];
-        GeoAux<T> A;
-        geometric_control<T>(c, in.s.p - des.p, Rm, in.s.v, ang_v, des, u, &A);
-        un[0] = A.force - c.gravity;
-        un[1] = A.w_des.x; un[2] = A.w_des.y; un[3] = A.w_des.z;
-      } else {
-        T u[4];
-        lqr_omega_control<T>(c, *static_cast<const LqrGain<T>*>(Kp), rpy, in.s.v, in.s.p, des.p, des.v, des.yaw, u);
-        un[0] = u[0] - c.gravity;                                                    // CBFTest.py:339
-        un[1] = u[1]; un[2] = u[2]; un[3] = u[3];
-      }
-      W.pos[tid][0] = in.s.p.x + in.P.cx;
-      W.pos[tid][1] = in.s.p.y + in.P.cy;
-      W.pos[tid][2] = in.s.p.z + in.P.cz;
-      W.de[tid][0] = rpy.x - T(0);
-      W.de[tid][1] = rpy.y - T(0);
-      W.de[tid][2] = in.s.v.x - des.v.x;
-      W.de[tid][3] = in.s.v.y - des.v.y;
-      W.de[tid][4] = in.s.v.z - des.v.z;
-      su_all[tid] = un[0];
-      sun[0][tid] = un[0]; sun[1][tid] = un[1]; sun[2][tid] = un[2]; sun[3][tid] = un[3];
-    }
     if (wave == 0) {
       // hand-out order of this step's QPs: envs that iterated last step first (their solves are the long ones), stable within a class
       if (GB <= 64) {
@@ -1272,7 +1335,8 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
 
     // ---- stage B: the workgroup's envs, one per wave at a time ----
     {
-      Scratch& S = W.sc[wave];
+      const CbfParams<T> P = fresh(P0);
+      Scratch& S = slice_of(wave).sc;
       while (true) {
         int tk = 0;
         if (lane == 0) tk = atomicAdd(&sticket, 1);
@@ -1280,6 +1344,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         if (tk >= nenv) break;                                     // wave-uniform
         const int el = sorder[tk];                                 // env of the workgroup (uniform)
         const int d0 = el * D;
+        const unsigned char* ebase = raw + (size_t)(d0 >> 6) * kObsWave + (size_t)(d0 & 63) * kRec;   // the env's first record
+        int tl = lane;
+        asm volatile("" : "+v"(tl));                               // re-read per env: 4 LDS reads instead of 16 registers held across the stages
         T ca[R][NV], cb[R][NV], b[R];
         int ia[R], ib[R];
         bool vld[R], act[R];
@@ -1287,11 +1354,50 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           act[r] = false;
-          cbf_o2_slot<T>(P, W.pos, W.de, sob, d0, lane + 64 * r, rpair[r], npairs, nobs_rows, m, nq, ca[r][0], cb[r][0], b[r], ia[r], ib[r], vld[r], bad);
+          const RollSlot sl = stab[r][tl];
+          const int kind = sl.kind & 255;
+          ia[r] = (sl.kind >> 8) & 255;
+          ib[r] = (sl.kind >> 16) & 255;
+          ca[r][0] = cb[r][0] = b[r] = T(0);
+          vld[r] = false;
+          if (kind == 1 || kind == 2) {
+            const T* ra = reinterpret_cast<const T*>(ebase + sl.offA);
+            const T* rb = kind == 1 ? reinterpret_cast<const T*>(ebase + sl.offB)
+                                    : reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(&sobrec[0][0]) + sl.offB);
+            T A8[8], B8[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+              A8[v] = ra[v];
+              B8[v] = rb[v];
+            }
+            T hr, lg;
+            cbf_row_o2<T>(P, A8[0] - B8[0], A8[1] - B8[1], A8[2] - B8[2], A8[3] - B8[3], A8[4] - B8[4], A8[5] - B8[5], A8[6] - B8[6],
+                          A8[7] - B8[7], sDs[sl.ds], &hr, &lg);
+            ca[r][0] = -lg;
+            cb[r][0] = kind == 1 ? lg : T(0);
+            b[r] = hr;
+            // normalisation and reach test: the arithmetic of cbf_o2_slot
+            const T n2 = m_fma(ca[r][0], ca[r][0], cb[r][0] * cb[r][0]);
+            if (n2 > T(0)) {
+              const T inv = m_rsqrt(n2);
+              ca[r][0] *= inv;
+              cb[r][0] *= inv;
+              b[r] *= inv;
+              vld[r] = true;
+              const T reach = (m_abs(ca[r][0]) + m_abs(cb[r][0])) * P.umax[0];
+              if (b[r] < -reach * (T(1) + T(sizeof(T) == 4 ? 1e-5 : 1e-10))) bad = true;
+            } else if (b[r] < T(0)) {
+              bad = true;                                          // 0 * u <= h with h < 0
+            }
+          } else if (kind >= 3) {                                  // +-u_var <= umax (cbf/cbf.py:400-412): unit norm as it stands
+            ca[r][0] = kind == 3 ? T(1) : T(-1);
+            b[r] = P.umax[0];
+            vld[r] = true;
+          }
         }
         bool converged = false;
         int it = 0, q = 0;
-        gi_solve<T, R, NMAX, NV, false, kQS>(lane, nq, max_iter, tol2, __any(bad), ca, cb, b, ia, ib, vld, act, &su_all[d0], S.sd, S.slam, S.sdi,
+        gi_solve<T, R, NMAX, NV, false, kQS>(lane, D, max_iter, tol2, __any(bad), ca, cb, b, ia, ib, vld, act, &su_all[d0], S.sd, S.slam, S.sdi,
                                              S.sQ, S.sR, S.sact, nullptr, converged, it, q);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)
         __builtin_amdgcn_s_setprio(0);
@@ -1310,60 +1416,88 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     }
     __syncthreads();
 
-    // ---- stage C: low level + physics of drone i ----
+    // ---- stage C of this step, then stage A of the next: one drone per lane, state in registers ----
+    const bool want = obs_log != nullptr || k == n_steps - 1;
+    const bool more = k + 1 < n_steps;
+    t += ctrl_dt;
     T o[kObsDim];
-    State<T> s;
-    Resid<T> rs;
-    T u[4] = {T(0), T(0), T(0), T(0)};
+    unsigned iu = (unsigned)i;
+    int tq = tid;
+    asm volatile("" : "+v"(iu), "+v"(tq));                         // addresses are formed here, not held (spilled) across the loop
+    const Consts<T> c = fresh(c0);
+    const CbfParams<T> P = fresh(P0);
     if (valid) {
-      const int conv = sconv[tid / D];
-      const T safe = su_all[tid];
-      const T un0 = sun[0][tid], un1 = sun[1][tid], un2 = sun[2][tid], un3 = sun[3][tid];
+      const int conv = sconv[tq >> log2D];
+      const T safe = su_all[tq];
+      T u[4];
       u[0] = (conv ? safe : un0) + c.gravity;                                                // CBFTest.py:346
       u[1] = conv ? m_clamp(un1, -P.umax[1], P.umax[1]) : un1;
       u[2] = conv ? m_clamp(un2, -P.umax[2], P.umax[2]) : un2;
       u[3] = conv ? m_clamp(un3, -P.umax[3], P.umax[3]) : un3;
-      s.p = {st[0][tid], st[1][tid], st[2][tid]};
-      s.q[0] = st[3][tid]; s.q[1] = st[4][tid]; s.q[2] = st[5][tid]; s.q[3] = st[6][tid];
-      s.v = {st[7][tid], st[8][tid], st[9][tid]};
-      s.w = {st[10][tid], st[11][tid], st[12][tid]};
-    }
-    __syncthreads();                                             // raw is the observation staging from here on
-    const bool want = obs_log != nullptr || k == n_steps - 1;
-    if (valid) {
-      if (COMP) load_resid<T, T>(state_lo, ld, i, rs);
+      s.p = {st[0][tq], st[1][tq], st[2][tq]};
+      s.q[0] = st[3][tq]; s.q[1] = st[4][tq]; s.q[2] = st[5][tq]; s.q[3] = st[6][tq];
+      s.v = {st[7][tq], st[8][tq], st[9][tq]};
+      s.w = {st[10][tq], st[11][tq], st[12][tq]};
+      Resid<T> rs;
+      if (COMP) load_resid<T, T>(state_lo, ld, iu, rs);
       LowLevelState<T> L;
-      L.last_omega = {ll[0 * ld + i], ll[1 * ld + i], ll[2 * ld + i]};
-      L.integral = {ll[3 * ld + i], ll[4 * ld + i], ll[5 * ld + i]};
+      L.last_omega = {ll[0 * ld + iu], ll[1 * ld + iu], ll[2 * ld + iu]};
+      L.integral = {ll[3 * ld + iu], ll[4 * ld + iu], ll[5 * ld + iu]};
       T act4[4], prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4];
       thrust_omega_control(c, (T)ctrl_dt, u, s.w, L, act4);
-      ll[0 * ld + i] = L.last_omega.x; ll[1 * ld + i] = L.last_omega.y; ll[2 * ld + i] = L.last_omega.z;
-      ll[3 * ld + i] = L.integral.x; ll[4 * ld + i] = L.integral.y; ll[5 * ld + i] = L.integral.z;
+      ll[0 * ld + iu] = L.last_omega.x; ll[1 * ld + iu] = L.last_omega.y; ll[2 * ld + iu] = L.last_omega.z;
+      ll[3 * ld + iu] = L.integral.x; ll[4 * ld + iu] = L.integral.y; ll[5 * ld + iu] = L.integral.z;
       aviary_step_any<T, false, false, COMP>(c, s, rs, act4, prev, clipped);
-      if (COMP) store_resid<T, T>(state_lo, ld, i, rs);
-      if (last_rpm && k == n_steps - 1)
-        for (int j = 0; j < 4; ++j) last_rpm[j * ld + i] = clipped[j];
-      st[0][tid] = s.p.x; st[1][tid] = s.p.y; st[2][tid] = s.p.z;
-      st[3][tid] = s.q[0]; st[4][tid] = s.q[1]; st[5][tid] = s.q[2]; st[6][tid] = s.q[3];
-      st[7][tid] = s.v.x; st[8][tid] = s.v.y; st[9][tid] = s.v.z;
-      st[10][tid] = s.w.x; st[11][tid] = s.w.y; st[12][tid] = s.w.z;
+      if (COMP) store_resid<T, T>(state_lo, ld, iu, rs);
+      if (last_rpm && !more)
+        for (int j = 0; j < 4; ++j) last_rpm[j * ld + iu] = clipped[j];
       if (want) {
         struct alignas(2 * sizeof(T)) V2 {
           T v[2];
         };
-        const V2 c2 = *reinterpret_cast<const V2*>(lem + 4 * ld + 2 * (size_t)i);
-        pack_obs(s, V3<T>{c2.v[0], c2.v[1], lem[6 * ld + i]}, clipped, o);
+        const V2 c2 = *reinterpret_cast<const V2*>(lem + 4 * ld + 2 * (size_t)iu);
+        pack_obs(s, V3<T>{c2.v[0], c2.v[1], lem[6 * ld + iu]}, clipped, o);
       }
-      if (k == n_steps - 1) store_state<T, T>(state, ld, i, s);
+      if (!more) store_state<T, T>(state, ld, iu, s);
     }
     if (want) {
-      T* dst = obs_log != nullptr ? obs_log + (size_t)slot * n * kObsDim : obs_last;
-      write_obs_rows<T, T>(raw, dst, n, i, valid, o);
-      if (obs_log != nullptr && obs_last != nullptr && k == n_steps - 1) write_obs_rows<T, T>(raw, obs_last, n, i, valid, o);
+      // write_obs_rows with this stage's fresh indices: rows -> the wave's staging slice -> 16-byte coalesced non-temporal stores
+      T* dst = obs_log != nullptr ? obs_log + (size_t)slot * n * kObsDim : obs_last;      // (log AND obs_last: the host copies the last slot)
+      constexpr int kRowBytes = kObsDim * (int)sizeof(T);
+      const int lq = tq & 63;
+      unsigned char* lds_wave = raw + (tq >> 6) * kObsWave;
+      if (valid) {
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        alignas(16) T row[kObsDim];
+#pragma unroll
+        for (int j = 0; j < kObsDim; ++j) row[j] = o[j];
+#pragma unroll
+        for (int j = 0; j < kRowBytes / 16; ++j) reinterpret_cast<v4u*>(lds_wave + lq * kRowBytes)[j] = reinterpret_cast<const v4u*>(row)[j];
+      }
+      MDS_WAVE_SYNC();
+      const int wave_base = (int)iu - lq;
+      const int rows = min(64, n - wave_base);
+      if (rows > 0) {
+        const int bytes = rows * kRowBytes;
+        unsigned char* gdst = reinterpret_cast<unsigned char*>(dst) + (size_t)wave_base * kRowBytes;
+#pragma unroll
+        for (int it = 0; it < kRowBytes / 16; ++it) {
+          const int off = (it * 64 + lq) * 16;
+          if (off + 16 <= bytes) {
+            typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(*reinterpret_cast<const v4u*>(lds_wave + off), reinterpret_cast<v4u*>(gdst + off));
+          }
+        }
+      }
+      MDS_WAVE_SYNC();                                             // the slice is stage A's record / scratch space next
     }
     slot = slot + 1 == n_slots ? 0 : slot + 1;
-    t += ctrl_dt;
-    __syncthreads();                                             // staging drained before stage A overwrites Work
+    if (valid && more) {                                           // (the wave's own staging slice is drained: write_obs_rows ends with a wave sync)
+      unsigned ia2 = (unsigned)i;
+      int ta2 = tid;
+      asm volatile("" : "+v"(ia2), "+v"(ta2));
+      stage_a(c, load_params(ia2), t, ta2);
+    }
   }
 }
 
