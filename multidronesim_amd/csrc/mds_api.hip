@@ -2010,6 +2010,15 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
   void* rpm = rpm_track(h);
   const size_t es = elem_size(h->cfg.dtype);
   h->cbf_last_step_kernel = 2;
+  // tuning aid: MDS_TUNE_ROLL_STAMPS=1 -> per-wave shader-clock ticks by part of the step, summed over this call, printed to stderr
+  // (synchronises the stream: never set it in production)
+  unsigned long long* stamps_dev = nullptr;
+  const size_t n_stamp = (size_t)grid.x * nw * 9;
+  if (const char* e = getenv("MDS_TUNE_ROLL_STAMPS"))
+    if (e[0] == '1') {
+      MDS_HIP(hipMalloc((void**)&stamps_dev, n_stamp * sizeof(unsigned long long) * ((n_steps + steps_per_launch - 1) / steps_per_launch)));
+    }
+  unsigned long long* const stamps_base = stamps_dev;
   int slot = first_slot;
   double t = t0;
   for (int k0 = 0; k0 < n_steps; k0 += steps_per_launch) {
@@ -2019,7 +2028,7 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
   k_cbf_rollout<T, NOM, COMP, (sizeof(T) == 8 ? NWD : NWF)><<<grid, 64 * nw, 0, st>>>(CC, CP, gain, h->n, h->ld, h->cfg.num_envs, t, dt, ks, (T*)h->state, (T*)h->state_lo,  \
                                                                (const T*)h->lem, (T*)rpm, (T*)h->ll, h->pair_ij, (const T*)h->obstacles,        \
                                                                (T*)obs_log, slot, log_slots > 0 ? log_slots : 1, (T*)obs, (int*)status, (int*)slog, \
-                                                               h->cbf_cost, max_iter, (T)((TOL) * (TOL)))
+                                                               h->cbf_cost, max_iter, (T)((TOL) * (TOL)), stamps_dev)
 #define MDS_CR_N(T, CC, CP, COMP, TOL)                        \
   do {                                                        \
     if (h->cbf_nominal == 1) MDS_CR(T, CC, CP, 1, COMP, TOL); \
@@ -2034,6 +2043,29 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
     // t advances on the host exactly as inside the kernel (one += per step), so that consecutive launches continue the same sequence
     for (int j = 0; j < ks; ++j) t += dt;
     if (obs_log) slot = (slot + ks) % log_slots;
+    if (stamps_dev) stamps_dev += n_stamp;
+  }
+  if (stamps_base) {
+    const int launches = (n_steps + steps_per_launch - 1) / steps_per_launch;
+    std::vector<unsigned long long> hs(n_stamp * launches);
+    MDS_HIP(hipStreamSynchronize(st));
+    MDS_HIP(hipMemcpy(hs.data(), stamps_base, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(stamps_base);
+    static const char* part[9] = {"wait before B", "stage B", "wait after B", "stage C", "obs rows", "stage A", " B: ticket", " B: rows", " B: scan+solve"};
+    const size_t waves = (size_t)grid.x * nw;
+    double tot_mean = 0;
+    for (int p = 0; p < 9; ++p) {
+      double sum = 0, mx = 0;
+      for (size_t w = 0; w < waves; ++w) {
+        double v = 0;
+        for (int l = 0; l < launches; ++l) v += (double)hs[(size_t)l * n_stamp + w * 9 + p];
+        sum += v;
+        if (v > mx) mx = v;
+      }
+      if (p < 6) tot_mean += sum / waves / n_steps;
+      fprintf(stderr, "[mds roll stamps] %-14s mean %9.0f  max %9.0f ticks per wave and step\n", part[p], sum / waves / n_steps, mx / n_steps);
+    }
+    fprintf(stderr, "[mds roll stamps] total mean %.0f ticks per wave and step, %d steps, %zu waves\n", tot_mean, n_steps, waves);
   }
   if (obs_log) {       // the kernel materialises each step's observation once, in its log slot: obs_dev gets a copy of the last one
     const size_t row = (size_t)h->n * kObsDim * es;

@@ -1209,7 +1209,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
                                                         const T* __restrict__ obstacles, T* __restrict__ obs_log, int slot,
                                                         const int n_slots, T* __restrict__ obs_last, int* __restrict__ status,
                                                         int* __restrict__ status_log, int* __restrict__ cost_io, const int max_iter,
-                                                        const T tol2) {
+                                                        const T tol2, unsigned long long* __restrict__ stamps) {
   constexpr int NT = 64 * NW;
   constexpr int R = 4, NMAX = 16, NV = 1;
   constexpr int kQS = (NMAX + 3) / 4 * 4 + 4;
@@ -1236,6 +1236,27 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   __shared__ T sDs[kCbfMaxObs + 1];
   __shared__ int sconv[GBMAX], scost[GBMAX], sorder[GBMAX];    // per env of the workgroup: QP solved; iterations of its last solve; hand-out order
   __shared__ int sticket;
+  // tuning aid (stamps != NULL, MDS_TUNE_ROLL_STAMPS=1 on the host): shader-clock ticks every wave spent in each part of the step,
+  // summed over the launch's steps -> stamps[(workgroup * NW + wave) * 6 + part]: 0 wait for stage B, 1 stage B, 2 wait after
+  // stage B, 3 stage C, 4 observation rows, 5 stage A
+  __shared__ unsigned long long sst[NW][9];
+  unsigned long long tk0 = 0;
+  unsigned long long tk1 = 0;
+  auto stamp_b = [&](int part) {
+    if (stamps != nullptr) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      if ((threadIdx.x & 63) == 0) sst[threadIdx.x >> 6][part] += now - tk1;
+      tk1 = now;
+    }
+  };
+  auto stamp = [&](int part) {
+    if (stamps != nullptr) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      if ((threadIdx.x & 63) == 0) sst[threadIdx.x >> 6][part] += now - tk0;
+      tk0 = now;
+    }
+  };
+  if (stamps != nullptr && threadIdx.x < NW * 9) sst[threadIdx.x / 9][threadIdx.x % 9] = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = P0.num_drones, GB = NT / D;                    // envs per workgroup
   const int i = blockIdx.x * NT + tid;
@@ -1315,6 +1336,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   };
   if (valid && n_steps > 0) stage_a(c0, load_params((unsigned)i), t, tid);
   const int log2D = 31 - __clz(D);                             // D is 4, 8 or 16
+  const int nbs = (cbf_num_pairs(D) + D * P0.n_obs + 63) >> 6;   // row slots that hold barrier rows
 
   for (int k = 0; k < n_steps; ++k) {
     if (wave == 0) {
@@ -1331,18 +1353,22 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       }
       if (lane == 0) sticket = 0;
     }
+    if (stamps != nullptr && k == 0) tk0 = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    stamp(0);
 
     // ---- stage B: the workgroup's envs, one per wave at a time ----
     {
       const CbfParams<T> P = fresh(P0);
       Scratch& S = slice_of(wave).sc;
+      if (stamps != nullptr) tk1 = __builtin_amdgcn_s_memtime();
       while (true) {
         int tk = 0;
         if (lane == 0) tk = atomicAdd(&sticket, 1);
         tk = __builtin_amdgcn_readfirstlane(tk);
         if (tk >= nenv) break;                                     // wave-uniform
         const int el = sorder[tk];                                 // env of the workgroup (uniform)
+        stamp_b(6);
         const int d0 = el * D;
         const unsigned char* ebase = raw + (size_t)(d0 >> 6) * kObsWave + (size_t)(d0 & 63) * kRec;   // the env's first record
         int tl = lane;
@@ -1351,6 +1377,13 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         int ia[R], ib[R];
         bool vld[R], act[R];
         bool bad = false;
+        // Rows r = lane + 64 k.  Slots below nbs hold barrier rows (and possibly the first box rows): ONE straight-line body for all of them
+        // -- every lane runs the barrier arithmetic (lanes of other kinds on a harmless record pair, their result replaced by a select),
+        // so that the scheduler interleaves the slots' independent chains instead of walking one exec-masked branch per slot.
+        // The normalisation without its branch: n2 == 0 leaves the row unscaled (inv = 1) and turns the reach test into b < 0, exactly
+        // the two cases of cbf_o2_slot.
+        auto build_rows = [&](auto nbc) {
+        constexpr int NBS = decltype(nbc)::value;                  // compile time: the slots' bodies share one basic block
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           act[r] = false;
@@ -1358,12 +1391,12 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
           const int kind = sl.kind & 255;
           ia[r] = (sl.kind >> 8) & 255;
           ib[r] = (sl.kind >> 16) & 255;
-          ca[r][0] = cb[r][0] = b[r] = T(0);
-          vld[r] = false;
-          if (kind == 1 || kind == 2) {
-            const T* ra = reinterpret_cast<const T*>(ebase + sl.offA);
-            const T* rb = kind == 1 ? reinterpret_cast<const T*>(ebase + sl.offB)
-                                    : reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(&sobrec[0][0]) + sl.offB);
+          if (r < NBS) {
+            const bool bar = kind == 1 || kind == 2;
+            const unsigned char* pa = ebase + (bar ? sl.offA : 0);
+            const unsigned char* pb = kind == 1 ? ebase + sl.offB : reinterpret_cast<const unsigned char*>(&sobrec[0][0]) + (kind == 2 ? sl.offB : 0);
+            const T* ra = reinterpret_cast<const T*>(pa);
+            const T* rb = reinterpret_cast<const T*>(pb);
             T A8[8], B8[8];
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
@@ -1372,29 +1405,33 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
             }
             T hr, lg;
             cbf_row_o2<T>(P, A8[0] - B8[0], A8[1] - B8[1], A8[2] - B8[2], A8[3] - B8[3], A8[4] - B8[4], A8[5] - B8[5], A8[6] - B8[6],
-                          A8[7] - B8[7], sDs[sl.ds], &hr, &lg);
-            ca[r][0] = -lg;
-            cb[r][0] = kind == 1 ? lg : T(0);
-            b[r] = hr;
-            // normalisation and reach test: the arithmetic of cbf_o2_slot
-            const T n2 = m_fma(ca[r][0], ca[r][0], cb[r][0] * cb[r][0]);
-            if (n2 > T(0)) {
-              const T inv = m_rsqrt(n2);
-              ca[r][0] *= inv;
-              cb[r][0] *= inv;
-              b[r] *= inv;
-              vld[r] = true;
-              const T reach = (m_abs(ca[r][0]) + m_abs(cb[r][0])) * P.umax[0];
-              if (b[r] < -reach * (T(1) + T(sizeof(T) == 4 ? 1e-5 : 1e-10))) bad = true;
-            } else if (b[r] < T(0)) {
-              bad = true;                                          // 0 * u <= h with h < 0
-            }
-          } else if (kind >= 3) {                                  // +-u_var <= umax (cbf/cbf.py:400-412): unit norm as it stands
-            ca[r][0] = kind == 3 ? T(1) : T(-1);
-            b[r] = P.umax[0];
-            vld[r] = true;
+                          A8[7] - B8[7], sDs[bar ? sl.ds : 0], &hr, &lg);
+            T cak = -lg, cbk = kind == 1 ? lg : T(0), bk = hr;
+            const T n2 = m_fma(cak, cak, cbk * cbk);
+            const bool pos = n2 > T(0);
+            const T inv = pos ? m_rsqrt(n2) : T(1);
+            cak *= inv;
+            cbk *= inv;
+            bk *= inv;
+            const T reach = (m_abs(cak) + m_abs(cbk)) * P.umax[0];
+            bad = bad | (bar & (bk < -reach * (T(1) + T(sizeof(T) == 4 ? 1e-5 : 1e-10))));       // (bitwise: no short-circuit branch)
+            // +-u_var <= umax (cbf/cbf.py:400-412): unit norm as it stands
+            const T box_c = kind == 3 ? T(1) : (kind == 4 ? T(-1) : T(0)), box_b = kind >= 3 ? P.umax[0] : T(0);
+            ca[r][0] = bar ? cak : box_c;
+            cb[r][0] = bar ? cbk : T(0);
+            b[r] = bar ? bk : box_b;
+            vld[r] = (bar & pos) | (kind >= 3);
+          } else {
+            ca[r][0] = kind == 3 ? T(1) : (kind == 4 ? T(-1) : T(0));
+            cb[r][0] = T(0);
+            b[r] = kind >= 3 ? P.umax[0] : T(0);
+            vld[r] = kind >= 3;
           }
         }
+        };
+        if (nbs <= 3) build_rows(wv::Ic<3>{});
+        else build_rows(wv::Ic<4>{});
+        stamp_b(7);
         bool converged = false;
         int it = 0, q = 0;
         gi_solve<T, R, NMAX, NV, false, kQS>(lane, D, max_iter, tol2, __any(bad), ca, cb, b, ia, ib, vld, act, &su_all[d0], S.sd, S.slam, S.sdi,
@@ -1412,9 +1449,12 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
           }
         }
         MDS_WAVE_SYNC();
+        stamp_b(8);
       }
     }
+    stamp(1);
     __syncthreads();
+    stamp(2);
 
     // ---- stage C of this step, then stage A of the next: one drone per lane, state in registers ----
     const bool want = obs_log != nullptr || k == n_steps - 1;
@@ -1460,6 +1500,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       }
       if (!more) store_state<T, T>(state, ld, iu, s);
     }
+    stamp(3);
     if (want) {
       // write_obs_rows with this stage's fresh indices: rows -> the wave's staging slice -> 16-byte coalesced non-temporal stores
       T* dst = obs_log != nullptr ? obs_log + (size_t)slot * n * kObsDim : obs_last;      // (log AND obs_last: the host copies the last slot)
@@ -1491,6 +1532,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       }
       MDS_WAVE_SYNC();                                             // the slice is stage A's record / scratch space next
     }
+    stamp(4);
     slot = slot + 1 == n_slots ? 0 : slot + 1;
     if (valid && more) {                                           // (the wave's own staging slice is drained: write_obs_rows ends with a wave sync)
       unsigned ia2 = (unsigned)i;
@@ -1498,6 +1540,11 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       asm volatile("" : "+v"(ia2), "+v"(ta2));
       stage_a(c, load_params(ia2), t, ta2);
     }
+    stamp(5);
+  }
+  if (stamps != nullptr) {
+    __syncthreads();
+    if (threadIdx.x < NW * 9) stamps[(size_t)blockIdx.x * NW * 9 + threadIdx.x] = sst[threadIdx.x / 9][threadIdx.x % 9];
   }
 }
 
