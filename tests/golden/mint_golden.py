@@ -284,6 +284,47 @@ def mint_attitude_flow(ref):
     print("attitude_flow", R_next.shape, "max |w| dt", float(np.max(np.linalg.norm(w, axis=1) * dt)))
 
 
+def mint_euler_convention(ref):
+    """The rpy convention of the observation (obs[7:10]) pinned on the reference tree.
+
+    Upstream fills obs[7:10] with pybullet's getEulerFromQuaternion (not in the tree); every linear-model consumer in the tree reads it
+    through obs_to_lin_model (utils/model_conversions.py:36-40) and turns it back into a rotation with the tree's own convention:
+    rpy_to_rot (utils/model_conversions.py:4-19, R = Rz Ry Rx) and scipy 'xyz' (control/lqr/lqr_omega_controller.py:97-101), while the
+    quaternion of the same observation goes through Rotation.from_quat (obs_to_geo_model, :108-113).  For the two readings of one
+    observation to agree, rpy_to_rot(obs[7:10]) must equal the rotation of obs[3:7].  Stored: random quaternions (general attitudes,
+    pitch within 1e-6 .. 1e-2 of +-pi/2, and exact +-pi/2), the rotation obs_to_geo_model gives them, and -- for the rpy the oracle's
+    euler_from_quat_bullet assigns at minting time -- the reference's rpy_to_rot(rpy) and scipy's from_euler('xyz', rpy) as
+    lqr_omega_controller uses it."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import np_oracle as O
+    mc = ref["mc"]
+    rng = np.random.default_rng(77)
+    n_gen, n_near = 192, 96
+    eul = np.concatenate([
+        np.stack([rng.uniform(-np.pi, np.pi, n_gen), rng.uniform(-1.5, 1.5, n_gen), rng.uniform(-np.pi, np.pi, n_gen)], axis=1),
+        # near the gimbal lock: |pitch| = pi/2 - eps, eps from 1e-2 down to 1e-6 (both sides of pybullet's 0.99999 threshold, which
+        # sits at eps = 4.47e-3), and exactly pi/2
+        np.stack([rng.uniform(-np.pi, np.pi, n_near), np.tile([1.0, -1.0], n_near // 2) * (np.pi / 2 - np.tile(np.repeat(
+            [1e-2, 6e-3, 4.5e-3, 4.4e-3, 1e-3, 1e-4, 1e-5, 1e-6], 2), n_near // 16)), rng.uniform(-np.pi, np.pi, n_near)], axis=1),
+        np.array([[0.3, np.pi / 2, -0.8], [-1.1, -np.pi / 2, 2.0], [0.0, np.pi / 2, 0.0], [0.0, 0.0, 0.0]]),
+    ])
+    # quaternions straight from the Euler angles (extrinsic xyz = R = Rz Ry Rx), float64; random sign flips (q and -q are one attitude)
+    q = Rotation.from_euler("xyz", eul).as_quat()
+    q *= np.where(rng.uniform(size=(len(q), 1)) < 0.5, -1.0, 1.0)
+    obs = np.zeros((len(q), 20))
+    obs[:, 3:7] = q
+    R_quat = np.array([mc.obs_to_geo_model(o)[3:12].reshape(3, 3) for o in obs])          # the tree's reading of the quaternion
+    rpy = O.euler_from_quat_bullet(q)                                                      # what the build puts into obs[7:10]
+    R_rpy = np.array([mc.rpy_to_rot(r) for r in rpy])                                      # the tree's reading of that rpy
+    R_rpy_scipy = Rotation.from_euler("xyz", rpy).as_matrix()                              # lqr_omega_controller.py:98
+    sarg = -2.0 * (q[:, 0] * q[:, 2] - q[:, 3] * q[:, 1]) / (q * q).sum(1)
+    np.savez(os.path.join(OUT, "euler_convention.npz"), quat=q, euler_in=eul, rpy=rpy, R_quat=R_quat, R_rpy=R_rpy, R_rpy_scipy=R_rpy_scipy,
+             gimbal=np.abs(sarg) >= 0.99999, **{"meta_" + k: v for k, v in META.items()})
+    g = np.abs(sarg) >= 0.99999
+    print("euler_convention: %d attitudes, %d in the gimbal branches; max |rpy_to_rot(rpy) - R(q)| outside them %.2e, inside %.2e" % (
+        len(q), g.sum(), np.abs(R_rpy - R_quat)[~g].max(), np.abs(R_rpy - R_quat)[g].max()))
+
+
 def mint_closed_loop_reference_in_the_loop(ref):
     """The do_control loop of simulations/EnvGeometric.py:431-473 with the REFERENCE's own objects in it: per drone a
     trajectories/Lemniscate.py object sampled at t, a control/geometric.py GeometricControl.compute(obs) (through the reference's
@@ -639,6 +680,7 @@ if __name__ == "__main__":
     mint_dynamics(ref)
     mint_dyn_wrench_accel(ref)
     mint_attitude_flow(ref)
+    mint_euler_convention(ref)
     mint_closed_loop_reference_in_the_loop(ref)
     mint_closed_loop_lqr_reference_in_the_loop(ref)
     mint_cbf(ref)

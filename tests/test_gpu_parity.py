@@ -978,3 +978,37 @@ def test_state_ptrs_views_match_get_state(mds, dtype):
     st2 = env.get_state().reshape(-1, 13)
     np.testing.assert_allclose(st2[:, 9], 0.25, atol=1e-3)
     env.close()
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_observation_rpy_is_the_reference_trees_convention_incl_gimbal_branches(mds, dtype):
+    """obs[7:10] of the device (euler_from_quat in csrc/mds_math.hpp, pybullet's getEulerFromQuaternion restated with its +-0.99999
+    gimbal branches) on the attitudes of tests/golden/euler_convention.npz -- minted from the reference tree: random attitudes, pitch
+    within 1e-6 .. 1e-2 of +-pi/2 on both sides of the branch threshold, and exactly +-pi/2.  float64: the rpy of the fixture to 1e-12
+    (same branch everywhere).  float32: away from the branches 5e-6 rad (wrapped); at the branches rounding the quaternion to fp32 may
+    land an attitude on the other side of the threshold, where rpy jumps although the attitude does not -- there the check is the one
+    that matters to the consumers: rpy_to_rot(rpy) (utils/model_conversions.py:4-19) gives the attitude of the quaternion to 5e-3,
+    the bound of pybullet's own branch approximation."""
+    from scipy.spatial.transform import Rotation
+    d = np.load(os.path.join(G, "euler_convention.npz"))
+    q, rpy_ref, g = d["quat"], d["rpy"], d["gimbal"]
+    n = len(q)
+    env = make_env(mds, n, 1, np.zeros((n, 1, 3)), np.zeros((n, 1, 3)), dtype=dtype)
+    st = np.zeros((n, 13))
+    st[:, 3:7] = q
+    env.set_state(st)
+    obs = np_obs(env._computeObs())
+    np.testing.assert_allclose(obs[:, 3:7], q, rtol=0, atol=1e-15 if dtype == "float64" else 6e-8)
+    rpy = obs[:, 7:10]
+    if dtype == "float64":
+        np.testing.assert_allclose(rpy, rpy_ref, rtol=0, atol=1e-12)
+        assert (rpy[g][:, 0] == 0).all() and g.sum() >= 48
+    else:
+        wrap = lambda a: (a + np.pi) % (2 * np.pi) - np.pi
+        far = np.abs(np.abs(d["euler_in"][:, 1]) - np.pi / 2) > 2e-2              # well away from the threshold (4.47e-3)
+        assert far.sum() >= 190
+        assert np.abs(wrap(rpy[far] - rpy_ref[far])).max() < 5e-6
+        R = Rotation.from_euler("xyz", rpy).as_matrix()                              # == rpy_to_rot (fixture: R_rpy == R_rpy_scipy)
+        assert np.abs(R - d["R_quat"]).max() < 5e-3
+        assert np.abs(R[far] - d["R_quat"][far]).max() < 5e-6
+    env.close()

@@ -298,3 +298,27 @@ def test_closed_loop_lqr_with_the_reference_objects_in_the_loop():
             k = (i + 1) // every
             np.testing.assert_allclose(act, d["action_log"][k - 1], rtol=1e-7)
             np.testing.assert_allclose(obs, d["obs_log"][k], rtol=0, atol=1e-7)
+
+
+def test_euler_convention_is_the_reference_trees():
+    """obs[7:10] as the build fills it (pybullet's getEulerFromQuaternion, restated: oracle.euler_from_quat_bullet) read back through the
+    reference tree's own convention must give the attitude of obs[3:7]: the fixture holds, minted from the tree, the rotation
+    obs_to_geo_model assigns to each quaternion (utils/model_conversions.py:108-113), rpy_to_rot(rpy) (:4-19, R = Rz Ry Rx) and scipy
+    'xyz' as control/lqr/lqr_omega_controller.py:97-101 applies it.  Outside pybullet's gimbal branches (|sin pitch| < 0.99999) the
+    three agree to 1e-12; inside them pybullet returns roll = 0, yaw = 2 atan2(+-x, -+y), exact only AT pitch = +-pi/2: the attitude error
+    is bounded by acos(0.99999) = 4.47e-3 rad there (upstream behaviour, kept)."""
+    d = np.load(os.path.join(G, "euler_convention.npz"))
+    q, g = d["quat"], d["gimbal"]
+    rpy = O.euler_from_quat_bullet(q)
+    np.testing.assert_allclose(rpy, d["rpy"], rtol=0, atol=1e-13)                       # the restatement has not moved since minting
+    assert g.sum() >= 48 and (~g).sum() >= 200 and (rpy[g][:, 0] == 0).all()            # both regimes covered; roll = 0 in the branches
+    assert np.abs(np.abs(rpy[g][:, 1]) - np.pi / 2).max() == 0.0
+    np.testing.assert_allclose(d["R_rpy"], d["R_rpy_scipy"], rtol=0, atol=1e-14)         # rpy_to_rot == scipy 'xyz' (the tree's two readings)
+    np.testing.assert_allclose(d["R_rpy"][~g], d["R_quat"][~g], rtol=0, atol=1e-12)      # convention pinned: R(rpy) == R(q)
+    assert np.abs(d["R_rpy"][g] - d["R_quat"][g]).max() < 4.6e-3                          # gimbal branches: pybullet's own approximation
+    # exactly at +-pi/2 the branch formula is exact
+    ex = np.abs(np.abs(d["euler_in"][:, 1]) - np.pi / 2) == 0
+    assert ex.sum() >= 3
+    np.testing.assert_allclose(d["R_rpy"][ex], d["R_quat"][ex], rtol=0, atol=1e-7)
+    # the oracle's quaternion -> rotation (used by its physics) is the tree's too
+    np.testing.assert_allclose(O.quat_to_rotmat_bullet(q), d["R_quat"], rtol=0, atol=1e-13)
