@@ -72,12 +72,12 @@ def open_loop_setup(n, seed=1, tilt=0.02):
 
 
 def oracle_cbf_closed_loop(xyz, rpy, P, steps, Kcbf, umax, safety_radius, zscale, x_obs, obs_r, pyb_freq=100, ctrl_freq=100,
-                           consts=O.CF2P, nominal="geometric", order=2, Fmin=None, Fmax=None, first_rpm=0.0, physics="dyn"):
+                           consts=O.CF2P, nominal="geometric", order=2, Fmin=None, Fmax=None, first_rpm=0.0, physics="dyn", record_at=None):
     """simulations/CBFTest.py:303-350 on the oracle, per env: geometric nominal (return_omegas) ->
     u_hat = (force - M G, w_des), xdes = [0,0,yaw, vel, pos] -> ECBF QP (fallback to nominal) ->
     + M G -> ThrustOmega low level -> env.step.  order 3 / nominal "lqr_yank_omega": the loop of
     simulations/CBFTestOrd3.py:306-352 (yank - M G, xdes with G M in slot 3, YankOmega low level, nothing added back).
-    Returns (obs [E,D,20], status history [steps,E])."""
+    Returns (obs [E,D,20], status history [steps,E]); with record_at = (m1, m2, ...) also {m: obs after m steps}."""
     E, D = xyz.shape[0], xyz.shape[1]
     n = E * D
     Pf = P.reshape(-1, 7)
@@ -89,6 +89,7 @@ def oracle_cbf_closed_loop(xyz, rpy, P, steps, Kcbf, umax, safety_radius, zscale
     obs = ora.step(np.full((n, 4), float(first_rpm)))     # the order-3 loop integrates thrust from the RPM echo: start it at hover
     t = 0.0
     hist = []
+    rec = {}
     for k in range(steps):
         pos, vel, acc, yaw, yd = O.lemniscate(t, Pf[:, 0], Pf[:, 1], Pf[:, 2:5], Pf[:, 5], Pf[:, 6])
         if nominal == "lqr_omega":       # simulations/CBFTest.py:290-293, :339
@@ -119,4 +120,8 @@ def oracle_cbf_closed_loop(xyz, rpy, P, steps, Kcbf, umax, safety_radius, zscale
         rpm = ll.compute_low_level(usafe, obs, ora.CTRL_TIMESTEP)
         obs = ora.step(rpm)
         t += ora.CTRL_TIMESTEP
+        if record_at is not None and k + 1 in record_at:
+            rec[k + 1] = obs.reshape(E, D, 20).copy()
+    if record_at is not None:
+        return obs.reshape(E, D, 20), np.array(hist), rec
     return obs.reshape(E, D, 20), np.array(hist)

@@ -186,13 +186,20 @@ def test_thrust_omega_golden(mds, model):
         env.close()
 
 
-@pytest.mark.parametrize("dtype,tol", [("float64", 1e-11), ("float32", 1e-4), ("float32c", 5e-5)])
-def test_c4_closed_loop_matches_oracle(mds, dtype, tol):
-    """Config 4 pipeline (geometric nominal -> ECBF QP -> ThrustOmega -> step), 8 envs x 6 drones on
-    crossing Lemniscates with 4 sphere obstacles, 150 control steps, against the oracle loop.  Measured (profiles/r02_fp32_gates.log):
-    float64 4.6e-14, float32 2.1e-5 (4.9e-5 at 300 steps), compensated fp32 9.5e-6; statuses equal at every step."""
+# gates = next round number above what tests/tools/c4_parity_probe.py measures on MI355X (gpurun_out/r3_parity_probe.log, round 3):
+# max abs state error against the float64 oracle at steps 150 / 220 (the bench window) / 1000 (north_star's horizon):
+#   float64 4.9e-14 / 6.6e-14 / 1.9e-12, float32 2.7e-5 / 3.5e-5 / 1.4e-3, float32c 8.2e-6 / 1.1e-5 / 3.6e-4; statuses equal at every step.
+# The closed loop amplifies a perturbation ~1e3-fold over 1000 steps on this scene (float64's own 1e-15 rounding ends at 2e-12), so
+# fp32 -- 6e-8 per stored state -- cannot hold north_star's 1e-5 to step 1000 on C4 whatever the kernel does; it holds it over the
+# bench window on the bench's headline scene (test_c4_full_size_properties).
+@pytest.mark.parametrize("dtype,tol150,tol220,tol1000", [("float64", 1e-11, 1e-11, 1e-9), ("float32", 1e-4, 1e-4, 5e-3), ("float32c", 5e-5, 5e-5, 2e-3)])
+def test_c4_closed_loop_matches_oracle(mds, dtype, tol150, tol220, tol1000):
+    """Config 4 pipeline (geometric nominal -> ECBF QP -> ThrustOmega -> step), 8 envs x 6 drones on crossing Lemniscates with 4
+    sphere obstacles, against the oracle loop over 1000 control steps (north_star's horizon; the bench window ends at step 220):
+    per-env statuses equal at EVERY step -- 19 % of the env-steps of this scene are infeasible, so both branches are exercised --
+    and the state within the gates above at steps 150, 220 and 1000."""
     from tests import helpers as H2
-    E, D, steps = 8, 6, 150
+    E, D, steps = 8, 6, 1000
     xyz, rpy, P = H2.c2_setup(E, D, phase="c3", offset=0.0, omega=1.0)
     xyz[..., 2] = 0.5 + 0.25 * np.arange(D)            # stacked start: barrier rows act through e_z
     P[..., 4] = 0.5 + 0.12 * np.arange(D)              # trajectories 12 cm apart vertically: rows become active
@@ -203,16 +210,21 @@ def test_c4_closed_loop_matches_oracle(mds, dtype, tol):
     env.set_trajectories(P)
     cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2)
     trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
-    oobs, ohist = H2.oracle_cbf_closed_loop(xyz, rpy, P, steps, cbf.Kcbf.reshape(-1), cbf.umax, 0.1, 1.0, x_obs, obs_r)
+    marks = {150: tol150, 220: tol220, 1000: tol1000}
+    _, ohist, ref = H2.oracle_cbf_closed_loop(xyz, rpy, P, steps, cbf.Kcbf.reshape(-1), cbf.umax, 0.1, 1.0, x_obs, obs_r, record_at=tuple(marks))
+    assert 0.05 < ohist.mean() < 0.5                     # feasible and infeasible env-steps both occur
     env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
-    t, n_fallback_match = 0.0, 0
+    t = 0.0
     for k in range(steps):
         gobs, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
-        np.testing.assert_array_equal(st.cpu().numpy(), ohist[k])
+        got = st.cpu().numpy()
+        assert np.array_equal(got, ohist[k]), f"{dtype}: status differs from the oracle's first at step {k}: envs {np.nonzero(got != ohist[k])[0].tolist()}"
         t += env.CTRL_TIMESTEP
-    g = gobs.double().cpu().numpy()
-    assert np.abs(g[..., :16] - oobs[..., :16]).max() < tol
-    assert np.isfinite(g).all()
+        if k + 1 in marks:
+            g = gobs.double().cpu().numpy()
+            err = np.abs(g[..., :16] - ref[k + 1][..., :16]).max()
+            assert err < marks[k + 1], f"{dtype}: state error {err:.2e} at step {k + 1}"
+            assert np.isfinite(g).all()
     env.close()
 
 
@@ -431,53 +443,88 @@ def test_cbf_filter_longest_first_dispatch_is_invisible(mds):
     env.close()
 
 
-def test_c4_full_size_properties(mds):
-    """BASELINE config 4 at its full size (16 384 envs x 16 drones, the bench's scene) through size-independent properties:
-    replicated envs stay bitwise equal wherever they sit in the batch (the longest-first dispatch permutes the envs between
-    calls), a 64-env batch holding the same envs gives the same bits, every row is finite with a unit quaternion and a
-    0/1 status, and a strided sample of envs follows the oracle loop."""
+@pytest.mark.parametrize("scene,z,tol40,tol220", [("under", -3.0, 5e-6, 1e-5), ("level", 0.5, 5e-6, 1e-1)])
+def test_c4_full_size_properties(mds, scene, z, tol40, tol220):
+    """BASELINE config 4 at its full size (16 384 envs x 16 drones) over the bench's window (220 control steps = 20 warm-up + T = 200),
+    on the bench's two scenes: 'under' (spheres at z = -3: the C4 headline -- every QP feasible, a third of the envs iterating) and
+    'level' (SURVEY 8d's spheres at z = 0.5: a third of the envs infeasible).  Size-independent properties: replicated envs stay
+    bitwise equal wherever they sit in the batch (the longest-first dispatch permutes the envs between calls), a 64-env batch holding
+    the same envs gives the same bits, every row is finite with a unit quaternion and a 0/1 status.  Against the oracle: a strided
+    sample of 8 envs -- statuses equal at EVERY one of the 220 steps, state within 5e-6 at step 40 and, at step 220, within
+    north_star's 1e-5 on 'under' (measured 2.6e-6, tests/tools/c4_parity_probe.py).  'level' is a chaotic closed loop -- the float64
+    kernel itself ends 6e-11 from the float64 oracle, a 1e4-fold amplification of its rounding in 220 steps -- and fp32 agrees to
+    2.5e-2 there (gate 1e-1); its statuses still equal the oracle's at every step.  The persistent rollout kernel
+    (mds_rollout_cbf_geometric_fused) must reproduce the step-by-step loop's statuses for ALL 16 384 envs at every step."""
     from tests import helpers as H2
-    E, D, steps = 16384, 16, 40
-    xyz, rpy, P = H2.c2_setup(E, D, phase="c3")
+    E, D, steps = 16384, 16, 220
+    xyz, rpy, P = H2.c2_setup(E, D, seed=1000, phase="c3")      # (bench.py's generator and seed)
     P[..., 4] = 0.5 + 0.3 * np.arange(D)
     xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
     for dst in (8192, 16384 - 64 - 5):                         # copies of envs 0..63
         xyz[dst:dst + 64], P[dst:dst + 64] = xyz[0:64], P[0:64]
-    x_obs = [np.array([[sx * 0.5, sy * 0.5, 0.5], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
+    x_obs = [np.array([[sx * 0.5, sy * 0.5, z], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
     obs_r = [0.1] * 4
     poles = np.array([-2.2, -2.4])
+    idx = np.arange(0, E, E // 8)
 
-    def run(lo, hi):
+    def run(lo, hi, fused=False):
         env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz[lo:hi], initial_rpys=rpy[lo:hi],
                              physics=mds.Physics.DYN, pyb_freq=100, ctrl_freq=100, num_envs=hi - lo, dtype="float32")
         env.set_trajectories(P[lo:hi])
         cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2, cbf_poles=poles)
         trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
         env.step(mds.torch.zeros((hi - lo, D, 4), dtype=env.dtype))
-        t, hist = 0.0, []
-        for k in range(steps):
-            o, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
-            hist.append(st.clone())
-            t += env.CTRL_TIMESTEP
-        out = (o.clone(), mds.torch.stack(hist), cbf.Kcbf.reshape(-1).copy(), np.array(cbf.umax, dtype=np.float64))
+        o40 = its = None
+        if fused:
+            slog = mds.torch.empty((steps, hi - lo), dtype=mds.torch.int32, device=env.device)
+            o, _ = env.rollout_cbf_geometric_fused(0.0, steps, trk, x_obs, obs_r, steps_per_launch=44, status_log=slog)
+            o, hist = o.clone(), slog
+        else:
+            t, hist, its = 0.0, [], []
+            for k in range(steps):
+                o, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
+                hist.append(st.clone())
+                if k >= 20:
+                    its.append((cbf.last_iterations() > 0).float().mean())
+                if k == 39 and hi - lo == E:
+                    o40 = o[idx].double().cpu().numpy()
+                t += env.CTRL_TIMESTEP
+            o, hist, its = o.clone(), mds.torch.stack(hist), mds.torch.stack(its).cpu().numpy()
+        out = (o, hist, cbf.Kcbf.reshape(-1).copy(), np.array(cbf.umax, dtype=np.float64), o40, its)
         env.close()
         return out
 
-    obs, hist, Kcbf, umax = run(0, E)
+    obs, hist, Kcbf, umax, o40, its = run(0, E)
     for dst in (8192, 16384 - 64 - 5):
         assert mds.torch.equal(obs[0:64], obs[dst:dst + 64])
         assert mds.torch.equal(hist[:, 0:64], hist[:, dst:dst + 64])
-    so, sh, _, _ = run(0, 64)                                    # no dispatch classes at this size
+    so, sh, *_ = run(0, 64)                                      # no dispatch classes at this size
     assert mds.torch.equal(so, obs[0:64]) and mds.torch.equal(sh, hist[:, 0:64])
     assert mds.torch.isfinite(obs).all()
     assert (obs[..., 3:7].norm(dim=-1) - 1).abs().max().item() < 1e-5
     assert set(np.unique(hist.cpu().numpy()).tolist()) <= {0, 1}
-    assert 0.0 < hist.float().mean().item() < 0.9
-    idx = np.arange(0, E, E // 8)
-    oobs, ohist = H2.oracle_cbf_closed_loop(xyz[idx], rpy[idx], P[idx], steps, Kcbf, umax, 0.1, 1.0, x_obs, obs_r)
+    fb = hist[20:].float().mean(dim=1).cpu().numpy()             # share of infeasible envs at each step of the bench window
+    if scene == "under":
+        assert fb.max() == 0.0, f"the headline scene must keep every QP feasible over the window: {fb.max()}"
+        assert 0.1 < its.mean() < 0.9 and its[-1] > 0.05         # ... and active: a sizeable share of the envs iterate, also at the end
+    else:
+        assert 0.1 < fb.mean() < 0.9
+    _, ohist, orec = H2.oracle_cbf_closed_loop(xyz[idx], rpy[idx], P[idx], steps, Kcbf, umax, 0.1, 1.0, x_obs, obs_r, record_at=(40, 220))
     np.testing.assert_array_equal(hist[:, idx].cpu().numpy(), np.array(ohist))
-    g = obs[idx].double().cpu().numpy()
-    assert np.abs(g[..., :16] - oobs.reshape(g.shape)[..., :16]).max() < 1e-4
+    e40 = np.abs(o40[..., :16] - orec[40][..., :16]).max()
+    e220 = np.abs(obs[idx].double().cpu().numpy()[..., :16] - orec[220][..., :16]).max()
+    assert e40 < tol40 and e220 < tol220, (scene, e40, e220)
+    # The persistent kernel at full size against the step-by-step loop.  The two contract FMAs differently (observations equal to
+    # rounding); 'under' amplifies that to 1e-6 at most and every one of the 3.6 M env-step statuses is the same.  'level' is chaotic
+    # and a third of its QPs sit at the feasibility boundary: measured (MI355X, round 3), 35 env-steps of 3 604 480 differ, all in a
+    # handful of envs that took the other branch once and went their own way from there -- the same thing a different compiler
+    # version would do to the step-by-step loop itself.  Gate: no env on 'under', at most 16 envs (0.1 %) on 'level'.
+    fo, fh, *_ = run(0, E, fused=True)
+    envs_diff = int((fh != hist).any(dim=0).sum().item())
+    assert envs_diff <= (0 if scene == "under" else 16), f"statuses of {envs_diff} envs differ between the persistent rollout and the step-by-step loop"
+    same = ~(fh != hist).any(dim=0)[idx].cpu().numpy()
+    ef = (fo[idx].double() - obs[idx].double()).abs()[..., :16].amax(dim=(1, 2)).cpu().numpy()
+    assert ef[same].max() < 2 * tol220, ef
 
 
 @pytest.mark.parametrize("nominal", ["geometric", "lqr_omega"])
