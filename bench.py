@@ -749,7 +749,7 @@ def main(argv=None):
     es = {torch.float16: 2, torch.float32: 4, torch.float64: 8}[env.dtype]
     bytes_per = (BYTES_PER_DRONE_STEP_C4 if c4 else BYTES_PER_DRONE_STEP) * es // 4
     if args.dtype == "float32c":
-        bytes_per += 104                                  # 13 residuals read and written
+        bytes_per += 32                                   # the residuals of the three body rates (one 16-byte group) read and written
     if c5:
         bytes_per = 13 * es * 2 + 4 * es + 20 * es       # R state + W state + R action + W obs (origin read not counted)
     if fused_T and c5:
@@ -969,14 +969,15 @@ def main(argv=None):
                 line["roofline"]["hbm_resident"] = {"error": str(exc)}
             torch.cuda.empty_cache()
             for key, dty, integ, bpd in (("rk4", "float32", "rk4", BYTES_PER_DRONE_STEP), ("f64", "float64", "euler", 2 * BYTES_PER_DRONE_STEP),
-                                         ("f32c", "float32c", "euler", BYTES_PER_DRONE_STEP + 104)):
+                                         ("f32c", "float32c", "euler", BYTES_PER_DRONE_STEP + 32)):
                 try:
                     us, used, sane = extra_c3_variant(CtrlAviary, DroneModel, Physics, torch, local_rank, device, E, D, phase, 1000, dty, integ, 200, 0)
                     gb = bpd * n_local / (us * 1e-6) / 1e9
                     line[key] = {"what": {"rk4": "same C3 step with the classical RK4 integrator (north_star's), fp32",
                                           "f64": "same C3 step in float64 (the reference's precision), explicit Euler",
-                                          "f32c": "same C3 step in fp32 with compensated state accumulation (MDS_F32C: 13 residuals read and written, "
-                                                  "open-loop 1000-step error 3e-6 instead of 1.4e-5)"}[key],
+                                          "f32c": "same C3 step in fp32 with compensated accumulation (MDS_F32C: two-sum inside the step, the residuals of the "
+                                                  "three body rates kept between steps, +32 B per drone-step; open-loop 1000-step error 6e-6 instead of "
+                                                  "1.4e-5: north_star's 1e-5 tolerance without a controller in the loop)"}[key],
                                  "us_per_step": us, "value": n_local / (us * 1e-6), "unit": "drone-steps/s", "bytes_per_drone_step": bpd,
                                  "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBPS, "streams": used, "steps": 200, "state_sane": sane}
                 except Exception as exc:

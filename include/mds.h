@@ -60,12 +60,13 @@ typedef enum mds_status {
   MDS_EUNSUPPORTED = -6 /* combination not built (e.g. order-3 CBF with fp16 storage) */
 } mds_status;
 
-/* MDS_F32C: fp32 buffers and fp32 arithmetic like MDS_F32, but every one of the 13 state components is kept as an fp32 value plus an
- * fp32 residual and the integrators accumulate into the pair (two-sum): the storage rounding of an uncontrolled quadrotor (four
- * chained integrators, ~t^2.5) goes away -- open-loop 240 Hz flight holds 3e-6 instead of 1.4e-5 after 1000 steps -- for 104 more
- * bytes per drone-step (13 residuals read and written).  Served by mds_step, mds_step_geometric, mds_step_cbf_geometric,
- * mds_step_nominal and the mds_rollout_* loops built on them (mds_rollout_geometric, mds_rollout_step[_fused], mds_rollout_cbf_geometric);
- * DYN / DYN_DRAG physics, Euler and RK4.  Not built: the state-in-registers kernels (mds_rollout_*_fused), mds_step_lqr, mds_step_dslpid. */
+/* MDS_F32C: fp32 buffers and fp32 arithmetic like MDS_F32, with compensated accumulation: inside a control step the integrators add
+ * into (value, residual) pairs (two-sum), and between control steps the handle keeps the residuals of the three BODY RATES (one
+ * 16-byte group per drone: +32 B per drone-step).  The rounding of the stored rate -- a random walk that turns the attitude and
+ * tilts the thrust -- is what limits an uncontrolled fp32 quadrotor: open-loop 240 Hz flight holds 6e-6 instead of 1.4e-5 after 1000
+ * steps (north_star's 1e-5).  (Round 2 kept all 13 residuals, +104 B, for 3e-6; residuals of the quaternion alone buy nothing:
+ * tests/test_emul_device_math.py.)  Served by every step and rollout entry point of DYN / DYN_DRAG physics, Euler and RK4; the
+ * ground-effect / downwash physics modes reject the dtype at mds_create. */
 typedef enum mds_dtype { MDS_F32 = 0, MDS_F64 = 1, MDS_F16 = 2, MDS_F32C = 3 } mds_dtype;
 /* DYN / DYN_DRAG: [UPSTREAM] Physics.DYN (+ _drag), every entry point.  DYN_GND / DYN_DW / DYN_GND_DRAG_DW add [UPSTREAM]
  * _groundEffect / _downwash (Physics.PYB_GND, PYB_DW, PYB_GND_DRAG_DW: Bullet external forces there, extra terms of the DYN wrench
@@ -139,8 +140,8 @@ int mds_reset(mds_handle* h, const double* xyz_host, const double* rpy_host, voi
  * four components per 16-byte group: stride 4 for k < 12, 1 for k = 12).  origin_dev[k] (may be NULL): the origin planes,
  * stride 1, float for MDS_F32 / MDS_F16 handles and double for MDS_F64; world position = state position + origin.  The
  * pointers stay valid until mds_destroy, except that the ground-effect / downwash physics modes swap their two state
- * buffers every substep (ask again after each mds_step there).  MDS_F32C handles: these are the fp32 values; the residual planes
- * stay private (mds_get_state returns value + residual). */
+ * buffers every substep (ask again after each mds_step there).  MDS_F32C handles: these are the fp32 values; the rate residuals
+ * stay private (mds_get_state returns value + residual for the body rates). */
 int mds_state_ptrs(mds_handle* h, void* comp_dev[13], size_t stride_elems[13], void* origin_dev[3]);
 
 /* Test / checkpoint access to the 13-float state in the WORLD frame (host double [n,13]).

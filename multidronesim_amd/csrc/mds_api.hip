@@ -75,7 +75,7 @@ struct mds_handle {
   int n;
   size_t ld;           // plane stride (elements)
   void* state;         // S [13][ld]
-  void* state_lo = nullptr;      // MDS_F32C: float [13][ld] residual planes (compensated accumulation), same packed layout
+  void* state_lo = nullptr;      // MDS_F32C: float [ld][4] = residuals of the three body rates + pad (load_resid in mds_kernels.hip)
   void* origin;        // T [3][ld]
   void* last_rpm;      // T [4][ld]
   void* lem;           // T [7][ld]
@@ -248,12 +248,6 @@ static int split_join(mds_handle* h, hipStream_t st, int rc_body) {
 static inline dim3 grid_for(int n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 static inline bool is_comp(const mds_handle* h) { return h->cfg.dtype == MDS_F32C; }
 static inline bool is_f32(const mds_handle* h) { return h->cfg.dtype == MDS_F32 || h->cfg.dtype == MDS_F32C; }   // fp32 buffers
-// entry points whose kernels keep the state in registers across steps or integrate it in place without the residual planes
-#define MDS_NO_COMP(h, who)                                                                                                          \
-  do {                                                                                                                               \
-    if ((h) && is_comp(h)) return fail(MDS_EUNSUPPORTED, who ": not built for MDS_F32C (compensated fp32) handles");                 \
-  } while (0)
-
 template <typename T> static void fill_cbf(const mds_handle* h, const mds_cbf_params& p, CbfParams<T>& o) {
   o.order = p.order;
   o.n_obs = p.n_obs;
@@ -392,8 +386,8 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
     mds_set_dslpid_gains(h, &dg);
   }
   hipError_t e = hipMalloc(&h->state, 13 * h->ld * es);
-  if (e == hipSuccess && is_comp(h)) e = hipMalloc(&h->state_lo, 13 * h->ld * es);
-  if (e == hipSuccess && is_comp(h)) e = hipMemset(h->state_lo, 0, 13 * h->ld * es);
+  if (e == hipSuccess && is_comp(h)) e = hipMalloc(&h->state_lo, 4 * h->ld * es);
+  if (e == hipSuccess && is_comp(h)) e = hipMemset(h->state_lo, 0, 4 * h->ld * es);
   if (e == hipSuccess && h->envfx) e = hipMalloc(&h->state_alt, 13 * h->ld * es);
   if (e == hipSuccess && h->envfx) e = hipMemset(h->state_alt, 0, 13 * h->ld * es);
   if (e == hipSuccess && h->envfx) e = hipMalloc(&h->act_scratch, (size_t)h->n * 4 * es);
@@ -1040,7 +1034,7 @@ int mds_rollout_step_fused(mds_handle* h, const void* actions, int n_action_sets
   if (!h || !actions || n_action_sets < 1 || first_step < 0 || n_steps < 0 || (obs_log && log_slots < 1) || episode_len < 0 ||
       steps_per_launch < 1)
     return fail(MDS_EINVAL, "mds_rollout_step_fused: arguments");
-  if (h->envfx || is_comp(h))   // env-mates interact every substep / residual planes: no state-in-registers form; the step-by-step loop serves it
+  if (h->envfx)                 // env-mates interact every substep: no state-in-registers form; the step-by-step loop serves it
     return mds_rollout_step(h, actions, n_action_sets, first_step, n_steps, obs_log, log_slots, episode_len, stream);
   if (episode_len > 0 && !h->init_pose) return fail(MDS_ESTATE, "mds_rollout_step_fused: episode resets need an earlier mds_reset");
   const size_t es = elem_size(h->cfg.dtype), act_bytes = (size_t)h->n * 4 * es, obs_bytes = (size_t)h->n * kObsDim * es;
@@ -1063,7 +1057,8 @@ int mds_rollout_step_fused(mds_handle* h, const void* actions, int n_action_sets
 #define MDS_RS(RK4, DRAG)                                                                                                     \
   MDS_DISPATCH(h, (k_rollout_step<T, S, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, h->n, h->ld, (S*)h->state, (const T*)h->origin,  \
                                                                             (T*)rpm_track(h), (const S*)actions, a0, n_action_sets, \
-                                                                            (S*)obs_log, s0, obs_log ? log_slots : 1, (int)chunk)))
+                                                                            (S*)obs_log, s0, obs_log ? log_slots : 1, (int)chunk, \
+                                                                            (S*)h->state_lo)))
     if (rk4 && drag) MDS_RS(true, true);
     else if (rk4) MDS_RS(true, false);
     else if (drag) MDS_RS(false, true);
@@ -1101,7 +1096,6 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
 // ctrl: 0 GeometricControl, 1 LQRController (12-state), 2 LQROmegaController + ThrustOmega, 3 LQRYankOmegaController + YankOmega
 static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream, int ctrl, const char* who) {
   if (!h || n_steps < 0) return fail(MDS_EINVAL, who);
-  MDS_NO_COMP(h, "mds_rollout_*_fused");
   if (h->envfx) {
     // ground effect / downwash: env-mates interact every physics substep, so there is no state-in-registers form; the same loop
     // runs step by step (one launch per substep), each step's observation written straight into its slot of the log
@@ -1147,11 +1141,11 @@ static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, v
   MDS_DISPATCH(h, (k_rollout_geometric<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, gain, h->n, h->ld, t0, dt,                       \
                                                                                        n_steps, (S*)h->state, (const T*)h->lem,       \
                                                                                        (T*)rpm_track(h), (S*)obs_log, (S*)obs_last,   \
-                                                                                       (T*)h->ll, (const S*)obs_last)))
+                                                                                       (T*)h->ll, (const S*)obs_last, (S*)h->state_lo)))
 #define MDS_ROLLT(RK4, DRAG, CTRL)                                                                                                 \
   MDS_DISPATCH(h, (k_rollout_traj<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, gain, h->n, h->ld, t0, dt,                                 \
                                                                                   n_steps, (S*)h->state, (const T*)h->origin, SegTable{h->segs, h->nseg_total}, \
-                                                                                  h->tinfo, (T*)rpm_track(h), (S*)obs_log, (S*)obs_last)))
+                                                                                  h->tinfo, (T*)rpm_track(h), (S*)obs_log, (S*)obs_last, (S*)h->state_lo)))
 #define MDS_ROLL_C(CTRL)                                                    \
   do {                                                                      \
     if (h->traj_mode == 2) {   /* general trajectories: segment tables */   \
@@ -1502,7 +1496,7 @@ int mds_dslpid_reset(mds_handle* h, void* stream) {
   k_dslpid<T, S, STEP, RK4, DRAG><<<PID_GRID, kBlock, 0, st>>>(C, G, h->n, h->ld, (T)(1.0 / h->cfg.ctrl_freq), (S*)h->state, \
                                                                (const T*)h->origin, (T*)rpm_track(h), (T*)h->pid,            \
                                                                (const S*)obs_in, (const S*)tpos, (const S*)trpy, (S*)obs,   \
-                                                               (S*)act, PID_B0)
+                                                               (S*)act, PID_B0, (S*)h->state_lo)
 #define MDS_PID_DTYPE(STEP, RK4, DRAG)                                                        \
   do {                                                                                        \
     if (h->cfg.dtype == MDS_F64) MDS_PID_LAUNCH(double, double, h->cd, h->pid_d, STEP, RK4, DRAG); \
@@ -1553,7 +1547,6 @@ int mds_dslpid_compute(mds_handle* h, const void* obs_in, const void* tpos, cons
 int mds_step_dslpid(mds_handle* h, const void* tpos, const void* trpy, void* obs, void* act, void* stream) {
   MDS_DEV(h);
   if (!h || !tpos || !trpy) return fail(MDS_EINVAL, "mds_step_dslpid: null argument");
-  MDS_NO_COMP(h, "mds_step_dslpid");
   if (!aligned16(obs) || !aligned16(act)) return fail(MDS_EALIGN, "mds_step_dslpid: obs_dev/action_dev");
   if (h->envfx) return step_env_dslpid(h, tpos, trpy, obs, act, (hipStream_t)stream);
   launch_step_dslpid(h, tpos, trpy, obs, act, (hipStream_t)stream);
@@ -1565,7 +1558,6 @@ int mds_rollout_dslpid(mds_handle* h, const void* tpos, const void* trpy, int n_
                        int obs_every_step, void* stream) {
   MDS_DEV(h);
   if (!h || !tpos || !trpy || n_target_sets < 1 || first_step < 0 || n_steps < 0) return fail(MDS_EINVAL, "mds_rollout_dslpid: arguments");
-  MDS_NO_COMP(h, "mds_rollout_dslpid");
   if (!aligned16(obs)) return fail(MDS_EALIGN, "mds_rollout_dslpid: obs_dev");
   hipStream_t st = (hipStream_t)stream;
   const size_t set_bytes = (size_t)h->n * 3 * elem_size(h->cfg.dtype);
@@ -1672,7 +1664,6 @@ int mds_lqr_compute(mds_handle* h, const void* obs, const void* des, void* u, vo
 int mds_step_lqr(mds_handle* h, double t, void* obs, void* act, void* stream) {
   MDS_DEV(h);
   if (!h) return fail(MDS_EINVAL, "mds_step_lqr: null handle");
-  MDS_NO_COMP(h, "mds_step_lqr");
   if (!h->has_traj) return fail(MDS_ESTATE, "mds_step_lqr: call mds_set_lemniscate / mds_set_trajectory_segments first");
   if (!h->has_lqr12) return fail(MDS_ESTATE, "mds_step_lqr: call mds_set_lqr_gain first");
   if (!aligned16(obs) || !aligned16(act)) return fail(MDS_EALIGN, "mds_step_lqr: obs_dev/action_dev");
@@ -1682,7 +1673,8 @@ int mds_step_lqr(mds_handle* h, double t, void* obs, void* act, void* stream) {
   const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
 #define MDS_LQR_T(T, S, C, K, RK4, DRAG)                                                                                          \
   k_step_lqr<T, S, RK4, DRAG><<<grid, kBlock, 0, st>>>(C, K, h->n, h->ld, t, h->traj_mode, (S*)h->state, (const T*)h->origin,     \
-                                                       (const T*)h->lem, SegTable{h->segs, h->nseg_total}, h->tinfo, (T*)rpm_track(h), (S*)obs, (S*)act)
+                                                       (const T*)h->lem, SegTable{h->segs, h->nseg_total}, h->tinfo, (T*)rpm_track(h), (S*)obs, (S*)act, \
+                                                       (S*)h->state_lo)
 #define MDS_LQR(RK4, DRAG)                                                                    \
   do {                                                                                        \
     if (h->cfg.dtype == MDS_F64) MDS_LQR_T(double, double, h->cd, h->lqr12_d, RK4, DRAG);     \
@@ -2083,7 +2075,7 @@ int mds_step_nominal(mds_handle* h, double t, void* obs, void* action, void* str
   if (h->cfg.dtype == MDS_F16) return fail(MDS_EUNSUPPORTED, "mds_step_nominal: fp16 storage");
   // no action wanted: the one-step instance of the whole-rollout kernel does LQR + low level + physics in one launch
   // (212 B per drone-step instead of 392 B over two launches: 34 / 48 us -> 18 us at C3)
-  if (!action && h->has_traj && h->traj_mode == 1 && !h->envfx && !is_comp(h))
+  if (!action && h->has_traj && h->traj_mode == 1 && !h->envfx)
     return rollout_fused(h, t, 1, nullptr, obs, stream, h->cbf_nominal == 2 ? 3 : 2, "mds_step_nominal");
   return step_nominal_lowlevel(h, t, obs, nullptr, action, stream, false, "mds_step_nominal");
 }

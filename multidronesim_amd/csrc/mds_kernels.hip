@@ -99,18 +99,26 @@ template <typename T, typename S> __device__ __forceinline__ State<T> state_as_s
   return o;
 }
 
-// residual planes of the compensated storage (MDS_F32C): same packed layout as the state
+// Residual storage of the compensated dtype (MDS_F32C): the BODY RATES only -- one 4-wide group per drone, (r_wx, r_wy, r_wz, 0) at
+// lo[4 i ..].  Round 2 kept a residual for each of the 13 components (+104 B per drone-step); measured on the device templates
+// (tests/emul, 256 drones, open loop, 240 Hz x 1000 steps, max abs state error against the float64 oracle, five seeds): plain fp32
+// 1.0-1.4e-5; residuals of q only 1.1e-5, p and q 9.8e-6, w only 4.6-6.2e-6, p and w 3.2-4.8e-6, all thirteen 2.5-3.3e-6.  The
+// rounding of the stored RATE (6e-8 of ~1 rad/s per step, a random walk) is what tilts the thrust; the quaternion's own stored
+// rounding is second order.  So the dtype keeps the three rate residuals (+32 B per drone-step: one 16-byte load and store) and
+// runs the step's accumulations compensated in registers (all 13, across the substeps of a control step); what the other ten
+// residuals hold at the end of the step is dropped.
+__host__ __device__ __forceinline__ size_t ridx(int k, size_t i) { return 4 * i + (size_t)(k - 10); }   // k = 10, 11, 12 (w)
 template <typename S, typename T> __device__ __forceinline__ void load_resid(const S* __restrict__ lo, size_t ld, size_t i, Resid<T>& r) {
-  State<T> t;
-  load_state<S, T>(lo, ld, i, t);
-  r.p = t.p; r.v = t.v; r.w = t.w;
-  for (int k = 0; k < 4; ++k) r.q[k] = t.q[k];
+  (void)ld;
+  T a[4];
+  load4<S, T>(lo + 4 * i, a);
+  resid_zero(r);
+  r.w = {a[0], a[1], a[2]};
 }
 template <typename S, typename T> __device__ __forceinline__ void store_resid(S* __restrict__ lo, size_t ld, size_t i, const Resid<T>& r) {
-  State<T> t;
-  t.p = r.p; t.v = r.v; t.w = r.w;
-  for (int k = 0; k < 4; ++k) t.q[k] = r.q[k];
-  store_state<S, T>(lo, ld, i, t);
+  (void)ld;
+  const T a[4] = {r.w.x, r.w.y, r.w.z, T(0)};
+  store4<S, T>(lo + 4 * i, a);
 }
 // one control step of the rigid body, plain or with compensated accumulation
 template <typename T, bool RK4, bool DRAG, bool COMP>
@@ -222,11 +230,15 @@ template <typename T, typename S, bool RK4, bool DRAG>
 __global__ __launch_bounds__(kBlock) void k_rollout_step(const Consts<T> c, const int n, const size_t ld, S* __restrict__ state,
                                                          const T* __restrict__ origin, T* __restrict__ last_rpm,
                                                          const S* __restrict__ actions, int a0, const int n_sets,
-                                                         S* __restrict__ obs_log, int s0, const int n_slots, const int n_steps) {
+                                                         S* __restrict__ obs_log, int s0, const int n_slots, const int n_steps,
+                                                         S* __restrict__ state_lo = nullptr) {
   __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const bool valid = i < n;
   State<T> s;
+  Resid<T> r;
+  resid_zero(r);
+  if (valid && state_lo) load_resid<S, T>(state_lo, ld, i, r);
   V3<T> org = {T(0), T(0), T(0)};
   T prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4] = {T(0), T(0), T(0), T(0)};
   if (valid) {
@@ -240,7 +252,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_step(const Consts<T> c, cons
     if (valid) {
       T act[4];
       load4<S, T>(actions + ((size_t)a0 * n + i) * 4, act);
-      aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
+      if (state_lo) aviary_step_comp<T, RK4, DRAG>(c, s, r, act, prev, clipped);
+      else aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
       if (obs_log != nullptr) pack_obs(s, org, clipped, o);
     }
     if (obs_log != nullptr) write_obs_rows<S, T>(lds, obs_log + (size_t)s0 * n * kObsDim, n, i, valid, o);
@@ -249,6 +262,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_step(const Consts<T> c, cons
   }
   if (valid) {
     store_state<S, T>(state, ld, i, s);
+    if (state_lo) store_resid<S, T>(state_lo, ld, i, r);
     if ((DRAG || last_rpm) && n_steps > 0)
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
   }
@@ -536,14 +550,16 @@ __global__ __launch_bounds__(kBlock) void k_step_lqr(const Consts<T> c, const Lq
                                                      const int traj_mode, S* __restrict__ state, const T* __restrict__ origin,
                                                      const T* __restrict__ lem, const SegTable segs,
                                                      const int* __restrict__ tinfo, T* __restrict__ last_rpm, S* __restrict__ obs,
-                                                     S* __restrict__ action_out) {
+                                                     S* __restrict__ action_out, S* __restrict__ state_lo = nullptr) {
   __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const bool valid = i < n;
   T o[kObsDim];
   State<T> s;
+  Resid<T> r;                  // state_lo != NULL (MDS_F32C handles, a uniform branch): compensated accumulation
   if (valid) {
     load_state<S, T>(state, ld, i, s);
+    if (state_lo) load_resid<S, T>(state_lo, ld, i, r);
     const V3<T> org = {origin[i], origin[ld + i], origin[2 * ld + i]};
     Desired<T> des;
     if (traj_mode == 1) {
@@ -558,14 +574,18 @@ __global__ __launch_bounds__(kBlock) void k_step_lqr(const Consts<T> c, const Lq
       for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
     lqr12_control<T>(c, K, euler_from_quat(s.q), quat_rotate(s.q, s.w), s.v, s.p - des.p, des.v, des.yaw, des.yaw_rate, u);
     input_to_action(c, u, act);
-    aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
+    if (state_lo) aviary_step_comp<T, RK4, DRAG>(c, s, r, act, prev, clipped);
+    else aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
     if (DRAG || last_rpm)
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
     if (action_out) store4<S, T>(action_out + (size_t)i * 4, act);
     if (obs) pack_obs(s, org, clipped, o);
   }
   if (obs) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
-  if (valid) store_state<S, T>(state, ld, i, s);
+  if (valid) {
+    store_state<S, T>(state, ld, i, s);
+    if (state_lo) store_resid<S, T>(state_lo, ld, i, r);
+  }
 }
 
 // LQRController.compute(obs) (lqr_controller.py:83-113): obs [n,20], des [n,11] (pos, vel, -, yaw, omega) -> u [n,4], action [n,4]
@@ -612,11 +632,14 @@ __global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c,
                                                               const double ctrl_dt, const int n_steps, S* __restrict__ state,
                                                               const T* __restrict__ lem, T* __restrict__ last_rpm,
                                                               S* __restrict__ obs_log, S* __restrict__ obs_last,
-                                                              T* __restrict__ ll = nullptr, const S* __restrict__ obs_prev = nullptr) {
+                                                              T* __restrict__ ll = nullptr, const S* __restrict__ obs_prev = nullptr,
+                                                              S* __restrict__ state_lo = nullptr) {
   __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const bool valid = i < n;
   GeoIn<T> in;
+  resid_zero(in.r);            // state_lo != NULL (MDS_F32C handles, a uniform branch): compensated accumulation, all 13 residuals in registers
+  if (valid && state_lo) load_resid<S, T>(state_lo, ld, i, in.r);
   T prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4] = {T(0), T(0), T(0), T(0)};
   LowLevelState<T> L;
   L.last_omega = L.integral = {T(0), T(0), T(0)};
@@ -655,7 +678,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c,
         else if (CTRL == 2) thrust_omega_control(c, (T)ctrl_dt, u, in.s.w, L, act);
         else yank_omega_control(c, (T)ctrl_dt, u, clipped, in.s.w, L, act);
       }
-      aviary_step<T, RK4, DRAG>(c, in.s, act, prev, clipped);
+      if (state_lo) aviary_step_comp<T, RK4, DRAG>(c, in.s, in.r, act, prev, clipped);
+      else aviary_step<T, RK4, DRAG>(c, in.s, act, prev, clipped);
       if (want) pack_obs(in.s, V3<T>{in.P.cx, in.P.cy, in.P.cz}, clipped, o);
     }
     if (obs_log != nullptr) write_obs_rows<S, T>(lds, obs_log + (size_t)k * n * kObsDim, n, i, valid, o);
@@ -664,6 +688,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c,
   }
   if (valid) {
     store_state<S, T>(state, ld, i, in.s);
+    if (state_lo) store_resid<S, T>(state_lo, ld, i, in.r);
     if (DRAG || (last_rpm && n_steps > 0))
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = DRAG ? prev[k] : clipped[k];
     if (CTRL >= 2) {
@@ -679,11 +704,14 @@ __global__ __launch_bounds__(kBlock) void k_rollout_traj(const Consts<T> c, cons
                                                          const double ctrl_dt, const int n_steps, S* __restrict__ state,
                                                          const T* __restrict__ origin, const SegTable segs,
                                                          const int* __restrict__ tinfo, T* __restrict__ last_rpm,
-                                                         S* __restrict__ obs_log, S* __restrict__ obs_last) {
+                                                         S* __restrict__ obs_log, S* __restrict__ obs_last, S* __restrict__ state_lo = nullptr) {
   __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const bool valid = i < n;
   State<T> s;
+  Resid<T> r;
+  resid_zero(r);
+  if (valid && state_lo) load_resid<S, T>(state_lo, ld, i, r);
   V3<T> org = {T(0), T(0), T(0)};
   TrajInfo ti = {0, 1, 0, 0};
   T prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4] = {T(0), T(0), T(0), T(0)};
@@ -708,7 +736,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_traj(const Consts<T> c, cons
                          des.yaw_rate, u);
       }
       input_to_action(c, u, act);
-      aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
+      if (state_lo) aviary_step_comp<T, RK4, DRAG>(c, s, r, act, prev, clipped);
+      else aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
       if (want) pack_obs(s, org, clipped, o);
     }
     if (obs_log != nullptr) write_obs_rows<S, T>(lds, obs_log + (size_t)k * n * kObsDim, n, i, valid, o);
@@ -717,6 +746,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_traj(const Consts<T> c, cons
   }
   if (valid) {
     store_state<S, T>(state, ld, i, s);
+    if (state_lo) store_resid<S, T>(state_lo, ld, i, r);
     if (DRAG || (last_rpm && n_steps > 0))
       for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = DRAG ? prev[k] : clipped[k];
   }
@@ -936,15 +966,17 @@ __global__ __launch_bounds__(kBlock) void k_dslpid(const Consts<T> c, const DslP
                                                    S* __restrict__ state, const T* __restrict__ origin, T* __restrict__ last_rpm,
                                                    T* __restrict__ pid, const S* __restrict__ obs_in, const S* __restrict__ tpos,
                                                    const S* __restrict__ trpy, S* __restrict__ obs, S* __restrict__ action_out,
-                                                   const int batch0) {
+                                                   const int batch0, S* __restrict__ state_lo = nullptr) {
   __shared__ __align__(16) unsigned char lds[STEP ? (kBlock * kObsDim * sizeof(S)) : 16];
   // batch0: first 256-drone batch of this launch (mds_rollout_dslpid may step the two halves of the shard on two streams)
   const int i = (batch0 + blockIdx.x) * kBlock + threadIdx.x;
   const bool valid = i < n;
   T o[kObsDim];
   State<T> s;
+  Resid<T> r;                   // STEP with state_lo != NULL (MDS_F32C handles, a uniform branch): compensated accumulation
   if (valid) {
     V3<T> org = {T(0), T(0), T(0)};
+    if (STEP && state_lo) load_resid<S, T>(state_lo, ld, i, r);
     if (STEP || !obs_in) {      // controller only with obs_in == NULL: from the handle's own state (ground effect / downwash steps)
       load_state<S, T>(state, ld, i, s);
       org = {origin[i], origin[ld + i], origin[2 * ld + i]};
@@ -970,7 +1002,8 @@ __global__ __launch_bounds__(kBlock) void k_dslpid(const Consts<T> c, const DslP
     if (STEP) {
       if (DRAG)
         for (int k = 0; k < 4; ++k) prev[k] = last_rpm[k * ld + i];
-      aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
+      if (state_lo) aviary_step_comp<T, RK4, DRAG>(c, s, r, act, prev, clipped);
+      else aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
       if (DRAG || last_rpm)
         for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = clipped[k];
       if (obs) pack_obs(s, org, clipped, o);
@@ -978,7 +1011,10 @@ __global__ __launch_bounds__(kBlock) void k_dslpid(const Consts<T> c, const DslP
   }
   if (STEP) {
     if (obs) write_obs_rows<S, T>(lds, obs, n, i, valid, o);
-    if (valid) store_state<S, T>(state, ld, i, s);
+    if (valid) {
+      store_state<S, T>(state, ld, i, s);
+      if (state_lo) store_resid<S, T>(state_lo, ld, i, r);
+    }
   }
 }
 
@@ -1007,7 +1043,7 @@ __global__ __launch_bounds__(kBlock) void k_get_obs(const int n, const size_t ld
 // ------------------------------------------------------------------------------------
 // set-up kernels (double in, storage out; not on the hot path)
 // ------------------------------------------------------------------------------------
-// state_lo (compensated storage, else NULL): what the rounding to S dropped
+// state_lo (compensated storage, else NULL): what the rounding to S dropped from the body rates (load_resid's layout)
 template <typename T, typename S>
 __global__ void k_reset(const int n, const size_t ld, const double* __restrict__ xyz, const double* __restrict__ rpy,
                         const T* __restrict__ origin, S* __restrict__ state, T* __restrict__ last_rpm, const int i0,
@@ -1020,8 +1056,9 @@ __global__ void k_reset(const int n, const size_t ld, const double* __restrict__
     const double v = k < 3 ? xyz[3 * i + k] - (double)origin[k * ld + i] : (k < 7 ? q[k - 3] : 0.0);
     const S hi = (S)v;
     state[sidx(k, i, ld)] = hi;
-    if (state_lo) state_lo[sidx(k, i, ld)] = (S)(v - (double)hi);
+    if (state_lo && k >= 10) state_lo[ridx(k, i)] = (S)(v - (double)hi);
   }
+  if (state_lo) state_lo[4 * (size_t)i + 3] = (S)0;
   for (int k = 0; k < 4; ++k) last_rpm[k * ld + i] = T(0);
 }
 
@@ -1031,14 +1068,13 @@ __global__ void k_set_origin(const int n, const size_t ld, const double* __restr
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   for (int k = 0; k < 3; ++k) {
-    const double world = (double)state[sidx(k, i, ld)] + (state_lo ? (double)state_lo[sidx(k, i, ld)] : 0.0) + (double)origin[k * ld + i];
+    const double world = (double)state[sidx(k, i, ld)] + (double)origin[k * ld + i];      // (no position residual is stored)
     const T no = (T)new_origin[3 * i + k];
     origin[k * ld + i] = no;
     const double local = world - (double)no;
-    const S hi = (S)local;
-    state[sidx(k, i, ld)] = hi;
-    if (state_lo) state_lo[sidx(k, i, ld)] = (S)(local - (double)hi);
+    state[sidx(k, i, ld)] = (S)local;
   }
+  (void)state_lo;
 }
 
 template <typename T, typename S>
@@ -1048,7 +1084,7 @@ __global__ void k_get_state(const int n, const size_t ld, const S* __restrict__ 
   if (i >= n) return;
   for (int k = 0; k < 13; ++k) {
     double v = (double)state[sidx(k, i, ld)];
-    if (state_lo) v += (double)state_lo[sidx(k, i, ld)];
+    if (state_lo && k >= 10) v += (double)state_lo[ridx(k, i)];
     if (k < 3) v += (double)origin[k * ld + i];
     out[13 * (size_t)i + k] = v;
   }
@@ -1064,8 +1100,9 @@ __global__ void k_set_state(const int n, const size_t ld, const double* __restri
     if (k < 3) v -= (double)origin[k * ld + i];
     const S hi = (S)v;
     state[sidx(k, i, ld)] = hi;
-    if (state_lo) state_lo[sidx(k, i, ld)] = (S)(v - (double)hi);
+    if (state_lo && k >= 10) state_lo[ridx(k, i)] = (S)(v - (double)hi);
   }
+  if (state_lo) state_lo[4 * (size_t)i + 3] = (S)0;
 }
 
 template <typename T>

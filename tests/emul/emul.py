@@ -42,7 +42,10 @@ class Emul:
     def __init__(self, dtype="f32", num_envs=1, num_drones=1, pyb_freq=100, ctrl_freq=100, physics=0, integrator=0,
                  model=MDS_CF2P):
         L = lib()
-        comp = dtype == "f32c"           # fp32 arithmetic, compensated state accumulation (MDS_F32C)
+        comp = dtype.startswith("f32c")  # fp32 arithmetic, compensated accumulation: "f32c" = MDS_F32C as the device stores it (residuals
+        mask = {"f32c": 8, "f32c13": 15}.get(dtype, 8) if comp else 0      # of the body rates only); "f32c13" = all 13, "f32c:<mask>" = study
+        if comp and ":" in dtype:
+            mask = int(dtype.split(":")[1])
         dtype = "f32" if comp else dtype
         self.sfx = dtype
         self.cfg = MdsConfig()
@@ -55,6 +58,7 @@ class Emul:
         self.h = C.c_void_p(getattr(L, f"emul_create_{dtype}")(C.byref(self.cfg), C.byref(self.gains)))
         if comp:
             self._f("emul_set_comp")(self.h, C.c_int(1))
+            L.emul_set_comp_mask_f32(self.h, C.c_int(mask))
 
     def _f(self, name):
         return getattr(lib(), f"{name}_{self.sfx}")

@@ -34,6 +34,8 @@ template <typename T> struct Emul {
   Consts<T> c;
   int n;
   int comp = 0;          // 1: compensated accumulation (MDS_F32C)
+  int comp_mask = 8;     // which residuals survive a step (1 p, 2 q, 4 v, 8 w).  8 = the device's MDS_F32C storage (body rates only,
+                         // load_resid / store_resid in mds_kernels.hip); other masks: the study behind that choice
   Resid<T>* r;
   State<T>* s;
   T (*prev)[4];
@@ -56,6 +58,14 @@ template <typename T> static void* emul_create(const mds_config* cfg, const mds_
   return e;
 }
 
+// residuals that are not stored are lost between control steps
+template <typename T> static void emul_drop_unstored(Emul<T>* e, int i) {
+  Resid<T>& r = e->r[i];
+  if (!(e->comp_mask & 1)) r.p = {T(0), T(0), T(0)};
+  if (!(e->comp_mask & 2)) r.q[0] = r.q[1] = r.q[2] = r.q[3] = T(0);
+  if (!(e->comp_mask & 4)) r.v = {T(0), T(0), T(0)};
+  if (!(e->comp_mask & 8)) r.w = {T(0), T(0), T(0)};
+}
 template <typename T> static void emul_set_state(void* h, const double* st) {
   Emul<T>* e = (Emul<T>*)h;
   for (int i = 0; i < e->n; ++i) {
@@ -69,6 +79,7 @@ template <typename T> static void emul_set_state(void* h, const double* st) {
       for (int k = 0; k < 4; ++k) r.q[k] = (T)(o[3 + k] - (double)s.q[k]);
       r.v = {(T)(o[7] - (double)s.v.x), (T)(o[8] - (double)s.v.y), (T)(o[9] - (double)s.v.z)};
       r.w = {(T)(o[10] - (double)s.w.x), (T)(o[11] - (double)s.w.y), (T)(o[12] - (double)s.w.z)};
+      emul_drop_unstored(e, i);
     }
   }
 }
@@ -107,6 +118,7 @@ template <typename T> static void emul_step(void* h, const double* action, doubl
     for (int k = 0; k < 4; ++k) act[k] = (T)action[4 * i + k];
     if (e->comp) emul_aviary_step_comp(e->c, e->s[i], e->r[i], act, e->prev[i], clipped);
     else emul_aviary_step(e->c, e->s[i], act, e->prev[i], clipped);
+    if (e->comp) emul_drop_unstored(e, i);
     if (obs) {
       pack_obs(e->s[i], V3<T>{(T)e->org[i][0], (T)e->org[i][1], (T)e->org[i][2]}, clipped, o);
       for (int k = 0; k < 20; ++k) obs[20 * i + k] = o[k];
@@ -125,6 +137,7 @@ template <typename T> static void emul_step_geo(void* h, double t, double* obs, 
     input_to_action(e->c, u, act);
     if (e->comp) emul_aviary_step_comp(e->c, s, e->r[i], act, e->prev[i], clipped);
     else emul_aviary_step(e->c, s, act, e->prev[i], clipped);
+    if (e->comp) emul_drop_unstored(e, i);
     if (act_out)
       for (int k = 0; k < 4; ++k) act_out[4 * i + k] = act[k];
     if (obs) {
@@ -174,6 +187,7 @@ extern "C" {
 void* emul_create_f32(const mds_config* c, const mds_geometric_gains* g) { return emul_create<float>(c, g); }
 void* emul_create_f64(const mds_config* c, const mds_geometric_gains* g) { return emul_create<double>(c, g); }
 void emul_set_comp_f32(void* h, int on) { ((Emul<float>*)h)->comp = on; }
+void emul_set_comp_mask_f32(void* h, int mask) { ((Emul<float>*)h)->comp_mask = mask; }
 void emul_set_comp_f64(void* h, int on) { ((Emul<double>*)h)->comp = on; }
 void emul_set_state_f32(void* h, const double* s) { emul_set_state<float>(h, s); }
 void emul_set_state_f64(void* h, const double* s) { emul_set_state<double>(h, s); }

@@ -89,29 +89,27 @@ def test_device_step_accelerations_match_the_reference_tree(dt, atol_v, rtol_w):
 
 
 def test_compensated_fp32_open_loop_holds_1e5_over_1000_steps():
-    """The compensated accumulation of the device templates (step_euler_wrench_comp, integrate_q_comp: value + residual per state
-    component) on the CPU build: uncontrolled 240 Hz flight, 1000 steps, against the float64 oracle -- 1e-5 holds (plain fp32: 1.4e-5)."""
+    """The compensated accumulation of the device templates (step_euler_wrench_comp, integrate_q_comp) on the CPU build, with the
+    residuals the device keeps between control steps: uncontrolled 240 Hz flight, 1000 steps, against the float64 oracle.
+    MDS_F32C stores the residuals of the three BODY RATES only (+32 B per drone-step); the study behind that choice, max abs state
+    error at step 1000: plain fp32 1.4e-5; residuals of q only 1.1e-5 (no help: the stored quaternion is not the lever, the stored
+    rate that turns it is), w only 6.2e-6, p and w 4.8e-6, all thirteen 3.3e-6 (+104 B)."""
     n = 256
     xyz, rpy, ph = H.open_loop_setup(n)
-    errs = {}
-    for dt in ("f32", "f32c"):
-        ora = O.AviaryOracle(xyz, rpy, pyb_freq=240, ctrl_freq=240)
-        em = E.Emul(dt, num_envs=n, pyb_freq=240, ctrl_freq=240)
+
+    def run(dt, integrator=0):
+        ora = O.AviaryOracle(xyz, rpy, pyb_freq=240, ctrl_freq=240, integrator="rk4" if integrator else "euler")
+        em = E.Emul(dt, num_envs=n, pyb_freq=240, ctrl_freq=240, integrator=integrator)
         em.set_state(np.concatenate([ora.pos, ora.quat, ora.vel, ora.rates], axis=1))
         s0 = em.get_state()
         ora.pos, ora.quat, ora.vel, ora.rates = s0[:, 0:3].copy(), s0[:, 3:7].copy(), s0[:, 7:10].copy(), s0[:, 10:13].copy()
         for k in range(1000):
             a = H.open_loop_rpm(k, ora.CTRL_TIMESTEP, ph)
             obs, eo = ora.step(a), em.step(a)
-        errs[dt] = np.abs(eo[:, :16] - obs[:, :16]).max()
-    assert errs["f32c"] < 5e-6 and errs["f32c"] < 0.5 * errs["f32"], errs
-    # RK4 with the same accumulation
-    ora = O.AviaryOracle(xyz, rpy, pyb_freq=240, ctrl_freq=240, integrator="rk4")
-    em = E.Emul("f32c", num_envs=n, pyb_freq=240, ctrl_freq=240, integrator=1)
-    em.set_state(np.concatenate([ora.pos, ora.quat, ora.vel, ora.rates], axis=1))
-    s0 = em.get_state()
-    ora.pos, ora.quat, ora.vel, ora.rates = s0[:, 0:3].copy(), s0[:, 3:7].copy(), s0[:, 7:10].copy(), s0[:, 10:13].copy()
-    for k in range(1000):
-        a = H.open_loop_rpm(k, ora.CTRL_TIMESTEP, ph)
-        obs, eo = ora.step(a), em.step(a)
-    assert np.abs(eo[:, :16] - obs[:, :16]).max() < 1e-5
+        return np.abs(eo[:, :16] - obs[:, :16]).max()
+
+    errs = {dt: run(dt) for dt in ("f32", "f32c", "f32c:2", "f32c13")}
+    assert errs["f32c"] < 8e-6 and errs["f32c"] < 0.6 * errs["f32"], errs              # the device's storage: north_star's 1e-5 holds
+    assert errs["f32c:2"] > 0.7 * errs["f32"], errs                                      # quaternion residuals alone buy nothing
+    assert errs["f32c13"] < errs["f32c"] < 3 * errs["f32c13"], errs                      # ten more residuals: less than 2x better
+    assert run("f32c", integrator=1) < 1e-5                                              # RK4 with the same accumulation

@@ -64,12 +64,13 @@ def test_step_f64_matches_oracle_1000_steps(mds, kw):
     env.close()
 
 
-@pytest.mark.parametrize("dtype,gate_500,gate_1000", [("float32", 1e-5, 3e-5), ("float32c", 2e-6, 1e-5)])
+@pytest.mark.parametrize("dtype,gate_500,gate_1000", [("float32", 1e-5, 3e-5), ("float32c", 5e-6, 1e-5)])
 def test_step_f32_open_loop(mds, dtype, gate_500, gate_1000):
     """fp32 state, uncontrolled near-hover flight at 240 Hz.  Open loop the quadrotor is a chain of integrators, so the rounding of
     the stored state grows ~t^2.5: plain fp32 holds 1e-5 for 500 steps and 1.4e-5 at 1000 (gate 3e-5); with compensated accumulation
-    (MDS_F32C: value + residual per component, two-sum) north_star's 1e-5 holds over the full 1000 steps (measured 3.2e-6).  The
-    closed-loop configs below hold 1e-5 over 1000 steps in plain fp32."""
+    (MDS_F32C: two-sum inside the step, the residuals of the three body rates kept between steps: +32 B per drone-step) north_star's
+    1e-5 holds over the full 1000 steps (measured 6.2e-6; with all 13 residuals, round 2's +104 B: 3.2e-6).  The closed-loop
+    configs below hold 1e-5 over 1000 steps in plain fp32."""
     n = 256
     xyz, rpy, ph = H.open_loop_setup(n)
     ora = O.AviaryOracle(xyz, rpy, pyb_freq=240, ctrl_freq=240)
@@ -91,10 +92,10 @@ def test_step_f32_open_loop(mds, dtype, gate_500, gate_1000):
 
 
 def test_compensated_fp32_storage_round_trips_and_equals_fp32_paths(mds):
-    """MDS_F32C bookkeeping: set_state / get_state carry value + residual (a float64 state survives to ~1e-14), set_origin re-bases
-    both, reset clears the residuals; the fused geometric step, its C rollout on two chains and the segment-table kernel accept the
-    dtype (closed loop within 1e-5 of the oracle over 300 steps, two-chain rollout bitwise equal to the step-by-step loop); the
-    state-in-registers kernels refuse it."""
+    """MDS_F32C bookkeeping: set_state / get_state carry value + residual for the body rates (a float64 rate survives to ~1e-14, the
+    other components to fp32 rounding), reset clears the residuals; the fused geometric step, its C rollout on two chains and the
+    segment-table kernel accept the dtype (closed loop within 1e-5 of the oracle over 300 steps, two-chain rollout bitwise equal to
+    the step-by-step loop); so do the state-in-registers kernels, mds_step_lqr and mds_step_dslpid (round 3)."""
     torch = mds.torch
     E, D = 37, 7
     xyz, rpy, P = H.c2_setup(E, D, phase="c3")
@@ -104,10 +105,16 @@ def test_compensated_fp32_storage_round_trips_and_equals_fp32_paths(mds):
     st = rng.normal(size=(E * D, 13))
     st[:, 3:7] /= np.linalg.norm(st[:, 3:7], axis=1, keepdims=True)
     env.set_state(st)
-    np.testing.assert_allclose(env.get_state().reshape(-1, 13), st, rtol=0, atol=1e-13)
-    env.set_trajectories(P)                                   # re-bases the local frame (origin = centres), residuals follow
+    got = env.get_state().reshape(-1, 13)
+    np.testing.assert_allclose(got[:, 10:13], st[:, 10:13], rtol=0, atol=1e-13)         # rates: value + residual
+    np.testing.assert_allclose(got[:, :10], st[:, :10], rtol=0, atol=4e-7)              # the rest: fp32 values
+    assert np.abs(got[:, :10] - st[:, :10]).max() > 1e-9
+    env.set_trajectories(P)                                   # re-bases the local frame (origin = centres)
     np.testing.assert_allclose(env.get_state().reshape(-1, 13), st, rtol=0, atol=1e-6)      # origin is an fp32 value
     env.reset()
+    np.testing.assert_array_equal(env.get_state().reshape(-1, 13)[:, 10:13], 0.0)         # rates and their residuals cleared
+    env.close()
+    env = make_env(mds, E, D, xyz, rpy, "float32c")           # (a fresh env: positions carry no residual, so env and b must be set up alike)
     env.set_trajectories(P)
     obs_o, _ = H.oracle_closed_loop(xyz, rpy, P, 300)
     env.step(torch.zeros((E, D, 4), dtype=env.dtype))
@@ -124,10 +131,42 @@ def test_compensated_fp32_storage_round_trips_and_equals_fp32_paths(mds):
     assert b.last_rollout_streams() == 2
     np.testing.assert_array_equal(r.cpu().numpy(), g.cpu().numpy())
     np.testing.assert_array_equal(b.get_state(), env.get_state())
-    with pytest.raises(RuntimeError):
-        env.rollout_geometric_fused(0.0, 5)
+    # the state-in-registers rollout continues the same loop: 50 more steps in one launch against 50 more single steps
+    for k in range(50):
+        g = env.step_geometric(t)
+        t += env.CTRL_TIMESTEP
+    t300 = 0.0
+    for _ in range(300):
+        t300 += b.CTRL_TIMESTEP
+    r2, _ = b.rollout_geometric_fused(t300, 50)
+    assert np.abs(np_obs(r2)[:, :16] - np_obs(g)[:, :16]).max() < 2e-6
+    np.testing.assert_allclose(b.get_state(), env.get_state(), rtol=0, atol=2e-6)
     env.close()
     b.close()
+    # mds_step_lqr and mds_step_dslpid on the compensated dtype: same closed loops as fp32 to rounding, rate residuals kept
+    from multidronesim_amd.control import LQRController
+    from multidronesim_amd.model import LinearizedModel
+    outs = {}
+    for dt in ("float32", "float32c"):
+        e2 = make_env(mds, E, D, xyz, rpy, dt)
+        e2.set_trajectories(P)
+        LQRController(e2, LinearizedModel(e2))
+        e2.step(torch.zeros((E, D, 4), dtype=e2.dtype))
+        t = 0.0
+        for k in range(100):
+            o = e2.step_lqr(t)
+            t += e2.CTRL_TIMESTEP
+        outs[dt] = np_obs(o).copy()
+        e2.close()
+    assert np.isfinite(outs["float32c"]).all() and np.abs(outs["float32c"][:, :16] - outs["float32"][:, :16]).max() < 1e-4
+    tp = xyz + np.array([0.0, 0.0, 0.5])
+    for dt in ("float32", "float32c"):
+        e3 = make_env(mds, E, D, xyz, rpy, dt, pyb=240, ctrl=240)
+        for k in range(100):
+            o = e3.step_dslpid(tp, np.zeros_like(tp))
+        outs[dt] = np_obs(o).copy()
+        e3.close()
+    assert np.isfinite(outs["float32c"]).all() and np.abs(outs["float32c"][:, :16] - outs["float32"][:, :16]).max() < 1e-4
     with pytest.raises(RuntimeError):
         make_env(mds, 2, 2, *H.c2_setup(2, 2)[:2], "float32c", physics=mds.Physics.PYB_GND)
 
