@@ -76,17 +76,44 @@ def make_inputs(E, D, phase, seed):
 
 
 def dist_env():
-    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    """RANK, LOCAL_RANK, WORLD_SIZE of this process.  A rendezvous environment that is only half there is an error here, not a
+    default: a rank without LOCAL_RANK would silently share GPU 0 with rank 0."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        missing = [k for k in ("RANK", "LOCAL_RANK") if k not in os.environ]
+        if missing:
+            raise SystemExit(f"bench.py: WORLD_SIZE={world} but {', '.join(missing)} not set: launch with torch.distributed.run "
+                             "(or plainly with --gpus N, which starts the ranks itself)")
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), world
 
 
 def dist_init(backend):
+    import datetime
     import torch.distributed as dist
     rank, local_rank, world = dist_env()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # a peer that never arrives (or dies before the first barrier) ends the run with an error after this many seconds instead of
+        # the backend's default of 10-30 minutes
+        tmo = float(os.environ.get("MDS_BENCH_DIST_TIMEOUT", "300"))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=tmo))
     return rank, local_rank, world
+
+
+def ensure_built(rank, world, local_rank, lib_path, build_fn, device=None):
+    """Every rank needs the library; one builds it.  The decision is COLLECTIVE: each rank reports whether it sees the file, the MAX of
+    "missing" over the ranks decides, so that all of them take the same path through the barrier whatever the file system showed
+    each one (rank 1 may look after rank 0 has finished building: deciding locally would leave rank 0 alone at the barrier)."""
+    missing = 0.0 if os.path.exists(lib_path) else 1.0
+    need = max_over_ranks(missing, world, device) > 0.0
+    if need:
+        if rank == 0 and not os.path.exists(lib_path):
+            build_fn()
+        barrier(world, local_rank if device is not None and device.type == "cuda" else None)
+        if not os.path.exists(lib_path):
+            raise SystemExit(f"bench.py: rank {rank}: {lib_path} is still missing after rank 0's build")
+    return need
 
 
 def barrier(world, device_index=None):
@@ -558,6 +585,7 @@ def main(argv=None):
     ap.add_argument("--c5-log-gb", type=float, default=200.0, help="c5: size of the rollout log ring in GB (SURVEY 8d: sized for the 288 GB of HBM)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU tests of the N>1 path")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # CPU test of the exit-code relay
+    ap.add_argument("--dry-run-build-file", default=None, help=argparse.SUPPRESS)              # CPU test of the collective build decision
     ap.add_argument("--gather-obs", action="store_true",
                     help="after the timed region, also time the optional whole-swarm observation all-gather (RCCL over xGMI); never part of `value`")
     args = ap.parse_args(argv)
@@ -578,15 +606,28 @@ def main(argv=None):
     if args.dry_run_cpu:
         rank, local_rank, world = dist_init("gloo")
         device = torch.device("cpu")
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
         if rank == args.dry_run_fail_rank:
             raise SystemExit(3)
+        built = None
+        if args.dry_run_build_file:            # the "rank 0 builds, the others wait" path on a stand-in file
+            def fake_build():
+                time.sleep(0.5)
+                open(args.dry_run_build_file, "w").write("built by rank 0\n")
+            if rank == 1:
+                time.sleep(1.0)                # rank 1 looks late: after rank 0 could have finished building
+            built = ensure_built(rank, world, local_rank, args.dry_run_build_file, fake_build, device)
         barrier(world)
         t0 = time.perf_counter()
+        w0 = time.time()
         time.sleep(0.01 * (rank + 1))          # stand-in work; the slowest rank defines the time
         mine_s = time.perf_counter() - t0
+        w1 = time.time()
         barrier(world)
         elapsed = max_over_ranks(time.perf_counter() - t0, world, device)
         per_rank = gather_over_ranks(mine_s, world, device)
+        starts, ends = gather_over_ranks(w0, world, device), gather_over_ranks(w1, world, device)
         gathered = None
         if args.gather_obs:                    # the optional swarm all-gather, on CPU tensors over gloo
             from multidronesim_amd.swarm import all_gather_observations
@@ -595,6 +636,7 @@ def main(argv=None):
             gathered = [int(g.shape[0]), [float(g[3 * r, 0, 0]) for r in range(world)]]
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "elapsed": elapsed, "ranks_seen": len(per_rank), "elapsed_per_rank": per_rank,
+                              "value_per_rank": [1.0 / e for e in per_rank], "node_wall": max(ends) - min(starts), "built": built,
                               "gathered": gathered}), flush=True)
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -616,10 +658,7 @@ def main(argv=None):
     red_dev = device if backend == "nccl" else torch.device("cpu")        # where the timing reductions live
 
     import __graft_entry__
-    if not os.path.exists(__graft_entry__.LIB):
-        if rank == 0:
-            __graft_entry__.build()
-        barrier(world, local_rank)
+    ensure_built(rank, world, local_rank, __graft_entry__.LIB, __graft_entry__.build, red_dev)
     from multidronesim_amd.envs.CtrlAviary import CtrlAviary, DroneModel, Physics
 
     xyz, rpy, P = make_inputs(E, D, phase, 1000 + rank)          # every rank owns different envs
@@ -644,7 +683,10 @@ def main(argv=None):
         # (default 200, clamped to 70 % of what is free) -- the observation stream then really goes to HBM, slot after slot
         slot_bytes = E * D * 20 * {torch.float16: 2, torch.float32: 4, torch.float64: 8}[env.dtype]
         free_b = torch.cuda.mem_get_info(device)[0]
-        c5_T = max(16, int(min(args.c5_log_gb * 1e9, 0.7 * free_b) // slot_bytes))
+        # 70 % of what is free, shared by the ranks that sit on this device (the one-GPU rehearsal of the N > 1 path puts them all on
+        # device 0), with 4 GB left for the extras' own envs and logs
+        sharing = world if os.environ.get("MDS_BENCH_SHARE_GPU") == "1" else 1
+        c5_T = max(16, int(max(0.0, min(args.c5_log_gb * 1e9, 0.7 * free_b / sharing - 4e9)) // slot_bytes))
         c5_log = torch.empty((c5_T, E, D, 20), dtype=env.dtype, device=device)
         c5_act_tab = torch.stack(c5_actions).contiguous()                       # [8,E,D,4]: the action table of the C loop
         c5_actions = [c5_act_tab[k] for k in range(8)]
@@ -728,16 +770,21 @@ def main(argv=None):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(torch.cuda.current_stream(device))       # same stream the kernels are enqueued on
     wall0 = time.perf_counter()                         # the K steps start here: the marker above is not one of them
+    node_t0 = time.time()                               # (one node: the ranks share this clock)
     run(args.warmup * dt, args.steps)
     ev1.record(torch.cuda.current_stream(device))
     torch.cuda.synchronize(device)
     wall_mine = time.perf_counter() - wall0             # this rank's K steps: first enqueue .. its synchronize returns
+    node_t1 = time.time()
     barrier(world, local_rank)                          # closing bracket; its own latency (an RCCL barrier, ~100 us) is not part of the K steps
     dev_ms = ev0.elapsed_time(ev1)
     elapsed = max_over_ranks(wall_mine, world, red_dev)  # the slowest rank's time
     dev_ms_max = max_over_ranks(dev_ms, world, red_dev)
     dev_ms_ranks = gather_over_ranks(dev_ms, world, red_dev)
     wall_ranks = gather_over_ranks(wall_mine, world, red_dev)
+    # first start .. last finish over the ranks: includes the start skew after the opening barrier, which the per-rank intervals (and
+    # `value` = units / the slowest rank's interval, the contract's MAX over ranks) do not see
+    node_wall = max(gather_over_ranks(node_t1, world, red_dev)) - min(gather_over_ranks(node_t0, world, red_dev))
     used_streams = env.last_rollout_streams() if c_loop else 1
 
     obs = c5_log[(c5_k[0] - 1) % c5_T] if c5 else env._obs
@@ -778,6 +825,8 @@ def main(argv=None):
                      "us_per_step": us_per_step, "bytes_per_launch": bytes_per * n_local, "streams": used_streams},
         "device_ms_per_step_max_rank": dev_ms_max / args.steps, "ranks_seen": len(dev_ms_ranks),
         "device_ms_per_rank": dev_ms_ranks, "value_per_rank": [n_local * args.steps / w for w in wall_ranks], "state_sane": ok,
+        "node_wall": {"ms_per_step": node_wall * 1e3 / args.steps, "value": total_units / node_wall,
+                      "what": "first rank's start .. last rank's finish (host clock of the node): `value` with the ranks' start skew counted"},
     }
     if split:
         # each stream runs `steps` half-shard launches inside the timed region, so us_per_step is also the average
@@ -904,7 +953,8 @@ def main(argv=None):
                                  "bytes_per_drone_step": b2, "achieved_GBps": b2 * n_local / (us * 1e-6) / 1e9,
                                  "bound": "VALU (state in registers; the action table is read, the observation log written)",
                                  "kernel": "k_rollout_step<float,_Float16,false,false>",
-                                 "state_sane": bool(torch.isfinite(c5_log[:16]).all().item())}
+                                 # the slots this run wrote last (the log is a ring: step j -> slot j % slots)
+                                 "state_sane": bool(all(torch.isfinite(c5_log[(C5_EPISODE * (reps + 1) - 1 - j) % c5_T]).all().item() for j in range(16)))}
     env.close()
     del env
     if args.workload == "c3" and world == 1 and not fused_T and not args.python_loop and extras and not rk4:

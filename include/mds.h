@@ -23,7 +23,10 @@
  *     Because they only enqueue, the mds_step* / mds_rollout* calls can be recorded by a stream capture on `stream`
  *     (hipStreamBeginCapture, torch.cuda.graph) and replayed as a hipGraph; a two-chain rollout forks from and joins back into
  *     the capturing stream through its event pair, which is the capture-legal pattern.  (Scalar arguments such as t are baked into
- *     the graph; replay buys nothing at these kernel sizes)
+ *     the graph; replay buys nothing at these kernel sizes)  The ground-effect / downwash physics modes step a
+ *     double-buffered state and flip the handle's two buffers on the host once per substep; a captured call bakes the buffers of
+ *     the moment into the graph, so under capture a call with an odd number of substeps appends a device-to-device copy of the
+ *     state back into the buffer it started from (every replay then starts and ends in the same buffer; eager calls only flip).
  *   - Every call taking a handle runs on the handle's device (mds_config.device) and leaves the calling thread's current
  *     HIP device as it found it; device pointers passed in must belong to that device.
  *   - Every call returns MDS_OK (0) or a negative mds_status; nothing throws or aborts
@@ -234,7 +237,8 @@ int mds_reset_async(mds_handle* h, void* stream);
  * semantics hold.  ROCm maps a process's streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues: in a process with more than
  * two or three other ACTIVE streams the internal stream may share a queue with the caller's and the chains then run one after the
  * other (results unchanged, time lost).  Raise GPU_MAX_HW_QUEUES, or set MDS_SPLIT_STREAM_PRIORITY=high (or low) before the handle's
- * streams are created: a stream of another priority level has hardware queues of its own. */
+ * streams are created: a stream of another priority level has hardware queues of its own.  The variable is read at every stream
+ * creation (mds_create / the first mds_set_rollout_streams(h, 2) of a handle), so handles created after a change see it. */
 int mds_set_rollout_streams(mds_handle* h, int n_streams);
 /* What the most recent mds_rollout_geometric / mds_rollout_step / mds_rollout_dslpid / mds_rollout_cbf_geometric of this handle did: 1 = the
  * caller's stream only, 2 = two chains on the internal streams, 0 = no rollout yet. */

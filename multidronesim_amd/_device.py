@@ -21,14 +21,32 @@ def require_gpu(device_index: int) -> torch.device:
 
 
 def default_device_index() -> int:
-    """The GPU a handle is created on when the caller names none: this rank's own (LOCAL_RANK, one process per GPU) when the
-    process sees several, else the thread's current torch device."""
+    """The GPU a handle is created on when the caller names none.  The thread's current torch device when the caller has chosen
+    one (torch.cuda.set_device / a device context: anything but device 0), so that helper handles (trajectory evaluation, DSLPID)
+    land beside an env created with an explicit ``device=``; else this rank's own GPU (LOCAL_RANK, one process per GPU) when the
+    process sees several; else device 0.  An env created with an explicit ``device=`` takes precedence over LOCAL_RANK."""
     import os
     if not torch.cuda.is_available():
         return 0
+    cur = torch.cuda.current_device()
+    if cur != 0:
+        return cur
+    if _last_env_device is not None:          # the GPU of the env created last with an explicit device= (helpers serve that env)
+        return _last_env_device
     if torch.cuda.device_count() > 1 and "LOCAL_RANK" in os.environ:
         return int(os.environ["LOCAL_RANK"]) % torch.cuda.device_count()
-    return torch.cuda.current_device()
+    return cur
+
+
+_last_env_device = None
+
+
+def note_env_device(index: int) -> None:
+    """Called by the env constructor when the caller named its GPU: helper handles created afterwards without a device of their own
+    (trajectory evaluation, DSLPID) follow it instead of LOCAL_RANK (a rehearsal that puts every rank on device 0, or a process that
+    drives several GPUs, would otherwise get cross-device tensors)."""
+    global _last_env_device
+    _last_env_device = int(index)
 
 
 def stream_ptr(device: torch.device) -> int:

@@ -194,10 +194,8 @@ static int split_streams_ready(mds_handle* h) {
     // ROCm multiplexes a process's streams onto GPU_MAX_HW_QUEUES (4 by default) hardware queues; when the caller's stream and this one share
     // a queue the two chains serialise (C4 with 8 other active streams in the process: 49 -> 87 us per step).  A stream of another priority
     // level lives on queues of its own: MDS_SPLIT_STREAM_PRIORITY=high|low is for such applications (no measurable cost or gain otherwise).
-    static const int prio_mode = [] {
-      const char* e = getenv("MDS_SPLIT_STREAM_PRIORITY");
-      return !e ? 0 : (e[0] == 'h' || e[0] == '1') ? 1 : (e[0] == 'l' || e[0] == '2') ? 2 : 0;
-    }();
+    const char* pe = getenv("MDS_SPLIT_STREAM_PRIORITY");          // read per stream creation (per handle), as mds.h says
+    const int prio_mode = !pe ? 0 : (pe[0] == 'h' || pe[0] == '1') ? 1 : (pe[0] == 'l' || pe[0] == '2') ? 2 : 0;
     if (prio_mode) {
       int lo = 0, hi = 0;
       MDS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -418,9 +416,19 @@ int mds_create(const mds_config* cfg, mds_handle** out) {
   }
   // shards large enough for the auto policy of the two-chain rollouts get their streams and events now (smallest auto
   // threshold: the CBF loop, 2^16 drones); smaller ones only if mds_set_rollout_streams(h, 2) asks for them
-  if (const char* v = getenv("MDS_TUNE_SPLIT_OFFSET")) h->split_offset = atoi(v);
-  if (const char* v = getenv("MDS_TUNE_SPLIT_LDS")) h->split_lds = atoi(v);
-  if (const char* v = getenv("MDS_TUNE_SPLIT_MIN_STEPS")) h->split_min_steps = atoi(v);
+  // tuning variables: garbage or out-of-range values fall back to the defaults instead of turning into an opaque launch failure
+  // (a negative LDS pad cast to size_t, or one above what a workgroup may own, fails every two-chain launch)
+  if (const char* v = getenv("MDS_TUNE_SPLIT_OFFSET")) h->split_offset = atoi(v) == 1 ? 1 : 0;
+  if (const char* v = getenv("MDS_TUNE_SPLIT_LDS")) {
+    const long lds = strtol(v, nullptr, 10);
+    int lds_max = 0;
+    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device) != hipSuccess) lds_max = 65536;
+    h->split_lds = (lds >= 0 && lds <= lds_max - (long)(kBlock * kObsDim * 8)) ? (int)lds : 32768;
+  }
+  if (const char* v = getenv("MDS_TUNE_SPLIT_MIN_STEPS")) {
+    const long ms = strtol(v, nullptr, 10);
+    h->split_min_steps = (ms >= 0 && ms <= 1000000) ? (int)ms : 0;
+  }
   if ((size_t)h->n >= kSplitMinDrones / 4) {
     if (int rc = split_streams_ready(h)) {
       mds_destroy(h);
@@ -612,10 +620,27 @@ static void launch_step_plain(mds_handle* h, const void* action, void* obs, hipS
 // [UPSTREAM] BaseAviary.step under ground effect / downwash: one launch per physics substep on the double-buffered state
 // (k_step_env).  first_substep: substeps [first_substep, K) are run (a controller kernel has already done substep 0 and left its
 // action in `action`).
-static int step_env_plain(mds_handle* h, const void* action, void* obs, hipStream_t st, int first_substep) {
+// Stream capture and the double-buffered state.  Every substep reads one buffer, writes the other and flips the handle's pointers on
+// the host; a captured call bakes the pointers of the moment into its graph, so a call with an odd number of substeps would replay
+// A -> B every time and never advance.  Under capture such a call ends with a copy of the state back into the buffer it started
+// from (`home`) and leaves the handle pointing there: every replay then starts and ends in the same buffer.  Eager calls flip only.
+static bool stream_is_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+}
+static int envfx_return_home(mds_handle* h, void* home, hipStream_t st) {
+  if (h->state == home || !stream_is_capturing(st)) return MDS_OK;
+  MDS_HIP(hipMemcpyAsync(home, h->state, 13 * h->ld * elem_size(h->cfg.dtype), hipMemcpyDeviceToDevice, st));
+  h->state_alt = h->state;
+  h->state = home;
+  return MDS_OK;
+}
+
+static int step_env_plain(mds_handle* h, const void* action, void* obs, hipStream_t st, int first_substep, void* home = nullptr) {
   const dim3 grid = grid_for(h->n, kBlock);
   const int K = h->cfg.pyb_freq / h->cfg.ctrl_freq, D = h->cfg.num_drones;
   void* rpm = rpm_track(h);
+  if (!home) home = h->state;
   for (int k = first_substep; k < K; ++k) {
     void* ob = k == K - 1 ? obs : nullptr;
     if (h->cfg.dtype == MDS_F64) {
@@ -628,7 +653,7 @@ static int step_env_plain(mds_handle* h, const void* action, void* obs, hipStrea
     void* t = h->state; h->state = h->state_alt; h->state_alt = t;
   }
   MDS_HIP(hipGetLastError());
-  return MDS_OK;
+  return envfx_return_home(h, home, st);
 }
 
 // One control step of a controller path under ground effect / downwash: k_step_ctrl_env (trajectory sample or given input ->
@@ -664,9 +689,10 @@ static int step_env_ctrl(mds_handle* h, int ctrl, double t, const void* u_in, do
 #undef MDS_CE_D
 #undef MDS_CE
   MDS_HIP(hipGetLastError());
+  void* home = h->state;
   void* tmp = h->state; h->state = h->state_alt; h->state_alt = tmp;
-  if (K > 1) return step_env_plain(h, h->act_scratch, obs, st, 1);
-  return MDS_OK;
+  if (K > 1) return step_env_plain(h, h->act_scratch, obs, st, 1, home);
+  return envfx_return_home(h, home, st);
 }
 
 int mds_step(mds_handle* h, const void* action, void* obs, void* stream) {

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .. import _capi as capi
-from .._device import DTYPE_BY_NAME, TORCH_DTYPE, default_device_index, require_gpu, stream_ptr, to_device
+from .._device import DTYPE_BY_NAME, TORCH_DTYPE, default_device_index, note_env_device, require_gpu, stream_ptr, to_device
 from ..utils.enums import DroneModel, Physics
 
 __all__ = ["BaseAviary", "DroneModel", "Physics"]
@@ -69,6 +69,8 @@ class BaseAviary:
                           RuntimeWarning, stacklevel=3)
         if device is None:
             device = default_device_index()
+        else:
+            note_env_device(device.index if isinstance(device, torch.device) else int(device))
         self.device = require_gpu(device)
         self._lib = lib
         self.DRONE_MODEL, self.PHYSICS = drone_model, physics

@@ -70,3 +70,56 @@ def test_each_rank_gets_different_envs_and_same_shape():
     np.testing.assert_allclose(a[2][0, :, 6], 2 * np.pi * np.arange(8) / 8.25)
     c = bench.make_inputs(4, 4, "c2", 0)
     np.testing.assert_allclose(c[2][0, :, 6], -(np.pi / 4) * (np.arange(4) - 1))
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT
+    env.update(extra)
+    return env
+
+
+def test_world_size_mismatch_exits_with_a_message():
+    """`--gpus 3` under a 2-rank launch: every rank exits non-zero with a message before any barrier (nobody waits for a third rank)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-run-cpu"]
+    out = subprocess.run(cmd, cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=240)
+    assert out.returncode != 0
+    assert "--gpus 3 but WORLD_SIZE=2" in out.stderr + out.stdout
+
+
+def test_missing_local_rank_exits_with_a_message():
+    """A rendezvous environment without LOCAL_RANK is refused (the rank would silently share GPU 0 with rank 0), not defaulted."""
+    env = _clean_env(RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29535")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0
+    assert "LOCAL_RANK not set" in out.stderr + out.stdout
+
+
+def test_a_rank_that_never_arrives_ends_in_an_error_not_a_hang():
+    """Rank 0 started by hand, rank 1 never starts: the rendezvous gives up after MDS_BENCH_DIST_TIMEOUT seconds with a non-zero exit
+    (the backend's default would keep the process at the rendezvous for 10-30 minutes)."""
+    import time
+    env = _clean_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29536", MDS_BENCH_DIST_TIMEOUT="8")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=180)
+    assert out.returncode != 0
+    assert time.time() - t0 < 120
+
+
+def test_rank_zero_builds_while_the_others_wait(tmp_path):
+    """The library-is-missing path: the decision to build is collective (MAX of "missing" over the ranks), rank 0 builds, everybody meets
+    at the barrier -- also when rank 1 only looks after rank 0 has finished (a local decision would leave rank 0 alone at the
+    barrier), and when the file is already there."""
+    lib = tmp_path / "libfake.so"
+    for pre_existing in (False, True):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--dry-run-build-file", str(lib)]
+        out = subprocess.run(cmd, cwd=ROOT, env=_clean_env(MDS_BENCH_DIST_TIMEOUT="60"), capture_output=True, text=True, timeout=240)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        assert rec["built"] is (not pre_existing) and lib.exists()
+        assert rec["ranks_seen"] == 2 and len(rec["value_per_rank"]) == 2 and len(rec["elapsed_per_rank"]) == 2
+        assert rec["node_wall"] >= max(rec["elapsed_per_rank"]) - 1e-3      # first start .. last finish covers every rank's interval

@@ -1051,3 +1051,45 @@ def test_observation_rpy_is_the_reference_trees_convention_incl_gimbal_branches(
         assert np.abs(R - d["R_quat"]).max() < 5e-3
         assert np.abs(R[far] - d["R_quat"][far]).max() < 5e-6
     env.close()
+
+
+@pytest.mark.parametrize("pyb,ctrl", [(240, 240), (240, 80), (240, 120)])
+def test_ground_effect_steps_can_be_captured_and_replayed(mds, pyb, ctrl):
+    """The ground-effect / downwash modes step a double-buffered state and flip the handle's buffers on the host per substep.  A
+    captured call bakes the buffers of the moment into its graph: with an odd number of substeps per call (pyb == ctrl: one; 240 / 80:
+    three) every replay would read the same stale buffer and the state would never advance.  Under capture such a call ends with a
+    copy back into the buffer it started from: 5 replays of a captured mds_step == 5 eager steps, bit for bit (even counts too)."""
+    torch = mds.torch
+    E, D = 23, 5
+    xyz, rpy, _ = H.c2_setup(E, D)
+    xyz[..., 2] = 0.05 + 0.2 * np.arange(D)                    # stacked near the ground: both effects act
+    envs = [make_env(mds, E, D, xyz, rpy, "float32", pyb, ctrl, mds.Physics.PYB_GND_DRAG_DW) for _ in range(2)]
+    act = (envs[0].HOVER_RPM * (1 + 0.03 * torch.randn((E, D, 4), device="cuda", generator=torch.Generator(device="cuda").manual_seed(9)))).to(envs[0].dtype)
+    obs = [torch.zeros((E, D, 20), dtype=envs[0].dtype, device="cuda") for _ in range(2)]
+    lib, Cc = envs[0]._lib, C
+
+    def step(e, o, stream):
+        rc = lib.mds_step(e._h, Cc.c_void_p(act.data_ptr()), Cc.c_void_p(o.data_ptr()), Cc.c_void_p(stream.cuda_stream))
+        assert rc == 0, rc
+    for r in range(5):
+        step(envs[0], obs[0], torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            step(envs[1], obs[1], side)
+    torch.cuda.current_stream().wait_stream(side)
+    for r in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(obs[0].cpu().numpy(), obs[1].cpu().numpy())
+    np.testing.assert_array_equal(envs[0].get_state(), envs[1].get_state())
+    assert np.abs(envs[0].get_state()[..., 0:3] - xyz).max() > 1e-4          # the state did advance
+    # eager calls after the replays continue from the replayed state
+    step(envs[0], obs[0], torch.cuda.current_stream())
+    step(envs[1], obs[1], torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(obs[0].cpu().numpy(), obs[1].cpu().numpy())
+    for e in envs:
+        e.close()
