@@ -368,9 +368,10 @@ def c4_window_stats(torch, env, tracker, c4_obs, c4_r, first, steps):
                                      "max": int(it.max().item())}}
 
 
-def c4_pmc_traffic(scene, n_local):
-    """Counter traffic of ONE control step (all its launches), from the committed summary of the separate rocprofv3 --pmc passes."""
-    path = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_c4_{scene}.json")
+def c4_pmc_traffic(scene, n_local, fused=False):
+    """Counter traffic of ONE control step (all its launches), from the committed summary of the separate rocprofv3 --pmc passes
+    (profiles/tools/r03_profile.sh): the step-by-step form (QP launch + low-level launch) or the persistent rollout kernel."""
+    path = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_c4_{scene}{'_fused' if fused else ''}.json")
     try:
         rec = json.load(open(path))
         per = rec["traffic_bytes_per_step"] / rec["drones_per_step_counted"]
@@ -413,9 +414,9 @@ def measure_c4(CtrlAviary, DroneModel, Physics, torch, local_rank, device, scene
            "roofline": {"bound": "hbm", "bytes_per_drone_step": BYTES_PER_DRONE_STEP_C4, "achieved": gb, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": gb / HBM_PEAK_GBPS,
                         "note": "algorithmic bytes of SURVEY 8d (280 B per drone-step); the path is VALU / latency bound, not HBM bound"}}
-    tr, src = c4_pmc_traffic(scene, n_local)
+    tr, src = c4_pmc_traffic(scene, n_local, bool(fused_T))
     if tr is not None:
-        out["roofline"].update({"traffic": tr, "traffic_source": src, "wasted_traffic_ratio": tr / (BYTES_PER_DRONE_STEP_C4 * n_local)})
+        out["roofline"].update({"traffic": tr, "traffic_source": src, "traffic_over_algorithmic": tr / (BYTES_PER_DRONE_STEP_C4 * n_local)})
     if stats:
         try:
             out["window"] = c4_window_stats(torch, env, tracker, c4_obs, c4_r, warmup, steps)
@@ -847,9 +848,9 @@ def main(argv=None):
         # HBM traffic from the PMC counters cannot be read inside this process; the committed summary of the
         # separate rocprofv3 --pmc passes (profiles/, same kernel) is reported, scaled to this run's launch shape.
         per_launch = n_local // 2 if split else n_local
-        tr, src = _pmc_traffic("r02_pmc_traffic_c3big.json" if args.workload == "c3big" else "r02_pmc_traffic_c3.json", per_launch)
+        tr, src = _pmc_traffic("r02_pmc_traffic_c3big.json" if args.workload == "c3big" else "r03_pmc_traffic_c3.json", per_launch)
         if tr is None and args.workload == "c3":
-            tr, src = _pmc_traffic("r01e_pmc_traffic_c3.json", per_launch)
+            tr, src = _pmc_traffic("r02_pmc_traffic_c3.json", per_launch)
         if tr is not None:
             line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr, src
     extras = not args.no_extras
@@ -896,9 +897,9 @@ def main(argv=None):
         line["roofline"]["bytes_per_drone_step"] = BYTES_PER_DRONE_STEP_C4
         line["roofline"]["note"] = ("algorithmic bytes of SURVEY 8d (280 B per drone-step: the fused step's 212 + u_hat 16 + xdes 36 + u_safe 16); the path is "
                                     "VALU / latency bound, `frac` says how far from the HBM roofline that leaves it")
-        tr, src = c4_pmc_traffic(args.c4_scene, n_local)
+        tr, src = c4_pmc_traffic(args.c4_scene, n_local, bool(fused_T))
         if tr is not None:
-            line["roofline"].update({"traffic": tr, "traffic_source": src, "wasted_traffic_ratio": tr / (BYTES_PER_DRONE_STEP_C4 * n_local)})
+            line["roofline"].update({"traffic": tr, "traffic_source": src, "traffic_over_algorithmic": tr / (BYTES_PER_DRONE_STEP_C4 * n_local)})
         line["config"]["scene"] = args.c4_scene
         line["config"]["scene_what"] = C4_SCENES[args.c4_scene][2]
         line["config"]["parity_note"] = ("fp32 vs the float64 oracle on this loop: see tests/test_gpu_cbf.py (status equality and state error over "
