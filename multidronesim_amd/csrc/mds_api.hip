@@ -138,6 +138,8 @@ struct mds_handle {
   void* gain_dev[3];   // device copies of the gains for the whole-rollout kernels: 0 LQR-12, 1 LQR-omega, 2 LQR-yank-omega (written by the mds_set_*_gain calls)
   Lqr12Gain<float> lqr12_f;
   Lqr12Gain<double> lqr12_d;
+  void* roll_params = nullptr;   // device RollParams<float | double> of the persistent CBF rollout kernel, refreshed when params_ver moves
+  int roll_params_ver = -1, params_ver = 0;
   void* state_alt;     // second state buffer of the ground-effect / downwash step (double-buffered substeps)
   void* act_scratch = nullptr;   // S [n,4]: the controller's action, replayed by the later substeps of a ground-effect / downwash step
   bool envfx;          // physics has ground effect and / or downwash
@@ -456,6 +458,7 @@ int mds_destroy(mds_handle* h) {
   if (h->cbf_order) (void)hipFree(h->cbf_order);
   if (h->cbf_count) (void)hipFree(h->cbf_count);
   if (h->cbf_cost) (void)hipFree(h->cbf_cost);
+  if (h->roll_params) (void)hipFree(h->roll_params);
   for (int k = 0; k < 3; ++k)
     if (h->gain_dev[k]) (void)hipFree(h->gain_dev[k]);
   if (h->cbf_unom) (void)hipFree(h->cbf_unom);
@@ -862,6 +865,7 @@ int mds_set_geometric_gains(mds_handle* h, const mds_geometric_gains* g) {
   h->gains = *g;
   fill_consts(h->cfg, h->gains, h->cf, h->wind);
   fill_consts(h->cfg, h->gains, h->cd, h->wind);
+  ++h->params_ver;
   return MDS_OK;
 }
 
@@ -870,6 +874,7 @@ int mds_set_wind(mds_handle* h, const double force_world[3]) {
   for (int k = 0; k < 3; ++k) h->wind[k] = force_world[k];
   fill_consts(h->cfg, h->gains, h->cf, h->wind);
   fill_consts(h->cfg, h->gains, h->cd, h->wind);
+  ++h->params_ver;
   return MDS_OK;
 }
 
@@ -1338,6 +1343,7 @@ int mds_cbf_configure(mds_handle* h, const mds_cbf_params* p, const double* obst
   h->cbf = *p;
   fill_cbf(h, *p, h->cbf_f);
   fill_cbf(h, *p, h->cbf_d);
+  ++h->params_ver;
   h->has_cbf = true;
   return MDS_OK;
 }
@@ -2031,19 +2037,27 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
   // tuning aid: MDS_TUNE_ROLL_STAMPS=1 -> per-wave shader-clock ticks by part of the step, summed over this call, printed to stderr
   // (synchronises the stream: never set it in production)
   unsigned long long* stamps_dev = nullptr;
-  const size_t n_stamp = (size_t)grid.x * nw * 9;
+  const size_t n_stamp = (size_t)grid.x * nw * 10;
   if (const char* e = getenv("MDS_TUNE_ROLL_STAMPS"))
     if (e[0] == '1') {
       MDS_HIP(hipMalloc((void**)&stamps_dev, n_stamp * sizeof(unsigned long long) * ((n_steps + steps_per_launch - 1) / steps_per_launch)));
     }
   unsigned long long* const stamps_base = stamps_dev;
+  // the kernel reads Consts / CbfParams from a device copy (RollParams): refreshed, in stream order, when either has changed
+  if (!h->roll_params) MDS_HIP(hipMalloc(&h->roll_params, sizeof(RollParams<double>)));
+  if (h->roll_params_ver != h->params_ver) {
+    if (h->cfg.dtype == MDS_F64) k_store_roll_params<double><<<1, 64, 0, st>>>(h->cd, h->cbf_d, (RollParams<double>*)h->roll_params);
+    else k_store_roll_params<float><<<1, 64, 0, st>>>(h->cf, h->cbf_f, (RollParams<float>*)h->roll_params);
+    MDS_HIP(hipGetLastError());
+    h->roll_params_ver = h->params_ver;
+  }
   int slot = first_slot;
   double t = t0;
   for (int k0 = 0; k0 < n_steps; k0 += steps_per_launch) {
     const int ks = n_steps - k0 < steps_per_launch ? n_steps - k0 : steps_per_launch;
     int32_t* slog = status_log ? status_log + (size_t)k0 * h->cfg.num_envs : nullptr;
 #define MDS_CR(T, CC, CP, NOM, COMP, TOL)                                                                                                      \
-  k_cbf_rollout<T, NOM, COMP, (sizeof(T) == 8 ? NWD : NWF)><<<grid, 64 * nw, 0, st>>>(CC, CP, gain, h->n, h->ld, h->cfg.num_envs, t, dt, ks, (T*)h->state, (T*)h->state_lo,  \
+  k_cbf_rollout<T, NOM, COMP, (sizeof(T) == 8 ? NWD : NWF)><<<grid, 64 * nw, 0, st>>>((const RollParams<T> MDS_CONST_AS*)h->roll_params, gain, h->n, h->ld, h->cfg.num_envs, t, dt, ks, (T*)h->state, (T*)h->state_lo,  \
                                                                (const T*)h->lem, (T*)rpm, (T*)h->ll, h->pair_ij, (const T*)h->obstacles,        \
                                                                (T*)obs_log, slot, log_slots > 0 ? log_slots : 1, (T*)obs, (int*)status, (int*)slog, \
                                                                h->cbf_cost, max_iter, (T)((TOL) * (TOL)), stamps_dev)
@@ -2069,14 +2083,14 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
     MDS_HIP(hipStreamSynchronize(st));
     MDS_HIP(hipMemcpy(hs.data(), stamps_base, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     (void)hipFree(stamps_base);
-    static const char* part[9] = {"wait before B", "stage B", "wait after B", "stage C", "obs rows", "stage A", " B: ticket", " B: rows", " B: scan+solve"};
+    static const char* part[10] = {"wait before B", "stage B", "wait after B", "stage C", "obs rows", "stage A", " B: ticket", " B: rows", " B: bookkeeping", " B: scan+solve"};
     const size_t waves = (size_t)grid.x * nw;
     double tot_mean = 0;
-    for (int p = 0; p < 9; ++p) {
+    for (int p = 0; p < 10; ++p) {
       double sum = 0, mx = 0;
       for (size_t w = 0; w < waves; ++w) {
         double v = 0;
-        for (int l = 0; l < launches; ++l) v += (double)hs[(size_t)l * n_stamp + w * 9 + p];
+        for (int l = 0; l < launches; ++l) v += (double)hs[(size_t)l * n_stamp + w * 10 + p];
         sum += v;
         if (v > mx) mx = v;
       }

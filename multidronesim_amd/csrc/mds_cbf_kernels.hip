@@ -1165,14 +1165,14 @@ struct RollSlot {       // row r = lane + 64 k of any env: what it is (built onc
 
 template <typename T> __device__ __forceinline__ RollSlot roll_slot_of(const CbfParams<T>& P, const int* __restrict__ pair_ij, const int r) {
   const int D = P.num_drones, npairs = cbf_num_pairs(D), nobs_rows = D * P.n_obs, m = npairs + nobs_rows + 2 * D;
-  constexpr int kRec = 9 * (int)sizeof(T);                     // record stride: 8 values + 1 pad (see k_cbf_rollout)
+  constexpr int kRec = 8 * (int)sizeof(T);                     // record stride (see k_cbf_rollout); bits 24 / 25 of kind: agent i / j >= 8
   RollSlot sl = {0, 0, 0, 0};
   if (r < npairs) {
     const int ij = pair_ij[r], ia = ij & 255, ib = ij >> 8;
-    sl = {ia * kRec, ib * kRec, 0, 1 | (ia << 8) | (ib << 16)};
+    sl = {ia * kRec, ib * kRec, 0, 1 | (ia << 8) | (ib << 16) | (((ia >> 3) & 1) << 24) | (((ib >> 3) & 1) << 25)};
   } else if (r < npairs + nobs_rows) {
     const int q = r - npairs, ag = (q * P.obs_magic) >> 16, oo = q - ag * P.n_obs;       // as cbf_o2_slot
-    sl = {ag * kRec, oo * kRec, 1 + oo, 2 | (ag << 8) | (ag << 16)};
+    sl = {ag * kRec, oo * kRec, 1 + oo, 2 | (ag << 8) | (ag << 16) | (((ag >> 3) & 1) << 24)};
   } else if (r < m) {
     const int q = r - npairs - nobs_rows, var = q < D ? q : q - D;
     sl = {var, 0, 0, (q < D ? 3 : 4) | (var << 8) | (var << 16)};
@@ -1201,8 +1201,41 @@ template <typename T> __device__ __forceinline__ CbfParams<T> fresh(CbfParams<T>
   return P;
 }
 
+// The kernel's constants live in a device copy read through a CONSTANT-address-space pointer that every stage makes fresh: each
+// stage loads the fields it uses with scalar loads where it uses them.  As by-value kernel arguments (65 dwords beside 14 pointers)
+// they were loop invariants held in SGPRs across all stages: the 106 SGPRs overflowed into VGPR lanes and every use paid a
+// v_readlane (133 in stage C alone).
+template <typename T> struct RollParams {
+  Consts<T> c;
+  CbfParams<T> P;
+};
+template <typename T> __global__ void k_store_roll_params(const Consts<T> c, const CbfParams<T> P, RollParams<T>* __restrict__ dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    dst->c = c;
+    dst->P = P;
+  }
+}
+#define MDS_CONST_AS __attribute__((address_space(4)))
+template <typename T> __device__ __forceinline__ const RollParams<T> MDS_CONST_AS* fresh_ptr(const RollParams<T> MDS_CONST_AS* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+// a by-value copy of a struct behind a constant-address-space pointer, word by word (the words that are used become scalar loads,
+// the others disappear)
+template <typename V> __device__ __forceinline__ V load_const(const V MDS_CONST_AS* p) {
+  static_assert(sizeof(V) % 4 == 0, "word-sized struct");
+  constexpr int N = (int)(sizeof(V) / 4);
+  const unsigned MDS_CONST_AS* w = reinterpret_cast<const unsigned MDS_CONST_AS*>(p);
+  unsigned tmp[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) tmp[k] = w[k];
+  V out;
+  __builtin_memcpy(&out, tmp, sizeof(V));
+  return out;
+}
+
 template <typename T, int NOM, bool COMP, int NW>
-__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout(const Consts<T> c0, const CbfParams<T> P0, const void* __restrict__ Kp, const int n,
+__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout(const RollParams<T> MDS_CONST_AS* __restrict__ rp, const void* __restrict__ Kp, const int n,
                                                         const size_t ld, const int E, double t, const double ctrl_dt, const int n_steps,
                                                         T* __restrict__ state, T* __restrict__ state_lo, const T* __restrict__ lem,
                                                         T* __restrict__ last_rpm, T* __restrict__ ll, const int* __restrict__ pair_ij,
@@ -1214,16 +1247,24 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   constexpr int R = 4, NMAX = 16, NV = 1;
   constexpr int kQS = (NMAX + 3) / 4 * 4 + 4;
   constexpr int GBMAX = NT / 4;                                // envs per workgroup (D >= 4)
-  // one drone's record: px py pz e_roll e_pitch e_vx e_vy e_vz + 1 pad -- at a 9-word stride the 16 agents' records start in 16 different
-  // LDS banks (at 8 words agents a and a + 4 collide on every field: 124 M conflict cycles against 81 M LDS-instruction cycles per launch)
-  constexpr int kRec = 9 * (int)sizeof(T);
+  // One drone's record: two 16-byte halves (px py pz e_roll | e_pitch e_vx e_vy e_vz), read by the row slots as two ds_read_b128 per
+  // agent.  At the plain 8-word stride agents a and a + 8 start in the same bank, and a 16-lane group of such a read that walks 16
+  // consecutive agents would take two passes: records 8..15 of every 16 keep their halves in swapped order (half h of record j sits
+  // at 16 (h ^ (j >> 3 & 1)) bytes), so that group reads 16 x 4 different banks.  (First version: 8 scalar fields at 8 words -- 124 M
+  // bank-conflict cycles against 81 M LDS-instruction cycles per launch; then a 9-word stride, conflict-free but 16 ds_read2_b32 per
+  // row slot: the LDS pipe was ~45 % busy and every LDS access of the kernel queued behind them.)
+  constexpr int kRec = 8 * (int)sizeof(T);
+  constexpr bool kSwz = sizeof(T) == 4;
+  struct alignas(16) V4 {
+    T v[4];
+  };
   struct Scratch {                                             // one wave's active-set solver
     T sd[NMAX], slam[NMAX], sdi[NMAX];
     T sQ[NMAX][kQS], sR[NMAX][kQS];
     int sact[NMAX];
   };
   struct alignas(16) Slice {                                   // one wave: stage A -> B data, aliased by its stage C observation staging
-    T rec[64][9];
+    T rec[64][8];
     Scratch sc;
   };
   constexpr int kObsWave = 64 * kObsDim * (int)sizeof(T);      // write_obs_rows' slice per wave
@@ -1232,14 +1273,14 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   __shared__ T st[13][NT];                                     // the state across stage B (lane-contiguous planes: conflict-free)
   __shared__ T su_all[NT];                                     // thrust variable of every drone: u_hat[0] in, QP minimiser out
   __shared__ __align__(16) RollSlot stab[R][64];               // row slot table
-  __shared__ __align__(16) T sobrec[kCbfMaxObs][9];            // obstacles as records with zero tracking errors
+  __shared__ __align__(16) T sobrec[kCbfMaxObs][8];            // obstacles as records with zero tracking errors (halves in plain order)
   __shared__ T sDs[kCbfMaxObs + 1];
   __shared__ int sconv[GBMAX], scost[GBMAX], sorder[GBMAX];    // per env of the workgroup: QP solved; iterations of its last solve; hand-out order
   __shared__ int sticket;
   // tuning aid (stamps != NULL, MDS_TUNE_ROLL_STAMPS=1 on the host): shader-clock ticks every wave spent in each part of the step,
   // summed over the launch's steps -> stamps[(workgroup * NW + wave) * 6 + part]: 0 wait for stage B, 1 stage B, 2 wait after
   // stage B, 3 stage C, 4 observation rows, 5 stage A
-  __shared__ unsigned long long sst[NW][9];
+  __shared__ unsigned long long sst[NW][10];
   unsigned long long tk0 = 0;
   unsigned long long tk1 = 0;
   auto stamp_b = [&](int part) {
@@ -1256,9 +1297,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       tk0 = now;
     }
   };
-  if (stamps != nullptr && threadIdx.x < NW * 9) sst[threadIdx.x / 9][threadIdx.x % 9] = 0;
+  if (stamps != nullptr && threadIdx.x < NW * 10) sst[threadIdx.x / 10][threadIdx.x % 10] = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int D = P0.num_drones, GB = NT / D;                    // envs per workgroup
+  const int D = rp->P.num_drones, GB = NT / D;                 // envs per workgroup
   const int i = blockIdx.x * NT + tid;
   const bool valid = i < n;
   const int env0 = (blockIdx.x * NT) / D;
@@ -1267,14 +1308,14 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
 
   // ---- once per launch ----
   {
-    const CbfParams<T>& P = P0;
+    const CbfParams<T> P = load_const(&rp->P);
   if (tid < R * 64) stab[tid >> 6][tid & 63] = roll_slot_of<T>(P, pair_ij, (tid & 63) + 64 * (tid >> 6));
   if (tid < kCbfMaxObs) {
     const bool on = tid < P.n_obs;
     sobrec[tid][0] = on ? obstacles[4 * tid] : T(0);
     sobrec[tid][1] = on ? obstacles[4 * tid + 1] : T(0);
     sobrec[tid][2] = on ? obstacles[4 * tid + 2] : T(0);
-    for (int k = 3; k < 9; ++k) sobrec[tid][k] = T(0);
+    for (int k = 3; k < 8; ++k) sobrec[tid][k] = T(0);
     sDs[1 + tid] = on ? P.safety_radius + obstacles[4 * tid + 3] : T(1);
   }
   if (tid == 0) sDs[0] = P.Ds_pair;
@@ -1308,14 +1349,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     }
     // obs_to_lin_model(obs, 9) - xdes with obs = pack_obs(state): world position, roll, pitch, world velocity; xdes = [0, 0, yaw, v_des, p_des]
     T* rc = slice_of(wq).rec[lq];
-    rc[0] = s.p.x + Pl.cx;
-    rc[1] = s.p.y + Pl.cy;
-    rc[2] = s.p.z + Pl.cz;
-    rc[3] = rpy.x - T(0);
-    rc[4] = rpy.y - T(0);
-    rc[5] = s.v.x - des.v.x;
-    rc[6] = s.v.y - des.v.y;
-    rc[7] = s.v.z - des.v.z;
+    const int sw = kSwz ? ((lq >> 3) & 1) : 0;                   // records 8..15 of every 16: halves swapped
+    *reinterpret_cast<V4*>(rc + 4 * sw) = V4{{s.p.x + Pl.cx, s.p.y + Pl.cy, s.p.z + Pl.cz, rpy.x - T(0)}};
+    *reinterpret_cast<V4*>(rc + 4 * (sw ^ 1)) = V4{{rpy.y - T(0), s.v.x - des.v.x, s.v.y - des.v.y, s.v.z - des.v.z}};
     su_all[tq] = un0;
     st[0][tq] = s.p.x; st[1][tq] = s.p.y; st[2][tq] = s.p.z;
     st[3][tq] = s.q[0]; st[4][tq] = s.q[1]; st[5][tq] = s.q[2]; st[6][tq] = s.q[3];
@@ -1334,9 +1370,12 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     Pl.cx = c2.v[0]; Pl.cy = c2.v[1]; Pl.cz = lem[6 * ld + iu];
     return Pl;
   };
-  if (valid && n_steps > 0) stage_a(c0, load_params((unsigned)i), t, tid);
+  if (valid && n_steps > 0) {
+    const Consts<T> c1 = load_const(&rp->c);
+    stage_a(c1, load_params((unsigned)i), t, tid);
+  }
   const int log2D = 31 - __clz(D);                             // D is 4, 8 or 16
-  const int nbs = (cbf_num_pairs(D) + D * P0.n_obs + 63) >> 6;   // row slots that hold barrier rows
+  const int nbs = (cbf_num_pairs(D) + D * rp->P.n_obs + 63) >> 6;   // row slots that hold barrier rows
 
   for (int k = 0; k < n_steps; ++k) {
     if (wave == 0) {
@@ -1359,18 +1398,26 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
 
     // ---- stage B: the workgroup's envs, one per wave at a time ----
     {
-      const CbfParams<T> P = fresh(P0);
+      const CbfParams<T> P = load_const(&fresh_ptr(rp)->P);
       Scratch& S = slice_of(wave).sc;
       if (stamps != nullptr) tk1 = __builtin_amdgcn_s_memtime();
+#if !defined(MDS_TUNE_ROLL_STATIC)
       while (true) {
         int tk = 0;
         if (lane == 0) tk = atomicAdd(&sticket, 1);
         tk = __builtin_amdgcn_readfirstlane(tk);
         if (tk >= nenv) break;                                     // wave-uniform
+#else
+      // A/B: the hand-out order dealt round-robin over the waves instead of the ticket counter (no LDS atomic per env).  Measured
+      // slower on every scene (MI355X, C4, us per control step, tickets -> static: far 29.5 -> 31.5, under 29.8 -> 31.9, level
+      // 41.2 -> 51.1): waves of a workgroup do not run at the same pace even when their envs cost the same, and the ticket absorbs it.
+      for (int tk = wave; tk < nenv; tk += NW) {
+#endif
         const int el = sorder[tk];                                 // env of the workgroup (uniform)
         stamp_b(6);
         const int d0 = el * D;
         const unsigned char* ebase = raw + (size_t)(d0 >> 6) * kObsWave + (size_t)(d0 & 63) * kRec;   // the env's first record
+        const int eswz = (d0 >> 3) & 1;                            // (D = 4, 8: an env's records sit in one half of a 16-record group)
         int tl = lane;
         asm volatile("" : "+v"(tl));                               // re-read per env: 4 LDS reads instead of 16 registers held across the stages
         T ca[R][NV], cb[R][NV], b[R];
@@ -1395,14 +1442,14 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
             const bool bar = kind == 1 || kind == 2;
             const unsigned char* pa = ebase + (bar ? sl.offA : 0);
             const unsigned char* pb = kind == 1 ? ebase + sl.offB : reinterpret_cast<const unsigned char*>(&sobrec[0][0]) + (kind == 2 ? sl.offB : 0);
-            const T* ra = reinterpret_cast<const T*>(pa);
-            const T* rb = reinterpret_cast<const T*>(pb);
-            T A8[8], B8[8];
-#pragma unroll
-            for (int v = 0; v < 8; ++v) {
-              A8[v] = ra[v];
-              B8[v] = rb[v];
-            }
+            // byte offset of half 0 (half 1 sits at the other 16): the agent's swap bit, flipped for envs that start at an odd multiple of 8
+            const int xa = (kSwz && bar) ? ((((sl.kind >> 24) & 1) ^ eswz) << 4) : 0;
+            const int xb = (kSwz && kind == 1) ? ((((sl.kind >> 25) & 1) ^ eswz) << 4) : 0;
+            constexpr int kHalf = 4 * (int)sizeof(T);
+            const V4 a0 = *reinterpret_cast<const V4*>(pa + (kSwz ? xa : 0)), a1 = *reinterpret_cast<const V4*>(pa + (kSwz ? (xa ^ 16) : kHalf));
+            const V4 b0 = *reinterpret_cast<const V4*>(pb + (kSwz ? xb : 0)), b1 = *reinterpret_cast<const V4*>(pb + (kSwz ? (xb ^ 16) : kHalf));
+            const T A8[8] = {a0.v[0], a0.v[1], a0.v[2], a0.v[3], a1.v[0], a1.v[1], a1.v[2], a1.v[3]};
+            const T B8[8] = {b0.v[0], b0.v[1], b0.v[2], b0.v[3], b1.v[0], b1.v[1], b1.v[2], b1.v[3]};
             T hr, lg;
             cbf_row_o2<T>(P, A8[0] - B8[0], A8[1] - B8[1], A8[2] - B8[2], A8[3] - B8[3], A8[4] - B8[4], A8[5] - B8[5], A8[6] - B8[6],
                           A8[7] - B8[7], sDs[bar ? sl.ds : 0], &hr, &lg);
@@ -1439,6 +1486,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)
         __builtin_amdgcn_s_setprio(0);
 #endif
+        stamp_b(9);
         if (lane == 0) {
           sconv[el] = converged ? 1 : 0;
           scost[el] = it;
@@ -1464,8 +1512,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     unsigned iu = (unsigned)i;
     int tq = tid;
     asm volatile("" : "+v"(iu), "+v"(tq));                         // addresses are formed here, not held (spilled) across the loop
-    const Consts<T> c = fresh(c0);
-    const CbfParams<T> P = fresh(P0);
+    const RollParams<T> MDS_CONST_AS* rq = fresh_ptr(rp);
+    const Consts<T> c = load_const(&rq->c);
+    const CbfParams<T> P = load_const(&rq->P);
     if (valid) {
       const int conv = sconv[tq >> log2D];
       const T safe = su_all[tq];
@@ -1544,7 +1593,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   }
   if (stamps != nullptr) {
     __syncthreads();
-    if (threadIdx.x < NW * 9) stamps[(size_t)blockIdx.x * NW * 9 + threadIdx.x] = sst[threadIdx.x / 9][threadIdx.x % 9];
+    if (threadIdx.x < NW * 10) stamps[(size_t)blockIdx.x * NW * 10 + threadIdx.x] = sst[threadIdx.x / 10][threadIdx.x % 10];
   }
 }
 
