@@ -994,7 +994,8 @@ def main(argv=None):
                 torch.cuda.empty_cache()
             if hasattr(CtrlAviary, "rollout_cbf_geometric_fused"):
                 try:
-                    c4x["feasible_active_fused"] = measure_c4(CtrlAviary, DroneModel, Physics, torch, local_rank, device, "under", fused_T=20, stats=False)
+                    c4x["feasible_active_fused"] = measure_c4(CtrlAviary, DroneModel, Physics, torch, local_rank, device, "under", fused_T=50, stats=False)
+                    c4x["survey_8d_fused"] = measure_c4(CtrlAviary, DroneModel, Physics, torch, local_rank, device, "level", fused_T=50, stats=False)
                 except Exception as exc:
                     c4x["feasible_active_fused"] = {"error": str(exc)}
                 torch.cuda.empty_cache()

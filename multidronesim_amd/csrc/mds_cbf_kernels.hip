@@ -459,6 +459,13 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
         best_k = k;
       }
     }
+    // No lane holds a violated row: converged.  The same decision as "wave maximum <= tol2" below, from one ballot instead of the DPP
+    // reduction + four v_readlane + compare chain -- the exit most envs take most steps (the scan of an env that needs no iteration
+    // cost as much as building its rows: 150 serial instructions, VALU -> scalar -> branch round trips).
+    if (!__any(best > tol2)) {
+      converged = true;
+      break;
+    }
     const T wbest = wv::max_nonneg<false>(best);
     if (!(wbest > tol2)) {
       converged = true;
@@ -1402,11 +1409,13 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       Scratch& S = slice_of(wave).sc;
       if (stamps != nullptr) tk1 = __builtin_amdgcn_s_memtime();
 #if !defined(MDS_TUNE_ROLL_STATIC)
+      // tickets are drawn one env ahead: the LDS atomic of the next env's ticket is in flight while this env's rows are built
+      int tk_next = 0;
+      if (lane == 0) tk_next = atomicAdd(&sticket, 1);
       while (true) {
-        int tk = 0;
-        if (lane == 0) tk = atomicAdd(&sticket, 1);
-        tk = __builtin_amdgcn_readfirstlane(tk);
+        const int tk = __builtin_amdgcn_readfirstlane(tk_next);
         if (tk >= nenv) break;                                     // wave-uniform
+        if (lane == 0) tk_next = atomicAdd(&sticket, 1);
 #else
       // A/B: the hand-out order dealt round-robin over the waves instead of the ticket counter (no LDS atomic per env).  Measured
       // slower on every scene (MI355X, C4, us per control step, tickets -> static: far 29.5 -> 31.5, under 29.8 -> 31.9, level
@@ -1415,6 +1424,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
 #endif
         const int el = sorder[tk];                                 // env of the workgroup (uniform)
         stamp_b(6);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)
+        __builtin_amdgcn_s_setprio(0);
+#endif
         const int d0 = el * D;
         const unsigned char* ebase = raw + (size_t)(d0 >> 6) * kObsWave + (size_t)(d0 & 63) * kRec;   // the env's first record
         const int eswz = (d0 >> 3) & 1;                            // (D = 4, 8: an env's records sit in one half of a 16-record group)
@@ -1479,12 +1491,17 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         if (nbs <= 3) build_rows(wv::Ic<3>{});
         else build_rows(wv::Ic<4>{});
         stamp_b(7);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)
+        // the scan, the bookkeeping and the next ticket are short serial chains (VALU -> scalar -> branch, LDS round trips): at equal
+        // priority they queue behind the other waves' dense row arithmetic on every instruction; they go first, the row build yields
+        __builtin_amdgcn_s_setprio(1);
+#endif
         bool converged = false;
         int it = 0, q = 0;
         gi_solve<T, R, NMAX, NV, false, kQS>(lane, D, max_iter, tol2, __any(bad), ca, cb, b, ia, ib, vld, act, &su_all[d0], S.sd, S.slam, S.sdi,
                                              S.sQ, S.sR, S.sact, nullptr, converged, it, q);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(1);                             // (gi_solve raised it to 3 if the env iterated)
 #endif
         stamp_b(9);
         if (lane == 0) {
@@ -1500,6 +1517,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         stamp_b(8);
       }
     }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)
+    __builtin_amdgcn_s_setprio(0);
+#endif
     stamp(1);
     __syncthreads();
     stamp(2);
