@@ -62,6 +62,20 @@ class GeometricEnv(_base.GeometricEnv):
                 self.obs_ts.append(t)
                 t += env.CTRL_TIMESTEP
             steps = 0
+        elif qpTracker is not None and not render:
+            # nominal -> QP -> low level -> step (:303-350), the whole run through the persistent kernel where the library covers the
+            # configuration (order 2, 4 / 8 / 16 drones per env, Lemniscates, Euler DYN at pyb == ctrl): 50 control steps per launch,
+            # every step's observation into the log, every step's statuses into st_log.  MDS_EUNSUPPORTED: the step loop below.
+            from .._capi import MdsError
+            try:
+                env.rollout_cbf_geometric_fused(0.0, steps, qpTracker, x_obs_list, obs_r_list, steps_per_launch=50, obs_log=log, status_log=st_log)
+                for i in range(steps):
+                    self.obs_ts.append(t)
+                    t += env.CTRL_TIMESTEP
+                steps = 0
+            except MdsError as exc:
+                if exc.status not in (-6, -5):          # unsupported combination / trajectories that are not Lemniscates
+                    raise
         for i in range(steps):
             if qpTracker is not None:     # nominal -> QP -> low level -> step (:303-350)
                 obs, st = env.step_cbf_geometric(t, qpTracker, x_obs_list, obs_r_list)
@@ -77,6 +91,7 @@ class GeometricEnv(_base.GeometricEnv):
         o = log.double().cpu().numpy()
         self.observations.extend(list(o[:, 0] if env.NUM_ENVS == 1 else o))
         self.obs = self.observations[-1]
+        self.last_cbf_kernel = env.cbf_last_step_kernel()    # 2: the persistent rollout kernel, 1: one launch per step, 0: QP + low-level launches
         self.statuses = st_log.cpu().numpy()          # 1 where the QP was infeasible and the nominal control was kept (modelled fallback: cbf/qptracker.py docstring)
         env.close()
 

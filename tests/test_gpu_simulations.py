@@ -67,22 +67,26 @@ def test_envgeometric_setpoint_and_batch(gpu):
         geo2.do_control()
 
 
-def test_cbftest_do_control_matches_oracle(gpu):
-    """simulations/CBFTest.py __main__ (:414-427): LQR-omega nominal, one sphere at the lemniscate centre, order-2 filter."""
+@pytest.mark.parametrize("nd,kernel", [(3, 0), (4, 2)])
+def test_cbftest_do_control_matches_oracle(gpu, nd, kernel):
+    """simulations/CBFTest.py __main__ (:414-427): LQR-omega nominal, one sphere at the lemniscate centre, order-2 filter.  With 3 drones
+    the loop runs step by step (QP launch + low-level launch), with 4 through the persistent rollout kernel (4 / 8 / 16 drones per env)."""
     from multidronesim_amd.simulations import CBFTest as S
-    args = S.parse_args(["--num_drones", "3", "--duration_sec", "1", "--dtype", "float64"])
+    args = S.parse_args(["--num_drones", str(nd), "--duration_sec", "1", "--dtype", "float64"])
     assert args.controller == "lqr" and args.init_rad == .2
     geo = S.GeometricEnv(args, circle_init=True)
-    geo.INIT_XYZS[:, 2] = 0.5 + 0.3 * np.arange(3)                                   # no ground here: start at flight height, stacked
+    geo.INIT_XYZS[:, 2] = 0.5 + 0.3 * np.arange(nd)                                  # no ground here: start at flight height, stacked
     env = geo.create_env()
-    trajs = [S.Lemniscate(center=np.array([0, 0, 0.5 + 0.3 * k]), omega=0.5, yaw_rate=0) for k in range(3)]
+    trajs = [S.Lemniscate(center=np.array([0, 0, 0.5 + 0.3 * k]), omega=0.5, yaw_rate=0) for k in range(nd)]
     cbf = S.DroneCBF(env, geo.linear_models, safety_radius=0.1, zscale=1)
-    trk = S.DroneQPTracker(cbf, num_robots=3)
+    trk = S.DroneQPTracker(cbf, num_robots=nd)
     x_obs = np.array([np.array([[0, 0, .5], np.zeros(3)])])
+    lib, h = env._lib, env._h
     geo.do_control(trajs=trajs, qpTracker=trk, x_obs_list=x_obs, obs_r_list=[.1])
     obs = np.asarray(geo.observations)
-    assert obs.shape == (100, 3, 20) and geo.statuses.shape == (100, 1)
-    P = np.array([[1.0, 0.5, 0, 0, 0.5 + 0.3 * k, 0.0, 0.0] for k in range(3)])
+    assert obs.shape == (100, nd, 20) and geo.statuses.shape == (100, 1)
+    assert geo.last_cbf_kernel == kernel                                             # which form the mirror ran
+    P = np.array([[1.0, 0.5, 0, 0, 0.5 + 0.3 * k, 0.0, 0.0] for k in range(nd)])
     oobs, ohist = H.oracle_cbf_closed_loop(geo.INIT_XYZS[None], geo.INIT_RPYS[None], P[None], 100, cbf.Kcbf.reshape(-1), cbf.umax, 0.1, 1.0,
                                            list(x_obs), [.1], nominal="lqr_omega")
     np.testing.assert_array_equal(geo.statuses, ohist)
