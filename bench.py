@@ -787,6 +787,7 @@ def main(argv=None):
     # `value` = units / the slowest rank's interval, the contract's MAX over ranks) do not see
     node_wall = max(gather_over_ranks(node_t1, world, red_dev)) - min(gather_over_ranks(node_t0, world, red_dev))
     used_streams = env.last_rollout_streams() if c_loop else 1
+    c4_kernel_ran = env.cbf_last_step_kernel() if c4 else None
 
     obs = c5_log[(c5_k[0] - 1) % c5_T] if c5 else env._obs
     ok = bool(torch.isfinite(obs).all().item()) and abs(float(obs[..., 3:7].norm(dim=-1).mean().item()) - 1.0) < 1e-3
@@ -890,10 +891,10 @@ def main(argv=None):
             line["config"]["launch"] = f"C loop (mds_rollout_step_fused), {fused_T} steps per launch, obs -> rollout log slot"
     if c4:
         st = env._cbf_status
-        line["roofline"]["kernel"] = ("k_cbf_step (one launch per step and env half: nominal controller, 4 QPs per wave, low level + physics)" if env.cbf_last_step_kernel() == 1 else
+        line["roofline"]["kernel"] = ("k_cbf_step (one launch per step and env half: nominal controller, 4 QPs per wave, low level + physics)" if c4_kernel_ran == 1 else
                                       "k_cbf_filter_gi + k_lowlevel_step (2 launches per step and env half from the second step on; the QP is issue/latency bound)")
         if fused_T:
-            line["roofline"]["kernel"] = f"k_cbf_rollout ({fused_T} control steps per launch: nominal controller, 4 QPs per wave, low level + physics, state in registers)"
+            line["roofline"]["kernel"] = f"k_cbf_rollout<float, 0, false, 8> ({fused_T} control steps per launch: a workgroup owns 32 envs; nominal controller, ticketed QPs, low level + physics; state in LDS / registers)"
         line["roofline"]["bytes_per_drone_step"] = BYTES_PER_DRONE_STEP_C4
         line["roofline"]["note"] = ("algorithmic bytes of SURVEY 8d (280 B per drone-step: the fused step's 212 + u_hat 16 + xdes 36 + u_safe 16); the path is "
                                     "VALU / latency bound, `frac` says how far from the HBM roofline that leaves it")
@@ -909,8 +910,11 @@ def main(argv=None):
                 line["cbf_window"] = c4_window_stats(torch, env, tracker, c4_obs, c4_r, args.warmup, args.steps)
             except Exception as exc:
                 line["cbf_window"] = {"error": str(exc)}
-        line["config"]["step_kernel"] = "one launch" if env.cbf_last_step_kernel() == 1 else "QP launch + low-level launch"   # what the library did
-        if not args.python_loop:
+        line["config"]["step_kernel"] = {2: f"persistent rollout kernel, {fused_T} control steps per launch", 1: "one launch per step"}.get(
+            c4_kernel_ran, "QP launch + low-level launch")          # what the library did in the timed call
+        if fused_T:
+            line["config"]["launch"] = f"persistent rollout kernel (mds_rollout_cbf_geometric_fused), {fused_T} steps per launch, every step's observation into a {fused_T}-slot ring"
+        elif not args.python_loop:
             line["config"]["launch"] = "C rollout loop, env halves on 2 streams" if split else "C rollout loop, one stream"
         line["cbf_fallback_frac_last_step"] = float((st != 0).float().mean().item())
         try:
