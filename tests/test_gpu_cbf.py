@@ -817,3 +817,43 @@ def test_cbf_persistent_rollout_rejects_what_it_does_not_cover(mds):
     assert ei.value.status == -6                    # MDS_EUNSUPPORTED
     env.rollout_cbf_geometric(0.0, 5, trk)          # the general loop serves it
     env.close()
+
+
+@pytest.mark.parametrize("D,n_obs,spl", [(4, 0, 1), (8, 2, 3), (4, 16, 7), (8, 0, 64)])
+def test_cbf_persistent_rollout_small_shapes(mds, D, n_obs, spl):
+    """The persistent kernel away from the C4 shape: 4 and 8 drones per env (128 / 64 envs per workgroup; with D = 4 and 16 obstacles the
+    barrier rows fill two row slots, with none a single one), no obstacles at all, one control step per launch and more steps per launch
+    than the call has, a single partial workgroup -- statuses equal to the step-by-step loop's at every step, state to rounding."""
+    E, steps = 11, 40
+    xyz, rpy, P = H.c2_setup(E, D, phase="c3", offset=1.0)
+    P[..., 4] = 0.5 + 0.15 * np.arange(D)                         # 15 cm apart: closer than the pair distance, rows go active
+    xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    rng = np.random.default_rng(3)
+    x_obs = [np.array([[*rng.uniform(-1.2, 1.2, size=2), rng.uniform(0.2, 1.5)], [0, 0, 0]]) for _ in range(n_obs)] or None
+    obs_r = [0.1] * n_obs if n_obs else None
+    out = {}
+    for form in ("step", "fused"):
+        env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                             pyb_freq=100, ctrl_freq=100, num_envs=E, dtype="float32")
+        env.set_trajectories(P)
+        cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2)
+        trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+        env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+        if form == "step":
+            t, hist = 0.0, []
+            for k in range(steps):
+                o, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
+                hist.append(st.cpu().numpy().copy())
+                t += env.CTRL_TIMESTEP
+            hist = np.array(hist)
+        else:
+            slog = mds.torch.full((steps, E), -1, dtype=mds.torch.int32, device=env.device)
+            o, st = env.rollout_cbf_geometric_fused(0.0, steps, trk, x_obs, obs_r, steps_per_launch=spl, status_log=slog)
+            assert env.cbf_last_step_kernel() == 2
+            hist = slog.cpu().numpy()
+        out[form] = (o.double().cpu().numpy().copy(), hist, env.get_state(), cbf.last_iterations().cpu().numpy().copy())
+        env.close()
+    np.testing.assert_array_equal(out["step"][1], out["fused"][1])
+    np.testing.assert_array_equal(out["step"][3], out["fused"][3])
+    np.testing.assert_allclose(out["fused"][0][..., :16], out["step"][0][..., :16], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out["fused"][2], out["step"][2], rtol=0, atol=1e-4)
