@@ -260,6 +260,8 @@ template <typename T> static void fill_cbf(const mds_handle* h, const mds_cbf_pa
   o.inv_zscale = (T)(1.0 / p.zscale);
   o.obs_magic = p.n_obs > 0 ? (65536 + p.n_obs - 1) / p.n_obs : 0;
   o.inv_c4 = (T)(1.0 / (p.zscale * p.zscale * p.zscale * p.zscale));
+  o.c4x4 = (T)(4.0 / (p.zscale * p.zscale * p.zscale * p.zscale));
+  o.c4x12 = (T)(12.0 / (p.zscale * p.zscale * p.zscale * p.zscale));
   o.inv_m = (T)(1.0 / h->cfg.M);
   o.g = (T)h->cfg.G;
   o.Fmin = (T)p.Fmin;

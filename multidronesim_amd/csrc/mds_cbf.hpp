@@ -21,6 +21,7 @@ template <typename T> struct CbfParams {
   T Ds_pair;      // 2 * safety_radius (:291)
   T safety_radius;
   T zscale, inv_zscale, inv_c4;
+  T c4x4, c4x12;  // 4 / zscale^4, 12 / zscale^4 (gradient and Hessian of (z / zscale)^4)
   int obs_magic;  // ceil(2^16 / n_obs): row index -> (agent, obstacle) without an integer division
   T inv_m, g;     // env.M, env.G (9.8) through the linear models
   T Fmin, Fmax;   // order 3 force box (:564-565)
@@ -29,23 +30,50 @@ template <typename T> struct CbfParams {
 // Order-2 row from the quantities it depends on: e = pos_i - pos_j (actual positions) and the differences of the tracking errors
 // d = (x_i - xdes_i) - (x_j - xdes_j) in roll, pitch and velocity.  Returns h_row and the thrust coefficient L_g L_f h (the omega
 // columns are zero with the omega linearisation).
+//
+// Takes its operands as the PAIRS the persistent rollout kernel keeps side by side in its LDS records -- (ex, ey),
+// (d_pitch, -d_roll), (dvx, dvy), (ez, dvz) -- with every fused multiply-add written out (contraction off: every kernel that
+// instantiates it rounds alike); 38 instructions.  A version of this body on a float ext_vector_type(2) (v_pk_mul_f32 /
+// v_pk_fma_f32) was measured and dropped: on MI355X a packed fp32 instruction issues at half the rate of a scalar one
+// (profiles/tools/ubench/valu_rate.hip: 0.96 vs 1.89 ns per instruction and SIMD at 8 waves), so packing buys no arithmetic
+// throughput, and the rollout kernel ran 1 % slower with it.
+// With s = ex^2 + ey^2 the Hessian of s^2 is Hxx = 4 s + 8 ex^2, Hyy = 4 s + 8 ey^2, 2 Hxy = 16 ex ey; the z terms use the
+// host-side products c4x4 = 4 / zscale^4, c4x12 = 12 / zscale^4; nDs4 = -Ds^4 (cbf_neg_ds4).
+#pragma clang fp contract(off)
+template <typename T> struct Pair {
+  T x, y;
+};
+template <typename T> MDS_HD Pair<T> operator-(Pair<T> a, Pair<T> b) { return {a.x - b.x, a.y - b.y}; }
+
+template <typename T> MDS_HD T cbf_neg_ds4(T Ds) {
+  const T Ds2 = Ds * Ds;
+  return -(Ds2 * Ds2);
+}
+
 template <typename T>
-MDS_HD void cbf_row_o2(const CbfParams<T>& P, T ex, T ey, T ez, T dr, T dp, T dvx, T dvy, T dvz, T Ds, T* h_row, T* Lg0) {
-  const T s = m_fma(ex, ex, ey * ey);
+MDS_HD void cbf_row_o2_pairs(const CbfParams<T>& P, Pair<T> exy, Pair<T> dpr, Pair<T> dvxy, Pair<T> ezvz, T nDs4, T* h_row, T* Lg0) {
+  const T ex = exy.x, ey = exy.y, ez = ezvz.x, dvx = dvxy.x, dvy = dvxy.y, dvz = ezvz.y;
+  const T ex2 = ex * ex, ey2 = ey * ey, ez2 = ez * ez;
+  const T s = ex2 + ey2;
   const T ezc = ez * P.inv_zscale;
   const T ezc2 = ezc * ezc;
-  const T Ds2 = Ds * Ds;
-  const T h = m_fma(s, s, m_fma(ezc2, ezc2, -(Ds2 * Ds2)));
-  const T gx = T(4) * ex * s, gy = T(4) * ey * s, gz = T(4) * ez * ez * ez * P.inv_c4;
-  const T Hxx = T(12) * ex * ex + T(4) * ey * ey, Hxy = T(8) * ex * ey, Hyy = T(4) * ex * ex + T(12) * ey * ey,
-          Hzz = T(12) * ez * ez * P.inv_c4;
-  const T dax = P.g * dp, day = -P.g * dr;
+  const T h = m_fma(s, s, m_fma(ezc2, ezc2, nDs4));
+  const T s4 = T(4) * s;
+  const T gx = ex * s4, gy = ey * s4, gz = (P.c4x4 * ez2) * ez;
+  const T Hxx = m_fma(T(8), ex2, s4), Hyy = m_fma(T(8), ey2, s4), Hxy2 = (T(16) * ex) * ey, Hzz = P.c4x12 * ez2;
+  const T dax = P.g * dpr.x, day = P.g * dpr.y;                 // g d_pitch, -g d_roll
   const T hdot = m_fma(gx, dvx, m_fma(gy, dvy, gz * dvz));
-  const T quad = Hxx * dvx * dvx + T(2) * Hxy * dvx * dvy + Hyy * dvy * dvy + Hzz * dvz * dvz;
-  const T Lf2 = m_fma(gx, dax, gy * day) + quad;
+  const T quad = m_fma(Hxx, dvx * dvx, m_fma(Hxy2, dvx * dvy, m_fma(Hyy, dvy * dvy, Hzz * (dvz * dvz))));
+  const T Lf2 = m_fma(gx, dax, m_fma(gy, day, quad));
   *h_row = m_fma(P.k[0], h, m_fma(P.k[1], hdot, Lf2));
   *Lg0 = gz * P.inv_m;
 }
+
+template <typename T>
+MDS_HD void cbf_row_o2(const CbfParams<T>& P, T ex, T ey, T ez, T dr, T dp, T dvx, T dvy, T dvz, T Ds, T* h_row, T* Lg0) {
+  cbf_row_o2_pairs<T>(P, Pair<T>{ex, ey}, Pair<T>{dp, -dr}, Pair<T>{dvx, dvy}, Pair<T>{ez, dvz}, cbf_neg_ds4(Ds), h_row, Lg0);
+}
+#pragma clang fp contract(fast)
 
 // One ECBF row from e = pos_i - pos_j (ACTUAL positions) and d = (x_i - xdes_i) - (x_j - xdes_j), the difference of the two
 // tracking errors in the model's state layout (d = x_i - xdes_i against an obstacle, cbf/cbf.py:380-392):

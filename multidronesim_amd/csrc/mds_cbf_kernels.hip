@@ -522,11 +522,53 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
         infeasible = true;
         break;
       }
+      constexpr bool ROW0 = NMAX <= 16;                                                  // z, r, lambda live in lanes 0..n-1 only
       // ---- everything this step reads from LDS, in one round trip ----
       T res = -wb;
 #pragma unroll
       for (int v = 0; v < NV; ++v) res = m_fma(wca[v], su[NV * wia + v], m_fma(two ? wcb[v] : T(0), su[NV * wib + v], res));
       const int ln = lane < NMAX ? lane : NMAX - 1;                                      // lanes >= n hold no row: clamp the address only
+#if !defined(MDS_TUNE_GI_NO_FIRST_STEP)
+      if (q == 0) {
+        // Empty active set (the first step of most solves, and the only one of more than half of them): the step runs along the
+        // row's own normal -- no Q, R or multipliers to read, no blocking row, no back substitution.  The general step below with
+        // q = 0, operation for operation (same sums in the same order: same bits), at a third of its instructions.
+        const T my_u = su[ln];
+        T zv = T(0);
+        if (lane < n) {
+          const int ag = lane / NV, vv = lane - ag * NV;
+#pragma unroll
+          for (int v = 0; v < NV; ++v)
+            if (v == vv) zv = (ag == wia ? wca[v] : T(0)) + ((two && ag == wib) ? wcb[v] : T(0));
+        }
+        const T zz = wv::allreduce_n<ROW0>(zv * zv, wv::Add());
+        const bool has_z = zz > GiEps<T>::z;
+        const T t = has_z ? res * m_rcp(zz) : GiEps<T>::inf;
+        if (!(t < GiEps<T>::inf)) {
+          infeasible = true;
+          break;
+        }
+        MDS_WAVE_SYNC();
+        if (lane < n) su[lane] = m_fma(-t, zv, my_u);
+        lam_new += t;
+        const T inz = m_rsqrt(zz), nz = zz * inz;
+        if (lane < n) sQ[lane][0] = zv * inz;
+        if (lane == 0) {
+          sR[0][0] = nz;
+          sdi[0] = inz;
+          slam[0] = lam_new;
+          sact[0] = wrow;
+        }
+        if (lane == owner) {
+#pragma unroll
+          for (int k = 0; k < R; ++k)
+            if (k == kk) act[k] = true;
+        }
+        q = 1;
+        MDS_WAVE_SYNC();
+        break;
+      }
+#endif
       T dc = T(0);
       {                                                                                  // d = Q^T a: read by every lane (clamped column) so that the
         T qa[NV], qb[NV];                                                                // reads join the step's one round trip, kept by lanes < q
@@ -583,7 +625,6 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
           else if (lane < k) rc = m_fma(-sR[lane][k], rk, rc);
         }
       }
-      constexpr bool ROW0 = NMAX <= 16;                                                  // z, r, lambda live in lanes 0..n-1 only
       const T zz = wv::allreduce_n<ROW0>(zv * zv, wv::Add());
       const T rmax = wv::max_nonneg<ROW0>(lane < q ? m_abs(rc) : T(0));
       T t1v = GiEps<T>::inf;
@@ -1163,51 +1204,42 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 && R == 4) ? 4 : 1) void k_cbf_
 #ifndef MDS_CBF_ROLL_NW
 #define MDS_CBF_ROLL_NW 8
 #endif
-struct RollSlot {       // row r = lane + 64 k of any env: what it is (built once per launch by roll_slot_of)
-  int offA;             // byte offset of agent i's record from the env's first record; box rows: the variable index
-  int offB;             // pair rows: agent j's record (same base); obstacle rows: byte offset of the obstacle's record in sobrec
-  int ds;               // index into sDs: 0 = pair distance 2 safety_radius, 1 + o = safety_radius + r_o
-  int kind;             // 0 none, 1 pair, 2 obstacle, 3 box row +u <= umax, 4 box row -u <= umax;  | agent i << 8 | agent j << 16
+#ifndef MDS_TUNE_ROLL_SKIP
+#define MDS_TUNE_ROLL_SKIP 0   // tuning aid (cost breakdown of stage B): 1 no row polynomial, 2 no normalisation, 4 no scan / solve, 8 no rows
+#endif
+struct RollSlot {       // row r = lane + 64 k of any env: what it is, as the row build consumes it (built once per launch by roll_slot_of)
+  int a0;               // barrier rows: byte offset of agent i's record half 0 from the env's first record (swizzle applied); else 0
+  int b0;               // pair rows: the same for agent j; other rows: byte offset of an obstacle record (obstacle o, or the first) in the
+                        // workgroup's LDS block
+  int ds;               // byte offset in the LDS block of -Ds^4: pair distance 2 safety_radius, or safety_radius + r_o
+  int kind;             // 0 none, 1 pair, 2 obstacle, 3 box row +u <= umax, 4 box row -u <= umax;  | agent i << 8 | agent j << 16 | pair << 24
 };
 
-template <typename T> __device__ __forceinline__ RollSlot roll_slot_of(const CbfParams<T>& P, const int* __restrict__ pair_ij, const int r) {
+// rec: record stride in bytes; swz: agents 8..15 keep their record halves swapped (16-byte halves, D = 16 only: see k_cbf_rollout);
+// sob / dso: byte offsets of the obstacle records and of the -Ds^4 table in the LDS block; wT: sizeof(T)
+template <typename T>
+__device__ __forceinline__ RollSlot roll_slot_of(const CbfParams<T>& P, const int* __restrict__ pair_ij, const int r, const int rec, const bool swz,
+                                                 const int sob, const int dso) {
   const int D = P.num_drones, npairs = cbf_num_pairs(D), nobs_rows = D * P.n_obs, m = npairs + nobs_rows + 2 * D;
-  constexpr int kRec = 8 * (int)sizeof(T);                     // record stride (see k_cbf_rollout); bits 24 / 25 of kind: agent i / j >= 8
-  RollSlot sl = {0, 0, 0, 0};
+  auto half0 = [&](int ag) { return ag * rec + ((swz && ((ag >> 3) & 1)) ? 16 : 0); };
+  RollSlot sl = {0, sob, dso, 0};
   if (r < npairs) {
     const int ij = pair_ij[r], ia = ij & 255, ib = ij >> 8;
-    sl = {ia * kRec, ib * kRec, 0, 1 | (ia << 8) | (ib << 16) | (((ia >> 3) & 1) << 24) | (((ib >> 3) & 1) << 25)};
+    sl = {half0(ia), half0(ib), dso, 1 | (ia << 8) | (ib << 16) | (1 << 24)};
   } else if (r < npairs + nobs_rows) {
     const int q = r - npairs, ag = (q * P.obs_magic) >> 16, oo = q - ag * P.n_obs;       // as cbf_o2_slot
-    sl = {ag * kRec, oo * kRec, 1 + oo, 2 | (ag << 8) | (ag << 16) | (((ag >> 3) & 1) << 24)};
+    sl = {half0(ag), sob + oo * rec, dso + (1 + oo) * (int)sizeof(T), 2 | (ag << 8) | (ag << 16)};
   } else if (r < m) {
     const int q = r - npairs - nobs_rows, var = q < D ? q : q - D;
-    sl = {var, 0, 0, (q < D ? 3 : 4) | (var << 8) | (var << 16)};
+    sl = {0, sob, dso, (q < D ? 3 : 4) | (var << 8) | (var << 16)};
   }
   return sl;
 }
 
 // Kernel arguments are loop invariants of a kernel that never leaves its step loop: left alone, the compiler hoists every VGPR copy
 // a VALU instruction with two scalar operands needs (and every address it can form) out of the loop, keeps them live across all
-// three stages and spills them.  These make a local copy's fields "redefined here" (an empty asm per scalar register, no
-// instruction): whatever is derived from them is formed inside the stage that uses it.
-template <typename V> __device__ __forceinline__ void sfresh(V& v) { asm volatile("" : "+s"(v)); }
-template <typename T> __device__ __forceinline__ Consts<T> fresh(Consts<T> c) {
-  sfresh(c.kf); sfresh(c.km); sfresh(c.arm); sfresh(c.mass); sfresh(c.inv_mass); sfresh(c.gravity); sfresh(c.max_rpm); sfresh(c.hover_rpm);
-  sfresh(c.thrust_corr); sfresh(c.dt); sfresh(c.g_ctrl); sfresh(c.cos_max_tilt); sfresh(c.tan_max_tilt); sfresh(c.min_motor_thrust);
-  sfresh(c.max_motor_thrust); sfresh(c.inv_2L); sfresh(c.inv_4r); sfresh(c.inv_kf);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    sfresh(c.J[k]); sfresh(c.invJ[k]); sfresh(c.drag[k]); sfresh(c.wind[k]); sfresh(c.kp[k]); sfresh(c.kv[k]); sfresh(c.kR[k]); sfresh(c.kw[k]);
-  }
-  return c;
-}
-template <typename T> __device__ __forceinline__ CbfParams<T> fresh(CbfParams<T> P) {
-  sfresh(P.k[0]); sfresh(P.k[1]); sfresh(P.k[2]); sfresh(P.umax[0]); sfresh(P.umax[1]); sfresh(P.umax[2]); sfresh(P.umax[3]); sfresh(P.Ds_pair);
-  sfresh(P.safety_radius); sfresh(P.zscale); sfresh(P.inv_zscale); sfresh(P.inv_c4); sfresh(P.inv_m); sfresh(P.g); sfresh(P.Fmin); sfresh(P.Fmax);
-  return P;
-}
-
+// three stages and spills them.
+//
 // The kernel's constants live in a device copy read through a CONSTANT-address-space pointer that every stage makes fresh: each
 // stage loads the fields it uses with scalar loads where it uses them.  As by-value kernel arguments (65 dwords beside 14 pointers)
 // they were loop invariants held in SGPRs across all stages: the 106 SGPRs overflowed into VGPR lanes and every use paid a
@@ -1254,12 +1286,13 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   constexpr int R = 4, NMAX = 16, NV = 1;
   constexpr int kQS = (NMAX + 3) / 4 * 4 + 4;
   constexpr int GBMAX = NT / 4;                                // envs per workgroup (D >= 4)
-  // One drone's record: two 16-byte halves (px py pz e_roll | e_pitch e_vx e_vy e_vz), read by the row slots as two ds_read_b128 per
-  // agent.  At the plain 8-word stride agents a and a + 8 start in the same bank, and a 16-lane group of such a read that walks 16
-  // consecutive agents would take two passes: records 8..15 of every 16 keep their halves in swapped order (half h of record j sits
-  // at 16 (h ^ (j >> 3 & 1)) bytes), so that group reads 16 x 4 different banks.  (First version: 8 scalar fields at 8 words -- 124 M
-  // bank-conflict cycles against 81 M LDS-instruction cycles per launch; then a 9-word stride, conflict-free but 16 ds_read2_b32 per
-  // row slot: the LDS pipe was ~45 % busy and every LDS access of the kernel queued behind them.)
+  // One drone's record: two 16-byte halves (px py e_pitch -e_roll | e_vx e_vy pz e_vz) -- the operand pairs of cbf_row_o2_pairs side
+  // by side --, read by the row slots as two ds_read_b128 per agent.  At the plain 8-word stride agents a and a + 8 start in the same
+  // bank, and a 16-lane group of such a read that walks 16 consecutive agents would take two passes: with D = 16, agents 8..15 keep
+  // their halves in swapped order (half h of agent a sits at 16 (h ^ (a >> 3)) bytes), so that group reads 16 x 4 different banks;
+  // envs of 4 or 8 drones span at most 64 banks as they stand.  (First version: 8 scalar fields at 8 words -- 124 M bank-conflict
+  // cycles against 81 M LDS-instruction cycles per launch; then a 9-word stride, conflict-free but 16 ds_read2_b32 per row slot: the
+  // LDS pipe was ~45 % busy and every LDS access of the kernel queued behind them.)
   constexpr int kRec = 8 * (int)sizeof(T);
   constexpr bool kSwz = sizeof(T) == 4;
   struct alignas(16) V4 {
@@ -1276,12 +1309,15 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   };
   constexpr int kObsWave = 64 * kObsDim * (int)sizeof(T);      // write_obs_rows' slice per wave
   static_assert(sizeof(Slice) <= (size_t)kObsWave, "a wave's records + solver scratch must fit in its observation staging slice");
-  __shared__ __align__(16) unsigned char raw[NW * kObsWave];
+  static_assert(kObsWave % (16 * kRec) == 0, "an env's first record sits at a multiple of D * kRec bytes (pair rows OR their offsets in)");
+  // the LDS block the row build addresses by byte offset: [NW wave slices | obstacle records | -Ds^4 table]
+  constexpr int kSobOff = NW * kObsWave, kDsOff = kSobOff + kCbfMaxObs * kRec, kBlock = kDsOff + (kCbfMaxObs + 1 + 3) / 4 * 4 * (int)sizeof(T);
+  __shared__ __align__(128) unsigned char raw[kBlock];
+  T(*const sobrec)[8] = reinterpret_cast<T(*)[8]>(raw + kSobOff);     // obstacles as records with zero tracking errors (halves in plain order)
+  T* const sDs = reinterpret_cast<T*>(raw + kDsOff);                  // -Ds^4: [0] pairs, [1 + o] obstacle o
   __shared__ T st[13][NT];                                     // the state across stage B (lane-contiguous planes: conflict-free)
   __shared__ T su_all[NT];                                     // thrust variable of every drone: u_hat[0] in, QP minimiser out
   __shared__ __align__(16) RollSlot stab[R][64];               // row slot table
-  __shared__ __align__(16) T sobrec[kCbfMaxObs][8];            // obstacles as records with zero tracking errors (halves in plain order)
-  __shared__ T sDs[kCbfMaxObs + 1];
   __shared__ int sconv[GBMAX], scost[GBMAX], sorder[GBMAX];    // per env of the workgroup: QP solved; iterations of its last solve; hand-out order
   __shared__ int sticket;
   // tuning aid (stamps != NULL, MDS_TUNE_ROLL_STAMPS=1 on the host): shader-clock ticks every wave spent in each part of the step,
@@ -1316,16 +1352,18 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   // ---- once per launch ----
   {
     const CbfParams<T> P = load_const(&rp->P);
-  if (tid < R * 64) stab[tid >> 6][tid & 63] = roll_slot_of<T>(P, pair_ij, (tid & 63) + 64 * (tid >> 6));
+  if (tid < R * 64) stab[tid >> 6][tid & 63] = roll_slot_of<T>(P, pair_ij, (tid & 63) + 64 * (tid >> 6), kRec, kSwz && P.num_drones == 16, kSobOff, kDsOff);
   if (tid < kCbfMaxObs) {
     const bool on = tid < P.n_obs;
-    sobrec[tid][0] = on ? obstacles[4 * tid] : T(0);
-    sobrec[tid][1] = on ? obstacles[4 * tid + 1] : T(0);
-    sobrec[tid][2] = on ? obstacles[4 * tid + 2] : T(0);
-    for (int k = 3; k < 8; ++k) sobrec[tid][k] = T(0);
-    sDs[1 + tid] = on ? P.safety_radius + obstacles[4 * tid + 3] : T(1);
+    for (int k = 0; k < 8; ++k) sobrec[tid][k] = T(0);
+    if (on) {
+      sobrec[tid][0] = obstacles[4 * tid];
+      sobrec[tid][1] = obstacles[4 * tid + 1];
+      sobrec[tid][6] = obstacles[4 * tid + 2];
+    }
+    sDs[1 + tid] = cbf_neg_ds4(on ? P.safety_radius + obstacles[4 * tid + 3] : T(1));
   }
-  if (tid == 0) sDs[0] = P.Ds_pair;
+  if (tid == 0) sDs[0] = cbf_neg_ds4(P.Ds_pair);
   }
   if (tid < GB) scost[tid] = (tid < nenv && cost_io) ? cost_io[env0 + tid] : 0;
   State<T> s;
@@ -1356,9 +1394,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     }
     // obs_to_lin_model(obs, 9) - xdes with obs = pack_obs(state): world position, roll, pitch, world velocity; xdes = [0, 0, yaw, v_des, p_des]
     T* rc = slice_of(wq).rec[lq];
-    const int sw = kSwz ? ((lq >> 3) & 1) : 0;                   // records 8..15 of every 16: halves swapped
-    *reinterpret_cast<V4*>(rc + 4 * sw) = V4{{s.p.x + Pl.cx, s.p.y + Pl.cy, s.p.z + Pl.cz, rpy.x - T(0)}};
-    *reinterpret_cast<V4*>(rc + 4 * (sw ^ 1)) = V4{{rpy.y - T(0), s.v.x - des.v.x, s.v.y - des.v.y, s.v.z - des.v.z}};
+    const int sw = kSwz ? ((lq >> 3) & (D >> 4)) : 0;            // D = 16, agents 8..15: halves swapped
+    *reinterpret_cast<V4*>(rc + 4 * sw) = V4{{s.p.x + Pl.cx, s.p.y + Pl.cy, rpy.y - T(0), -(rpy.x - T(0))}};
+    *reinterpret_cast<V4*>(rc + 4 * (sw ^ 1)) = V4{{s.v.x - des.v.x, s.v.y - des.v.y, s.p.z + Pl.cz, s.v.z - des.v.z}};
     su_all[tq] = un0;
     st[0][tq] = s.p.x; st[1][tq] = s.p.y; st[2][tq] = s.p.z;
     st[3][tq] = s.q[0]; st[4][tq] = s.q[1]; st[5][tq] = s.q[2]; st[6][tq] = s.q[3];
@@ -1428,58 +1466,92 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         __builtin_amdgcn_s_setprio(0);
 #endif
         const int d0 = el * D;
-        const unsigned char* ebase = raw + (size_t)(d0 >> 6) * kObsWave + (size_t)(d0 & 63) * kRec;   // the env's first record
-        const int eswz = (d0 >> 3) & 1;                            // (D = 4, 8: an env's records sit in one half of a 16-record group)
+        const unsigned ebase = (unsigned)(d0 >> 6) * kObsWave + (unsigned)(d0 & 63) * kRec;   // the env's first record in the LDS block
         int tl = lane;
         asm volatile("" : "+v"(tl));                               // re-read per env: 4 LDS reads instead of 16 registers held across the stages
         T ca[R][NV], cb[R][NV], b[R];
         int ia[R], ib[R];
         bool vld[R], act[R];
         bool bad = false;
-        // Rows r = lane + 64 k.  Slots below nbs hold barrier rows (and possibly the first box rows): ONE straight-line body for all of them
-        // -- every lane runs the barrier arithmetic (lanes of other kinds on a harmless record pair, their result replaced by a select),
-        // so that the scheduler interleaves the slots' independent chains instead of walking one exec-masked branch per slot.
+        // Rows r = lane + 64 k.  Slots below NBS hold barrier rows -- all of them in slots below NBS - 1, beside the first box rows in
+        // slot NBS - 1: ONE straight-line body per slot, every lane runs the barrier arithmetic (lanes of other kinds on a harmless
+        // record pair, their result replaced by a select), all slots' LDS reads issued together (one round trip per env).
         // The normalisation without its branch: n2 == 0 leaves the row unscaled (inv = 1) and turns the reach test into b < 0, exactly
         // the two cases of cbf_o2_slot.
         auto build_rows = [&](auto nbc) {
         constexpr int NBS = decltype(nbc)::value;                  // compile time: the slots' bodies share one basic block
+        constexpr int kHalf = 4 * (int)sizeof(T);
+        RollSlot sl[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) sl[r] = stab[r][tl];
+        using P2 = Pair<T>;
+        P2 oa[NBS][4], ob[NBS][4];                                 // operand pairs of agent i / agent j or obstacle: (px py) (e_pitch -e_roll) (e_vx e_vy) (pz e_vz)
+        T nds4[NBS];
+        int pm[NBS];
+#pragma unroll
+        for (int r = 0; r < NBS; ++r) {
+          pm[r] = (sl[r].kind << 7) >> 31;                         // all ones on a pair row
+          const unsigned pa = ebase + (unsigned)sl[r].a0, pb = ((unsigned)pm[r] & ebase) | (unsigned)sl[r].b0;
+          const V4 a0 = *reinterpret_cast<const V4*>(raw + pa), a1 = *reinterpret_cast<const V4*>(raw + (kSwz ? (pa ^ 16u) : pa + kHalf));
+          const V4 b0 = *reinterpret_cast<const V4*>(raw + pb), b1 = *reinterpret_cast<const V4*>(raw + (kSwz ? (pb ^ 16u) : pb + kHalf));
+          oa[r][0] = P2{a0.v[0], a0.v[1]}; oa[r][1] = P2{a0.v[2], a0.v[3]}; oa[r][2] = P2{a1.v[0], a1.v[1]}; oa[r][3] = P2{a1.v[2], a1.v[3]};
+          ob[r][0] = P2{b0.v[0], b0.v[1]}; ob[r][1] = P2{b0.v[2], b0.v[3]}; ob[r][2] = P2{b1.v[0], b1.v[1]}; ob[r][3] = P2{b1.v[2], b1.v[3]};
+          nds4[r] = *reinterpret_cast<const T*>(raw + sl[r].ds);
+        }
+#pragma unroll
+        for (int r = 0; r < NBS; ++r)                              // every slot's operands in ONE LDS round trip
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            MDS_PIN2(oa[r][c].x, oa[r][c].y);
+            MDS_PIN2(ob[r][c].x, ob[r][c].y);
+          }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           act[r] = false;
-          const RollSlot sl = stab[r][tl];
-          const int kind = sl.kind & 255;
-          ia[r] = (sl.kind >> 8) & 255;
-          ib[r] = (sl.kind >> 16) & 255;
+          const int kind = sl[r].kind & 255;
+          ia[r] = (sl[r].kind >> 8) & 255;
+          ib[r] = (sl[r].kind >> 16) & 255;
           if (r < NBS) {
-            const bool bar = kind == 1 || kind == 2;
-            const unsigned char* pa = ebase + (bar ? sl.offA : 0);
-            const unsigned char* pb = kind == 1 ? ebase + sl.offB : reinterpret_cast<const unsigned char*>(&sobrec[0][0]) + (kind == 2 ? sl.offB : 0);
-            // byte offset of half 0 (half 1 sits at the other 16): the agent's swap bit, flipped for envs that start at an odd multiple of 8
-            const int xa = (kSwz && bar) ? ((((sl.kind >> 24) & 1) ^ eswz) << 4) : 0;
-            const int xb = (kSwz && kind == 1) ? ((((sl.kind >> 25) & 1) ^ eswz) << 4) : 0;
-            constexpr int kHalf = 4 * (int)sizeof(T);
-            const V4 a0 = *reinterpret_cast<const V4*>(pa + (kSwz ? xa : 0)), a1 = *reinterpret_cast<const V4*>(pa + (kSwz ? (xa ^ 16) : kHalf));
-            const V4 b0 = *reinterpret_cast<const V4*>(pb + (kSwz ? xb : 0)), b1 = *reinterpret_cast<const V4*>(pb + (kSwz ? (xb ^ 16) : kHalf));
-            const T A8[8] = {a0.v[0], a0.v[1], a0.v[2], a0.v[3], a1.v[0], a1.v[1], a1.v[2], a1.v[3]};
-            const T B8[8] = {b0.v[0], b0.v[1], b0.v[2], b0.v[3], b1.v[0], b1.v[1], b1.v[2], b1.v[3]};
             T hr, lg;
-            cbf_row_o2<T>(P, A8[0] - B8[0], A8[1] - B8[1], A8[2] - B8[2], A8[3] - B8[3], A8[4] - B8[4], A8[5] - B8[5], A8[6] - B8[6],
-                          A8[7] - B8[7], sDs[bar ? sl.ds : 0], &hr, &lg);
-            T cak = -lg, cbk = kind == 1 ? lg : T(0), bk = hr;
+#if (MDS_TUNE_ROLL_SKIP & 1)   // tuning aid: the row polynomial replaced by a sum of its operands (rows always satisfied)
+            hr = T(100) + nds4[r];
+            for (int c = 0; c < 4; ++c) hr += (oa[r][c].x - ob[r][c].x) + (oa[r][c].y - ob[r][c].y);
+            lg = T(1);
+#else
+            cbf_row_o2_pairs<T>(P, oa[r][0] - ob[r][0], oa[r][1] - ob[r][1], oa[r][2] - ob[r][2], oa[r][3] - ob[r][3], nds4[r], &hr, &lg);
+#endif
+            T cak = -lg, cbk, bk = hr;
+            if constexpr (sizeof(T) == 4) cbk = __builtin_bit_cast(float, __builtin_bit_cast(int, lg) & pm[r]);   // pair rows: +lg at agent j
+            else cbk = pm[r] ? lg : T(0);
+#if (MDS_TUNE_ROLL_SKIP & 2)   // tuning aid: no normalisation
+            const bool pos = true;
+            const T inv = T(1);
+#else
             const T n2 = m_fma(cak, cak, cbk * cbk);
             const bool pos = n2 > T(0);
             const T inv = pos ? m_rsqrt(n2) : T(1);
+#endif
             cak *= inv;
             cbk *= inv;
             bk *= inv;
             const T reach = (m_abs(cak) + m_abs(cbk)) * P.umax[0];
-            bad = bad | (bar & (bk < -reach * (T(1) + T(sizeof(T) == 4 ? 1e-5 : 1e-10))));       // (bitwise: no short-circuit branch)
-            // +-u_var <= umax (cbf/cbf.py:400-412): unit norm as it stands
-            const T box_c = kind == 3 ? T(1) : (kind == 4 ? T(-1) : T(0)), box_b = kind >= 3 ? P.umax[0] : T(0);
-            ca[r][0] = bar ? cak : box_c;
-            cb[r][0] = bar ? cbk : T(0);
-            b[r] = bar ? bk : box_b;
-            vld[r] = (bar & pos) | (kind >= 3);
+            const bool unreachable = bk < -reach * (T(1) + T(sizeof(T) == 4 ? 1e-5 : 1e-10));
+            if (r < NBS - 1) {                                     // barrier rows only
+              bad = bad | unreachable;                             // (bitwise: no short-circuit branch)
+              ca[r][0] = cak;
+              cb[r][0] = cbk;
+              b[r] = bk;
+              vld[r] = pos;
+            } else {
+              const bool bar = kind == 1 || kind == 2;
+              bad = bad | (bar & unreachable);
+              // +-u_var <= umax (cbf/cbf.py:400-412): unit norm as it stands
+              const T box_c = kind == 3 ? T(1) : (kind == 4 ? T(-1) : T(0)), box_b = kind >= 3 ? P.umax[0] : T(0);
+              ca[r][0] = bar ? cak : box_c;
+              cb[r][0] = bar ? cbk : T(0);
+              b[r] = bar ? bk : box_b;
+              vld[r] = (bar & pos) | (kind >= 3);
+            }
           } else {
             ca[r][0] = kind == 3 ? T(1) : (kind == 4 ? T(-1) : T(0));
             cb[r][0] = T(0);
@@ -1488,8 +1560,16 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
           }
         }
         };
-        if (nbs <= 3) build_rows(wv::Ic<3>{});
-        else build_rows(wv::Ic<4>{});
+#if (MDS_TUNE_ROLL_SKIP & 8)   // tuning aid: no rows at all
+        for (int r = 0; r < R; ++r) { ca[r][0] = cb[r][0] = b[r] = T(0); ia[r] = ib[r] = 0; vld[r] = act[r] = false; }
+        if (false)
+#endif
+        switch (__builtin_amdgcn_readfirstlane(nbs)) {             // (wave-uniform; a scalar branch)
+          case 1: build_rows(wv::Ic<1>{}); break;
+          case 2: build_rows(wv::Ic<2>{}); break;
+          case 3: build_rows(wv::Ic<3>{}); break;
+          default: build_rows(wv::Ic<4>{}); break;
+        }
         stamp_b(7);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)
         // the scan, the bookkeeping and the next ticket are short serial chains (VALU -> scalar -> branch, LDS round trips): at equal
@@ -1498,6 +1578,14 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
 #endif
         bool converged = false;
         int it = 0, q = 0;
+#if (MDS_TUNE_ROLL_SKIP & 4)   // tuning aid: no scan, no solve (the rows are still built: their sum decides "converged")
+        {
+          T acc = T(0);
+          for (int r = 0; r < R; ++r) acc += ca[r][0] + cb[r][0] + b[r] + T(ia[r] + ib[r]) + (vld[r] ? T(1) : T(0));
+          converged = !__any(bad) && __any(acc > T(-1e30));
+        }
+        if (false)
+#endif
         gi_solve<T, R, NMAX, NV, false, kQS>(lane, D, max_iter, tol2, __any(bad), ca, cb, b, ia, ib, vld, act, &su_all[d0], S.sd, S.slam, S.sdi,
                                              S.sQ, S.sR, S.sact, nullptr, converged, it, q);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)
