@@ -2020,9 +2020,10 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
   const int m2 = D * (D - 1) / 2 + D * h->cbf.n_obs + 2 * D;
   // what the persistent kernel covers (everything else: mds_rollout_cbf_geometric, one or two launches per step)
   if (h->cbf.order != 2 || h->cbf_hildreth || D < 4 || D > 16 || 64 % D != 0 || m2 > 256 || h->envfx || h->cfg.integrator != MDS_INTEGRATOR_EULER ||
-      has_drag(h) || h->cbf_nominal > 1 || h->cfg.dtype == MDS_F16 || h->cfg.pyb_freq != h->cfg.ctrl_freq)
+      has_drag(h) || h->cbf_nominal > 1 || h->cfg.dtype == MDS_F16 || h->cfg.pyb_freq != h->cfg.ctrl_freq || h->n > (1 << 27))
     return fail(MDS_EUNSUPPORTED, "mds_rollout_cbf_geometric_fused: order-2 CBF, D in {4, 8, 16}, <= 256 rows per env, explicit Euler at "
-                                  "pyb_freq == ctrl_freq without drag / ground effect / downwash, geometric or LQR-omega nominal, f32 / f32c / f64");
+                                  "pyb_freq == ctrl_freq without drag / ground effect / downwash, geometric or LQR-omega nominal, f32 / f32c / f64, "
+                                  "at most 2^27 drones (32-bit byte offsets into the per-drone planes)");
   if (n_steps == 0) return MDS_OK;
   hipStream_t st = (hipStream_t)stream;
   // wavefronts per workgroup: 8 in fp32 (two workgroups per CU at <= 128 VGPRs); 4 in double (one wavefront per SIMD: the double
@@ -2045,6 +2046,14 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
       MDS_HIP(hipMalloc((void**)&stamps_dev, n_stamp * sizeof(unsigned long long) * ((n_steps + steps_per_launch - 1) / steps_per_launch)));
     }
   unsigned long long* const stamps_base = stamps_dev;
+  // tuning aid: MDS_TUNE_ROLL_EXTRA_LDS=<bytes> of unused dynamic LDS per workgroup (fewer workgroups per CU: occupancy experiments)
+  size_t extra_lds = 0;
+  if (const char* e = getenv("MDS_TUNE_ROLL_EXTRA_LDS")) {
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (end == e || *end != '\0' || v < 0 || v > 65536) return fail(MDS_EINVAL, "MDS_TUNE_ROLL_EXTRA_LDS: expected 0..65536 bytes");
+    extra_lds = (size_t)v;
+  }
   // the kernel reads Consts / CbfParams from a device copy (RollParams): refreshed, in stream order, when either has changed
   if (!h->roll_params) MDS_HIP(hipMalloc(&h->roll_params, sizeof(RollParams<double>)));
   if (h->roll_params_ver != h->params_ver) {
@@ -2059,7 +2068,7 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
     const int ks = n_steps - k0 < steps_per_launch ? n_steps - k0 : steps_per_launch;
     int32_t* slog = status_log ? status_log + (size_t)k0 * h->cfg.num_envs : nullptr;
 #define MDS_CR(T, CC, CP, NOM, COMP, TOL)                                                                                                      \
-  k_cbf_rollout<T, NOM, COMP, (sizeof(T) == 8 ? NWD : NWF)><<<grid, 64 * nw, 0, st>>>((const RollParams<T> MDS_CONST_AS*)h->roll_params, gain, h->n, h->ld, h->cfg.num_envs, t, dt, ks, (T*)h->state, (T*)h->state_lo,  \
+  k_cbf_rollout<T, NOM, COMP, (sizeof(T) == 8 ? NWD : NWF)><<<grid, 64 * nw, extra_lds, st>>>((const RollParams<T> MDS_CONST_AS*)h->roll_params, gain, h->n, h->ld, h->cfg.num_envs, t, dt, ks, (T*)h->state, (T*)h->state_lo,  \
                                                                (const T*)h->lem, (T*)rpm, (T*)h->ll, h->pair_ij, (const T*)h->obstacles,        \
                                                                (T*)obs_log, slot, log_slots > 0 ? log_slots : 1, (T*)obs, (int*)status, (int*)slog, \
                                                                h->cbf_cost, max_iter, (T)((TOL) * (TOL)), stamps_dev)

@@ -33,7 +33,7 @@ template <typename T> struct CbfParams {
 //
 // Takes its operands as the PAIRS the persistent rollout kernel keeps side by side in its LDS records -- (ex, ey),
 // (d_pitch, -d_roll), (dvx, dvy), (ez, dvz) -- with every fused multiply-add written out (contraction off: every kernel that
-// instantiates it rounds alike); 38 instructions.  A version of this body on a float ext_vector_type(2) (v_pk_mul_f32 /
+// instantiates it rounds alike); 36 instructions.  A version of this body on a float ext_vector_type(2) (v_pk_mul_f32 /
 // v_pk_fma_f32) was measured and dropped: on MI355X a packed fp32 instruction issues at half the rate of a scalar one
 // (profiles/tools/ubench/valu_rate.hip: 0.96 vs 1.89 ns per instruction and SIMD at 8 waves), so packing buys no arithmetic
 // throughput, and the rollout kernel ran 1 % slower with it.
@@ -50,23 +50,60 @@ template <typename T> MDS_HD T cbf_neg_ds4(T Ds) {
   return -(Ds2 * Ds2);
 }
 
+// N rows at once, statement by statement across the rows: N independent dependency chains side by side in program order (the
+// persistent rollout kernel runs one wave per env and is bound by the latency of such chains, not by arithmetic throughput).
+template <typename T, int N>
+MDS_HD void cbf_row_o2_pairs(const CbfParams<T>& P, const Pair<T> (&exy)[N], const Pair<T> (&dpr)[N], const Pair<T> (&dvxy)[N],
+                             const Pair<T> (&ezvz)[N], const T (&nDs4)[N], T (&h_row)[N], T (&Lg0)[N]) {
+#define MDS_ROWS(stmt)          \
+  _Pragma("unroll") for (int r = 0; r < N; ++r) { stmt; }
+  T ex2[N], ey2[N], ez2[N], s[N], ezc[N], ezc2[N], h[N], s4[N], gx[N], gy[N], gz[N], Hxx[N], Hyy[N], Hxy2[N], Hzz[N], dax[N], day[N];
+  T hdot[N], quad[N], Lf2[N], vxx[N], vxy[N], vyy[N], vzz[N];
+  MDS_ROWS(ex2[r] = exy[r].x * exy[r].x)
+  MDS_ROWS(ey2[r] = exy[r].y * exy[r].y)
+  MDS_ROWS(ez2[r] = ezvz[r].x * ezvz[r].x)
+  MDS_ROWS(s[r] = ex2[r] + ey2[r])
+  MDS_ROWS(ezc[r] = ezvz[r].x * P.inv_zscale)
+  MDS_ROWS(ezc2[r] = ezc[r] * ezc[r])
+  MDS_ROWS(h[r] = m_fma(ezc2[r], ezc2[r], nDs4[r]))
+  MDS_ROWS(h[r] = m_fma(s[r], s[r], h[r]))
+  MDS_ROWS(s4[r] = T(4) * s[r])
+  MDS_ROWS(gx[r] = exy[r].x * s4[r])
+  MDS_ROWS(gy[r] = exy[r].y * s4[r])
+  MDS_ROWS(gz[r] = (P.c4x4 * ez2[r]) * ezvz[r].x)
+  MDS_ROWS(Hxx[r] = m_fma(T(8), ex2[r], s4[r]))
+  MDS_ROWS(Hyy[r] = m_fma(T(8), ey2[r], s4[r]))
+  MDS_ROWS(Hxy2[r] = (T(16) * exy[r].x) * exy[r].y)
+  MDS_ROWS(Hzz[r] = P.c4x12 * ez2[r])
+  MDS_ROWS(dax[r] = P.g * dpr[r].x)                            // g d_pitch
+  MDS_ROWS(day[r] = P.g * dpr[r].y)                            // -g d_roll
+  MDS_ROWS(hdot[r] = gz[r] * ezvz[r].y)
+  MDS_ROWS(hdot[r] = m_fma(gy[r], dvxy[r].y, hdot[r]))
+  MDS_ROWS(hdot[r] = m_fma(gx[r], dvxy[r].x, hdot[r]))
+  MDS_ROWS(vxx[r] = dvxy[r].x * dvxy[r].x)
+  MDS_ROWS(vxy[r] = dvxy[r].x * dvxy[r].y)
+  MDS_ROWS(vyy[r] = dvxy[r].y * dvxy[r].y)
+  MDS_ROWS(vzz[r] = ezvz[r].y * ezvz[r].y)
+  MDS_ROWS(quad[r] = Hzz[r] * vzz[r])
+  MDS_ROWS(quad[r] = m_fma(Hyy[r], vyy[r], quad[r]))
+  MDS_ROWS(quad[r] = m_fma(Hxy2[r], vxy[r], quad[r]))
+  MDS_ROWS(quad[r] = m_fma(Hxx[r], vxx[r], quad[r]))
+  MDS_ROWS(Lf2[r] = m_fma(gy[r], day[r], quad[r]))
+  MDS_ROWS(Lf2[r] = m_fma(gx[r], dax[r], Lf2[r]))
+  MDS_ROWS(h_row[r] = m_fma(P.k[1], hdot[r], Lf2[r]))
+  MDS_ROWS(h_row[r] = m_fma(P.k[0], h[r], h_row[r]))
+  MDS_ROWS(Lg0[r] = gz[r] * P.inv_m)
+#undef MDS_ROWS
+}
+
 template <typename T>
 MDS_HD void cbf_row_o2_pairs(const CbfParams<T>& P, Pair<T> exy, Pair<T> dpr, Pair<T> dvxy, Pair<T> ezvz, T nDs4, T* h_row, T* Lg0) {
-  const T ex = exy.x, ey = exy.y, ez = ezvz.x, dvx = dvxy.x, dvy = dvxy.y, dvz = ezvz.y;
-  const T ex2 = ex * ex, ey2 = ey * ey, ez2 = ez * ez;
-  const T s = ex2 + ey2;
-  const T ezc = ez * P.inv_zscale;
-  const T ezc2 = ezc * ezc;
-  const T h = m_fma(s, s, m_fma(ezc2, ezc2, nDs4));
-  const T s4 = T(4) * s;
-  const T gx = ex * s4, gy = ey * s4, gz = (P.c4x4 * ez2) * ez;
-  const T Hxx = m_fma(T(8), ex2, s4), Hyy = m_fma(T(8), ey2, s4), Hxy2 = (T(16) * ex) * ey, Hzz = P.c4x12 * ez2;
-  const T dax = P.g * dpr.x, day = P.g * dpr.y;                 // g d_pitch, -g d_roll
-  const T hdot = m_fma(gx, dvx, m_fma(gy, dvy, gz * dvz));
-  const T quad = m_fma(Hxx, dvx * dvx, m_fma(Hxy2, dvx * dvy, m_fma(Hyy, dvy * dvy, Hzz * (dvz * dvz))));
-  const T Lf2 = m_fma(gx, dax, m_fma(gy, day, quad));
-  *h_row = m_fma(P.k[0], h, m_fma(P.k[1], hdot, Lf2));
-  *Lg0 = gz * P.inv_m;
+  const Pair<T> a[1] = {exy}, b[1] = {dpr}, c[1] = {dvxy}, d[1] = {ezvz};
+  const T n[1] = {nDs4};
+  T hr[1], lg[1];
+  cbf_row_o2_pairs<T, 1>(P, a, b, c, d, n, hr, lg);
+  *h_row = hr[0];
+  *Lg0 = lg[0];
 }
 
 template <typename T>

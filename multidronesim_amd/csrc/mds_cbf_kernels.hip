@@ -1,6 +1,7 @@
 // ECBF safety filter kernels (a11-a15): constraint rows of cbf/cbf.py and the QP of
 // cbf/qptracker.py:86-114, one wavefront per environment.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "mds_cbf.hpp"
 
@@ -1204,6 +1205,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 && R == 4) ? 4 : 1) void k_cbf_
 #ifndef MDS_CBF_ROLL_NW
 #define MDS_CBF_ROLL_NW 8
 #endif
+#ifndef MDS_ROLL_STAMPS
+#define MDS_ROLL_STAMPS 0       // 1: per-stage shader-clock stamps compiled in (profiles/tools/r03_stamps.sh builds such a library)
+#endif
 #ifndef MDS_TUNE_ROLL_SKIP
 #define MDS_TUNE_ROLL_SKIP 0   // tuning aid (cost breakdown of stage B): 1 no row polynomial, 2 no normalisation, 4 no scan / solve, 8 no rows
 #endif
@@ -1273,6 +1277,14 @@ template <typename V> __device__ __forceinline__ V load_const(const V MDS_CONST_
   return out;
 }
 
+// element idx of a per-lane plane behind a UNIFORM base pointer, addressed by a 32-bit byte offset: the access compiles to the
+// scalar-base + 32-bit-VGPR-offset form, one VGPR of address shared by every plane of the stage (64-bit per-lane addresses, one
+// pair per plane, are what the step loop of k_cbf_rollout spilled).  idx * sizeof(U) < 2^32: planes of at most 2^28 doubles.
+template <typename U> __device__ __forceinline__ U* lane_ptr(U* uniform_base, unsigned idx) {
+  using B = std::conditional_t<std::is_const_v<U>, const unsigned char, unsigned char>;
+  return reinterpret_cast<U*>(reinterpret_cast<B*>(uniform_base) + idx * (unsigned)sizeof(U));
+}
+
 template <typename T, int NOM, bool COMP, int NW>
 __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout(const RollParams<T> MDS_CONST_AS* __restrict__ rp, const void* __restrict__ Kp, const int n,
                                                         const size_t ld, const int E, double t, const double ctrl_dt, const int n_steps,
@@ -1320,27 +1332,33 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   __shared__ __align__(16) RollSlot stab[R][64];               // row slot table
   __shared__ int sconv[GBMAX], scost[GBMAX], sorder[GBMAX];    // per env of the workgroup: QP solved; iterations of its last solve; hand-out order
   __shared__ int sticket;
-  // tuning aid (stamps != NULL, MDS_TUNE_ROLL_STAMPS=1 on the host): shader-clock ticks every wave spent in each part of the step,
-  // summed over the launch's steps -> stamps[(workgroup * NW + wave) * 6 + part]: 0 wait for stage B, 1 stage B, 2 wait after
-  // stage B, 3 stage C, 4 observation rows, 5 stage A
-  __shared__ unsigned long long sst[NW][10];
+  // tuning aid (a build with -DMDS_ROLL_STAMPS=1, stamps != NULL, MDS_TUNE_ROLL_STAMPS=1 on the host): shader-clock ticks every wave
+  // spent in each part of the step, summed over the launch's steps -> stamps[(workgroup * NW + wave) * 10 + part]: 0 wait for stage
+  // B, 1 stage B, 2 wait after stage B, 3 stage C, 4 observation rows, 5 stage A; within B: 6 ticket, 7 rows, 8 bookkeeping, 9 scan +
+  // solve.  Compiled out of the product: the two running stamps are loop-carried 64-bit values that the step loop otherwise spills.
+#if MDS_ROLL_STAMPS
+  constexpr bool kStamps = true;
+#else
+  constexpr bool kStamps = false;
+#endif
+  __shared__ unsigned long long sst[kStamps ? NW : 1][10];
   unsigned long long tk0 = 0;
   unsigned long long tk1 = 0;
   auto stamp_b = [&](int part) {
-    if (stamps != nullptr) {
+    if (kStamps && stamps != nullptr) {
       const unsigned long long now = __builtin_amdgcn_s_memtime();
       if ((threadIdx.x & 63) == 0) sst[threadIdx.x >> 6][part] += now - tk1;
       tk1 = now;
     }
   };
   auto stamp = [&](int part) {
-    if (stamps != nullptr) {
+    if (kStamps && stamps != nullptr) {
       const unsigned long long now = __builtin_amdgcn_s_memtime();
       if ((threadIdx.x & 63) == 0) sst[threadIdx.x >> 6][part] += now - tk0;
       tk0 = now;
     }
   };
-  if (stamps != nullptr && threadIdx.x < NW * 10) sst[threadIdx.x / 10][threadIdx.x % 10] = 0;
+  if (kStamps && stamps != nullptr && threadIdx.x < NW * 10) sst[threadIdx.x / 10][threadIdx.x % 10] = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = rp->P.num_drones, GB = NT / D;                 // envs per workgroup
   const int i = blockIdx.x * NT + tid;
@@ -1405,14 +1423,13 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   };
   auto load_params = [&](unsigned iu) {
     LemniscateParams<T> Pl;
-    T a4[4];
-    load4<T, T>(lem + 4 * (size_t)iu, a4);
     struct alignas(2 * sizeof(T)) V2 {
       T v[2];
     };
-    const V2 c2 = *reinterpret_cast<const V2*>(lem + 4 * ld + 2 * (size_t)iu);
-    Pl.a = a4[0]; Pl.omega = a4[1]; Pl.yaw_rate = a4[2]; Pl.phase_shift = a4[3];
-    Pl.cx = c2.v[0]; Pl.cy = c2.v[1]; Pl.cz = lem[6 * ld + iu];
+    const V4 a4 = *lane_ptr(reinterpret_cast<const V4*>(lem), iu);
+    const V2 c2 = *lane_ptr(reinterpret_cast<const V2*>(lem + 4 * ld), iu);
+    Pl.a = a4.v[0]; Pl.omega = a4.v[1]; Pl.yaw_rate = a4.v[2]; Pl.phase_shift = a4.v[3];
+    Pl.cx = c2.v[0]; Pl.cy = c2.v[1]; Pl.cz = *lane_ptr(lem + 6 * ld, iu);
     return Pl;
   };
   if (valid && n_steps > 0) {
@@ -1437,7 +1454,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       }
       if (lane == 0) sticket = 0;
     }
-    if (stamps != nullptr && k == 0) tk0 = __builtin_amdgcn_s_memtime();
+    if (kStamps && stamps != nullptr && k == 0) tk0 = __builtin_amdgcn_s_memtime();
     __syncthreads();
     stamp(0);
 
@@ -1445,7 +1462,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     {
       const CbfParams<T> P = load_const(&fresh_ptr(rp)->P);
       Scratch& S = slice_of(wave).sc;
-      if (stamps != nullptr) tk1 = __builtin_amdgcn_s_memtime();
+      if (kStamps && stamps != nullptr) tk1 = __builtin_amdgcn_s_memtime();
 #if !defined(MDS_TUNE_ROLL_STATIC)
       // tickets are drawn one env ahead: the LDS atomic of the next env's ticket is in flight while this env's rows are built
       int tk_next = 0;
@@ -1502,56 +1519,73 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         for (int r = 0; r < NBS; ++r)                              // every slot's operands in ONE LDS round trip
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            MDS_PIN2(oa[r][c].x, oa[r][c].y);
-            MDS_PIN2(ob[r][c].x, ob[r][c].y);
+            asm volatile("" : "+v"(oa[r][c].x));
+            asm volatile("" : "+v"(oa[r][c].y));
+            asm volatile("" : "+v"(ob[r][c].x));
+            asm volatile("" : "+v"(ob[r][c].y));
           }
+        // the barrier arithmetic of all NBS slots, statement by statement across the slots: NBS independent chains side by side
+        Pair<T> exy[NBS], dpr[NBS], dvxy[NBS], ezvz[NBS];
+        T hr[NBS], lg[NBS];
+#pragma unroll
+        for (int r = 0; r < NBS; ++r) {
+          exy[r] = oa[r][0] - ob[r][0];
+          dpr[r] = oa[r][1] - ob[r][1];
+          dvxy[r] = oa[r][2] - ob[r][2];
+          ezvz[r] = oa[r][3] - ob[r][3];
+        }
+#if (MDS_TUNE_ROLL_SKIP & 1)   // tuning aid: the row polynomial replaced by a sum of its operands (rows always satisfied)
+        for (int r = 0; r < NBS; ++r) {
+          hr[r] = T(100) + nds4[r] + exy[r].x + exy[r].y + dpr[r].x + dpr[r].y + dvxy[r].x + dvxy[r].y + ezvz[r].x + ezvz[r].y;
+          lg[r] = T(1);
+        }
+#else
+        cbf_row_o2_pairs<T, NBS>(P, exy, dpr, dvxy, ezvz, nds4, hr, lg);
+#endif
+        T cak[NBS], cbk[NBS], bk[NBS], n2[NBS], inv[NBS], reach[NBS];
+        bool pos[NBS], unreachable[NBS];
+#define MDS_SLOTS(stmt)         \
+  _Pragma("unroll") for (int r = 0; r < NBS; ++r) { stmt; }
+        MDS_SLOTS(cak[r] = -lg[r])
+        if constexpr (sizeof(T) == 4) {
+          MDS_SLOTS(cbk[r] = __builtin_bit_cast(float, __builtin_bit_cast(int, lg[r]) & pm[r]))     // pair rows: +lg at agent j
+        } else {
+          MDS_SLOTS(cbk[r] = pm[r] ? lg[r] : T(0))
+        }
+#if (MDS_TUNE_ROLL_SKIP & 2)   // tuning aid: no normalisation
+        MDS_SLOTS(pos[r] = true; inv[r] = T(1); n2[r] = T(1))
+#else
+        MDS_SLOTS(n2[r] = m_fma(cak[r], cak[r], cbk[r] * cbk[r]))
+        MDS_SLOTS(pos[r] = n2[r] > T(0))
+        MDS_SLOTS(inv[r] = pos[r] ? m_rsqrt(n2[r]) : T(1))
+#endif
+        MDS_SLOTS(cak[r] *= inv[r])
+        MDS_SLOTS(cbk[r] *= inv[r])
+        MDS_SLOTS(bk[r] = hr[r] * inv[r])
+        MDS_SLOTS(reach[r] = (m_abs(cak[r]) + m_abs(cbk[r])) * P.umax[0])
+        MDS_SLOTS(unreachable[r] = bk[r] < -reach[r] * (T(1) + T(sizeof(T) == 4 ? 1e-5 : 1e-10)))
+#undef MDS_SLOTS
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           act[r] = false;
           const int kind = sl[r].kind & 255;
           ia[r] = (sl[r].kind >> 8) & 255;
           ib[r] = (sl[r].kind >> 16) & 255;
-          if (r < NBS) {
-            T hr, lg;
-#if (MDS_TUNE_ROLL_SKIP & 1)   // tuning aid: the row polynomial replaced by a sum of its operands (rows always satisfied)
-            hr = T(100) + nds4[r];
-            for (int c = 0; c < 4; ++c) hr += (oa[r][c].x - ob[r][c].x) + (oa[r][c].y - ob[r][c].y);
-            lg = T(1);
-#else
-            cbf_row_o2_pairs<T>(P, oa[r][0] - ob[r][0], oa[r][1] - ob[r][1], oa[r][2] - ob[r][2], oa[r][3] - ob[r][3], nds4[r], &hr, &lg);
-#endif
-            T cak = -lg, cbk, bk = hr;
-            if constexpr (sizeof(T) == 4) cbk = __builtin_bit_cast(float, __builtin_bit_cast(int, lg) & pm[r]);   // pair rows: +lg at agent j
-            else cbk = pm[r] ? lg : T(0);
-#if (MDS_TUNE_ROLL_SKIP & 2)   // tuning aid: no normalisation
-            const bool pos = true;
-            const T inv = T(1);
-#else
-            const T n2 = m_fma(cak, cak, cbk * cbk);
-            const bool pos = n2 > T(0);
-            const T inv = pos ? m_rsqrt(n2) : T(1);
-#endif
-            cak *= inv;
-            cbk *= inv;
-            bk *= inv;
-            const T reach = (m_abs(cak) + m_abs(cbk)) * P.umax[0];
-            const bool unreachable = bk < -reach * (T(1) + T(sizeof(T) == 4 ? 1e-5 : 1e-10));
-            if (r < NBS - 1) {                                     // barrier rows only
-              bad = bad | unreachable;                             // (bitwise: no short-circuit branch)
-              ca[r][0] = cak;
-              cb[r][0] = cbk;
-              b[r] = bk;
-              vld[r] = pos;
-            } else {
-              const bool bar = kind == 1 || kind == 2;
-              bad = bad | (bar & unreachable);
-              // +-u_var <= umax (cbf/cbf.py:400-412): unit norm as it stands
-              const T box_c = kind == 3 ? T(1) : (kind == 4 ? T(-1) : T(0)), box_b = kind >= 3 ? P.umax[0] : T(0);
-              ca[r][0] = bar ? cak : box_c;
-              cb[r][0] = bar ? cbk : T(0);
-              b[r] = bar ? bk : box_b;
-              vld[r] = (bar & pos) | (kind >= 3);
-            }
+          if (r < NBS - 1) {                                       // barrier rows only
+            bad = bad | unreachable[r];                            // (bitwise: no short-circuit branch)
+            ca[r][0] = cak[r];
+            cb[r][0] = cbk[r];
+            b[r] = bk[r];
+            vld[r] = pos[r];
+          } else if (r < NBS) {
+            const bool bar = kind == 1 || kind == 2;
+            bad = bad | (bar & unreachable[r]);
+            // +-u_var <= umax (cbf/cbf.py:400-412): unit norm as it stands
+            const T box_c = kind == 3 ? T(1) : (kind == 4 ? T(-1) : T(0)), box_b = kind >= 3 ? P.umax[0] : T(0);
+            ca[r][0] = bar ? cak[r] : box_c;
+            cb[r][0] = bar ? cbk[r] : T(0);
+            b[r] = bar ? bk[r] : box_b;
+            vld[r] = (bar & pos[r]) | (kind >= 3);
           } else {
             ca[r][0] = kind == 3 ? T(1) : (kind == 4 ? T(-1) : T(0));
             cb[r][0] = T(0);
@@ -1615,14 +1649,20 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     // ---- stage C of this step, then stage A of the next: one drone per lane, state in registers ----
     const bool want = obs_log != nullptr || k == n_steps - 1;
     const bool more = k + 1 < n_steps;
-    t += ctrl_dt;
-    T o[kObsDim];
+    {                                                              // (uniform: kept in SGPRs -- as a VGPR pair the step loop spilled it)
+      const unsigned long long tb = __builtin_bit_cast(unsigned long long, t + ctrl_dt);
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)tb), hi = __builtin_amdgcn_readfirstlane((unsigned)(tb >> 32));
+      t = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    }
     unsigned iu = (unsigned)i;
     int tq = tid;
     asm volatile("" : "+v"(iu), "+v"(tq));                         // addresses are formed here, not held (spilled) across the loop
     const RollParams<T> MDS_CONST_AS* rq = fresh_ptr(rp);
     const Consts<T> c = load_const(&rq->c);
     const CbfParams<T> P = load_const(&rq->P);
+    constexpr int kRowBytes = kObsDim * (int)sizeof(T);
+    const int lq = tq & 63;
+    unsigned char* lds_wave = raw + (tq >> 6) * kObsWave;          // the wave's staging slice (its records / solver scratch of stage B: done with)
     if (valid) {
       const int conv = sconv[tq >> log2D];
       const T safe = su_all[tq];
@@ -1637,13 +1677,14 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       s.w = {st[10][tq], st[11][tq], st[12][tq]};
       Resid<T> rs;
       if (COMP) load_resid<T, T>(state_lo, ld, iu, rs);
+      // per-lane planes through a uniform base + a 32-bit byte offset (lane_ptr): one VGPR of address for all of them
       LowLevelState<T> L;
-      L.last_omega = {ll[0 * ld + iu], ll[1 * ld + iu], ll[2 * ld + iu]};
-      L.integral = {ll[3 * ld + iu], ll[4 * ld + iu], ll[5 * ld + iu]};
+      L.last_omega = {*lane_ptr(ll + 0 * ld, iu), *lane_ptr(ll + 1 * ld, iu), *lane_ptr(ll + 2 * ld, iu)};
+      L.integral = {*lane_ptr(ll + 3 * ld, iu), *lane_ptr(ll + 4 * ld, iu), *lane_ptr(ll + 5 * ld, iu)};
       T act4[4], prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4];
       thrust_omega_control(c, (T)ctrl_dt, u, s.w, L, act4);
-      ll[0 * ld + iu] = L.last_omega.x; ll[1 * ld + iu] = L.last_omega.y; ll[2 * ld + iu] = L.last_omega.z;
-      ll[3 * ld + iu] = L.integral.x; ll[4 * ld + iu] = L.integral.y; ll[5 * ld + iu] = L.integral.z;
+      *lane_ptr(ll + 0 * ld, iu) = L.last_omega.x; *lane_ptr(ll + 1 * ld, iu) = L.last_omega.y; *lane_ptr(ll + 2 * ld, iu) = L.last_omega.z;
+      *lane_ptr(ll + 3 * ld, iu) = L.integral.x; *lane_ptr(ll + 4 * ld, iu) = L.integral.y; *lane_ptr(ll + 5 * ld, iu) = L.integral.z;
       aviary_step_any<T, false, false, COMP>(c, s, rs, act4, prev, clipped);
       if (COMP) store_resid<T, T>(state_lo, ld, iu, rs);
       if (last_rpm && !more)
@@ -1652,36 +1693,30 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         struct alignas(2 * sizeof(T)) V2 {
           T v[2];
         };
-        const V2 c2 = *reinterpret_cast<const V2*>(lem + 4 * ld + 2 * (size_t)iu);
-        pack_obs(s, V3<T>{c2.v[0], c2.v[1], lem[6 * ld + iu]}, clipped, o);
+        const V2 c2 = *lane_ptr(reinterpret_cast<const V2*>(lem + 4 * ld), iu);
+        alignas(16) T o[kObsDim];
+        pack_obs(s, V3<T>{c2.v[0], c2.v[1], *lane_ptr(lem + 6 * ld, iu)}, clipped, o);
+        // the row goes to the wave's staging slice at once (20 values held across the rest of the stage were spilled to scratch)
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int j = 0; j < kRowBytes / 16; ++j) reinterpret_cast<v4u*>(lds_wave + lq * kRowBytes)[j] = reinterpret_cast<const v4u*>(o)[j];
       }
       if (!more) store_state<T, T>(state, ld, iu, s);
     }
     stamp(3);
     if (want) {
-      // write_obs_rows with this stage's fresh indices: rows -> the wave's staging slice -> 16-byte coalesced non-temporal stores
+      // write_obs_rows with this stage's fresh indices: the wave's staging slice -> 16-byte coalesced non-temporal stores
       T* dst = obs_log != nullptr ? obs_log + (size_t)slot * n * kObsDim : obs_last;      // (log AND obs_last: the host copies the last slot)
-      constexpr int kRowBytes = kObsDim * (int)sizeof(T);
-      const int lq = tq & 63;
-      unsigned char* lds_wave = raw + (tq >> 6) * kObsWave;
-      if (valid) {
-        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-        alignas(16) T row[kObsDim];
-#pragma unroll
-        for (int j = 0; j < kObsDim; ++j) row[j] = o[j];
-#pragma unroll
-        for (int j = 0; j < kRowBytes / 16; ++j) reinterpret_cast<v4u*>(lds_wave + lq * kRowBytes)[j] = reinterpret_cast<const v4u*>(row)[j];
-      }
       MDS_WAVE_SYNC();
-      const int wave_base = (int)iu - lq;
+      const int wave_base = __builtin_amdgcn_readfirstlane((int)iu - lq);                  // uniform: scalar base + 32-bit lane offsets
       const int rows = min(64, n - wave_base);
       if (rows > 0) {
         const int bytes = rows * kRowBytes;
         unsigned char* gdst = reinterpret_cast<unsigned char*>(dst) + (size_t)wave_base * kRowBytes;
 #pragma unroll
         for (int it = 0; it < kRowBytes / 16; ++it) {
-          const int off = (it * 64 + lq) * 16;
-          if (off + 16 <= bytes) {
+          const unsigned off = (unsigned)(it * 64 + lq) * 16u;
+          if ((int)off + 16 <= bytes) {
             typedef unsigned int v4u __attribute__((ext_vector_type(4)));
             __builtin_nontemporal_store(*reinterpret_cast<const v4u*>(lds_wave + off), reinterpret_cast<v4u*>(gdst + off));
           }
@@ -1699,7 +1734,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     }
     stamp(5);
   }
-  if (stamps != nullptr) {
+  if (kStamps && stamps != nullptr) {
     __syncthreads();
     if (threadIdx.x < NW * 10) stamps[(size_t)blockIdx.x * NW * 10 + threadIdx.x] = sst[threadIdx.x / 10][threadIdx.x % 10];
   }
