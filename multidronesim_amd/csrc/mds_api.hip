@@ -2067,11 +2067,16 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
   for (int k0 = 0; k0 < n_steps; k0 += steps_per_launch) {
     const int ks = n_steps - k0 < steps_per_launch ? n_steps - k0 : steps_per_launch;
     int32_t* slog = status_log ? status_log + (size_t)k0 * h->cfg.num_envs : nullptr;
-#define MDS_CR(T, CC, CP, NOM, COMP, TOL)                                                                                                      \
-  k_cbf_rollout<T, NOM, COMP, (sizeof(T) == 8 ? NWD : NWF)><<<grid, 64 * nw, extra_lds, st>>>((const RollParams<T> MDS_CONST_AS*)h->roll_params, gain, h->n, h->ld, h->cfg.num_envs, t, dt, ks, (T*)h->state, (T*)h->state_lo,  \
-                                                               (const T*)h->lem, (T*)rpm, (T*)h->ll, h->pair_ij, (const T*)h->obstacles,        \
-                                                               (T*)obs_log, slot, log_slots > 0 ? log_slots : 1, (T*)obs, (int*)status, (int*)slog, \
-                                                               h->cbf_cost, max_iter, (T)((TOL) * (TOL)), stamps_dev)
+#define MDS_CR(T, CC, CP, NOM, COMP, TOL)                                                                                                        \
+  do {                                                                                                                                           \
+    RollArgs<T> ra;                                                                                                                              \
+    ra.rp = (const RollParams<T> MDS_CONST_AS*)h->roll_params; ra.Kp = gain; ra.n = (int)h->n; ra.ld = h->ld; ra.E = h->cfg.num_envs;             \
+    ra.t = t; ra.ctrl_dt = dt; ra.n_steps = ks; ra.state = (T*)h->state; ra.state_lo = (T*)h->state_lo; ra.lem = (const T*)h->lem;                \
+    ra.last_rpm = (T*)rpm; ra.ll = (T*)h->ll; ra.pair_ij = h->pair_ij; ra.obstacles = (const T*)h->obstacles; ra.obs_log = (T*)obs_log;           \
+    ra.slot = slot; ra.n_slots = log_slots > 0 ? log_slots : 1; ra.obs_last = (T*)obs; ra.status = (int*)status; ra.status_log = (int*)slog;      \
+    ra.cost_io = h->cbf_cost; ra.max_iter = max_iter; ra.tol2 = (T)((TOL) * (TOL)); ra.stamps = stamps_dev;                                       \
+    k_cbf_rollout<T, NOM, COMP, (sizeof(T) == 8 ? NWD : NWF)><<<grid, 64 * nw, extra_lds, st>>>(ra);                                              \
+  } while (0)
 #define MDS_CR_N(T, CC, CP, COMP, TOL)                        \
   do {                                                        \
     if (h->cbf_nominal == 1) MDS_CR(T, CC, CP, 1, COMP, TOL); \

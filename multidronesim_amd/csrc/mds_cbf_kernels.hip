@@ -1277,6 +1277,36 @@ template <typename V> __device__ __forceinline__ V load_const(const V MDS_CONST_
   return out;
 }
 
+// The arguments of k_cbf_rollout, passed as ONE struct by value: the kernel never touches the parameter itself but reads the fields
+// through the kernarg segment pointer, made fresh per stage (fresh_args) -- scalar loads where a field is used, instead of 40 SGPRs
+// of loop invariants that the step loop kept spilling to VGPR lanes (a v_readlane, often with wait states, per use).
+template <typename T> struct RollArgs {
+  const RollParams<T> MDS_CONST_AS* rp;
+  const void* Kp;
+  int n;
+  size_t ld;
+  int E;
+  double t, ctrl_dt;
+  int n_steps;
+  T *state, *state_lo;
+  const T* lem;
+  T *last_rpm, *ll;
+  const int* pair_ij;
+  const T* obstacles;
+  T* obs_log;
+  int slot, n_slots;
+  T* obs_last;
+  int *status, *status_log, *cost_io;
+  int max_iter;
+  T tol2;
+  unsigned long long* stamps;
+};
+template <typename T> __device__ __forceinline__ const RollArgs<T> MDS_CONST_AS* fresh_args() {
+  const RollArgs<T> MDS_CONST_AS* p = (const RollArgs<T> MDS_CONST_AS*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
 // element idx of a per-lane plane behind a UNIFORM base pointer, addressed by a 32-bit byte offset: the access compiles to the
 // scalar-base + 32-bit-VGPR-offset form, one VGPR of address shared by every plane of the stage (64-bit per-lane addresses, one
 // pair per plane, are what the step loop of k_cbf_rollout spilled).  idx * sizeof(U) < 2^32: planes of at most 2^28 doubles.
@@ -1286,14 +1316,8 @@ template <typename U> __device__ __forceinline__ U* lane_ptr(U* uniform_base, un
 }
 
 template <typename T, int NOM, bool COMP, int NW>
-__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout(const RollParams<T> MDS_CONST_AS* __restrict__ rp, const void* __restrict__ Kp, const int n,
-                                                        const size_t ld, const int E, double t, const double ctrl_dt, const int n_steps,
-                                                        T* __restrict__ state, T* __restrict__ state_lo, const T* __restrict__ lem,
-                                                        T* __restrict__ last_rpm, T* __restrict__ ll, const int* __restrict__ pair_ij,
-                                                        const T* __restrict__ obstacles, T* __restrict__ obs_log, int slot,
-                                                        const int n_slots, T* __restrict__ obs_last, int* __restrict__ status,
-                                                        int* __restrict__ status_log, int* __restrict__ cost_io, const int max_iter,
-                                                        const T tol2, unsigned long long* __restrict__ stamps) {
+__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout(const RollArgs<T>) {
+
   constexpr int NT = 64 * NW;
   constexpr int R = 4, NMAX = 16, NV = 1;
   constexpr int kQS = (NMAX + 3) / 4 * 4 + 4;
@@ -1341,6 +1365,11 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
 #else
   constexpr bool kStamps = false;
 #endif
+  const RollArgs<T> MDS_CONST_AS* a0 = fresh_args<T>();        // (the arguments: read through the kernarg segment where they are used)
+  const int n_steps = a0->n_steps;
+  double t = a0->t;
+  int slot = a0->slot;
+  unsigned long long* const stamps = kStamps ? a0->stamps : nullptr;
   __shared__ unsigned long long sst[kStamps ? NW : 1][10];
   unsigned long long tk0 = 0;
   unsigned long long tk1 = 0;
@@ -1360,17 +1389,18 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   };
   if (kStamps && stamps != nullptr && threadIdx.x < NW * 10) sst[threadIdx.x / 10][threadIdx.x % 10] = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int D = rp->P.num_drones, GB = NT / D;                 // envs per workgroup
+  const int D = a0->rp->P.num_drones, GB = NT / D;             // envs per workgroup
   const int i = blockIdx.x * NT + tid;
-  const bool valid = i < n;
+  const bool valid = i < a0->n;
   const int env0 = (blockIdx.x * NT) / D;
-  const int nenv = min(GB, E - env0);                          // envs this workgroup really owns (>= 1: the grid covers n)
+  const int nenv = min(GB, a0->E - env0);                          // envs this workgroup really owns (>= 1: the grid covers n)
   auto slice_of = [&](int w) -> Slice& { return *reinterpret_cast<Slice*>(raw + (size_t)w * kObsWave); };
 
   // ---- once per launch ----
   {
-    const CbfParams<T> P = load_const(&rp->P);
-  if (tid < R * 64) stab[tid >> 6][tid & 63] = roll_slot_of<T>(P, pair_ij, (tid & 63) + 64 * (tid >> 6), kRec, kSwz && P.num_drones == 16, kSobOff, kDsOff);
+    const CbfParams<T> P = load_const(&a0->rp->P);
+    const T* obstacles = a0->obstacles;
+  if (tid < R * 64) stab[tid >> 6][tid & 63] = roll_slot_of<T>(P, a0->pair_ij, (tid & 63) + 64 * (tid >> 6), kRec, kSwz && P.num_drones == 16, kSobOff, kDsOff);
   if (tid < kCbfMaxObs) {
     const bool on = tid < P.n_obs;
     for (int k = 0; k < 8; ++k) sobrec[tid][k] = T(0);
@@ -1383,16 +1413,16 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   }
   if (tid == 0) sDs[0] = cbf_neg_ds4(P.Ds_pair);
   }
-  if (tid < GB) scost[tid] = (tid < nenv && cost_io) ? cost_io[env0 + tid] : 0;
+  if (tid < GB) scost[tid] = (tid < nenv && a0->cost_io) ? a0->cost_io[env0 + tid] : 0;
   State<T> s;
   s.p = s.v = s.w = {T(0), T(0), T(0)};
   s.q[0] = s.q[1] = s.q[2] = T(0);
   s.q[3] = T(1);
-  if (valid) load_state<T, T>(state, ld, i, s);
+  if (valid) load_state<T, T>(a0->state, a0->ld, i, s);
   T un0 = T(0), un1 = T(0), un2 = T(0), un3 = T(0);            // u_hat of this step (stage A -> stage C, in registers across stage B)
 
   // stage A of drone i on the state in registers at time ta: u_hat, the record, the stash of the state
-  auto stage_a = [&](const Consts<T>& c, const LemniscateParams<T>& Pl, const double ta, const int tq) {
+  auto stage_a = [&](const RollArgs<T> MDS_CONST_AS* a, const Consts<T>& c, const LemniscateParams<T>& Pl, const double ta, const int tq) {
     const int lq = tq & 63, wq = tq >> 6;
     const Desired<T> des = lemniscate_local(Pl, ta);
     const V3<T> rpy = euler_from_quat(s.q);
@@ -1406,7 +1436,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       un1 = A.w_des.x; un2 = A.w_des.y; un3 = A.w_des.z;
     } else {
       T u[4];
-      lqr_omega_control<T>(c, *static_cast<const LqrGain<T>*>(Kp), rpy, s.v, s.p, des.p, des.v, des.yaw, u);
+      lqr_omega_control<T>(c, *static_cast<const LqrGain<T>*>(a->Kp), rpy, s.v, s.p, des.p, des.v, des.yaw, u);
       un0 = u[0] - c.gravity;                                                      // CBFTest.py:339
       un1 = u[1]; un2 = u[2]; un3 = u[3];
     }
@@ -1421,7 +1451,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     st[7][tq] = s.v.x; st[8][tq] = s.v.y; st[9][tq] = s.v.z;
     st[10][tq] = s.w.x; st[11][tq] = s.w.y; st[12][tq] = s.w.z;
   };
-  auto load_params = [&](unsigned iu) {
+  auto load_params = [&](const RollArgs<T> MDS_CONST_AS* a, unsigned iu) {
+    const T* lem = a->lem;
+    const size_t ld = a->ld;
     LemniscateParams<T> Pl;
     struct alignas(2 * sizeof(T)) V2 {
       T v[2];
@@ -1433,11 +1465,11 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     return Pl;
   };
   if (valid && n_steps > 0) {
-    const Consts<T> c1 = load_const(&rp->c);
-    stage_a(c1, load_params((unsigned)i), t, tid);
+    const Consts<T> c1 = load_const(&a0->rp->c);
+    stage_a(a0, c1, load_params(a0, (unsigned)i), t, tid);
   }
   const int log2D = 31 - __clz(D);                             // D is 4, 8 or 16
-  const int nbs = (cbf_num_pairs(D) + D * rp->P.n_obs + 63) >> 6;   // row slots that hold barrier rows
+  const int nbs = (cbf_num_pairs(D) + D * a0->rp->P.n_obs + 63) >> 6;   // row slots that hold barrier rows
 
   for (int k = 0; k < n_steps; ++k) {
     if (wave == 0) {
@@ -1460,7 +1492,10 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
 
     // ---- stage B: the workgroup's envs, one per wave at a time ----
     {
-      const CbfParams<T> P = load_const(&fresh_ptr(rp)->P);
+      const RollArgs<T> MDS_CONST_AS* ab = fresh_args<T>();
+      const CbfParams<T> P = load_const(&ab->rp->P);
+      const int max_iter = ab->max_iter;
+      const T tol2 = ab->tol2;
       Scratch& S = slice_of(wave).sc;
       if (kStamps && stamps != nullptr) tk1 = __builtin_amdgcn_s_memtime();
 #if !defined(MDS_TUNE_ROLL_STATIC)
@@ -1627,12 +1662,13 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
 #endif
         stamp_b(9);
         if (lane == 0) {
+          const RollArgs<T> MDS_CONST_AS* al = fresh_args<T>();
           sconv[el] = converged ? 1 : 0;
           scost[el] = it;
-          if (status_log) status_log[(size_t)k * E + env0 + el] = converged ? 0 : 1;
+          if (al->status_log) al->status_log[(size_t)k * al->E + env0 + el] = converged ? 0 : 1;
           if (k == n_steps - 1) {
-            status[env0 + el] = converged ? 0 : 1;
-            if (cost_io) cost_io[env0 + el] = it;
+            al->status[env0 + el] = converged ? 0 : 1;
+            if (al->cost_io) al->cost_io[env0 + el] = it;
           }
         }
         MDS_WAVE_SYNC();
@@ -1647,6 +1683,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     stamp(2);
 
     // ---- stage C of this step, then stage A of the next: one drone per lane, state in registers ----
+    const RollArgs<T> MDS_CONST_AS* ac = fresh_args<T>();
+    T* const obs_log = ac->obs_log;
+    const double ctrl_dt = ac->ctrl_dt;
     const bool want = obs_log != nullptr || k == n_steps - 1;
     const bool more = k + 1 < n_steps;
     {                                                              // (uniform: kept in SGPRs -- as a VGPR pair the step loop spilled it)
@@ -1657,7 +1696,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     unsigned iu = (unsigned)i;
     int tq = tid;
     asm volatile("" : "+v"(iu), "+v"(tq));                         // addresses are formed here, not held (spilled) across the loop
-    const RollParams<T> MDS_CONST_AS* rq = fresh_ptr(rp);
+    const RollParams<T> MDS_CONST_AS* rq = ac->rp;
     const Consts<T> c = load_const(&rq->c);
     const CbfParams<T> P = load_const(&rq->P);
     constexpr int kRowBytes = kObsDim * (int)sizeof(T);
@@ -1675,8 +1714,11 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       s.q[0] = st[3][tq]; s.q[1] = st[4][tq]; s.q[2] = st[5][tq]; s.q[3] = st[6][tq];
       s.v = {st[7][tq], st[8][tq], st[9][tq]};
       s.w = {st[10][tq], st[11][tq], st[12][tq]};
+      const size_t ld = ac->ld;
+      T* const ll = ac->ll;
+      const T* const lem = ac->lem;
       Resid<T> rs;
-      if (COMP) load_resid<T, T>(state_lo, ld, iu, rs);
+      if (COMP) load_resid<T, T>(ac->state_lo, ld, iu, rs);
       // per-lane planes through a uniform base + a 32-bit byte offset (lane_ptr): one VGPR of address for all of them
       LowLevelState<T> L;
       L.last_omega = {*lane_ptr(ll + 0 * ld, iu), *lane_ptr(ll + 1 * ld, iu), *lane_ptr(ll + 2 * ld, iu)};
@@ -1686,9 +1728,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       *lane_ptr(ll + 0 * ld, iu) = L.last_omega.x; *lane_ptr(ll + 1 * ld, iu) = L.last_omega.y; *lane_ptr(ll + 2 * ld, iu) = L.last_omega.z;
       *lane_ptr(ll + 3 * ld, iu) = L.integral.x; *lane_ptr(ll + 4 * ld, iu) = L.integral.y; *lane_ptr(ll + 5 * ld, iu) = L.integral.z;
       aviary_step_any<T, false, false, COMP>(c, s, rs, act4, prev, clipped);
-      if (COMP) store_resid<T, T>(state_lo, ld, iu, rs);
-      if (last_rpm && !more)
-        for (int j = 0; j < 4; ++j) last_rpm[j * ld + iu] = clipped[j];
+      if (COMP) store_resid<T, T>(ac->state_lo, ld, iu, rs);
+      if (!more && ac->last_rpm)
+        for (int j = 0; j < 4; ++j) ac->last_rpm[j * ld + iu] = clipped[j];
       if (want) {
         struct alignas(2 * sizeof(T)) V2 {
           T v[2];
@@ -1701,12 +1743,13 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
 #pragma unroll
         for (int j = 0; j < kRowBytes / 16; ++j) reinterpret_cast<v4u*>(lds_wave + lq * kRowBytes)[j] = reinterpret_cast<const v4u*>(o)[j];
       }
-      if (!more) store_state<T, T>(state, ld, iu, s);
+      if (!more) store_state<T, T>(ac->state, ld, iu, s);
     }
     stamp(3);
     if (want) {
       // write_obs_rows with this stage's fresh indices: the wave's staging slice -> 16-byte coalesced non-temporal stores
-      T* dst = obs_log != nullptr ? obs_log + (size_t)slot * n * kObsDim : obs_last;      // (log AND obs_last: the host copies the last slot)
+      const int n = ac->n;
+      T* dst = obs_log != nullptr ? obs_log + (size_t)slot * n * kObsDim : ac->obs_last;      // (log AND obs_last: the host copies the last slot)
       MDS_WAVE_SYNC();
       const int wave_base = __builtin_amdgcn_readfirstlane((int)iu - lq);                  // uniform: scalar base + 32-bit lane offsets
       const int rows = min(64, n - wave_base);
@@ -1725,12 +1768,13 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       MDS_WAVE_SYNC();                                             // the slice is stage A's record / scratch space next
     }
     stamp(4);
-    slot = slot + 1 == n_slots ? 0 : slot + 1;
+    slot = slot + 1 == ac->n_slots ? 0 : slot + 1;
     if (valid && more) {                                           // (the wave's own staging slice is drained: write_obs_rows ends with a wave sync)
       unsigned ia2 = (unsigned)i;
       int ta2 = tid;
       asm volatile("" : "+v"(ia2), "+v"(ta2));
-      stage_a(c, load_params(ia2), t, ta2);
+      const RollArgs<T> MDS_CONST_AS* aa = fresh_args<T>();
+      stage_a(aa, c, load_params(aa, ia2), t, ta2);
     }
     stamp(5);
   }
