@@ -1351,7 +1351,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   __shared__ __align__(128) unsigned char raw[kBlock];
   T(*const sobrec)[8] = reinterpret_cast<T(*)[8]>(raw + kSobOff);     // obstacles as records with zero tracking errors (halves in plain order)
   T* const sDs = reinterpret_cast<T*>(raw + kDsOff);                  // -Ds^4: [0] pairs, [1 + o] obstacle o
-  __shared__ T st[13][NT];                                     // the state across stage B (lane-contiguous planes: conflict-free)
+  __shared__ T st[14][NT];                                     // the state and u_hat[0] across stage B (lane-contiguous planes: conflict-free)
   __shared__ T su_all[NT];                                     // thrust variable of every drone: u_hat[0] in, QP minimiser out
   __shared__ __align__(16) RollSlot stab[R][64];               // row slot table
   __shared__ int sconv[GBMAX], scost[GBMAX], sorder[GBMAX];    // per env of the workgroup: QP solved; iterations of its last solve; hand-out order
@@ -1419,13 +1419,14 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   s.q[0] = s.q[1] = s.q[2] = T(0);
   s.q[3] = T(1);
   if (valid) load_state<T, T>(a0->state, a0->ld, i, s);
-  T un0 = T(0), un1 = T(0), un2 = T(0), un3 = T(0);            // u_hat of this step (stage A -> stage C, in registers across stage B)
+  T un1 = T(0), un2 = T(0), un3 = T(0);                        // u_hat[1..3] of this step (stage A -> stage C, in registers across stage B; [0]: st[13])
 
   // stage A of drone i on the state in registers at time ta: u_hat, the record, the stash of the state
   auto stage_a = [&](const RollArgs<T> MDS_CONST_AS* a, const Consts<T>& c, const LemniscateParams<T>& Pl, const double ta, const int tq) {
     const int lq = tq & 63, wq = tq >> 6;
     const Desired<T> des = lemniscate_local(Pl, ta);
     const V3<T> rpy = euler_from_quat(s.q);
+    T un0;
     if (NOM == 0) {
       const M3<T> Rm = quat_to_rot(s.q);
       const V3<T> ang_v = mul(Rm, s.w);
@@ -1446,6 +1447,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     *reinterpret_cast<V4*>(rc + 4 * sw) = V4{{s.p.x + Pl.cx, s.p.y + Pl.cy, rpy.y - T(0), -(rpy.x - T(0))}};
     *reinterpret_cast<V4*>(rc + 4 * (sw ^ 1)) = V4{{s.v.x - des.v.x, s.v.y - des.v.y, s.p.z + Pl.cz, s.v.z - des.v.z}};
     su_all[tq] = un0;
+    st[13][tq] = un0;                                              // (su_all holds the QP's answer after stage B)
     st[0][tq] = s.p.x; st[1][tq] = s.p.y; st[2][tq] = s.p.z;
     st[3][tq] = s.q[0]; st[4][tq] = s.q[1]; st[5][tq] = s.q[2]; st[6][tq] = s.q[3];
     st[7][tq] = s.v.x; st[8][tq] = s.v.y; st[9][tq] = s.v.z;
@@ -1478,8 +1480,10 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         const bool has = lane < nenv;
         const bool heavy = has && scost[has ? lane : 0] >= kCbfMediumIters;
         const unsigned long long mh = __ballot(heavy), ml = __ballot(has && !heavy);
-        const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-        const int pos = heavy ? __popcll(mh & below) : __popcll(mh) + __popcll(ml & below);
+        auto below = [](unsigned long long m) {                    // set bits of m in the lanes below this one (v_mbcnt: no per-lane mask to hold)
+          return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        };
+        const int pos = heavy ? below(mh) : __popcll(mh) + below(ml);
         if (has) sorder[pos] = lane;
       } else {
         for (int e = lane; e < nenv; e += 64) sorder[e] = e;
@@ -1693,9 +1697,11 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)tb), hi = __builtin_amdgcn_readfirstlane((unsigned)(tb >> 32));
       t = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
     }
-    unsigned iu = (unsigned)i;
+    unsigned wg0 = blockIdx.x * NT;
+    asm volatile("" : "+s"(wg0));                                  // the drone index is formed here (one add), not held -- spilled -- across the loop
     int tq = tid;
-    asm volatile("" : "+v"(iu), "+v"(tq));                         // addresses are formed here, not held (spilled) across the loop
+    asm volatile("" : "+v"(tq));
+    const unsigned iu = wg0 + (unsigned)tq;
     const RollParams<T> MDS_CONST_AS* rq = ac->rp;
     const Consts<T> c = load_const(&rq->c);
     const CbfParams<T> P = load_const(&rq->P);
@@ -1706,7 +1712,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       const int conv = sconv[tq >> log2D];
       const T safe = su_all[tq];
       T u[4];
-      u[0] = (conv ? safe : un0) + c.gravity;                                                // CBFTest.py:346
+      u[0] = (conv ? safe : st[13][tq]) + c.gravity;                                                // CBFTest.py:346
       u[1] = conv ? m_clamp(un1, -P.umax[1], P.umax[1]) : un1;
       u[2] = conv ? m_clamp(un2, -P.umax[2], P.umax[2]) : un2;
       u[3] = conv ? m_clamp(un3, -P.umax[3], P.umax[3]) : un3;
@@ -1770,9 +1776,11 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     stamp(4);
     slot = slot + 1 == ac->n_slots ? 0 : slot + 1;
     if (valid && more) {                                           // (the wave's own staging slice is drained: write_obs_rows ends with a wave sync)
-      unsigned ia2 = (unsigned)i;
+      unsigned wg1 = blockIdx.x * NT;
+      asm volatile("" : "+s"(wg1));
       int ta2 = tid;
-      asm volatile("" : "+v"(ia2), "+v"(ta2));
+      asm volatile("" : "+v"(ta2));
+      const unsigned ia2 = wg1 + (unsigned)ta2;
       const RollArgs<T> MDS_CONST_AS* aa = fresh_args<T>();
       stage_a(aa, c, load_params(aa, ia2), t, ta2);
     }
