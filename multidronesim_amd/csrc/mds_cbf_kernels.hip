@@ -1708,7 +1708,20 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     constexpr int kRowBytes = kObsDim * (int)sizeof(T);
     const int lq = tq & 63;
     unsigned char* lds_wave = raw + (tq >> 6) * kObsWave;          // the wave's staging slice (its records / solver scratch of stage B: done with)
-    if (valid) {
+    // the next step's trajectory parameters: requested here, consumed by stage A below (their L2 latency under this stage's arithmetic)
+    // (unconditional, from a clamped index: nothing to merge, so nothing waits for the loads before stage A)
+    const unsigned il = min(iu, (unsigned)ac->n - 1u);
+    const LemniscateParams<T> Pl_next = load_params(ac, il);
+    LowLevelState<T> L;                                            // the low level's PID memory of this drone: requested with them
+    {
+      const size_t ld = ac->ld;
+      const T* const ll = ac->ll;
+      L.last_omega = {*lane_ptr(ll + 0 * ld, il), *lane_ptr(ll + 1 * ld, il), *lane_ptr(ll + 2 * ld, il)};
+      L.integral = {*lane_ptr(ll + 3 * ld, il), *lane_ptr(ll + 4 * ld, il), *lane_ptr(ll + 5 * ld, il)};
+    }
+    {
+      // Every lane runs the stage (a lane past the last drone on a clamped index, its stores skipped): no divergent region for the
+      // compiler to sink the loads above into.
       const int conv = sconv[tq >> log2D];
       const T safe = su_all[tq];
       T u[4];
@@ -1722,34 +1735,28 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       s.w = {st[10][tq], st[11][tq], st[12][tq]};
       const size_t ld = ac->ld;
       T* const ll = ac->ll;
-      const T* const lem = ac->lem;
       Resid<T> rs;
-      if (COMP) load_resid<T, T>(ac->state_lo, ld, iu, rs);
+      if (COMP) load_resid<T, T>(ac->state_lo, ld, il, rs);
       // per-lane planes through a uniform base + a 32-bit byte offset (lane_ptr): one VGPR of address for all of them
-      LowLevelState<T> L;
-      L.last_omega = {*lane_ptr(ll + 0 * ld, iu), *lane_ptr(ll + 1 * ld, iu), *lane_ptr(ll + 2 * ld, iu)};
-      L.integral = {*lane_ptr(ll + 3 * ld, iu), *lane_ptr(ll + 4 * ld, iu), *lane_ptr(ll + 5 * ld, iu)};
       T act4[4], prev[4] = {T(0), T(0), T(0), T(0)}, clipped[4];
       thrust_omega_control(c, (T)ctrl_dt, u, s.w, L, act4);
-      *lane_ptr(ll + 0 * ld, iu) = L.last_omega.x; *lane_ptr(ll + 1 * ld, iu) = L.last_omega.y; *lane_ptr(ll + 2 * ld, iu) = L.last_omega.z;
-      *lane_ptr(ll + 3 * ld, iu) = L.integral.x; *lane_ptr(ll + 4 * ld, iu) = L.integral.y; *lane_ptr(ll + 5 * ld, iu) = L.integral.z;
+      if (valid) {
+        *lane_ptr(ll + 0 * ld, iu) = L.last_omega.x; *lane_ptr(ll + 1 * ld, iu) = L.last_omega.y; *lane_ptr(ll + 2 * ld, iu) = L.last_omega.z;
+        *lane_ptr(ll + 3 * ld, iu) = L.integral.x; *lane_ptr(ll + 4 * ld, iu) = L.integral.y; *lane_ptr(ll + 5 * ld, iu) = L.integral.z;
+      }
       aviary_step_any<T, false, false, COMP>(c, s, rs, act4, prev, clipped);
-      if (COMP) store_resid<T, T>(ac->state_lo, ld, iu, rs);
-      if (!more && ac->last_rpm)
+      if (COMP && valid) store_resid<T, T>(ac->state_lo, ld, iu, rs);
+      if (valid && !more && ac->last_rpm)
         for (int j = 0; j < 4; ++j) ac->last_rpm[j * ld + iu] = clipped[j];
       if (want) {
-        struct alignas(2 * sizeof(T)) V2 {
-          T v[2];
-        };
-        const V2 c2 = *lane_ptr(reinterpret_cast<const V2*>(lem + 4 * ld), iu);
         alignas(16) T o[kObsDim];
-        pack_obs(s, V3<T>{c2.v[0], c2.v[1], *lane_ptr(lem + 6 * ld, iu)}, clipped, o);
+        pack_obs(s, V3<T>{Pl_next.cx, Pl_next.cy, Pl_next.cz}, clipped, o);                  // (the trajectory centre: this drone's, whatever the step)
         // the row goes to the wave's staging slice at once (20 values held across the rest of the stage were spilled to scratch)
         typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int j = 0; j < kRowBytes / 16; ++j) reinterpret_cast<v4u*>(lds_wave + lq * kRowBytes)[j] = reinterpret_cast<const v4u*>(o)[j];
       }
-      if (!more) store_state<T, T>(ac->state, ld, iu, s);
+      if (valid && !more) store_state<T, T>(ac->state, ld, iu, s);
     }
     stamp(3);
     if (want) {
@@ -1776,13 +1783,10 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     stamp(4);
     slot = slot + 1 == ac->n_slots ? 0 : slot + 1;
     if (valid && more) {                                           // (the wave's own staging slice is drained: write_obs_rows ends with a wave sync)
-      unsigned wg1 = blockIdx.x * NT;
-      asm volatile("" : "+s"(wg1));
       int ta2 = tid;
       asm volatile("" : "+v"(ta2));
-      const unsigned ia2 = wg1 + (unsigned)ta2;
       const RollArgs<T> MDS_CONST_AS* aa = fresh_args<T>();
-      stage_a(aa, c, load_params(aa, ia2), t, ta2);
+      stage_a(aa, c, Pl_next, t, ta2);
     }
     stamp(5);
   }
