@@ -138,8 +138,6 @@ struct mds_handle {
   void* gain_dev[3];   // device copies of the gains for the whole-rollout kernels: 0 LQR-12, 1 LQR-omega, 2 LQR-yank-omega (written by the mds_set_*_gain calls)
   Lqr12Gain<float> lqr12_f;
   Lqr12Gain<double> lqr12_d;
-  void* roll_params = nullptr;   // device RollParams<float | double> of the persistent CBF rollout kernel, refreshed when params_ver moves
-  int roll_params_ver = -1, params_ver = 0;
   void* state_alt;     // second state buffer of the ground-effect / downwash step (double-buffered substeps)
   void* act_scratch = nullptr;   // S [n,4]: the controller's action, replayed by the later substeps of a ground-effect / downwash step
   bool envfx;          // physics has ground effect and / or downwash
@@ -460,7 +458,6 @@ int mds_destroy(mds_handle* h) {
   if (h->cbf_order) (void)hipFree(h->cbf_order);
   if (h->cbf_count) (void)hipFree(h->cbf_count);
   if (h->cbf_cost) (void)hipFree(h->cbf_cost);
-  if (h->roll_params) (void)hipFree(h->roll_params);
   for (int k = 0; k < 3; ++k)
     if (h->gain_dev[k]) (void)hipFree(h->gain_dev[k]);
   if (h->cbf_unom) (void)hipFree(h->cbf_unom);
@@ -867,7 +864,6 @@ int mds_set_geometric_gains(mds_handle* h, const mds_geometric_gains* g) {
   h->gains = *g;
   fill_consts(h->cfg, h->gains, h->cf, h->wind);
   fill_consts(h->cfg, h->gains, h->cd, h->wind);
-  ++h->params_ver;
   return MDS_OK;
 }
 
@@ -876,7 +872,6 @@ int mds_set_wind(mds_handle* h, const double force_world[3]) {
   for (int k = 0; k < 3; ++k) h->wind[k] = force_world[k];
   fill_consts(h->cfg, h->gains, h->cf, h->wind);
   fill_consts(h->cfg, h->gains, h->cd, h->wind);
-  ++h->params_ver;
   return MDS_OK;
 }
 
@@ -1345,7 +1340,6 @@ int mds_cbf_configure(mds_handle* h, const mds_cbf_params* p, const double* obst
   h->cbf = *p;
   fill_cbf(h, *p, h->cbf_f);
   fill_cbf(h, *p, h->cbf_d);
-  ++h->params_ver;
   h->has_cbf = true;
   return MDS_OK;
 }
@@ -2054,14 +2048,6 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
     if (end == e || *end != '\0' || v < 0 || v > 65536) return fail(MDS_EINVAL, "MDS_TUNE_ROLL_EXTRA_LDS: expected 0..65536 bytes");
     extra_lds = (size_t)v;
   }
-  // the kernel reads Consts / CbfParams from a device copy (RollParams): refreshed, in stream order, when either has changed
-  if (!h->roll_params) MDS_HIP(hipMalloc(&h->roll_params, sizeof(RollParams<double>)));
-  if (h->roll_params_ver != h->params_ver) {
-    if (h->cfg.dtype == MDS_F64) k_store_roll_params<double><<<1, 64, 0, st>>>(h->cd, h->cbf_d, (RollParams<double>*)h->roll_params);
-    else k_store_roll_params<float><<<1, 64, 0, st>>>(h->cf, h->cbf_f, (RollParams<float>*)h->roll_params);
-    MDS_HIP(hipGetLastError());
-    h->roll_params_ver = h->params_ver;
-  }
   int slot = first_slot;
   double t = t0;
   for (int k0 = 0; k0 < n_steps; k0 += steps_per_launch) {
@@ -2070,7 +2056,7 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
 #define MDS_CR(T, CC, CP, NOM, COMP, TOL)                                                                                                        \
   do {                                                                                                                                           \
     RollArgs<T> ra;                                                                                                                              \
-    ra.rp = (const RollParams<T> MDS_CONST_AS*)h->roll_params; ra.Kp = gain; ra.n = (int)h->n; ra.ld = h->ld; ra.E = h->cfg.num_envs;             \
+    ra.p.c = CC; ra.p.P = CP; ra.Kp = gain; ra.n = (int)h->n; ra.ld = h->ld; ra.E = h->cfg.num_envs;             \
     ra.t = t; ra.ctrl_dt = dt; ra.n_steps = ks; ra.state = (T*)h->state; ra.state_lo = (T*)h->state_lo; ra.lem = (const T*)h->lem;                \
     ra.last_rpm = (T*)rpm; ra.ll = (T*)h->ll; ra.pair_ij = h->pair_ij; ra.obstacles = (const T*)h->obstacles; ra.obs_log = (T*)obs_log;           \
     ra.slot = slot; ra.n_slots = log_slots > 0 ? log_slots : 1; ra.obs_last = (T*)obs; ra.status = (int*)status; ra.status_log = (int*)slog;      \

@@ -1242,27 +1242,15 @@ __device__ __forceinline__ RollSlot roll_slot_of(const CbfParams<T>& P, const in
 
 // Kernel arguments are loop invariants of a kernel that never leaves its step loop: left alone, the compiler hoists every VGPR copy
 // a VALU instruction with two scalar operands needs (and every address it can form) out of the loop, keeps them live across all
-// three stages and spills them.
-//
-// The kernel's constants live in a device copy read through a CONSTANT-address-space pointer that every stage makes fresh: each
-// stage loads the fields it uses with scalar loads where it uses them.  As by-value kernel arguments (65 dwords beside 14 pointers)
-// they were loop invariants held in SGPRs across all stages: the 106 SGPRs overflowed into VGPR lanes and every use paid a
-// v_readlane (133 in stage C alone).
+// three stages and spills them; held in SGPRs across all stages (65 dwords of constants beside 14 pointers) they overflowed the
+// 106 SGPRs into VGPR lanes and every use paid a v_readlane (133 in stage C alone).  k_cbf_rollout therefore reads its arguments
+// -- the constants included (RollArgs::p) -- through the kernarg segment pointer, made fresh per stage: scalar loads of the fields
+// a stage uses, where it uses them.
 template <typename T> struct RollParams {
   Consts<T> c;
   CbfParams<T> P;
 };
-template <typename T> __global__ void k_store_roll_params(const Consts<T> c, const CbfParams<T> P, RollParams<T>* __restrict__ dst) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    dst->c = c;
-    dst->P = P;
-  }
-}
 #define MDS_CONST_AS __attribute__((address_space(4)))
-template <typename T> __device__ __forceinline__ const RollParams<T> MDS_CONST_AS* fresh_ptr(const RollParams<T> MDS_CONST_AS* p) {
-  asm volatile("" : "+s"(p));
-  return p;
-}
 // a by-value copy of a struct behind a constant-address-space pointer, word by word (the words that are used become scalar loads,
 // the others disappear)
 template <typename V> __device__ __forceinline__ V load_const(const V MDS_CONST_AS* p) {
@@ -1281,7 +1269,7 @@ template <typename V> __device__ __forceinline__ V load_const(const V MDS_CONST_
 // through the kernarg segment pointer, made fresh per stage (fresh_args) -- scalar loads where a field is used, instead of 40 SGPRs
 // of loop invariants that the step loop kept spilling to VGPR lanes (a v_readlane, often with wait states, per use).
 template <typename T> struct RollArgs {
-  const RollParams<T> MDS_CONST_AS* rp;
+  RollParams<T> p;                // drone constants, controller gains, CBF parameters
   const void* Kp;
   int n;
   size_t ld;
@@ -1389,7 +1377,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   };
   if (kStamps && stamps != nullptr && threadIdx.x < NW * 10) sst[threadIdx.x / 10][threadIdx.x % 10] = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int D = a0->rp->P.num_drones, GB = NT / D;             // envs per workgroup
+  const int D = a0->p.P.num_drones, GB = NT / D;             // envs per workgroup
   const int i = blockIdx.x * NT + tid;
   const bool valid = i < a0->n;
   const int env0 = (blockIdx.x * NT) / D;
@@ -1398,7 +1386,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
 
   // ---- once per launch ----
   {
-    const CbfParams<T> P = load_const(&a0->rp->P);
+    const CbfParams<T> P = load_const(&a0->p.P);
     const T* obstacles = a0->obstacles;
   if (tid < R * 64) stab[tid >> 6][tid & 63] = roll_slot_of<T>(P, a0->pair_ij, (tid & 63) + 64 * (tid >> 6), kRec, kSwz && P.num_drones == 16, kSobOff, kDsOff);
   if (tid < kCbfMaxObs) {
@@ -1467,11 +1455,11 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     return Pl;
   };
   if (valid && n_steps > 0) {
-    const Consts<T> c1 = load_const(&a0->rp->c);
+    const Consts<T> c1 = load_const(&a0->p.c);
     stage_a(a0, c1, load_params(a0, (unsigned)i), t, tid);
   }
   const int log2D = 31 - __clz(D);                             // D is 4, 8 or 16
-  const int nbs = (cbf_num_pairs(D) + D * a0->rp->P.n_obs + 63) >> 6;   // row slots that hold barrier rows
+  const int nbs = (cbf_num_pairs(D) + D * a0->p.P.n_obs + 63) >> 6;   // row slots that hold barrier rows
 
   for (int k = 0; k < n_steps; ++k) {
     if (wave == 0) {
@@ -1496,10 +1484,6 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
 
     // ---- stage B: the workgroup's envs, one per wave at a time ----
     {
-      const RollArgs<T> MDS_CONST_AS* ab = fresh_args<T>();
-      const CbfParams<T> P = load_const(&ab->rp->P);
-      const int max_iter = ab->max_iter;
-      const T tol2 = ab->tol2;
       Scratch& S = slice_of(wave).sc;
       if (kStamps && stamps != nullptr) tk1 = __builtin_amdgcn_s_memtime();
 #if !defined(MDS_TUNE_ROLL_STATIC)
@@ -1521,6 +1505,8 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)
         __builtin_amdgcn_s_setprio(0);
 #endif
+        // the CBF parameters of the row build: scalar loads per env (held across the solver they were spilled to VGPR lanes)
+        const CbfParams<T> P = load_const(&fresh_args<T>()->p.P);
         const int d0 = el * D;
         const unsigned ebase = (unsigned)(d0 >> 6) * kObsWave + (unsigned)(d0 & 63) * kRec;   // the env's first record in the LDS block
         int tl = lane;
@@ -1659,6 +1645,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         }
         if (false)
 #endif
+        const RollArgs<T> MDS_CONST_AS* ab = fresh_args<T>();
+        const int max_iter = ab->max_iter;
+        const T tol2 = ab->tol2;
         gi_solve<T, R, NMAX, NV, false, kQS>(lane, D, max_iter, tol2, __any(bad), ca, cb, b, ia, ib, vld, act, &su_all[d0], S.sd, S.slam, S.sdi,
                                              S.sQ, S.sR, S.sact, nullptr, converged, it, q);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)
@@ -1702,9 +1691,8 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     int tq = tid;
     asm volatile("" : "+v"(tq));
     const unsigned iu = wg0 + (unsigned)tq;
-    const RollParams<T> MDS_CONST_AS* rq = ac->rp;
-    const Consts<T> c = load_const(&rq->c);
-    const CbfParams<T> P = load_const(&rq->P);
+    const Consts<T> c = load_const(&ac->p.c);
+    const CbfParams<T> P = load_const(&ac->p.P);
     constexpr int kRowBytes = kObsDim * (int)sizeof(T);
     const int lq = tq & 63;
     unsigned char* lds_wave = raw + (tq >> 6) * kObsWave;          // the wave's staging slice (its records / solver scratch of stage B: done with)
