@@ -1506,7 +1506,10 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         __builtin_amdgcn_s_setprio(0);
 #endif
         // the CBF parameters of the row build: scalar loads per env (held across the solver they were spilled to VGPR lanes)
-        const CbfParams<T> P = load_const(&fresh_args<T>()->p.P);
+        const RollArgs<T> MDS_CONST_AS* ab = fresh_args<T>();
+        const CbfParams<T> P = load_const(&ab->p.P);
+        const int max_iter = ab->max_iter;                         // (requested with them: the solver starts right after the scan)
+        const T tol2 = ab->tol2;
         const int d0 = el * D;
         const unsigned ebase = (unsigned)(d0 >> 6) * kObsWave + (unsigned)(d0 & 63) * kRec;   // the env's first record in the LDS block
         int tl = lane;
@@ -1645,24 +1648,15 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         }
         if (false)
 #endif
-        const RollArgs<T> MDS_CONST_AS* ab = fresh_args<T>();
-        const int max_iter = ab->max_iter;
-        const T tol2 = ab->tol2;
         gi_solve<T, R, NMAX, NV, false, kQS>(lane, D, max_iter, tol2, __any(bad), ca, cb, b, ia, ib, vld, act, &su_all[d0], S.sd, S.slam, S.sdi,
                                              S.sQ, S.sR, S.sact, nullptr, converged, it, q);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)
         __builtin_amdgcn_s_setprio(1);                             // (gi_solve raised it to 3 if the env iterated)
 #endif
         stamp_b(9);
-        if (lane == 0) {
-          const RollArgs<T> MDS_CONST_AS* al = fresh_args<T>();
+        if (lane == 0) {                                           // (status_log / status / cost_io: written from these after the barrier)
           sconv[el] = converged ? 1 : 0;
           scost[el] = it;
-          if (al->status_log) al->status_log[(size_t)k * al->E + env0 + el] = converged ? 0 : 1;
-          if (k == n_steps - 1) {
-            al->status[env0 + el] = converged ? 0 : 1;
-            if (al->cost_io) al->cost_io[env0 + el] = it;
-          }
         }
         MDS_WAVE_SYNC();
         stamp_b(8);
@@ -1679,6 +1673,13 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     const RollArgs<T> MDS_CONST_AS* ac = fresh_args<T>();
     T* const obs_log = ac->obs_log;
     const double ctrl_dt = ac->ctrl_dt;
+    if (tid < nenv) {                                              // the step's statuses, one coalesced store per workgroup
+      if (ac->status_log) ac->status_log[(size_t)k * ac->E + env0 + tid] = sconv[tid] ? 0 : 1;
+      if (k == n_steps - 1) {
+        ac->status[env0 + tid] = sconv[tid] ? 0 : 1;
+        if (ac->cost_io) ac->cost_io[env0 + tid] = scost[tid];
+      }
+    }
     const bool want = obs_log != nullptr || k == n_steps - 1;
     const bool more = k + 1 < n_steps;
     {                                                              // (uniform: kept in SGPRs -- as a VGPR pair the step loop spilled it)
