@@ -436,8 +436,8 @@ int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs_d
  * reference's observations.append(obs), CBFTest.py:351) into slot (first_slot + k) % log_slots; without a log only the last step's
  * observation is materialised.  obs_dev [n,20]: the last step's observation (out).  status_dev [E]: the last step's statuses as
  * mds_cbf_filter; status_log_dev: NULL or [n_steps, E], every step's.  Covers order 2, D in {4, 8, 16}, <= 256 rows per env,
- * explicit Euler at pyb_freq == ctrl_freq, DYN, geometric or LQR-omega nominal, f32 / f32c / f64; MDS_EUNSUPPORTED otherwise (use
- * mds_rollout_cbf_geometric).  Same QP, statuses and iteration counts as the step-by-step loop; observations equal to rounding (the
+ * explicit Euler at pyb_freq == ctrl_freq, DYN, geometric or LQR-omega nominal, f32 / f32c / f64, at most 2^27 drones per handle
+ * (32-bit byte offsets into the per-drone planes); MDS_EUNSUPPORTED otherwise (use mds_rollout_cbf_geometric).  Same QP, statuses and iteration counts as the step-by-step loop; observations equal to rounding (the
  * kernels contract FMAs differently, as the one-launch step does: mds_cbf_set_step_kernel). */
 int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int steps_per_launch, void* obs_log_dev, int log_slots,
                                     int first_slot, void* obs_dev, int32_t* status_dev, int32_t* status_log_dev, void* stream);
