@@ -406,7 +406,11 @@ int mds_cbf_set_nominal(mds_handle* h, int which);
  * of 64 up to 16, Euler, DYN, geometric or LQR-omega nominal, f32 / f32c / f64, no action output; three launches otherwise --
  * the faster form when few envs iterate (obstacles far away: 29 us against 40 us).  Same QP, same statuses and iteration
  * counts; observations equal to rounding (the two forms contract FMAs differently), so pick one per handle: each form's rollout
- * is bitwise its own step-by-step loop.  MDS_CBF_FUSED=1 in the environment selects 1 at mds_cbf_configure. */
+ * is bitwise its own step-by-step loop.  MDS_CBF_FUSED=1 in the environment selects 1 at mds_cbf_configure.
+ * 2: a step is ONE launch of the several-steps-per-launch kernel (k_cbf_rollout, see mds_rollout_cbf_geometric_fused) with one step,
+ * and mds_rollout_cbf_geometric becomes mds_rollout_cbf_geometric_fused at 25 steps per launch, where that kernel applies and no
+ * action output is asked for (form 0 otherwise) -- the fastest per-step form measured (C4: 27 us per control step against 38 us
+ * for form 0; 21.6 us at 50 steps per launch); bitwise the fused rollout's results whatever the steps per launch. */
 int mds_cbf_set_step_kernel(mds_handle* h, int one_launch);
 /* What the most recent mds_step_cbf_geometric / mds_rollout_cbf_geometric[_fused] of this handle launched: 2 the several-steps-per-launch
  * kernel, 1 the one-launch kernel, 0 the QP launch + the low-level launch, -1 no CBF-filtered step yet (negative mds_status for a null handle is -1 as well: check the handle). */

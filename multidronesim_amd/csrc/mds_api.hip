@@ -118,6 +118,7 @@ struct mds_handle {
                                         // no faster than one env per wave (see its header), so opt-in
   bool cbf_chain_nominal = true;        // MDS_CBF_CHAIN=0 at configure time: the C rollout loops launch the nominal kernel every step (A/B)
   int cbf_last_step_kernel = -1;        // what the most recent CBF-filtered step launched: 1 the one-launch kernel, 0 QP + low level
+  bool cbf_step_persistent = false;     // mds_cbf_set_step_kernel(h, 2): a CBF-filtered step = one launch of the persistent rollout kernel where it applies
   bool cbf_fused = false;               // mds_cbf_set_step_kernel / MDS_CBF_FUSED=1 at configure time: the one-launch CBF step (k_cbf_step) where it applies; it wins only
                                         // on scenes whose QPs need no iterations (see the kernel's header), so the default is the three launches
   void* cbf_unom;      // S [n,4]  scratch of mds_step_cbf_geometric
@@ -1756,8 +1757,9 @@ int mds_cbf_set_nominal(mds_handle* h, int which) {
 }
 
 int mds_cbf_set_step_kernel(mds_handle* h, int one_launch) {
-  if (!h || one_launch < 0 || one_launch > 1) return fail(MDS_EINVAL, "mds_cbf_set_step_kernel");
-  h->cbf_fused = one_launch != 0;
+  if (!h || one_launch < 0 || one_launch > 2) return fail(MDS_EINVAL, "mds_cbf_set_step_kernel");
+  h->cbf_fused = one_launch == 1;
+  h->cbf_step_persistent = one_launch == 2;
   for (int k = 0; k < 3; ++k) h->next_nom_ok[k] = false;
   return MDS_OK;
 }
@@ -1939,6 +1941,15 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
   return MDS_OK;
 }
 
+// what k_cbf_rollout covers (mds_rollout_cbf_geometric_fused; mds_cbf_set_step_kernel(h, 2))
+static bool roll_fused_applies(const mds_handle* h) {
+  const int D = h->cfg.num_drones;
+  const int m2 = D * (D - 1) / 2 + D * h->cbf.n_obs + 2 * D;
+  return h->has_cbf && h->cbf.order == 2 && !h->cbf_hildreth && D >= 4 && D <= 16 && 64 % D == 0 && m2 <= 256 && !h->envfx &&
+         h->cfg.integrator == MDS_INTEGRATOR_EULER && !has_drag(h) && h->cbf_nominal <= 1 && h->cfg.dtype != MDS_F16 &&
+         h->cfg.pyb_freq == h->cfg.ctrl_freq && h->n <= (1 << 27);
+}
+
 int mds_step_cbf_geometric(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream) {
   MDS_DEV(h);
   if (!h || !obs || !status) return fail(MDS_EINVAL, "mds_step_cbf_geometric: null argument");
@@ -1949,12 +1960,21 @@ int mds_step_cbf_geometric(mds_handle* h, double t, void* obs, int32_t* status, 
   if (ord3 != (h->cbf_nominal == 2))
     return fail(MDS_EUNSUPPORTED, "mds_step_cbf_geometric: order 3 needs (and order 2 excludes) the lqr-yank-omega nominal, mds_cbf_set_nominal(h, 2)");
   if (h->cfg.dtype == MDS_F16) return fail(MDS_EUNSUPPORTED, "mds_step_cbf_geometric: fp16 storage");
+  if (h->cbf_step_persistent && !action && roll_fused_applies(h)) {   // mds_cbf_set_step_kernel(h, 2): one launch of k_cbf_rollout, one step
+    for (int k = 0; k < 3; ++k) h->next_nom_ok[k] = false;
+    return mds_rollout_cbf_geometric_fused(h, t, 1, 1, nullptr, 0, 0, obs, status, nullptr, stream);
+  }
   return step_nominal_lowlevel(h, t, obs, status, action, stream, true, "mds_step_cbf_geometric");
 }
 
 int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs, int32_t* status, void* stream) {
   MDS_DEV(h);
   if (!h || !obs || !status || n_steps < 0) return fail(MDS_EINVAL, "mds_rollout_cbf_geometric: null argument");
+  if (h->cbf_step_persistent && h->has_cbf && h->cbf.order == 2 && h->cbf_nominal <= 1 && roll_fused_applies(h) && h->has_traj && h->traj_mode == 1) {
+    for (int k = 0; k < 3; ++k) h->next_nom_ok[k] = false;
+    h->last_rollout_streams = 1;
+    return mds_rollout_cbf_geometric_fused(h, t0, n_steps, 25, nullptr, 0, 0, obs, status, nullptr, stream);
+  }
   const double dt = 1.0 / h->cfg.ctrl_freq;
   // The env halves are independent step chains (a barrier row couples drones of one env only).  On two streams one half's
   // QP kernel (latency / ALU bound) runs beside the other half's nominal and low-level kernels (memory bound).  The split
@@ -2013,8 +2033,7 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
   const int D = h->cfg.num_drones;
   const int m2 = D * (D - 1) / 2 + D * h->cbf.n_obs + 2 * D;
   // what the persistent kernel covers (everything else: mds_rollout_cbf_geometric, one or two launches per step)
-  if (h->cbf.order != 2 || h->cbf_hildreth || D < 4 || D > 16 || 64 % D != 0 || m2 > 256 || h->envfx || h->cfg.integrator != MDS_INTEGRATOR_EULER ||
-      has_drag(h) || h->cbf_nominal > 1 || h->cfg.dtype == MDS_F16 || h->cfg.pyb_freq != h->cfg.ctrl_freq || h->n > (1 << 27))
+  if (!roll_fused_applies(h))
     return fail(MDS_EUNSUPPORTED, "mds_rollout_cbf_geometric_fused: order-2 CBF, D in {4, 8, 16}, <= 256 rows per env, explicit Euler at "
                                   "pyb_freq == ctrl_freq without drag / ground effect / downwash, geometric or LQR-omega nominal, f32 / f32c / f64, "
                                   "at most 2^27 drones (32-bit byte offsets into the per-drone planes)");

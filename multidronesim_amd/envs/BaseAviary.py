@@ -460,13 +460,17 @@ class BaseAviary:
         capi.check(self._lib.mds_cbf_set_nominal(self._h, {"geometric": 0, "lqr_omega": 1, "lqr_yank_omega": 2}[which]),
                    "mds_cbf_set_nominal")
 
-    def set_cbf_step_kernel(self, one_launch: bool):
-        """How the CBF-filtered step is issued (mds_cbf_set_step_kernel): False (default) the QP launch + the low-level launch, True
-        one launch per control step where it applies (the faster form when few envs need active-set iterations)."""
-        capi.check(self._lib.mds_cbf_set_step_kernel(self._h, C.c_int(1 if one_launch else 0)), "mds_cbf_set_step_kernel")
+    def set_cbf_step_kernel(self, one_launch):
+        """How the CBF-filtered step is issued (mds_cbf_set_step_kernel): False / 0 (default) the QP launch + the low-level launch,
+        True / 1 one launch per control step where it applies (the faster of the two when few envs need active-set iterations),
+        2 or "persistent" one launch of the several-steps-per-launch kernel per step (the fastest per-step form where it applies;
+        ``rollout_cbf_geometric`` then runs 25 steps per launch)."""
+        mode = 2 if one_launch == "persistent" else int(one_launch)
+        capi.check(self._lib.mds_cbf_set_step_kernel(self._h, C.c_int(mode)), "mds_cbf_set_step_kernel")
 
     def cbf_last_step_kernel(self) -> int:
-        """1: the most recent CBF-filtered step ran as one launch, 0: as QP launch + low-level launch, -1: none yet."""
+        """2: the most recent CBF-filtered step ran in the several-steps-per-launch kernel, 1: as one launch, 0: as QP launch +
+        low-level launch, -1: none yet."""
         return int(self._lib.mds_cbf_last_step_kernel(self._h))
 
     def step_cbf_geometric(self, t: float, tracker, x_obs=None, obs_r_list=None, return_action: bool = False):

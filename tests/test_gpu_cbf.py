@@ -861,3 +861,59 @@ def test_cbf_persistent_rollout_small_shapes(mds, D, n_obs, spl):
     np.testing.assert_array_equal(out["step"][3], out["fused"][3])
     np.testing.assert_allclose(out["fused"][0][..., :16], out["step"][0][..., :16], rtol=0, atol=1e-4)
     np.testing.assert_allclose(out["fused"][2], out["step"][2], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_cbf_step_kernel_persistent_per_step(mds, dtype):
+    """mds_cbf_set_step_kernel(h, 2): step_cbf_geometric is one launch of the several-steps-per-launch kernel with one step, and
+    rollout_cbf_geometric runs it at 25 steps per launch -- bitwise the fused rollout's results whatever the steps per launch; with an
+    action output asked for, and on a shape the kernel does not cover, the call falls back to the QP launch + low-level launch."""
+    E, D, steps = 37, 16, 30
+    xyz, rpy, P = H.c2_setup(E, D, phase="c3", offset=1.5)
+    P[..., 4] = 0.5 + 0.3 * np.arange(D)
+    xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    x_obs = [np.array([[sx * 0.5, sy * 0.5, 0.5], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
+    obs_r = [0.1] * 4
+
+    def make(nd=D):
+        a, b, c = (xyz, rpy, P) if nd == D else H.c2_setup(E, nd, phase="c3", offset=1.5)
+        env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=nd, initial_xyzs=a, initial_rpys=b, physics=mds.Physics.DYN,
+                             pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype)
+        env.set_trajectories(c)
+        cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(nd)], safety_radius=0.1, zscale=1.0, order=2)
+        trk = mds.DroneQPTracker(cbf, num_robots=nd, xdim=9, env=env)
+        env.step(mds.torch.zeros((E, nd, 4), dtype=env.dtype))
+        return env, cbf, trk
+
+    ref, _, tr = make()
+    o_ref, s_ref = ref.rollout_cbf_geometric_fused(0.0, steps, tr, x_obs, obs_r, steps_per_launch=50)
+    o_ref, s_ref, x_ref = o_ref.cpu().numpy().copy(), s_ref.cpu().numpy().copy(), ref.get_state()
+    ref.close()
+
+    env, _, trk = make()
+    env.set_cbf_step_kernel("persistent")
+    t = 0.0
+    for k in range(steps):
+        o, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
+        assert env.cbf_last_step_kernel() == 2
+        t += env.CTRL_TIMESTEP
+    np.testing.assert_array_equal(o.cpu().numpy(), o_ref)
+    np.testing.assert_array_equal(st.cpu().numpy(), s_ref)
+    np.testing.assert_array_equal(env.get_state(), x_ref)
+    env.close()
+
+    env, _, trk = make()
+    env.set_cbf_step_kernel(2)
+    o, st = env.rollout_cbf_geometric(0.0, steps, trk, x_obs, obs_r)
+    assert env.cbf_last_step_kernel() == 2
+    np.testing.assert_array_equal(o.cpu().numpy(), o_ref)
+    np.testing.assert_array_equal(st.cpu().numpy(), s_ref)
+    env.close()
+
+    env, _, trk = make(6)                       # D = 6: not covered -> form 0, no error
+    env.set_cbf_step_kernel(2)
+    env.step_cbf_geometric(0.0, trk, x_obs, obs_r)
+    assert env.cbf_last_step_kernel() == 0
+    env.rollout_cbf_geometric(0.01, 3, trk, x_obs, obs_r)
+    assert env.cbf_last_step_kernel() == 0
+    env.close()
