@@ -1673,11 +1673,15 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     const RollArgs<T> MDS_CONST_AS* ac = fresh_args<T>();
     T* const obs_log = ac->obs_log;
     const double ctrl_dt = ac->ctrl_dt;
-    if (tid < nenv) {                                              // the step's statuses, one coalesced store per workgroup
-      if (ac->status_log) ac->status_log[(size_t)k * ac->E + env0 + tid] = sconv[tid] ? 0 : 1;
-      if (k == n_steps - 1) {
-        ac->status[env0 + tid] = sconv[tid] ? 0 : 1;
-        if (ac->cost_io) ac->cost_io[env0 + tid] = scost[tid];
+    {                                                              // the step's statuses, one coalesced store per workgroup
+      int ts = tid;
+      asm volatile("" : "+v"(ts));                                 // (LDS addresses formed here, not held across the loop)
+      if (ts < nenv) {
+        if (ac->status_log) ac->status_log[(size_t)k * ac->E + env0 + ts] = sconv[ts] ? 0 : 1;
+        if (k == n_steps - 1) {
+          ac->status[env0 + ts] = sconv[ts] ? 0 : 1;
+          if (ac->cost_io) ac->cost_io[env0 + ts] = scost[ts];
+        }
       }
     }
     const bool want = obs_log != nullptr || k == n_steps - 1;

@@ -50,3 +50,23 @@ def test_no_mfma_and_no_barrier_in_hot_kernel(isa):
     assert len([o for o in ops if o.startswith("ds_write_b128")]) == 5
     assert len([o for o in ops if o.startswith("global_load_dwordx4")]) == 4        # 3 state groups + (a, omega, yaw_rate, phase)
     assert len([o for o in ops if o.startswith("global_load_dword ") or o.startswith("global_load_dword\t")]) <= 2
+
+
+def test_persistent_cbf_kernel_keeps_its_step_loop_free_of_scratch(isa):
+    """k_cbf_rollout<float, geometric nominal>: 4 096 wavefronts = 4 per SIMD for C4, so it must fit 128 VGPRs; and nothing may be
+    spilled inside the step loop -- a dozen serial scratch reloads per step cost a quarter of the kernel's time in round 3 (DESIGN.md
+    section 4, C4 (e)).  Spill slots outside the loop (the launch prologue) are tolerated; none is expected today."""
+    name = "_ZN3mds13k_cbf_rolloutIfLi0ELb0ELi8EEEvNS_8RollArgsIT_EE"
+    meta = isa[isa.index("amdhsa.kernels:"):]
+    blk = next(b for b in meta.split("\n  - ") if re.search(r"\.name:\s+" + re.escape(name) + r"\n", b))
+    assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 128
+    assert int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk).group(1)) <= 80 * 1024       # two workgroups per CU
+    ops = kernel_ops(isa, name)
+    bars = [k for k, o in enumerate(ops) if o.startswith("s_barrier")]
+    assert len(bars) == 2                                            # before and after stage B, nothing else
+    loop = ops[bars[0]:]                                             # (stage C + A follow the second barrier up to the loop's back edge)
+    assert not [o for o in loop if o.startswith("scratch_")], [o for o in loop if o.startswith("scratch_")][:4]
+    # per-lane planes are addressed as scalar base + 32-bit VGPR offset: no global access of the stage forms a 64-bit per-lane address
+    # in the step loop except the last-step-only stores of the state / RPM planes
+    late = ops[bars[1]:]
+    assert len([o for o in late if o.startswith("global_load") and ", off" in o and "s[" not in o]) <= 2
