@@ -442,7 +442,8 @@ int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs_d
  * mds_cbf_filter; status_log_dev: NULL or [n_steps, E], every step's.  Covers order 2, D in {4, 8, 16}, <= 256 rows per env,
  * explicit Euler at pyb_freq == ctrl_freq, DYN, geometric or LQR-omega nominal, f32 / f32c / f64, at most 2^27 drones per handle
  * (32-bit byte offsets into the per-drone planes); MDS_EUNSUPPORTED otherwise (use mds_rollout_cbf_geometric).  Same QP, statuses and iteration counts as the step-by-step loop; observations equal to rounding (the
- * kernels contract FMAs differently, as the one-launch step does: mds_cbf_set_step_kernel). */
+ * kernels contract FMAs differently, as the one-launch step does: mds_cbf_set_step_kernel).  The call only enqueues (kernel launches and one
+ * device-to-device copy of the last ring slot): it may be captured into a hipGraph. */
 int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int steps_per_launch, void* obs_log_dev, int log_slots,
                                     int first_slot, void* obs_dev, int32_t* status_dev, int32_t* status_log_dev, void* stream);
 

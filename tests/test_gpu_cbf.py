@@ -917,3 +917,45 @@ def test_cbf_step_kernel_persistent_per_step(mds, dtype):
     env.rollout_cbf_geometric(0.01, 3, trk, x_obs, obs_r)
     assert env.cbf_last_step_kernel() == 0
     env.close()
+
+
+def test_cbf_persistent_rollout_can_be_captured_into_a_hip_graph(mds):
+    """mds_rollout_cbf_geometric_fused only enqueues (kernel launches and one device-to-device copy of the last ring slot): a caller may
+    capture it into a hipGraph and replay it -- one replay of a captured 12-step call (5 + 5 + 2 steps per launch, observation ring,
+    status log) == the eager call, bit for bit, from the same state."""
+    torch = mds.torch
+    E, D, steps = 21, 16, 12
+    xyz, rpy, P = H.c2_setup(E, D, phase="c3", offset=1.5)
+    P[..., 4] = 0.5 + 0.3 * np.arange(D)
+    xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    x_obs = [np.array([[sx * 0.5, sy * 0.5, 0.5], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
+    obs_r = [0.1] * 4
+    res = []
+    for captured in (False, True):
+        env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                             pyb_freq=100, ctrl_freq=100, num_envs=E, dtype="float32")
+        env.set_trajectories(P)
+        cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2)
+        trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+        env.step(torch.zeros((E, D, 4), dtype=env.dtype))
+        cbf.configure(x_obs, obs_r)                                    # (uploads the obstacles: set-up, before any capture)
+        ring = torch.full((4, E, D, 20), float("nan"), dtype=env.dtype, device=env.device)
+        slog = torch.full((steps, E), -1, dtype=torch.int32, device=env.device)
+        call = lambda: env.rollout_cbf_geometric_fused(0.0, steps, trk, x_obs, obs_r, steps_per_launch=5, obs_log=ring, first_slot=1, status_log=slog)
+        if captured:
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    call()
+            torch.cuda.current_stream().wait_stream(side)
+            assert (slog.cpu().numpy() == -1).all()                    # capturing ran nothing
+            g.replay()
+        else:
+            call()
+        torch.cuda.synchronize()
+        res.append((ring.cpu().numpy().copy(), slog.cpu().numpy().copy(), env.get_state(), env._obs.cpu().numpy().copy()))
+        env.close()
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
