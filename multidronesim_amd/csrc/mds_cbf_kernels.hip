@@ -1208,6 +1208,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 && R == 4) ? 4 : 1) void k_cbf_
 #ifndef MDS_ROLL_STAMPS
 #define MDS_ROLL_STAMPS 0       // 1: per-stage shader-clock stamps compiled in (profiles/tools/r03_stamps.sh builds such a library)
 #endif
+#ifndef MDS_TUNE_ROLL_PRIO_C
+#define MDS_TUNE_ROLL_PRIO_C 2     // issue priority of stages C and A (row build 0, scan / bookkeeping 1, an iterating solve 3); 0..3 measure within 2 % of each other
+#endif
 #ifndef MDS_TUNE_ROLL_SKIP
 #define MDS_TUNE_ROLL_SKIP 0   // tuning aid (cost breakdown of stage B): 1 no row polynomial, 2 no normalisation, 4 no scan / solve, 8 no rows
 #endif
@@ -1663,7 +1666,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       }
     }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(MDS_TUNE_ROLL_PRIO_C);
 #endif
     stamp(1);
     __syncthreads();
