@@ -895,6 +895,9 @@ def main(argv=None):
                                       "k_cbf_filter_gi + k_lowlevel_step (2 launches per step and env half from the second step on; the QP is issue/latency bound)")
         if fused_T:
             line["roofline"]["kernel"] = f"k_cbf_rollout<float, 0, false, 8> ({fused_T} control steps per launch: a workgroup owns 32 envs; nominal controller, ticketed QPs, low level + physics; state in LDS / registers)"
+            line["roofline"]["us_per_launch"] = us_per_step * fused_T
+            line["roofline"]["bytes_per_launch"] = BYTES_PER_DRONE_STEP_C4 * n_local * fused_T
+            line["roofline"]["bytes_per_step"] = BYTES_PER_DRONE_STEP_C4 * n_local
         line["roofline"]["bytes_per_drone_step"] = BYTES_PER_DRONE_STEP_C4
         line["roofline"]["note"] = ("algorithmic bytes of SURVEY 8d (280 B per drone-step: the fused step's 212 + u_hat 16 + xdes 36 + u_safe 16); the path is "
                                     "VALU / latency bound, `frac` says how far from the HBM roofline that leaves it")
