@@ -260,6 +260,38 @@ def gather_over_ranks(value, world, device):
     return [float(t.item()) for t in out]
 
 
+def compare_models_line(torch, env, device, reps=50):
+    """mds_compare_models on the n observation rows of one control step (the loop body of simulations/CompareModels.py:48-56 over a
+    logged rollout, one launch): microseconds per launch by HIP events, algorithmic bytes 80 + 3 x 48 = 224 B per row (fp32)."""
+    import ctypes as C
+    from multidronesim_amd.model import LinearizedModel, QuadrotorDynamics
+    obs = env.step_geometric(0.0).reshape(-1, 20).contiguous()
+    n, es = obs.shape[0], obs.element_size()
+    lin, geo = LinearizedModel(env), QuadrotorDynamics(env.PYB_FREQ)
+    geo.load_env_params(env)
+    A, B = lin._mats()
+    PD = C.POINTER(C.c_double)
+    J = (C.c_double * 3)(geo.J[0, 0], geo.J[1, 1], geo.J[2, 2])
+    outs = [torch.empty((n, 12), dtype=obs.dtype, device=device) for _ in range(3)]
+    st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def launch():
+        rc = env._lib.mds_compare_models(env._h, C.c_int(n), C.c_void_p(obs.data_ptr()), A.ctypes.data_as(PD), B.ctypes.data_as(PD),
+                                         C.c_double(lin.mass * lin.g), C.c_double(geo.m), J, C.c_double(geo.g), C.c_void_p(outs[0].data_ptr()),
+                                         C.c_void_p(outs[1].data_ptr()), C.c_void_p(outs[2].data_ptr()), st)
+        if rc != 0:
+            raise RuntimeError(f"mds_compare_models failed: {rc}")
+
+    for _ in range(5):
+        launch()
+    us = _timed_steps(device, lambda: [launch() for _ in range(reps)], reps)
+    by = n * (20 + 36) * es
+    return {"what": "simulations/CompareModels.py:48-56 loop body (x_dot of the linear model, x_dot of the geometric model in its layout, the linear "
+                    "state) over one step's observations of the shard, one launch of k_compare_models",
+            "rows": n, "us_per_launch": us, "rows_per_s": n / (us * 1e-6), "bytes_per_row": (20 + 36) * es, "achieved_GBps": by / (us * 1e-6) / 1e9,
+            "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "finite": bool(all(torch.isfinite(o).all().item() for o in outs))}
+
+
 def _timed_steps(device, fn, steps):
     """HIP events on the stream the kernels are launched on, around fn(); microseconds per step."""
     import torch
@@ -963,6 +995,13 @@ def main(argv=None):
                                  "kernel": "k_rollout_step<float,_Float16,false,false>",
                                  # the slots this run wrote last (the log is a ring: step j -> slot j % slots)
                                  "state_sane": bool(all(torch.isfinite(c5_log[(C5_EPISODE * (reps + 1) - 1 - j) % c5_T]).all().item() for j in range(16)))}
+    if args.workload == "c3" and world == 1 and not fused_T and not args.python_loop and extras and not rk4:
+        # the call site of QuadrotorDynamics.dynamics (simulations/CompareModels.py:46-56) on one step's observations of the whole shard:
+        # one launch, 80 B read + 3 x 48 B written per row
+        try:
+            line["compare_models"] = compare_models_line(torch, env, device)
+        except Exception as exc:
+            line["compare_models"] = {"error": str(exc)}
     env.close()
     del env
     if args.workload == "c3" and world == 1 and not fused_T and not args.python_loop and extras and not rk4:

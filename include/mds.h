@@ -281,6 +281,28 @@ int mds_obs_to_model(mds_handle* h, const void* obs_dev, int dim, void* x_dev, v
 int mds_quadrotor_dynamics(int dtype, int count, const void* state_dev, const void* u_dev, double m, const double J[3],
                            double g, void* out_dev, void* stream);
 
+/* The call site of QuadrotorDynamics.dynamics -- simulations/CompareModels.py:46-56, the loop body over a logged rollout, as ONE launch:
+ * for each of `count` observation rows (obs_dev [count,20], e.g. the [T,D,20] history GeometricEnv.do_control leaves behind)
+ *   x_lin_dev    [count,12] = obs_to_lin_model(obs)                                      (utils/model_conversions.py:20-58, dim 12)
+ *   xdot_lin_dev [count,12] = LinearizedModel.calc_xdot_from_obs(obs) = A (x - x_eq) + B (u - u_eq), u = action_to_input(env, obs[16:20]),
+ *                             x_eq = (0 .. 0, position), u_eq = (u_eq0, 0, 0, 0), u_eq0 = mass * g of the model     (model/linearized.py:83-104)
+ *   xdot_geo_dev [count,12] = geo_x_dot_to_linear(QuadrotorDynamics.dynamics(None, obs_to_geo_model(obs), u))
+ *                                                                    (utils/model_conversions.py:105-135, model/dynamics.py:83-106)
+ * A_host [12,12], B_host [12,4] row-major doubles: the model's own matrices (A, B or Ahat, Bhat); dyn_m, dyn_J, dyn_g as
+ * mds_quadrotor_dynamics (after load_env_params: the env's m and g, the stale Hummingbird J).  Any output may be NULL (not all three).
+ * The handle supplies the env constants of action_to_input and the element type; count is independent of the handle's n. */
+int mds_compare_models(mds_handle* h, int count, const void* obs_dev, const double* A_host, const double* B_host, double u_eq0, double dyn_m,
+                       const double dyn_J[3], double dyn_g, void* xdot_lin_dev, void* xdot_geo_dev, void* x_lin_dev, void* stream);
+/* model/linearized.py:92-104 `LinearizedModel.calc_xdot(x, action)` on states of the caller's own -- the right-hand side
+ * roll_out_linear_system integrates (simulations/CompareModels.py:84-92): x_dev [count,12], action_dev [count,4] RPM -> xdot_dev [count,12]. */
+int mds_linear_xdot(mds_handle* h, int count, const void* x_dev, const void* action_dev, const double* A_host, const double* B_host,
+                    double u_eq0, void* xdot_dev, void* stream);
+/* utils/model_conversions.py:4-19 `rpy_to_rot(rpy)`: rpy_dev [count,3] -> R_dev [count,9] row-major, R = Rz(yaw) Ry(pitch) Rx(roll). */
+int mds_rpy_to_rot(int dtype, int count, const void* rpy_dev, void* R_dev, void* stream);
+/* utils/model_conversions.py:116-122 `geo_model_to_obs(x)`: x18_dev [count,18] (p, R row-major, v, w) -> obs16_dev [count,16]
+ * (p, quaternion xyzw as scipy's Rotation.from_matrix(R).as_quat() gives it, three zeros in the rpy slots, v, w). */
+int mds_geo_model_to_obs(int dtype, int count, const void* x18_dev, void* obs16_dev, void* stream);
+
 /* ---- ECBF safety filter (cbf/cbf.py, cbf/qptracker.py) ------------------------------------ */
 
 /* DroneCBF.__init__ (cbf/cbf.py:545-580) after its own derivations: Kcbf = place_poles gains

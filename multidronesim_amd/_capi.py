@@ -87,6 +87,10 @@ PROTOTYPES = {
     "mds_action_to_input": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "mds_obs_to_model": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "mds_quadrotor_dynamics": (C.c_int, [C.c_int, C.c_int, _P, _P, C.c_double, _PD, C.c_double, _P, _P]),
+    "mds_compare_models": (C.c_int, [_P, C.c_int, _P, _PD, _PD, C.c_double, C.c_double, _PD, C.c_double, _P, _P, _P, _P]),
+    "mds_linear_xdot": (C.c_int, [_P, C.c_int, _P, _P, _PD, _PD, C.c_double, _P, _P]),
+    "mds_rpy_to_rot": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
+    "mds_geo_model_to_obs": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
     "mds_cbf_configure": (C.c_int, [_P, C.POINTER(MdsCbfParams), _PD]),
     "mds_cbf_num_rows": (C.c_int, [_P]),
     "mds_cbf_rows": (C.c_int, [_P, _P, _P, _P, _P, _P]),

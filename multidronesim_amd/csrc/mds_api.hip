@@ -267,6 +267,30 @@ template <typename T> static void fill_cbf(const mds_handle* h, const mds_cbf_pa
   o.Fmax = (T)p.Fmax;
 }
 
+template <typename T> static void fill_lin_model(const double* A, const double* B, double u_eq0, LinModel<T>& M) {
+  for (int r = 0; r < 12; ++r) {
+    for (int k = 0; k < 12; ++k) M.A[r][k] = (T)A[r * 12 + k];
+    for (int k = 0; k < 4; ++k) M.B[r][k] = (T)B[r * 4 + k];
+  }
+  M.ueq0 = (T)u_eq0;
+}
+
+template <typename T, typename S>
+static void launch_compare_models(const Consts<T>& C, int count, const void* obs, const double* A, const double* B, double u_eq0, double dyn_m,
+                                  const double* dyn_J, double dyn_g, void* xdot_lin, void* xdot_geo, void* x_lin, hipStream_t st) {
+  LinModel<T> M;
+  fill_lin_model<T>(A, B, u_eq0, M);
+  k_compare_models<T, S><<<grid_for(count, kBlock), kBlock, 0, st>>>(C, M, count, (const S*)obs, (T)dyn_m, (T)dyn_J[0], (T)dyn_J[1], (T)dyn_J[2],
+                                                                      (T)dyn_g, (S*)xdot_lin, (S*)xdot_geo, (S*)x_lin);
+}
+template <typename T, typename S>
+static void launch_linear_xdot(const Consts<T>& C, int count, const void* x, const void* action, const double* A, const double* B, double u_eq0,
+                               void* xdot, hipStream_t st) {
+  LinModel<T> M;
+  fill_lin_model<T>(A, B, u_eq0, M);
+  k_linear_xdot<T, S><<<grid_for(count, 256), 256, 0, st>>>(C, M, count, (const S*)x, (const S*)action, (S*)xdot);
+}
+
 // set-up path: (re)write one gain struct to its device copy, synchronously
 static int upload_gain(mds_handle* h, int slot, const void* f32, size_t nf, const void* f64, size_t nd) {
   if (!h->gain_dev[slot]) MDS_HIP(hipMalloc(&h->gain_dev[slot], nd));
@@ -1287,6 +1311,54 @@ int mds_quadrotor_dynamics(int dtype, int count, const void* state, const void* 
                                                                (float)J[1], (float)J[2], (float)g, (half_t*)out);
   else
     return fail(MDS_EINVAL, "mds_quadrotor_dynamics: dtype");
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_compare_models(mds_handle* h, int count, const void* obs, const double* A, const double* B, double u_eq0, double dyn_m,
+                       const double dyn_J[3], double dyn_g, void* xdot_lin, void* xdot_geo, void* x_lin, void* stream) {
+  MDS_DEV(h);
+  if (!h || count < 0 || !obs || !A || !B || !dyn_J) return fail(MDS_EINVAL, "mds_compare_models: bad argument");
+  if (!xdot_lin && !xdot_geo && !x_lin) return fail(MDS_EINVAL, "mds_compare_models: no output requested");
+  if (!aligned16(obs) || !aligned16(xdot_lin) || !aligned16(xdot_geo) || !aligned16(x_lin)) return fail(MDS_EALIGN, "mds_compare_models");
+  if (count == 0) return MDS_OK;
+  MDS_DISPATCH(h, (launch_compare_models<T, S>(C, count, obs, A, B, u_eq0, dyn_m, dyn_J, dyn_g, xdot_lin, xdot_geo, x_lin, (hipStream_t)stream)));
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_linear_xdot(mds_handle* h, int count, const void* x, const void* action, const double* A, const double* B, double u_eq0, void* xdot,
+                    void* stream) {
+  MDS_DEV(h);
+  if (!h || count < 0 || !x || !action || !A || !B || !xdot) return fail(MDS_EINVAL, "mds_linear_xdot: bad argument");
+  if (count == 0) return MDS_OK;
+  MDS_DISPATCH(h, (launch_linear_xdot<T, S>(C, count, x, action, A, B, u_eq0, xdot, (hipStream_t)stream)));
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_rpy_to_rot(int dtype, int count, const void* rpy, void* R, void* stream) {
+  if (count < 0 || !rpy || !R) return fail(MDS_EINVAL, "mds_rpy_to_rot: bad argument");
+  if (count == 0) return MDS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid = grid_for(count, 256);
+  if (dtype == MDS_F32) k_rpy_to_rot<float, float><<<grid, 256, 0, st>>>(count, (const float*)rpy, (float*)R);
+  else if (dtype == MDS_F64) k_rpy_to_rot<double, double><<<grid, 256, 0, st>>>(count, (const double*)rpy, (double*)R);
+  else if (dtype == MDS_F16) k_rpy_to_rot<float, half_t><<<grid, 256, 0, st>>>(count, (const half_t*)rpy, (half_t*)R);
+  else return fail(MDS_EINVAL, "mds_rpy_to_rot: dtype");
+  MDS_HIP(hipGetLastError());
+  return MDS_OK;
+}
+
+int mds_geo_model_to_obs(int dtype, int count, const void* x18, void* obs16, void* stream) {
+  if (count < 0 || !x18 || !obs16) return fail(MDS_EINVAL, "mds_geo_model_to_obs: bad argument");
+  if (count == 0) return MDS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid = grid_for(count, 256);
+  if (dtype == MDS_F32) k_geo_model_to_obs<float, float><<<grid, 256, 0, st>>>(count, (const float*)x18, (float*)obs16);
+  else if (dtype == MDS_F64) k_geo_model_to_obs<double, double><<<grid, 256, 0, st>>>(count, (const double*)x18, (double*)obs16);
+  else if (dtype == MDS_F16) k_geo_model_to_obs<float, half_t><<<grid, 256, 0, st>>>(count, (const half_t*)x18, (half_t*)obs16);
+  else return fail(MDS_EINVAL, "mds_geo_model_to_obs: dtype");
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }

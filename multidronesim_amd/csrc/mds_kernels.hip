@@ -1227,4 +1227,138 @@ __global__ void k_quadrotor_dynamics(const int n, const S* __restrict__ state, c
   for (int k = 0; k < 12; ++k) out[(size_t)i * 12 + k] = (S)o[k];
 }
 
+// ------------------------------------------------------------------------------------
+// The call site of a5: simulations/CompareModels.py:46-56 over a logged rollout [count, 20] -> three [count, 12] arrays.
+// Streaming, HBM-bound (fp32: 80 B read + 3 x 48 B written per row): the wave's 64 rows are one contiguous span of every array, so
+// rows move through the wave's LDS slice in 16-byte chunks, coalesced on the memory side, one row per lane on the register side.
+// ------------------------------------------------------------------------------------
+template <typename S, typename T, int DIM>
+__device__ __forceinline__ void read_rows(unsigned char* __restrict__ lds_wave, const S* __restrict__ src, int n, int wave_base, int lane,
+                                          T out[DIM]) {
+  constexpr int kRowBytes = DIM * (int)sizeof(S);
+  constexpr int kUnit = (kRowBytes % 16 == 0) ? 16 : 8;
+  static_assert(kRowBytes % 8 == 0, "rows are moved in 8- or 16-byte units");
+  const int rows = min(kWave, n - wave_base);
+  const int bytes = rows * kRowBytes;
+  const unsigned char* g = reinterpret_cast<const unsigned char*>(src) + (size_t)wave_base * kRowBytes;
+  constexpr int kIters = (kWave * kRowBytes + kWave * 16 - 1) / (kWave * 16);
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    const int off = (it * kWave + lane) * 16;
+    if (off + 16 <= bytes) *reinterpret_cast<v4u*>(lds_wave + off) = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(g + off));
+    else if (off + 8 <= bytes) *reinterpret_cast<uint2*>(lds_wave + off) = *reinterpret_cast<const uint2*>(g + off);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  alignas(16) S row[DIM];
+  const unsigned char* r = lds_wave + (lane < rows ? lane : 0) * kRowBytes;        // lanes past the end: row 0 (finite, never stored)
+  if (kUnit == 16) {
+#pragma unroll
+    for (int k = 0; k < kRowBytes / 16; ++k) reinterpret_cast<uint4*>(row)[k] = reinterpret_cast<const uint4*>(r)[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < kRowBytes / 8; ++k) reinterpret_cast<uint2*>(row)[k] = reinterpret_cast<const uint2*>(r)[k];
+  }
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) out[k] = (T)row[k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                            // the slice is written again by write_rows
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <typename S, typename T, int DIM>
+__device__ __forceinline__ void write_rows(unsigned char* __restrict__ lds_wave, S* __restrict__ dst, int n, int wave_base, int lane,
+                                           const T v[DIM]) {
+  constexpr int kRowBytes = DIM * (int)sizeof(S);
+  constexpr int kUnit = (kRowBytes % 16 == 0) ? 16 : 8;
+  static_assert(kRowBytes % 8 == 0, "rows are moved in 8- or 16-byte units");
+  const int rows = min(kWave, n - wave_base);
+  if (lane < rows) {
+    alignas(16) S row[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) row[k] = (S)v[k];
+    unsigned char* w = lds_wave + lane * kRowBytes;
+    if (kUnit == 16) {
+#pragma unroll
+      for (int k = 0; k < kRowBytes / 16; ++k) reinterpret_cast<uint4*>(w)[k] = reinterpret_cast<const uint4*>(row)[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < kRowBytes / 8; ++k) reinterpret_cast<uint2*>(w)[k] = reinterpret_cast<const uint2*>(row)[k];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int bytes = rows * kRowBytes;
+  unsigned char* g = reinterpret_cast<unsigned char*>(dst) + (size_t)wave_base * kRowBytes;
+  constexpr int kIters = (kWave * kRowBytes + kWave * 16 - 1) / (kWave * 16);
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    const int off = (it * kWave + lane) * 16;
+    if (off + 16 <= bytes) __builtin_nontemporal_store(*reinterpret_cast<const v4u*>(lds_wave + off), reinterpret_cast<v4u*>(g + off));
+    else if (off + 8 <= bytes) *reinterpret_cast<uint2*>(g + off) = *reinterpret_cast<const uint2*>(lds_wave + off);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                            // reads before the slice's next writes
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <typename T, typename S>
+__global__ __launch_bounds__(kBlock) void k_compare_models(const Consts<T> c, const LinModel<T> M, const int n, const S* __restrict__ obs, const T dm,
+                                                           const T dJ0, const T dJ1, const T dJ2, const T dg, S* __restrict__ xdot_lin,
+                                                           S* __restrict__ xdot_geo, S* __restrict__ x_lin) {
+  __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int wave_base = blockIdx.x * kBlock + wave * kWave;
+  if (wave_base >= n) return;                                    // (wave-uniform; the staging uses wave-scope synchronisation only)
+  unsigned char* lds_wave = lds + wave * (kWave * kObsDim * (int)sizeof(S));
+  T o[kObsDim];
+  read_rows<S, T, kObsDim>(lds_wave, obs, n, wave_base, lane, o);
+  T xl[12], xd[12], xg[12];
+  const T dJ[3] = {dJ0, dJ1, dJ2};
+  compare_models_row<T>(c, M, o, dm, dJ, dg, xl, xd, xg);
+  if (xdot_lin) write_rows<S, T, 12>(lds_wave, xdot_lin, n, wave_base, lane, xd);
+  if (xdot_geo) write_rows<S, T, 12>(lds_wave, xdot_geo, n, wave_base, lane, xg);
+  if (x_lin) write_rows<S, T, 12>(lds_wave, x_lin, n, wave_base, lane, xl);
+}
+
+// model/linearized.py:92-104 calc_xdot(x, action) on states of the caller's own (the right-hand side CompareModels.py:84-92 integrates)
+template <typename T, typename S>
+__global__ void k_linear_xdot(const Consts<T> c, const LinModel<T> M, const int n, const S* __restrict__ x, const S* __restrict__ action,
+                              S* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T xi[12], a[4], u[4], o[12];
+  for (int k = 0; k < 12; ++k) xi[k] = (T)x[(size_t)i * 12 + k];
+  for (int k = 0; k < 4; ++k) a[k] = (T)action[(size_t)i * 4 + k];
+  action_to_input(c, a, 1, u);
+  linear_xdot(M, xi, u, o);
+  for (int k = 0; k < 12; ++k) out[(size_t)i * 12 + k] = (S)o[k];
+}
+
+// utils/model_conversions.py:4-19 rpy_to_rot: [n,3] -> [n,9] row-major
+template <typename T, typename S> __global__ void k_rpy_to_rot(const int n, const S* __restrict__ rpy, S* __restrict__ R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const M3<T> m = rpy_to_rot<T>(reduced_phase<T>(0.0, T(0), (T)rpy[(size_t)i * 3]), reduced_phase<T>(0.0, T(0), (T)rpy[(size_t)i * 3 + 1]),
+                                reduced_phase<T>(0.0, T(0), (T)rpy[(size_t)i * 3 + 2]));
+  for (int k = 0; k < 9; ++k) R[(size_t)i * 9 + k] = (S)m.m[k];
+}
+
+// utils/model_conversions.py:116-122 geo_model_to_obs: [n,18] (p, R row-major, v, w) -> [n,16] (p, quat xyzw, 0 0 0, v, w)
+template <typename T, typename S> __global__ void k_geo_model_to_obs(const int n, const S* __restrict__ x, S* __restrict__ obs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const S* s = x + (size_t)i * 18;
+  S* o = obs + (size_t)i * 16;
+  T m[9], q[4];
+  for (int k = 0; k < 9; ++k) m[k] = (T)s[3 + k];
+  rot_to_quat_scipy<T>(m, q);
+  o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+  for (int k = 0; k < 4; ++k) o[3 + k] = (S)q[k];
+  o[7] = o[8] = o[9] = (S)T(0);
+  for (int k = 0; k < 6; ++k) o[10 + k] = s[12 + k];
+}
+
 }  // namespace mds

@@ -902,4 +902,94 @@ template <typename T> MDS_HD void quadrotor_dynamics(const T s[18], const T u[4]
   out[11] = (u[3] - cx.z) / J[2];
 }
 
+// ------------------------------------------------------------------------------------
+// The call site of QuadrotorDynamics.dynamics: simulations/CompareModels.py:46-56 and the helpers it uses
+// ------------------------------------------------------------------------------------
+
+// utils/model_conversions.py:4-19 rpy_to_rot: R = Rz(yaw) Ry(pitch) Rx(roll), row-major (angles reduced by the caller for fp32)
+template <typename T> MDS_HD M3<T> rpy_to_rot(T roll, T pitch, T yaw) {
+  T sr, cr, sp, cp, sy, cy;
+  m_sincos(roll, &sr, &cr);
+  m_sincos(pitch, &sp, &cp);
+  m_sincos(yaw, &sy, &cy);
+  M3<T> R;
+  R.m[0] = cy * cp; R.m[1] = m_fma(cy * sp, sr, -(sy * cr)); R.m[2] = m_fma(cy * sp, cr, sy * sr);
+  R.m[3] = sy * cp; R.m[4] = m_fma(sy * sp, sr, cy * cr);    R.m[5] = m_fma(sy * sp, cr, -(cy * sr));
+  R.m[6] = -sp;     R.m[7] = cp * sr;                        R.m[8] = cp * cr;
+  return R;
+}
+
+// scipy's Rotation.from_matrix(R).as_quat() (xyzw) as geo_model_to_obs uses it (utils/model_conversions.py:119): the branch of
+// the largest of (R00, R11, R22, trace), the first maximum winning, then normalised; the sign is whatever that branch gives
+template <typename T> MDS_HD void rot_to_quat_scipy(const T m[9], T q[4]) {
+  const T tr = (m[0] + m[4]) + m[8];
+  int ch = 0;
+  T best = m[0];
+  if (m[4] > best) { best = m[4]; ch = 1; }
+  if (m[8] > best) { best = m[8]; ch = 2; }
+  if (tr > best) ch = 3;
+  if (ch == 3) {
+    q[0] = m[7] - m[5];
+    q[1] = m[2] - m[6];
+    q[2] = m[3] - m[1];
+    q[3] = T(1) + tr;
+  } else {
+    // i = ch, j = i + 1, k = i + 2 (mod 3): q[i] = 1 - tr + 2 m[i][i], q[j] = m[j][i] + m[i][j], q[k] = m[k][i] + m[i][k], q[3] = m[k][j] - m[j][k]
+    const int i = ch, j = (ch + 1) % 3, k = (ch + 2) % 3;
+    const T qi = (T(1) - tr) + T(2) * m[4 * i], qj = m[3 * j + i] + m[3 * i + j], qk = m[3 * k + i] + m[3 * i + k];
+    q[0] = i == 0 ? qi : (j == 0 ? qj : qk);
+    q[1] = i == 1 ? qi : (j == 1 ? qj : qk);
+    q[2] = i == 2 ? qi : (j == 2 ? qj : qk);
+    q[3] = m[3 * k + j] - m[3 * j + k];
+  }
+  const T inv = m_rsqrt((q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]));
+  for (int a = 0; a < 4; ++a) q[a] *= inv;
+}
+
+// model/linearized.py:92-104 LinearizedModel.calc_xdot: A (x - x_eq) + B (u - u_eq); x_eq = (0 .. 0, the position of x), u_eq = (M G, 0, 0, 0).
+// A [12][12], B [12][4] are the caller's dense matrices (the true pair or Ahat / Bhat): uniform operands.
+template <typename T> struct LinModel {
+  T A[12][12], B[12][4];
+  T ueq0;
+};
+template <typename T> MDS_HD void linear_xdot(const LinModel<T>& M, const T x[12], const T u[4], T out[12]) {
+  T dx[12], du[4];
+  for (int k = 0; k < 9; ++k) dx[k] = x[k];
+  dx[9] = x[9] - x[9]; dx[10] = x[10] - x[10]; dx[11] = x[11] - x[11];           // x - x_eq (NaN / inf propagate as in the reference)
+  du[0] = u[0] - M.ueq0; du[1] = u[1]; du[2] = u[2]; du[3] = u[3];
+  for (int r = 0; r < 12; ++r) {
+    T a = M.A[r][0] * dx[0];
+    for (int k = 1; k < 12; ++k) a = m_fma(M.A[r][k], dx[k], a);
+    T b = M.B[r][0] * du[0];
+    for (int k = 1; k < 4; ++k) b = m_fma(M.B[r][k], du[k], b);
+    out[r] = a + b;
+  }
+}
+
+// CompareModels.py:48-56 for one observation row: x_lin = obs_to_lin_model(obs); xdot_lin = calc_xdot_from_obs(obs);
+// xdot_geo = geo_x_dot_to_linear(dynamics(None, obs_to_geo_model(obs), action_to_input(env, obs[16:])))
+template <typename T>
+MDS_HD void compare_models_row(const Consts<T>& c, const LinModel<T>& M, const T o[20], T dm, const T dJ[3], T dg, T x_lin[12], T xdot_lin[12],
+                               T xdot_geo[12]) {
+  x_lin[0] = o[7]; x_lin[1] = o[8]; x_lin[2] = o[9];
+  x_lin[3] = o[13]; x_lin[4] = o[14]; x_lin[5] = o[15];
+  x_lin[6] = o[10]; x_lin[7] = o[11]; x_lin[8] = o[12];
+  x_lin[9] = o[0]; x_lin[10] = o[1]; x_lin[11] = o[2];
+  T u[4];
+  action_to_input(c, o + 16, 1, u);
+  linear_xdot(M, x_lin, u, xdot_lin);
+  T s[18], g[12];
+  const T q[4] = {o[3], o[4], o[5], o[6]};
+  const M3<T> R = quat_to_rot(q);
+  s[0] = o[0]; s[1] = o[1]; s[2] = o[2];
+  for (int k = 0; k < 9; ++k) s[3 + k] = R.m[k];
+  for (int k = 0; k < 6; ++k) s[12 + k] = o[10 + k];
+  quadrotor_dynamics<T>(s, u, dm, dJ, dg, g);
+  // geo_x_dot_to_linear (utils/model_conversions.py:124-135): (v, w, v_dot, w_dot) -> (w, w_dot, v_dot, v)
+  xdot_geo[0] = g[3]; xdot_geo[1] = g[4]; xdot_geo[2] = g[5];
+  xdot_geo[3] = g[9]; xdot_geo[4] = g[10]; xdot_geo[5] = g[11];
+  xdot_geo[6] = g[6]; xdot_geo[7] = g[7]; xdot_geo[8] = g[8];
+  xdot_geo[9] = g[0]; xdot_geo[10] = g[1]; xdot_geo[11] = g[2];
+}
+
 }  // namespace mds

@@ -25,3 +25,13 @@ class LinearizedOmegaModel:
         self.Ahat[4, 0] = -self.g * 1.2
         self.Bhat = self.B.copy()
         self.Bhat[5, 0] = 1.0 / (self.mass * 0.8)
+
+    def calc_xdot_from_obs(self, obs):
+        return self.calc_xdot(None, None)
+
+    def calc_xdot(self, x, action):
+        """Broken in the reference (linear_omega.py:63-80: the 12-long obs_to_lin_model(obs) against this model's own smaller A); raises the
+        same ValueError here.  The 12-state LinearizedModel is the one simulations/CompareModels.py uses."""
+        n = self.A.shape[0]
+        raise ValueError(f"matmul: Input operand 1 has a mismatch in its core dimension 0, with gufunc signature (n?,k),(k,m?)->(n?,m?) "
+                         f"(size 12 is different from {n})  [LinearizedOmegaModel.calc_xdot is broken in the reference]")

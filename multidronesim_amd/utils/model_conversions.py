@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .. import _capi as capi
-from .._device import stream_ptr, to_device
+from .._device import default_device_index, require_gpu, stream_ptr, to_device
 
 
 def _run(env, fn_name, x, *extra):
@@ -86,3 +86,47 @@ def obs_to_geo_model(obs, env=None):
 def calc_z_thrust(env, obs):
     """KF * sum(rpm^2) of the last clipped action in obs[..., -4:] (:137-143)."""
     return _obs_to_model(env, obs, 10)[..., 3]
+
+
+# ---- the helpers around the call site of QuadrotorDynamics.dynamics (simulations/CompareModels.py) ------------------
+_CODE = {torch.float64: capi.MDS_F64, torch.float32: capi.MDS_F32, torch.float16: capi.MDS_F16}
+
+
+def _rows(fn_name, x, in_dim, out_dim, out_shape):
+    """One stateless row kernel (no handle): NumPy in -> float64 on this rank's GPU -> NumPy out; device tensor in -> tensor out."""
+    lib = capi.load_library()
+    numpy_in = not isinstance(x, torch.Tensor)
+    dev = require_gpu(default_device_index()) if numpy_in or not x.is_cuda else x.device
+    dt = torch.float64 if numpy_in else x.dtype
+    xt = to_device(x, dev, dt).reshape(-1, in_dim)
+    out = torch.empty((xt.shape[0], out_dim), dtype=dt, device=dev)
+    capi.check(getattr(lib, fn_name)(C.c_int(_CODE[dt]), C.c_int(xt.shape[0]), C.c_void_p(xt.data_ptr()), C.c_void_p(out.data_ptr()),
+                                     C.c_void_p(stream_ptr(dev))), fn_name)
+    out = out.reshape(out_shape)
+    return out.cpu().numpy() if numpy_in else out
+
+
+def rpy_to_rot(rpy):
+    """R = Rz(yaw) Ry(pitch) Rx(roll) (:4-19); [..., 3] -> [..., 3, 3]."""
+    shape = tuple(np.shape(rpy))
+    if shape[-1] != 3:
+        raise ValueError(f"rpy must end in 3 components, got shape {shape}")
+    return _rows("mds_rpy_to_rot", rpy, 3, 9, shape[:-1] + (3, 3))
+
+
+def geo_model_to_obs(x):
+    """[pos, R row-major, vel, ang_v] -> the first 16 observation values: pos, quaternion (xyzw, as scipy's
+    Rotation.from_matrix(R).as_quat() gives it), three zeros in the rpy slots, vel, ang_v (:116-122); [..., 18] -> [..., 16]."""
+    shape = tuple(np.shape(x))
+    if shape[-1] != 18:
+        raise ValueError(f"x must end in 18 components, got shape {shape}")
+    return _rows("mds_geo_model_to_obs", x, 18, 16, shape[:-1] + (16,))
+
+
+def geo_x_dot_to_linear(geo_xdot):
+    """(v, w, v_dot, w_dot) of QuadrotorDynamics.dynamics -> the linear model's order (w, w_dot, v_dot, v) (:124-135).  A
+    re-ordering of twelve numbers with no arithmetic: done on whatever holds them (NumPy array or device tensor)."""
+    idx = [3, 4, 5, 9, 10, 11, 6, 7, 8, 0, 1, 2]
+    if isinstance(geo_xdot, torch.Tensor):
+        return geo_xdot[..., idx]
+    return np.asarray(geo_xdot)[..., idx]

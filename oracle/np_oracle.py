@@ -823,6 +823,94 @@ def obs_to_lin_model(obs, dim, c: DroneConsts = CF2P):
 
 
 # --------------------------------------------------------------------------------------
+# the call site of a5 -- simulations/CompareModels.py:46-56 (per logged observation: the linear model's x_dot, the geometric
+# model's x_dot in the linear model's layout, the linear state) and the helpers around it
+# --------------------------------------------------------------------------------------
+
+
+def rpy_to_rot(rpy):
+    """utils/model_conversions.py:4-19: R = Rz(yaw) Ry(pitch) Rx(roll)."""
+    rpy = np.asarray(rpy, dtype=np.float64)
+    cr, sr = np.cos(rpy[..., 0]), np.sin(rpy[..., 0])
+    cp, sp = np.cos(rpy[..., 1]), np.sin(rpy[..., 1])
+    cy, sy = np.cos(rpy[..., 2]), np.sin(rpy[..., 2])
+    R = np.empty(rpy.shape[:-1] + (3, 3))
+    R[..., 0, 0], R[..., 0, 1], R[..., 0, 2] = cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr
+    R[..., 1, 0], R[..., 1, 1], R[..., 1, 2] = sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr
+    R[..., 2, 0], R[..., 2, 1], R[..., 2, 2] = -sp, cp * sr, cp * cr
+    return R
+
+
+def rotmat_to_quat_scipy(R):
+    """scipy Rotation.from_matrix(R).as_quat() (xyzw) as utils/model_conversions.py:119 uses it: the branch with the largest of
+    (R00, R11, R22, trace) -- scipy's `_rotation.pyx` from_matrix --, normalised; the sign is whatever that branch gives."""
+    R = np.asarray(R, dtype=np.float64)
+    lead = R.shape[:-2]
+    Rf = R.reshape(-1, 3, 3)
+    q = np.empty((Rf.shape[0], 4))
+    dec = np.stack([Rf[:, 0, 0], Rf[:, 1, 1], Rf[:, 2, 2], Rf[:, 0, 0] + Rf[:, 1, 1] + Rf[:, 2, 2]], axis=1)
+    ch = np.argmax(dec, axis=1)
+    for n in range(Rf.shape[0]):
+        m, c = Rf[n], ch[n]
+        if c != 3:
+            i, j, k = c, (c + 1) % 3, (c + 2) % 3
+            q[n, i] = 1 - dec[n, 3] + 2 * m[i, i]
+            q[n, j] = m[j, i] + m[i, j]
+            q[n, k] = m[k, i] + m[i, k]
+            q[n, 3] = m[k, j] - m[j, k]
+        else:
+            q[n, 0] = m[2, 1] - m[1, 2]
+            q[n, 1] = m[0, 2] - m[2, 0]
+            q[n, 2] = m[1, 0] - m[0, 1]
+            q[n, 3] = 1 + dec[n, 3]
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return q.reshape(lead + (4,))
+
+
+def geo_model_to_obs(x18):
+    """utils/model_conversions.py:116-122: [pos, R row-major, vel, ang_v] -> the first 16 observation values (rpy slots 7:10 left 0)."""
+    x = np.asarray(x18, dtype=np.float64)
+    obs = np.zeros(x.shape[:-1] + (16,))
+    obs[..., 0:3] = x[..., 0:3]
+    obs[..., 3:7] = rotmat_to_quat_scipy(x[..., 3:12].reshape(x.shape[:-1] + (3, 3)))
+    obs[..., 10:13] = x[..., 12:15]
+    obs[..., 13:16] = x[..., 15:18]
+    return obs
+
+
+def geo_x_dot_to_linear(geo_xdot):
+    """utils/model_conversions.py:124-135: (v, w, v_dot, w_dot) -> the linear model's order (w, w_dot, v_dot, v)."""
+    g = np.asarray(geo_xdot, dtype=np.float64)
+    return np.concatenate([g[..., 3:6], g[..., 9:12], g[..., 6:9], g[..., 0:3]], axis=-1)
+
+
+def linear_calc_xdot(x12, action, A, B, c: DroneConsts = CF2P):
+    """model/linearized.py:92-104 LinearizedModel.calc_xdot: A (x - x_eq) + B (u - u_eq) with u = action_to_input(env, action),
+    x_eq = (0, ..., 0, position of x), u_eq = (M G, 0, 0, 0)."""
+    x = np.array(x12, dtype=np.float64)
+    u = action_to_input(action, c)
+    dx = x.copy()
+    dx[..., 9:12] = 0.0
+    du = u.copy()
+    du[..., 0] -= c.M * c.G
+    return np.einsum("ij,...j->...i", A, dx) + np.einsum("ij,...j->...i", B, du)
+
+
+def compare_models(obs, A, B, c: DroneConsts = CF2P, dyn_m=None, dyn_J=(1.05, 1.05, 2.05), dyn_g=None):
+    """The loop body of simulations/CompareModels.py:48-56 over observation rows: (x_dot_linear, x_dot_geometric, x_lin_obs).
+    The geometric side is QuadrotorDynamics after load_env_params(env): m, g from the env, J the stale Hummingbird one
+    (model/dynamics.py:8-20)."""
+    obs = np.asarray(obs, dtype=np.float64)
+    x_lin = obs_to_lin_model(obs, 12, c)
+    xdot_lin = linear_calc_xdot(x_lin, obs[..., 16:20], A, B, c)
+    p, R, v, w = obs_to_geo_model(obs)
+    s18 = np.concatenate([p, R.reshape(R.shape[:-2] + (9,)), v, w], axis=-1)
+    u = action_to_input(obs[..., 16:20], c)
+    geo = quadrotor_dynamics(s18, u, c.M if dyn_m is None else dyn_m, dyn_J, c.G if dyn_g is None else dyn_g)
+    return xdot_lin, geo_x_dot_to_linear(geo), x_lin
+
+
+# --------------------------------------------------------------------------------------
 # a11-a14: cbf/cbf.py rows in closed form (SURVEY.md 3.6; pinned against the dense
 # reference construction by tests/golden/cbf_rows_*.npz)
 # --------------------------------------------------------------------------------------

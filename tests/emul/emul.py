@@ -97,6 +97,16 @@ class Emul:
         self._f("emul_geo_compute")(self.h, C.c_int(n), dp(obs), dp(des), dp(rpm), dp(aux))
         return rpm, aux
 
+    def compare_models(self, obs, A, B, ueq0, dyn_m, dyn_J, dyn_g):
+        obs = np.ascontiguousarray(obs, dtype=np.float64)
+        A, B = np.ascontiguousarray(A, dtype=np.float64), np.ascontiguousarray(B, dtype=np.float64)
+        J = np.ascontiguousarray(dyn_J, dtype=np.float64)
+        n = obs.shape[0]
+        outs = [np.zeros((n, 12)) for _ in range(3)]
+        self._f("emul_compare_models")(self.h, C.c_int(n), dp(obs), dp(A), dp(B), C.c_double(ueq0), C.c_double(dyn_m), dp(J), C.c_double(dyn_g),
+                                       dp(outs[0]), dp(outs[1]), dp(outs[2]))
+        return outs                                                      # xdot_lin, xdot_geo, x_lin
+
     def lemniscate(self, t):
         des = np.zeros((self.n, 11))
         self._f("emul_lem")(self.h, C.c_double(t), dp(des))
@@ -110,3 +120,17 @@ def sincos_f32(x):
     PF = C.POINTER(C.c_float)
     lib().emul_sincos_f32(C.c_int(x.size), x.ctypes.data_as(PF), s.ctypes.data_as(PF), c.ctypes.data_as(PF))
     return s, c
+
+
+def rpy_to_rot(rpy, dtype="f64"):
+    rpy = np.ascontiguousarray(rpy, dtype=np.float64)
+    R = np.zeros((rpy.shape[0], 9))
+    getattr(lib(), f"emul_rpy_to_rot_{dtype}")(C.c_int(rpy.shape[0]), dp(rpy), dp(R))
+    return R.reshape(-1, 3, 3)
+
+
+def rot_to_quat(R, dtype="f64"):
+    R = np.ascontiguousarray(np.asarray(R, dtype=np.float64).reshape(-1, 9))
+    q = np.zeros((R.shape[0], 4))
+    getattr(lib(), f"emul_rot_to_quat_{dtype}")(C.c_int(R.shape[0]), dp(R), dp(q))
+    return q

@@ -183,6 +183,45 @@ template <typename T> static void emul_lem(void* h, double t, double* des) {
   }
 }
 
+// the call site of QuadrotorDynamics.dynamics (simulations/CompareModels.py:46-56) on the device templates
+template <typename T>
+static void emul_compare_models(void* h, int n, const double* obs, const double* A, const double* B, double ueq0, double dm, const double* dJ,
+                                double dg, double* xdot_lin, double* xdot_geo, double* x_lin) {
+  Emul<T>* e = (Emul<T>*)h;
+  LinModel<T> M;
+  for (int r = 0; r < 12; ++r) {
+    for (int k = 0; k < 12; ++k) M.A[r][k] = (T)A[r * 12 + k];
+    for (int k = 0; k < 4; ++k) M.B[r][k] = (T)B[r * 4 + k];
+  }
+  M.ueq0 = (T)ueq0;
+  const T J[3] = {(T)dJ[0], (T)dJ[1], (T)dJ[2]};
+  for (int i = 0; i < n; ++i) {
+    T o[20], xl[12], xd[12], xg[12];
+    for (int k = 0; k < 20; ++k) o[k] = (T)obs[20 * i + k];
+    compare_models_row<T>(e->c, M, o, (T)dm, J, (T)dg, xl, xd, xg);
+    for (int k = 0; k < 12; ++k) {
+      x_lin[12 * i + k] = xl[k];
+      xdot_lin[12 * i + k] = xd[k];
+      xdot_geo[12 * i + k] = xg[k];
+    }
+  }
+}
+template <typename T> static void emul_rpy_to_rot(int n, const double* rpy, double* R) {
+  for (int i = 0; i < n; ++i) {
+    const M3<T> m = rpy_to_rot<T>(reduced_phase<T>(0.0, T(0), (T)rpy[3 * i]), reduced_phase<T>(0.0, T(0), (T)rpy[3 * i + 1]),
+                                  reduced_phase<T>(0.0, T(0), (T)rpy[3 * i + 2]));
+    for (int k = 0; k < 9; ++k) R[9 * i + k] = m.m[k];
+  }
+}
+template <typename T> static void emul_rot_to_quat(int n, const double* R, double* q) {
+  for (int i = 0; i < n; ++i) {
+    T m[9], qq[4];
+    for (int k = 0; k < 9; ++k) m[k] = (T)R[9 * i + k];
+    rot_to_quat_scipy<T>(m, qq);
+    for (int k = 0; k < 4; ++k) q[4 * i + k] = qq[k];
+  }
+}
+
 extern "C" {
 void* emul_create_f32(const mds_config* c, const mds_geometric_gains* g) { return emul_create<float>(c, g); }
 void* emul_create_f64(const mds_config* c, const mds_geometric_gains* g) { return emul_create<double>(c, g); }
@@ -203,6 +242,14 @@ void emul_geo_compute_f32(void* h, int n, const double* o, const double* d, doub
 void emul_geo_compute_f64(void* h, int n, const double* o, const double* d, double* r, double* a) { emul_geo_compute<double>(h, n, o, d, r, a); }
 void emul_lem_f32(void* h, double t, double* d) { emul_lem<float>(h, t, d); }
 void emul_lem_f64(void* h, double t, double* d) { emul_lem<double>(h, t, d); }
+void emul_compare_models_f32(void* h, int n, const double* o, const double* A, const double* B, double u, double m, const double* J, double g,
+                             double* a, double* b, double* c) { emul_compare_models<float>(h, n, o, A, B, u, m, J, g, a, b, c); }
+void emul_compare_models_f64(void* h, int n, const double* o, const double* A, const double* B, double u, double m, const double* J, double g,
+                             double* a, double* b, double* c) { emul_compare_models<double>(h, n, o, A, B, u, m, J, g, a, b, c); }
+void emul_rpy_to_rot_f32(int n, const double* r, double* R) { emul_rpy_to_rot<float>(n, r, R); }
+void emul_rpy_to_rot_f64(int n, const double* r, double* R) { emul_rpy_to_rot<double>(n, r, R); }
+void emul_rot_to_quat_f32(int n, const double* R, double* q) { emul_rot_to_quat<float>(n, R, q); }
+void emul_rot_to_quat_f64(int n, const double* R, double* q) { emul_rot_to_quat<double>(n, R, q); }
 void emul_sincos_f32(int n, const float* x, float* s, float* c) {
   for (int i = 0; i < n; ++i) m_sincos(x[i], s + i, c + i);
 }

@@ -632,6 +632,54 @@ def mint_lqr12(ref):
     print("lqr12 K", out["K_true"].shape, "min-thrust clips", int((np.abs(out["act_true"] - lo) < 1e-6).sum()), "of", act.size)
 
 
+def mint_compare_models(ref):
+    """The call site of QuadrotorDynamics.dynamics -- simulations/CompareModels.py:46-56, the loop body over logged observation
+    rows, through the reference's own objects: LinearizedModel(env).calc_xdot_from_obs(obs) (model/linearized.py:83-104),
+    geo_x_dot_to_linear(QuadrotorDynamics[load_env_params(env)].dynamics(None, obs_to_geo_model(obs), action_to_input(env,
+    obs[16:]))) and obs_to_lin_model(obs); calc_xdot(x, action) on states that are NOT the observation's (the right-hand side
+    roll_out_linear_system integrates, :84-92), with the true and the deliberately wrong (Ahat, Bhat) pair; rpy_to_rot and
+    geo_model_to_obs (utils/model_conversions.py:4-19, :116-122).  Rows include RPMs above MAX_RPM (clipped by action_to_input),
+    at zero and negative (clipped to 0)."""
+    lin = load("model.linearized", REF + "/model/linearized.py")
+    mc = ref["mc"]
+    env = make_env()
+    rng = np.random.default_rng(21)
+    n = 320
+    obs = random_obs(rng, n, np.array([0.5, -0.4, 1.2]), np.array([0.2, -0.1, 0.05]), euler_max=0.9, w_max=3.0, pos_noise=1.0, vel_noise=1.0)
+    obs[:, 9] = rng.uniform(-3.1, 3.1, size=n)
+    obs[:, 3:7] = Rotation.from_euler("xyz", obs[:, 7:10]).as_quat()
+    obs[::7, 3:7] *= -1.0                                              # the same attitudes with the other quaternion sign
+    obs[:48, 16:20] = rng.uniform(-2000.0, 26000.0, size=(48, 4))      # below 0 and above MAX_RPM (21 702): clipped
+    obs[48:56, 16:20] = 0.0
+    model = lin.LinearizedModel(env)
+    Q = ref["dyn"].QuadrotorDynamics
+    gd = Q(env.PYB_FREQ)
+    gd.load_env_params(env)                                            # m, g from the env; J stays the Hummingbird one (:18)
+    xdot_lin = np.array([model.calc_xdot_from_obs(o) for o in obs])
+    xdot_geo = np.array([mc.geo_x_dot_to_linear(gd.dynamics(None, mc.obs_to_geo_model(o), mc.action_to_input(env, o[16:]))) for o in obs])
+    x_lin = np.array([mc.obs_to_lin_model(o) for o in obs])
+    x_free = x_lin + rng.normal(size=x_lin.shape) * 0.3                # calc_xdot on a state of its own
+    xdot_free = np.array([model.calc_xdot(x, o[16:]) for x, o in zip(x_free, obs)])
+    A0, B0 = model.A.copy(), model.B.copy()
+    model.A, model.B = model.Ahat, model.Bhat                          # what a caller gets who swaps in the 'noisy' pair
+    xdot_free_hat = np.array([model.calc_xdot(x, o[16:]) for x, o in zip(x_free, obs)])
+    rpy = rng.uniform(-np.pi, np.pi, size=(128, 3))
+    Rr = np.array([mc.rpy_to_rot(r) for r in rpy])
+    # geo_model_to_obs on rotations that exercise all four branches of scipy's from_matrix (largest of R00, R11, R22, trace)
+    eul = np.concatenate([rng.uniform(-np.pi, np.pi, size=(192, 3)),
+                          np.array([[np.pi, 0, 0], [0, np.pi, 0], [0, 0, np.pi], [3.0, 0.1, -0.1], [0.1, 3.0, 0.1], [0.1, -0.1, 3.0]])])
+    x18 = np.zeros((eul.shape[0], 18))
+    x18[:, 0:3] = rng.normal(size=(eul.shape[0], 3))
+    x18[:, 3:12] = Rotation.from_euler("xyz", eul).as_matrix().reshape(-1, 9)
+    x18[:, 12:] = rng.normal(size=(eul.shape[0], 6))
+    obs16 = np.array([mc.geo_model_to_obs(x) for x in x18])
+    np.savez_compressed(OUT + "/compare_models.npz", obs=obs, A=A0, B=B0, Ahat=model.Ahat, Bhat=model.Bhat, xdot_lin=xdot_lin, xdot_geo=xdot_geo,
+                        x_lin=x_lin, x_free=x_free, xdot_free=xdot_free, xdot_free_hat=xdot_free_hat, dyn_m=gd.m, dyn_g=gd.g,
+                        dyn_J=np.diag(gd.J), rpy=rpy, R_of_rpy=Rr, x18=x18, obs16=obs16, **META)
+    clipped = int(((obs[:, 16:20] > env.MAX_RPM) | (obs[:, 16:20] < 0)).sum())
+    print("compare_models", xdot_lin.shape, xdot_geo.shape, "clipped rpm entries", clipped, "quat w<0 rows", int((obs16[:, 6] < 0).sum()))
+
+
 def trajectory_cases(T):
     """The same constructor arguments are used for the reference classes (minting) and for the oracle /
     GPU classes (tests): T is a namespace with Lemniscate, Circle, Line, Wait, Compound, Rotate."""
@@ -674,6 +722,10 @@ def mint_trajectories():
 
 if __name__ == "__main__":
     ref = load_reference()
+    if len(sys.argv) > 1:                      # mint only the named fixtures: python mint_golden.py compare_models ...
+        for name in sys.argv[1:]:
+            globals()["mint_" + name](ref)
+        sys.exit(0)
     mint_lemniscate(ref)
     mint_geometric(ref)
     mint_mixer(ref)
@@ -688,5 +740,6 @@ if __name__ == "__main__":
     mint_lqr_omega(ref)
     mint_lqr_yank_omega(ref)
     mint_lqr12(ref)
+    mint_compare_models(ref)
     sys.path.insert(0, REF)
     mint_trajectories()

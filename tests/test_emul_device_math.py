@@ -113,3 +113,17 @@ def test_compensated_fp32_open_loop_holds_1e5_over_1000_steps():
     assert errs["f32c:2"] > 0.7 * errs["f32"], errs                                      # quaternion residuals alone buy nothing
     assert errs["f32c13"] < errs["f32c"] < 3 * errs["f32c13"], errs                      # ten more residuals: less than 2x better
     assert run("f32c", integrator=1) < 1e-5                                              # RK4 with the same accumulation
+
+
+@pytest.mark.parametrize("dt,tol_rel,tol_rot", [("f64", 1e-12, 1e-14), ("f32", 3e-5, 5e-7)])
+def test_device_compare_models_row_matches_the_reference(dt, tol_rel, tol_rot):
+    """compare_models_row / rpy_to_rot / rot_to_quat_scipy of csrc/mds_math.hpp (what k_compare_models, k_rpy_to_rot and
+    k_geo_model_to_obs run per lane) against the reference-minted compare_models.npz.  fp32: the motor-thrust differences behind the
+    torques cancel to ~1e-9 N m and are divided by a 2.4e-5 kg m^2 inertia -- errors are gated relative to 1 + |reference|."""
+    d = np.load(os.path.join(G, "compare_models.npz"))
+    e = E.Emul(dt)
+    a, b, c = e.compare_models(d["obs"], d["A"], d["B"], 0.027 * 9.8, float(d["dyn_m"]), d["dyn_J"], float(d["dyn_g"]))
+    for got, ref in ((a, d["xdot_lin"]), (b, d["xdot_geo"]), (c, d["x_lin"])):
+        assert (np.abs(got - ref) / (1 + np.abs(ref))).max() < tol_rel
+    np.testing.assert_allclose(E.rpy_to_rot(d["rpy"], dt), d["R_of_rpy"], rtol=0, atol=tol_rot)
+    np.testing.assert_allclose(E.rot_to_quat(d["x18"][:, 3:12], dt), d["obs16"][:, 3:7], rtol=0, atol=tol_rot)

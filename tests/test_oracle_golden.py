@@ -322,3 +322,28 @@ def test_euler_convention_is_the_reference_trees():
     np.testing.assert_allclose(d["R_rpy"][ex], d["R_quat"][ex], rtol=0, atol=1e-7)
     # the oracle's quaternion -> rotation (used by its physics) is the tree's too
     np.testing.assert_allclose(O.quat_to_rotmat_bullet(q), d["R_quat"], rtol=0, atol=1e-13)
+
+
+def test_compare_models_call_site_matches_reference():
+    """simulations/CompareModels.py:46-56 through the reference's own LinearizedModel / QuadrotorDynamics / model_conversions
+    (compare_models.npz): the loop body, calc_xdot on free states with (A, B) and (Ahat, Bhat), rpy_to_rot, geo_model_to_obs."""
+    d = load("compare_models.npz")
+    a, b, c = O.compare_models(d["obs"], d["A"], d["B"], dyn_m=float(d["dyn_m"]), dyn_J=d["dyn_J"], dyn_g=float(d["dyn_g"]))
+    np.testing.assert_allclose(a, d["xdot_lin"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(b, d["xdot_geo"], rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(c, d["x_lin"])
+    A0, B0 = O.linearized_AB()
+    np.testing.assert_array_equal(A0, d["A"])
+    np.testing.assert_array_equal(B0, d["B"])
+    Ah, Bh = O.linearized_AB(noisy=True)
+    np.testing.assert_allclose(O.linear_calc_xdot(d["x_free"], d["obs"][:, 16:], d["A"], d["B"]), d["xdot_free"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(O.linear_calc_xdot(d["x_free"], d["obs"][:, 16:], Ah, Bh), d["xdot_free_hat"], rtol=0, atol=1e-12)
+    # the stale-J quirk is in the fixture: the geometric side's w_dot divides by the Hummingbird inertia, the linear side by the env's
+    assert np.allclose(d["dyn_J"], [1.05, 1.05, 2.05]) and float(d["dyn_m"]) == 0.027
+    np.testing.assert_allclose(O.rpy_to_rot(d["rpy"]), d["R_of_rpy"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(O.geo_model_to_obs(d["x18"]), d["obs16"], rtol=0, atol=1e-15)
+    # all four branches of scipy's from_matrix are in the fixture (largest of R00, R11, R22, trace)
+    R = d["x18"][:, 3:12].reshape(-1, 3, 3)
+    dec = np.stack([R[:, 0, 0], R[:, 1, 1], R[:, 2, 2], np.trace(R, axis1=1, axis2=2)], axis=1)
+    assert set(np.argmax(dec, axis=1)) == {0, 1, 2, 3}
+    np.testing.assert_array_equal(O.geo_x_dot_to_linear(np.arange(12.0)), [3, 4, 5, 9, 10, 11, 6, 7, 8, 0, 1, 2])
