@@ -273,12 +273,14 @@ def compare_models_line(torch, env, device, reps=50):
     PD = C.POINTER(C.c_double)
     J = (C.c_double * 3)(geo.J[0, 0], geo.J[1, 1], geo.J[2, 2])
     outs = [torch.empty((n, 12), dtype=obs.dtype, device=device) for _ in range(3)]
-    st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    # marshalled once: numpy's .ctypes accessor alone costs more host time per call than the kernel runs
+    cargs = (env._h, C.c_int(n), C.c_void_p(obs.data_ptr()), A.ctypes.data_as(PD), B.ctypes.data_as(PD), C.c_double(lin.mass * lin.g),
+             C.c_double(geo.m), J, C.c_double(geo.g), C.c_void_p(outs[0].data_ptr()), C.c_void_p(outs[1].data_ptr()), C.c_void_p(outs[2].data_ptr()),
+             C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+    fn = env._lib.mds_compare_models
 
     def launch():
-        rc = env._lib.mds_compare_models(env._h, C.c_int(n), C.c_void_p(obs.data_ptr()), A.ctypes.data_as(PD), B.ctypes.data_as(PD),
-                                         C.c_double(lin.mass * lin.g), C.c_double(geo.m), J, C.c_double(geo.g), C.c_void_p(outs[0].data_ptr()),
-                                         C.c_void_p(outs[1].data_ptr()), C.c_void_p(outs[2].data_ptr()), st)
+        rc = fn(*cargs)
         if rc != 0:
             raise RuntimeError(f"mds_compare_models failed: {rc}")
 

@@ -280,7 +280,14 @@ static void launch_compare_models(const Consts<T>& C, int count, const void* obs
                                   const double* dyn_J, double dyn_g, void* xdot_lin, void* xdot_geo, void* x_lin, hipStream_t st) {
   LinModel<T> M;
   fill_lin_model<T>(A, B, u_eq0, M);
-  k_compare_models<T, S><<<grid_for(count, kBlock), kBlock, 0, st>>>(C, M, count, (const S*)obs, (T)dyn_m, (T)dyn_J[0], (T)dyn_J[1], (T)dyn_J[2],
+  // MDS_TUNE_CMP_LDS: unused dynamic LDS per workgroup (tuning only: fewer resident workgroups per CU, so that the launch runs in rounds
+  // whose load and store phases overlap instead of one round in lock step); out-of-range values are ignored
+  static const size_t pad = [] {
+    const char* v = getenv("MDS_TUNE_CMP_LDS");
+    const long x = v ? atol(v) : 0;
+    return (size_t)((x > 0 && x <= 120 * 1024) ? x : 0);
+  }();
+  k_compare_models<T, S><<<grid_for(count, kBlock), kBlock, pad, st>>>(C, M, count, (const S*)obs, (T)dyn_m, (T)dyn_J[0], (T)dyn_J[1], (T)dyn_J[2],
                                                                       (T)dyn_g, (S*)xdot_lin, (S*)xdot_geo, (S*)x_lin);
 }
 template <typename T, typename S>

@@ -192,7 +192,7 @@ def test_reference_api_names_present():
 
 
 def test_simulation_mirrors_set_up_on_cpu_and_need_the_gpu_to_run():
-    """simulations/{EnvGeometric,CBFTest,CBFTestOrd3}.py mirrors: argument parsing and the initial-condition arithmetic are host
+    """simulations/{EnvGeometric,EnvGeometricOmega,EnvGeometricYankOmega,CBFTest,CBFTestOrd3,CompareModels}.py mirrors: argument parsing and the initial-condition arithmetic are host
     code (as in the reference); creating the env without a GPU is a loud error, not a CPU simulation."""
     import numpy as np
     from multidronesim_amd import MdsError
@@ -206,10 +206,23 @@ def test_simulation_mirrors_set_up_on_cpu_and_need_the_gpu_to_run():
     np.testing.assert_allclose(geo.TARGET_RPYS[:, 2], np.pi / 2)
     g3 = CBFTestOrd3.GeometricEnv(CBFTestOrd3.parse_args(["--num_drones", "3"]), init_type="circle", center=np.array([0, 0, 0.5]))
     np.testing.assert_allclose(g3.INIT_XYZS[1], [.2 * np.cos(2 * np.pi / 3), .2 * np.sin(2 * np.pi / 3), 0.5], atol=1e-15)   # cos/sin + centre (:418-425)
+    # simulations/EnvGeometricOmega.py (:28, :57, :364-365: sin/cos at i/N) and EnvGeometricYankOmega.py (:28-30, :389-390: cos/sin at i/N)
+    from multidronesim_amd.simulations import CompareModels, EnvGeometricOmega, EnvGeometricYankOmega
+    ao, ay = EnvGeometricOmega.parse_args([]), EnvGeometricYankOmega.parse_args([])
+    assert (ao.duration_sec, ao.num_drones, ao.init_rad, ao.controller) == (50, 2, .2, "lqr")
+    assert (ay.duration_sec, ay.num_drones, ay.init_rad, ay.controller) == (5, 1, .2, "lqr")
+    go = EnvGeometricOmega.GeometricEnv(EnvGeometricOmega.parse_args(["--num_drones", "3"]), circle_init=True)
+    gy = EnvGeometricYankOmega.GeometricEnv(EnvGeometricYankOmega.parse_args(["--num_drones", "3"]), circle_init=True)
+    np.testing.assert_allclose(go.INIT_XYZS[1], [.2 * np.sin(2 * np.pi / 3), .2 * np.cos(2 * np.pi / 3), 0.0], atol=1e-15)
+    np.testing.assert_allclose(gy.INIT_XYZS[1], [.2 * np.cos(2 * np.pi / 3), .2 * np.sin(2 * np.pi / 3), 0.0], atol=1e-15)
+    np.testing.assert_allclose(gy.TARGET_RPYS[:, 2], np.pi / 2)
+    assert callable(CompareModels.compare_models) and callable(CompareModels.roll_out_linear_system) and CompareModels.parse_args is EnvGeometric.parse_args
     import torch
     if not torch.cuda.is_available():
         with pytest.raises(MdsError):
             geo.create_env()
+        with pytest.raises(MdsError):
+            go.create_env()
         with pytest.raises(MdsError):
             CBFTestOrd3.GeometricEnv(CBFTestOrd3.parse_args([]), init_type="lemniscate")       # evaluates a trajectory: device work
 
