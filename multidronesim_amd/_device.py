@@ -55,7 +55,8 @@ def stream_ptr(device: torch.device) -> int:
 
 def to_device(x, device, dtype) -> torch.Tensor:
     if isinstance(x, torch.Tensor):
-        return x.to(device=device, dtype=dtype).contiguous()
+        t = x.to(device=device, dtype=dtype).contiguous()
+        return t.clone() if t.data_ptr() % 16 else t      # a view that starts in mid-allocation (e.g. odd rows of an fp16 log): the C-ABI wants 16 bytes
     a = np.asarray(x)
     if not (a.flags.c_contiguous and a.flags.writeable):
         a = np.array(a, order="C")          # broadcast views etc.: torch wants a writable buffer
