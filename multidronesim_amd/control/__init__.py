@@ -5,3 +5,4 @@ from .low_level.yank_omega_ctrl import YankOmegaController  # noqa: F401
 from .lqr.lqr_omega_controller import LQROmegaController  # noqa: F401
 from .lqr.lqr_YO_controller import LQRYankOmegaController  # noqa: F401
 from .lqr.lqr_controller import LQRController  # noqa: F401
+from .lqr.crazyflie_lqr_controller import CrazyflieLQR  # noqa: F401
