@@ -177,3 +177,43 @@ def test_compare_models_on_a_logged_rollout_and_linear_roll_out(mds):
 
     ref = solve_ivp(f, [0, ts[-1]], rc[0, 0], t_eval=ts)
     np.testing.assert_allclose(res.y, ref.y, rtol=1e-8, atol=1e-8)
+
+
+def test_compare_models_full_size_properties(mds):
+    """BASELINE config 3's full shard (65 536 envs x 8 drones = 524 288 observation rows of a real fused step, fp32), too many rows for
+    the oracle: size-independent properties of the three arrays.  x_lin is a re-ordering of observation columns (bit-exact); the rows
+    of A and B that copy a state component (d rpy/dt = ang_v, d pos/dt = vel) and the geometric model's (w, v) slots reproduce those
+    columns bit for bit (1.0 * x + 0 * the rest is exact); the thrust rows of the two models agree to rounding where the attitude is
+    level; a 512-row sample equals the oracle."""
+    from multidronesim_amd.model import LinearizedModel, QuadrotorDynamics
+    from multidronesim_amd.simulations.CompareModels import compare_models
+    torch = mds.torch
+    E, D = 65536, 8
+    xyz, rpy, P = H.c2_setup(E, D, seed=3, phase="c3")
+    env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                         pyb_freq=100, ctrl_freq=100, num_envs=E, dtype="float32")
+    env.set_trajectories(P)
+    env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=env.device))
+    t = 0.0
+    for _ in range(30):
+        obs = env.step_geometric(t)
+        t += env.CTRL_TIMESTEP
+    obs = obs.reshape(-1, 20).clone()
+    lin, geo = LinearizedModel(env), QuadrotorDynamics(env.PYB_FREQ)
+    geo.load_env_params(env)
+    a, b, c = compare_models(lin, geo, obs)
+    assert a.shape == b.shape == c.shape == (E * D, 12) and all(bool(torch.isfinite(x).all()) for x in (a, b, c))
+    assert torch.equal(c, obs[:, [7, 8, 9, 13, 14, 15, 10, 11, 12, 0, 1, 2]])
+    assert torch.equal(a[:, 0:3], obs[:, 13:16]) and torch.equal(a[:, 9:12], obs[:, 10:13])
+    assert torch.equal(b[:, 0:3], obs[:, 13:16]) and torch.equal(b[:, 9:12], obs[:, 10:13])
+    # vertical acceleration: linear (F - m g) / m against geometric R33 F / m - g; equal up to (1 - R33) F / m and rounding
+    q = obs[:, 3:7].double()
+    r33 = 1 - 2 * (q[:, 0] ** 2 + q[:, 1] ** 2) / (q ** 2).sum(dim=1)
+    f_over_m = (a[:, 8].double() + env.G)
+    assert float((a[:, 8].double() - b[:, 8].double() - (1 - r33) * f_over_m).abs().max()) < 2e-4
+    idx = torch.randperm(E * D, generator=torch.Generator().manual_seed(0))[:512].to(obs.device)
+    A, B = O.linearized_AB()
+    ra, rb, rc = O.compare_models(obs[idx].double().cpu().numpy(), A, B, dyn_J=(1.05, 1.05, 2.05))
+    for got, ref in ((a[idx], ra), (b[idx], rb), (c[idx], rc)):
+        assert rel(got.double().cpu().numpy(), ref) < 3e-5
+    env.close()
