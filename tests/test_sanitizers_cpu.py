@@ -1,6 +1,6 @@
 """UndefinedBehaviorSanitizer run of the device arithmetic (the g++ build of csrc/mds_math.hpp, tests/emul):
 GPU sanitizers are not available on the pool, so the per-drone math is exercised under UBSan on the CPU --
-fused controller + physics (Euler, RK4, drag, substeps), saturating inputs included.  Runs in a subprocess."""
+fused controller + physics (Euler, RK4, drag, substeps), saturating inputs included, and the CompareModels templates on degenerate inputs.  Runs in a subprocess."""
 import os
 import shutil
 import subprocess
@@ -49,6 +49,24 @@ for dt in ("f32", "f64"):
         for k in range(300):
             obs, act = em.step_geometric(t); t += 1.0 / em.cfg.ctrl_freq
         assert np.isfinite(obs).all(), dt
+# (3) the CompareModels templates: arbitrary (also zero-norm and huge) quaternions, RPM far outside the clip range, rotation
+#     matrices at the branch boundaries of the matrix -> quaternion conversion, angles far outside [-pi, pi]
+for dt in ("f32", "f64"):
+    em = E.Emul(dt)
+    n = 256
+    obs = rng.normal(size=(n, 20)) * 5
+    obs[:8, 3:7] = 0.0
+    obs[8:16, 3:7] *= 1e15
+    obs[:, 16:20] = rng.uniform(-1e5, 1e5, size=(n, 4))
+    A, B = rng.normal(size=(12, 12)), rng.normal(size=(12, 4))
+    a, b, c = em.compare_models(obs, A, B, 0.26, 0.027, [1.05, 1.05, 2.05], 9.8)
+    assert np.isfinite(c).all() and np.isfinite(a[16:]).all() and np.isfinite(b[16:]).all(), dt
+    R = E.rpy_to_rot(rng.uniform(-50, 50, size=(64, 3)), dt)
+    assert np.isfinite(R).all() and np.abs(np.linalg.det(R) - 1).max() < 1e-3, dt
+    mats = np.concatenate([R, np.eye(3)[None], np.diag([1.0, -1, -1])[None], np.diag([-1.0, 1, -1])[None], np.diag([-1.0, -1, 1])[None],
+                           np.zeros((1, 3, 3))])
+    q = E.rot_to_quat(mats, dt)
+    assert np.isfinite(q[:-1]).all() and np.abs(np.linalg.norm(q[:-1], axis=1) - 1).max() < 1e-5, dt
 print("UBSAN_OK")
 '''
 
