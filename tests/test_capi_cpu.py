@@ -149,6 +149,7 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "np_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+                assert "c_oracle" not in txt and "libc_oracle" not in txt, f
                 assert "tests.emul" not in txt and "libmds_emul" not in txt, f
 
 
