@@ -1031,7 +1031,8 @@ def cbf_rows(x, xdes, order, Kcbf, umax, safety_radius, zscale, c: DroneConsts =
 #    last iterates (iteration limit, or a singular KKT system after iteration 0) and raises only
 #    the rank ValueError that P = I excludes -- so on such an env the reference most likely
 #    applies cvxopt's last iterate to all of its drones.  Parity on that branch: unpinned and
-#    probably different.
+#    probably different.  oracle/cvxopt_qp.py restates coneqp from its published algorithm (unpinned too) to
+#    make both statements measurable: tests/test_oracle_cvxopt_cpu.py, tests/tools/c4_cvxopt_probe.py.
 # --------------------------------------------------------------------------------------
 
 
