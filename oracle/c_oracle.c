@@ -124,7 +124,7 @@ static void input_to_action(const co_consts* c, const double u_in[4], double rpm
 
 /* control/geometric.py:59-115 GeometricControl.compute with its quirks: g = 9.81 (:20); obs[13:16] (world angular velocity) used as
  * the body rate (:63); R_des.transpose(0, 1) is a no-op on an ndarray so w_des_hat = R_des @ R_dot_des (:102) */
-static void geometric_compute(const co_consts* c, const double obs[20], const double des[11], double rpm[4]) {
+static void geometric_compute_ex(const co_consts* c, const double obs[20], const double des[11], double rpm[4], double* omegas /* NULL | [4]: force, w_des (return_omegas=True, :105-107) */) {
   const double m = c->M, g = c->g_ctrl;
   double R[9];
   quat_to_R_scipy(obs + 3, R);                                   /* obs_to_geo_model, utils/model_conversions.py:105-114 */
@@ -188,6 +188,11 @@ static void geometric_compute(const co_consts* c, const double obs[20], const do
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) W[3 * i + j] = Rd[3 * i] * Rdd[j] + Rd[3 * i + 1] * Rdd[3 + j] + Rd[3 * i + 2] * Rdd[6 + j];   /* :102 (no transpose) */
   const double w_des[3] = {W[7], W[2], W[3]};                    /* :103 */
+  if (omegas) {                                                  /* :105-107: force = f_des_world . (R e3) */
+    omegas[0] = f_w[0] * R[2] + f_w[1] * R[5] + f_w[2] * R[8];
+    omegas[1] = w_des[0]; omegas[2] = w_des[1]; omegas[3] = w_des[2];
+    return;
+  }
   /* attitude error and torque (:108-111) */
   double E[9];
   for (int i = 0; i < 3; ++i)
@@ -208,6 +213,10 @@ static void geometric_compute(const co_consts* c, const double obs[20], const do
   for (int k = 0; k < 3; ++k) torque[k] = c->J[k] * (-0.5 * c->KR[k] * vee[k] - c->Kw[k] * (w[k] - RTRdw[k])) - wJw[k];
   const double u[4] = {f_b[2] > 0.0 ? f_b[2] : 0.0, torque[0], torque[1], torque[2]};   /* :114 */
   input_to_action(c, u, rpm);                                    /* :115 */
+}
+
+static void geometric_compute(const co_consts* c, const double obs[20], const double des[11], double rpm[4]) {
+  geometric_compute_ex(c, obs, des, rpm, 0);
 }
 
 /* [UPSTREAM] BaseAviary._integrateQ: the exact exponential for a constant body rate over dt */
@@ -338,5 +347,312 @@ int co_geometric_loop(const co_consts* c, int n, int steps, double t0, int first
     }
     memcpy(obs_out + (size_t)i * CO_OBS, obs, sizeof(obs));
   }
+  return used;
+}
+
+/* ================================================================================================================================
+ * The CBF-filtered loop (BASELINE config 4): simulations/CBFTest.py:303-350 for ONE env of D drones per call of co_cbf_env_step --
+ * nominal GeometricControl(return_omegas) -> u_hat = (force - M G, w_des) (:339) -> DroneQPTracker.compute_control (cbf/qptracker.py:
+ * 22-34) on x = obs_to_lin_model(obs, 9), xdes = [0, 0, yaw, vel, pos] (:332-336) -> + M G (:346) -> LQROmegaController.
+ * compute_low_level -> ThrustOmegaController (control/lqr/lqr_omega_controller.py:77-88, control/low_level/thrust_omega_ctrl.py:81-132)
+ * -> env.step.  Order-2 ECBF rows in the closed form of SURVEY.md 3.6 (cbf/cbf.py:135-303 for the hover linearisation of
+ * model/linear_omega.py:46-53; pinned by tests/golden/cbf_rows_o2.npz), stacked in the reference's order (cbf/cbf.py:308-367: pairs
+ * i < j | +I | -I | obstacles agent-major).  The QP min 1/2 |u - u_hat|^2 s.t. G u <= h is solved EXACTLY by a dual active-set
+ * (Goldfarb-Idnani) iteration on the dense rows; an infeasible QP keeps u_hat with status 1 -- the MODELLED fallback of np_oracle.py /
+ * DESIGN.md, not the reference's behaviour there (cvxopt returns an iterate).
+ * ================================================================================================================================ */
+#define CO_MAXD 16
+#define CO_MAXOBS 8
+#define CO_MAXN (4 * CO_MAXD)
+#define CO_MAXM (CO_MAXD * (CO_MAXD - 1) / 2 + 8 * CO_MAXD + CO_MAXD * CO_MAXOBS)
+
+typedef struct {
+  double Kcbf[2], umax[4], safety_radius, zscale;       /* cbf/cbf.py:119-124, :566-572; DroneCBF(safety_radius, zscale) */
+  int n_obs;
+  double obs_xyz[CO_MAXOBS][3], obs_r[CO_MAXOBS];       /* x_obs_list[j][0], obs_r_list[j] (simulations/CBFTest.py:421-425) */
+} co_cbf;
+
+int co_sizeof_cbf(void) { return (int)sizeof(co_cbf); }
+
+/* one ECBF row between the 9-states xi, xj (rpy, vel, pos) with desired states xdi, xdj: h_ij and L_g (thrust column only for order 2) */
+static void cbf_pair_o2(const double* xi, const double* xj, const double* xdi, const double* xdj, double Ds, double zscale, const double K[2],
+                        double m, double g, double* hij, double* Lg0) {
+  const double c4 = zscale * zscale * zscale * zscale;
+  const double ex = xi[6] - xj[6], ey = xi[7] - xj[7], ez = xi[8] - xj[8];
+  const double s = ex * ex + ey * ey;
+  const double ezc = ez / zscale;
+  const double h = s * s + ezc * ezc * ezc * ezc - Ds * Ds * Ds * Ds;
+  const double gx = 4 * ex * s, gy = 4 * ey * s, gz = 4 * ez * ez * ez / c4;
+  const double Hxx = 12 * ex * ex + 4 * ey * ey, Hxy = 8 * ex * ey, Hyy = 4 * ex * ex + 12 * ey * ey, Hzz = 12 * ez * ez / c4;
+  double d[9];
+  for (int k = 0; k < 9; ++k) d[k] = (xi[k] - xdi[k]) - (xj[k] - xdj[k]);
+  const double dr = d[0], dp = d[1], dvx = d[3], dvy = d[4], dvz = d[5];
+  const double dax = g * dp, day = -g * dr;
+  const double hdot = gx * dvx + gy * dvy + gz * dvz;
+  const double quad = Hxx * dvx * dvx + 2 * Hxy * dvx * dvy + Hyy * dvy * dvy + Hzz * dvz * dvz;
+  const double Lf2 = gx * dax + gy * day + quad;
+  *hij = K[0] * h + K[1] * hdot + Lf2;
+  *Lg0 = gz / m;
+}
+
+/* CBF._build_ineq_const (cbf/cbf.py:308-367): x, xdes [D,9] -> G [m, 4D] row-major, h [m]; returns m */
+static int cbf_rows_o2(const co_consts* c, const co_cbf* b, int D, const double* x, const double* xdes, double* G, double* h) {
+  const int n = 4 * D;
+  int m = 0;
+  for (int i = 0; i < D - 1; ++i)
+    for (int j = i + 1; j < D; ++j) {
+      double hij, lg;
+      cbf_pair_o2(x + 9 * i, x + 9 * j, xdes + 9 * i, xdes + 9 * j, 2 * b->safety_radius, b->zscale, b->Kcbf, c->M, c->G, &hij, &lg);
+      double* row = G + (size_t)m * n;
+      memset(row, 0, n * sizeof(double));
+      row[4 * i] = -lg;
+      row[4 * j] = lg;
+      h[m++] = hij;
+    }
+  for (int sgn = 0; sgn < 2; ++sgn)                                  /* +I then -I, h = umax tiled (:400-412) */
+    for (int k = 0; k < n; ++k) {
+      double* row = G + (size_t)m * n;
+      memset(row, 0, n * sizeof(double));
+      row[k] = sgn ? -1.0 : 1.0;
+      h[m++] = b->umax[k & 3];
+    }
+  for (int i = 0; i < D; ++i)                                          /* obstacles, agent-major (:369-398): obstacle state = position only, xj_des = xj */
+    for (int j = 0; j < b->n_obs; ++j) {
+      double xo[9] = {0, 0, 0, 0, 0, 0, b->obs_xyz[j][0], b->obs_xyz[j][1], b->obs_xyz[j][2]};
+      double hij, lg;
+      cbf_pair_o2(x + 9 * i, xo, xdes + 9 * i, xo, b->safety_radius + b->obs_r[j], b->zscale, b->Kcbf, c->M, c->G, &hij, &lg);
+      double* row = G + (size_t)m * n;
+      memset(row, 0, n * sizeof(double));
+      row[4 * i] = -lg;
+      h[m++] = hij;
+    }
+  return m;
+}
+
+/* solve M r = rhs (q x q, symmetric positive definite up to rounding) by Gaussian elimination with partial pivoting; returns 0 if singular */
+static int solve_small(int q, double* M, double* rhs) {
+  for (int k = 0; k < q; ++k) {
+    int piv = k;
+    for (int i = k + 1; i < q; ++i)
+      if (fabs(M[i * q + k]) > fabs(M[piv * q + k])) piv = i;
+    if (M[piv * q + k] == 0.0) return 0;
+    if (piv != k) {
+      for (int j = 0; j < q; ++j) { const double t = M[k * q + j]; M[k * q + j] = M[piv * q + j]; M[piv * q + j] = t; }
+      const double t = rhs[k]; rhs[k] = rhs[piv]; rhs[piv] = t;
+    }
+    for (int i = k + 1; i < q; ++i) {
+      const double f = M[i * q + k] / M[k * q + k];
+      for (int j = k; j < q; ++j) M[i * q + j] -= f * M[k * q + j];
+      rhs[i] -= f * rhs[k];
+    }
+  }
+  for (int k = q - 1; k >= 0; --k) {
+    double a = rhs[k];
+    for (int j = k + 1; j < q; ++j) a -= M[k * q + j] * rhs[j];
+    rhs[k] = a / M[k * q + k];
+  }
+  return 1;
+}
+
+/* min 1/2 |u - uhat|^2 s.t. G u <= h: Goldfarb-Idnani dual active set with H = I on unit-norm rows (same feasible set, same minimiser).
+ * u [n] in: uhat, out: the minimiser.  Returns 1 solved, 0 infeasible (u untouched then).  *iters: constraint additions + drops. */
+static int qp_project(int n, int m, const double* G0, const double* h0, double* u_io, int* iters) {
+  static __thread double G[CO_MAXM * CO_MAXN], h[CO_MAXM], sc[CO_MAXM];
+  double u[CO_MAXN], lam[CO_MAXN], r[CO_MAXN], z[CO_MAXN], M[CO_MAXN * CO_MAXN];
+  int active[CO_MAXN], q = 0;
+  const double tol = 1e-10;
+  for (int k = 0; k < m; ++k) {
+    double rn = 0.0;
+    for (int j = 0; j < n; ++j) rn += G0[(size_t)k * n + j] * G0[(size_t)k * n + j];
+    rn = sqrt(rn);
+    if (rn == 0.0 && h0[k] < 0.0) return 0;                          /* 0 * u <= h with h < 0 */
+    const double rs = rn > 0.0 ? rn : 1.0;
+    for (int j = 0; j < n; ++j) G[(size_t)k * n + j] = G0[(size_t)k * n + j] / rs;
+    h[k] = rn > 0.0 ? h0[k] / rs : INFINITY;
+    sc[k] = isfinite(h[k]) ? (fabs(h[k]) > 1.0 ? fabs(h[k]) : 1.0) : 1.0;
+  }
+  memcpy(u, u_io, n * sizeof(double));
+  const int max_iter = 20 * (m + 10);
+  *iters = 0;
+  for (int it = 0; it < max_iter; ++it) {
+    int k = 0;
+    double best = -INFINITY, viol_k = 0.0;
+    for (int i = 0; i < m; ++i) {                                      /* most violated row, relative to max(1, |h|) */
+      double v = -h[i];
+      if (isfinite(h[i])) {
+        for (int j = 0; j < n; ++j) v += G[(size_t)i * n + j] * u[j];
+      } else {
+        v = -INFINITY;
+      }
+      if (v / sc[i] > best) { best = v / sc[i]; k = i; viol_k = v; }
+    }
+    if (viol_k <= tol * sc[k]) {
+      memcpy(u_io, u, n * sizeof(double));
+      return 1;
+    }
+    const double* gk = G + (size_t)k * n;
+    double lam_k = 0.0, gkgk = 0.0;
+    for (int j = 0; j < n; ++j) gkgk += gk[j] * gk[j];
+    for (;;) {                                                         /* bring row k in, dropping blocking rows on the way */
+      ++*iters;
+      if (q > 0) {
+        for (int a = 0; a < q; ++a) {
+          const double* ga = G + (size_t)active[a] * n;
+          double d = 0.0;
+          for (int j = 0; j < n; ++j) d += ga[j] * gk[j];
+          r[a] = d;
+          for (int b2 = 0; b2 < q; ++b2) {
+            const double* gb = G + (size_t)active[b2] * n;
+            double e = 0.0;
+            for (int j = 0; j < n; ++j) e += ga[j] * gb[j];
+            M[a * q + b2] = e;
+          }
+        }
+        if (!solve_small(q, M, r)) return 0;
+        for (int j = 0; j < n; ++j) {
+          double a = gk[j];
+          for (int b2 = 0; b2 < q; ++b2) a -= G[(size_t)active[b2] * n + j] * r[b2];
+          z[j] = a;
+        }
+      } else {
+        memcpy(z, gk, n * sizeof(double));
+      }
+      double zz = 0.0;
+      for (int j = 0; j < n; ++j) zz += z[j] * z[j];
+      double t1 = INFINITY, t2 = INFINITY;
+      int drop = -1;
+      for (int a = 0; a < q; ++a)
+        if (r[a] > 1e-14) {
+          const double cand = lam[a] / r[a];
+          if (cand < t1) { t1 = cand; drop = a; }
+        }
+      if (zz > 1e-18 * (gkgk > 1.0 ? gkgk : 1.0)) {
+        double v = -h[k];
+        for (int j = 0; j < n; ++j) v += gk[j] * u[j];
+        t2 = v / zz;
+      }
+      const double t = t1 < t2 ? t1 : t2;
+      if (!isfinite(t)) return 0;                                      /* rows inconsistent: infeasible */
+      if (isinf(t2)) {                                                 /* dual step only */
+        for (int a = 0; a < q; ++a) lam[a] -= t * r[a];
+        lam_k += t;
+      } else {
+        for (int j = 0; j < n; ++j) u[j] -= t * z[j];
+        for (int a = 0; a < q; ++a) lam[a] -= t * r[a];
+        lam_k += t;
+        if (t == t2) {
+          if (q >= n) return 0;
+          active[q] = k;
+          lam[q] = lam_k;
+          ++q;
+          break;
+        }
+      }
+      for (int a = drop; a < q - 1; ++a) { active[a] = active[a + 1]; lam[a] = lam[a + 1]; }
+      --q;
+      if (*iters > max_iter) return 0;
+    }
+  }
+  return 0;
+}
+
+/* control/low_level/thrust_omega_ctrl.py:81-132 through lqr_omega_controller.py:77-88: u = [thrust, w_des (body)], PID memory pid[6] =
+ * last_omega3 | integral3 (P = 17500, I = 10, D = 0; PWM2RPM 0.2685 / 4070.3; PWM in [20000, 65535]; torque clip +-3200; CF2P mixer) */
+static void thrust_omega_low_level(const co_consts* c, const double u[4], const double obs[20], double dt, double pid[6], double rpm[4]) {
+  double R[9], cur[3];
+  quat_to_R_scipy(obs + 3, R);
+  matTvec3(R, obs + 13, cur);                                          /* world rate -> body frame (:82-86) */
+  const double u0 = u[0] < 0.0 ? 0.0 : u[0];
+  double pwm_thrust = (sqrt(u0 / (c->KF * 4)) - 4070.3) / 0.2685;
+  pwm_thrust = pwm_thrust < 20000.0 ? 20000.0 : (pwm_thrust > 65535.0 ? 65535.0 : pwm_thrust);
+  double tq[3];
+  for (int k = 0; k < 3; ++k) {
+    const double rate_e = -(cur[k] - pid[k]) / dt;
+    const double e = u[1 + k] - cur[k];
+    pid[k] = cur[k];
+    double in = pid[3 + k] - e * dt;                                   /* sic: minus (:117) */
+    in = in < -1500.0 ? -1500.0 : (in > 1500.0 ? 1500.0 : in);
+    if (k < 2) in = in < -1.0 ? -1.0 : (in > 1.0 ? 1.0 : in);
+    pid[3 + k] = in;
+    const double t = 17500.0 * e + 10.0 * in + 0.0 * rate_e;
+    tq[k] = t < -3200.0 ? -3200.0 : (t > 3200.0 ? 3200.0 : t);
+  }
+  static const double MIX[4][3] = {{0, -1, -1}, {1, 0, 1}, {0, 1, -1}, {-1, 0, 1}};
+  for (int k = 0; k < 4; ++k) {
+    double pwm = pwm_thrust + MIX[k][0] * tq[0] + MIX[k][1] * tq[1] + MIX[k][2] * tq[2];
+    pwm = pwm < 20000.0 ? 20000.0 : (pwm > 65535.0 ? 65535.0 : pwm);
+    rpm[k] = 0.2685 * pwm + 4070.3;
+  }
+}
+
+/* One control step of one env: st [D,20], pid [D,6], obs [D,20] (current on entry, next on exit), P [D,7].  Returns the status
+ * (0 solved, 1 infeasible: modelled fallback) and the solver's iteration count through *iters. */
+static int cbf_env_step(const co_consts* c, const co_cbf* b, int D, double t, const double* P, double* st, double* pid, double* obs, int* iters) {
+  double x[CO_MAXD * 9], xdes[CO_MAXD * 9], un[CO_MAXN], us[CO_MAXN];
+  static __thread double G[CO_MAXM * CO_MAXN], h[CO_MAXM];
+  for (int i = 0; i < D; ++i) {
+    double des[11], om[4], rpm_unused[4];
+    lemniscate(t, P + 7 * i, des);
+    geometric_compute_ex(c, obs + 20 * i, des, rpm_unused, om);
+    un[4 * i] = om[0] - c->M * c->G;                                   /* CBFTest.py:339 */
+    un[4 * i + 1] = om[1]; un[4 * i + 2] = om[2]; un[4 * i + 3] = om[3];
+    const double* o = obs + 20 * i;                                    /* obs_to_lin_model(obs, 9): rpy, vel, pos */
+    double* xi = x + 9 * i;
+    xi[0] = o[7]; xi[1] = o[8]; xi[2] = o[9]; xi[3] = o[10]; xi[4] = o[11]; xi[5] = o[12]; xi[6] = o[0]; xi[7] = o[1]; xi[8] = o[2];
+    double* xd = xdes + 9 * i;                                         /* [0, 0, yaw, vel, pos] (:332-336) */
+    xd[0] = 0.0; xd[1] = 0.0; xd[2] = des[9]; xd[3] = des[3]; xd[4] = des[4]; xd[5] = des[5]; xd[6] = des[0]; xd[7] = des[1]; xd[8] = des[2];
+  }
+  const int n = 4 * D, m = cbf_rows_o2(c, b, D, x, xdes, G, h);
+  memcpy(us, un, n * sizeof(double));
+  const int ok = qp_project(n, m, G, h, us, iters);
+  if (!ok) memcpy(us, un, n * sizeof(double));
+  for (int i = 0; i < D; ++i) {
+    double u[4] = {us[4 * i] + c->M * c->G, us[4 * i + 1], us[4 * i + 2], us[4 * i + 3]}, rpm[4];   /* :346 */
+    thrust_omega_low_level(c, u, obs + 20 * i, c->ctrl_dt, pid + 6 * i, rpm);
+    aviary_step(c, st + (size_t)i * CO_STATE, rpm);
+    pack_obs(st + (size_t)i * CO_STATE, obs + 20 * i);
+  }
+  return ok ? 0 : 1;
+}
+
+/* dense rows of one env for the tests: x, xdes [D,9] -> G [m,4D], h [m]; returns m */
+int co_cbf_rows(const co_consts* c, const co_cbf* b, int D, const double* x, const double* xdes, double* G, double* h) {
+  return cbf_rows_o2(c, b, D, x, xdes, G, h);
+}
+/* the QP alone: returns 1 solved / 0 infeasible */
+int co_qp_project(int n, int m, const double* G, const double* h, double* u_io, int* iters) {
+  if (n > CO_MAXN || m > CO_MAXM) return -1;
+  return qp_project(n, m, G, h, u_io, iters);
+}
+/* The C4 loop for E envs of D drones: env.step(first action) is the caller's (co_step); st [E*D,20], pid [E*D,6] (zeros at the start),
+ * P [E*D,7]; `steps` control steps from t0; status_log [steps,E] (may be NULL), obs_out [E*D,20].  OpenMP over the envs. */
+int co_cbf_loop(const co_consts* c, const co_cbf* b, int E, int D, int steps, double t0, const double* P, double* st, double* pid, double* obs_out,
+                int* status_log, long long* iter_total, int threads) {
+  if (D > CO_MAXD || b->n_obs > CO_MAXOBS) return -1;
+  int used = 1;
+  long long total = 0;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+  {
+#pragma omp single
+    used = omp_get_num_threads();
+  }
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+#endif
+  for (int e = 0; e < E; ++e) {
+    double obs[CO_MAXD * 20];
+    for (int i = 0; i < D; ++i) pack_obs(st + (size_t)(e * D + i) * CO_STATE, obs + 20 * i);
+    double t = t0;
+    for (int k = 0; k < steps; ++k) {
+      int it = 0;
+      const int stt = cbf_env_step(c, b, D, t, P + (size_t)e * D * 7, st + (size_t)e * D * CO_STATE, pid + (size_t)e * D * 6, obs, &it);
+      if (status_log) status_log[(size_t)k * E + e] = stt;
+      total += it;
+      t += c->ctrl_dt;
+    }
+    memcpy(obs_out + (size_t)e * D * 20, obs, (size_t)D * 20 * sizeof(double));
+  }
+  if (iter_total) *iter_total = total;
   return used;
 }

@@ -88,3 +88,79 @@ def geometric_compute(obs, des, c=None):
     c = c or consts()
     lib().co_geometric_compute(C.byref(c), C.c_int(obs.shape[0]), _dp(obs), _dp(des), _dp(rpm))
     return rpm
+
+
+# ---- the CBF-filtered loop (BASELINE config 4) ----------------------------------------------------------------------------
+CO_MAXOBS = 8
+
+
+class Cbf(C.Structure):
+    _fields_ = [("Kcbf", C.c_double * 2), ("umax", C.c_double * 4), ("safety_radius", C.c_double), ("zscale", C.c_double), ("n_obs", C.c_int),
+                ("obs_xyz", (C.c_double * 3) * CO_MAXOBS), ("obs_r", C.c_double * CO_MAXOBS)]
+
+
+def cbf_params(Kcbf, umax, safety_radius, zscale, x_obs=None, obs_r=None):
+    """x_obs as the reference passes it (simulations/CBFTest.py:421-425): one (order, 3) state per sphere, position in row 0."""
+    assert lib().co_sizeof_cbf() == C.sizeof(Cbf), "co_cbf layout"
+    b = Cbf()
+    b.Kcbf[:] = [float(k) for k in np.asarray(Kcbf).reshape(-1)[:2]]
+    b.umax[:] = [float(k) for k in np.asarray(umax).reshape(-1)[:4]]
+    b.safety_radius, b.zscale = float(safety_radius), float(zscale)
+    n = 0 if obs_r is None else len(obs_r)
+    assert n <= CO_MAXOBS
+    b.n_obs = n
+    for j in range(n):
+        xo = np.asarray(x_obs[j], dtype=np.float64).reshape(-1, 3)[0]
+        b.obs_xyz[j][:] = [float(v) for v in xo]
+        b.obs_r[j] = float(obs_r[j])
+    return b
+
+
+def cbf_rows(x, xdes, b, c=None):
+    """CBF._build_ineq_const for one env: x, xdes [D,9] -> (G [m,4D], h [m]) in the reference's row order."""
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, 9))
+    xdes = np.ascontiguousarray(np.asarray(xdes, dtype=np.float64).reshape(-1, 9))
+    D = x.shape[0]
+    mmax = D * (D - 1) // 2 + 8 * D + D * b.n_obs
+    G, h = np.zeros((mmax, 4 * D)), np.zeros(mmax)
+    c = c or consts()
+    m = lib().co_cbf_rows(C.byref(c), C.byref(b), C.c_int(D), _dp(x), _dp(xdes), _dp(G), _dp(h))
+    assert m == mmax
+    return G, h
+
+
+def qp_project(uhat, G, h):
+    """-> (solved, u, iterations)"""
+    G = np.ascontiguousarray(np.asarray(G, dtype=np.float64))
+    h = np.ascontiguousarray(np.asarray(h, dtype=np.float64))
+    u = np.ascontiguousarray(np.asarray(uhat, dtype=np.float64).reshape(-1).copy())
+    it = C.c_int(0)
+    ok = lib().co_qp_project(C.c_int(u.size), C.c_int(h.size), _dp(G), _dp(h), _dp(u), C.byref(it))
+    if ok < 0:
+        raise ValueError("QP larger than the C oracle's static bounds")
+    return bool(ok), u, it.value
+
+
+class CbfLoopC:
+    """simulations/CBFTest.py:303-350 for E envs of D drones on the C restatement (geometric nominal, order-2 filter, ThrustOmega low level)."""
+
+    def __init__(self, xyz, rpy, b, pyb_freq=100, ctrl_freq=100):
+        xyz = np.asarray(xyz, dtype=np.float64)
+        self.E, self.D = xyz.shape[0], xyz.shape[1]
+        self.av = AviaryC(xyz.reshape(-1, 3), np.asarray(rpy, dtype=np.float64).reshape(-1, 3), pyb_freq, ctrl_freq)
+        self.b = b
+        self.pid = np.zeros((self.E * self.D, 6))
+        self.av.step(np.zeros((self.E * self.D, 4)))                        # env.step(zeros) before the loop (:296-300)
+
+    def run(self, P, steps, t0=0.0, threads=1):
+        """-> (obs [E,D,20], statuses [steps,E], solver iterations in all, threads used)"""
+        P = np.ascontiguousarray(np.asarray(P, dtype=np.float64).reshape(-1, 7))
+        obs = np.zeros((self.E * self.D, 20))
+        st = np.zeros((steps, self.E), dtype=np.int32)
+        tot = C.c_longlong(0)
+        lib().co_cbf_loop.restype = C.c_int
+        used = lib().co_cbf_loop(C.byref(self.av.c), C.byref(self.b), C.c_int(self.E), C.c_int(self.D), C.c_int(steps), C.c_double(t0), _dp(P),
+                                 _dp(self.av.st), _dp(self.pid), _dp(obs), st.ctypes.data_as(C.POINTER(C.c_int)), C.byref(tot), C.c_int(threads))
+        if used < 0:
+            raise ValueError("env larger than the C oracle's static bounds")
+        return obs.reshape(self.E, self.D, 20), st, tot.value, used

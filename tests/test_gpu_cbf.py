@@ -959,3 +959,32 @@ def test_cbf_persistent_rollout_can_be_captured_into_a_hip_graph(mds):
         env.close()
     for a, b in zip(*res):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-8), ("float32", 1e-5)])
+def test_c4_under_scene_512_envs_against_the_c_oracle_at_every_step(mds, dtype, tol):
+    """The C4 headline scene on 512 envs of the bench's generator (16 drones, four spheres at z = -3) over the bench window, against the
+    plain-C restatement (oracle/c_oracle.c: a second checker, fast enough for 1.8 M drone-steps): the persistent kernel's per-env
+    statuses equal the oracle's at EVERY one of the 220 steps (all 0 over the window: the unique-minimiser branch), the state at step
+    220 within `tol` (fp32: north_star's 1e-5), and the step-by-step loop gives the same statuses."""
+    from oracle import c_oracle as CO
+    E, D, steps = 512, 16, 220
+    xyz, rpy, P = H.c2_setup(E, D, seed=1000, phase="c3")       # bench.py's generator and seed
+    P[..., 4] = 0.5 + 0.3 * np.arange(D)
+    xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    x_obs = [np.array([[sx * 0.5, sy * 0.5, -3.0], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
+    obs_r = [0.1] * 4
+    env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                         pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype)
+    env.set_trajectories(P)
+    cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2, cbf_poles=np.array([-2.2, -2.4]))
+    trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+    ref, rst, its, _ = CO.CbfLoopC(xyz, rpy, CO.cbf_params(cbf.Kcbf.reshape(-1), cbf.umax, 0.1, 1.0, x_obs, obs_r)).run(P, steps, threads=8)
+    assert its > 0 and rst[20:].sum() == 0                      # active, and feasible over the window
+    env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+    slog = mds.torch.empty((steps, E), dtype=mds.torch.int32, device=env.device)
+    obs, _ = env.rollout_cbf_geometric_fused(0.0, steps, trk, x_obs, obs_r, steps_per_launch=44, status_log=slog)
+    np.testing.assert_array_equal(slog.cpu().numpy(), rst)
+    got = obs.double().cpu().numpy().reshape(E, D, 20)
+    assert np.abs(got[..., :16] - ref[..., :16]).max() < tol
+    env.close()

@@ -77,3 +77,60 @@ def test_c_oracle_step_pieces_match_numpy_oracle():
     for k in range(30):
         act = rng.uniform(-3000, 26000, size=(n, 4))
         np.testing.assert_allclose(a.step(act), ora.step(act), rtol=0, atol=1e-10)
+
+
+# ---- the CBF-filtered loop (BASELINE config 4) on the C restatement ----------------------------------------------------------
+def test_c_oracle_cbf_rows_match_the_reference_minted_rows():
+    """cbf_rows_o2.npz holds (G, h) built by the reference's own CBF._build_ineq_const: the C rows must be those rows, in that order."""
+    g = np.load(os.path.join(G, "cbf_rows_o2.npz"))
+    done = 0
+    for k in range(int(g["n_cases"])):
+        x, xd, xo, r, Gr, hr = (g[f"c{k}_{n}"] for n in ("x", "xdes", "xobs", "obsr", "G", "h"))
+        b = CO.cbf_params(g["Kcbf"], g["umax"], float(g["safety_radius"]), float(g["zscale"]), xo if len(r) else None, list(r) if len(r) else None)
+        Gc, hc = CO.cbf_rows(x, xd, b)
+        assert Gc.shape == Gr.shape
+        np.testing.assert_allclose(Gc, Gr, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(Gr).max()))
+        np.testing.assert_allclose(hc, hr, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(hr).max()))
+        done += 1
+    assert done >= 8
+
+
+def test_c_oracle_qp_equals_the_numpy_active_set_and_the_converged_interior_point():
+    from oracle import cvxopt_qp as CQ
+    from tests.test_oracle_cvxopt_cpu import make_qp
+    solved = 0
+    for seed in range(40):
+        Gm, h, uhat = make_qp(seed)
+        ok, u, _ = O.qp_project(uhat.reshape(-1), Gm, h)
+        okc, uc, it = CO.qp_project(uhat, Gm, h)
+        assert ok == okc                                              # the same feasibility decision
+        if ok:
+            solved += 1
+            np.testing.assert_allclose(uc, u, rtol=0, atol=1e-12)
+            tight = CQ.coneqp_l(np.eye(uhat.size), -uhat.reshape(-1), Gm, h, maxiters=200, abstol=1e-15, reltol=1e-14, feastol=1e-12)
+            np.testing.assert_allclose(uc, tight["x"], rtol=0, atol=1e-8)       # a third algorithm, the same point
+        else:
+            np.testing.assert_array_equal(uc, uhat.reshape(-1))       # untouched
+    assert solved >= 30
+
+
+@pytest.mark.parametrize("D,nobs", [(8, 1), (16, 4), (4, 0)])
+def test_c_oracle_cbf_loop_equals_numpy_oracle(D, nobs):
+    """simulations/CBFTest.py:303-350 on both restatements: statuses equal at every step (infeasible env-steps included), states to 1e-9."""
+    E, steps = 3, 120
+    xyz, rpy, P = H.c2_setup(E, D, phase="c3", offset=1.0)
+    P[..., 4] = 0.5 + 0.3 * np.arange(D)
+    xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    x_obs = [np.array([[0.3 * (-1) ** k, 0.2 * (-1) ** (k // 2), 0.9 + 0.3 * k], [0, 0, 0]]) for k in range(nobs)] or None
+    obs_r = [0.1] * nobs if nobs else None
+    Kcbf, umax = np.array([5.28, 4.6]), np.array([O.CF2P.MAX_THRUST, 10, 10, 10])
+    ref, hist = H.oracle_cbf_closed_loop(xyz, rpy, P, steps, Kcbf, umax, 0.1, 1.0, x_obs, obs_r)
+    L = CO.CbfLoopC(xyz, rpy, CO.cbf_params(Kcbf, umax, 0.1, 1.0, x_obs, obs_r))
+    got, st, its, _ = L.run(P, steps)
+    np.testing.assert_array_equal(st, np.array(hist))
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9)
+    assert its > 0
+    L2 = CO.CbfLoopC(xyz, rpy, CO.cbf_params(Kcbf, umax, 0.1, 1.0, x_obs, obs_r))
+    got2, st2, _, _ = L2.run(P, steps, threads=3)
+    np.testing.assert_array_equal(got2, got)
+    np.testing.assert_array_equal(st2, st)
