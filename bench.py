@@ -566,6 +566,36 @@ def cpu_baseline_c4(budget_s=8.0, E=2, D=16, scene="under"):
                       f"(dense 216-row G per env + exact active-set QP), {nfb} infeasible env-steps"}
 
 
+def cpu_baseline_c4_c_port(scene="under", D=16):
+    """The C4 loop on the plain-C restatement (oracle/c_oracle.c: dense 312-row G per env, exact dual active-set QP, ThrustOmega low
+    level, DYN step; float64), OpenMP over the envs on every host core of this GPU's share and on one core.  Bounded samples."""
+    from oracle import c_oracle as CO
+    from oracle import np_oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    x_obs, obs_r = c4_spheres(scene)
+    b = CO.cbf_params(O.place_poles_chain([-2.2, -2.4]), [O.CF2P.MAX_THRUST, 10.0, 10.0, 10.0], 0.1, 1.0, x_obs, obs_r)
+    out = {}
+    for tag, thr, E, steps in (("one_core", 1, 64, 200), ("all", cores, 64 * cores, 300)):
+        xyz, rpy, P = c4_inputs(E, D, 123)
+        CO.CbfLoopC(xyz[:cores], rpy[:cores], b).run(P[:cores], 2, threads=thr)      # thread pool and thread-local scratch up
+        L = CO.CbfLoopC(xyz, rpy, b)
+        L.run(P, 20, threads=thr)                                                    # into the window the bench times (steps 20 ...)
+        t0 = time.perf_counter()
+        obs, st, its, used = L.run(P, steps, t0=0.2, threads=thr)
+        el = time.perf_counter() - t0
+        out[tag] = {"value": E * D * steps / el, "unit": "drone-steps/s", "cores": int(used), "kind": "port",
+                    "sample": f"plain-C float64 restatement of the C4 loop (oracle/c_oracle.c, '{scene}' scene): {E} envs x {D} drones x {steps} "
+                              f"control steps in {el:.2f} s on {int(used)} thread(s); {int(st.sum())} infeasible env-steps, {its / (E * steps):.2f} "
+                              "active-set iterations per env-step", "finite": bool(np.isfinite(obs).all())}
+    res = dict(out["all"])
+    res["one_core"] = out["one_core"]
+    return res
+
+
 def cpu_baseline_c1(budget_s=6.0):
     """SURVEY 8d's CPU shape for BASELINE configs[0]: 2 drones hovering (MultiDroneExample.py), pyb = ctrl = 240 Hz x 10 s = 2400 control
     steps, the oracle's DSLPID + DYN step in the reference's per-drone loop shape, one core."""
@@ -1138,11 +1168,23 @@ def main(argv=None):
                 line["cpu_baseline"][key] = fn(min(8.0, args.cpu_budget / 2))
             except Exception as exc:
                 line["cpu_baseline"][key] = {"error": str(exc)}
+        try:                                   # the C4 loop's strongest CPU port beside the NumPy one (numpy_oracle inside it)
+            c4c = cpu_baseline_c4_c_port("under")
+            c4c["numpy_oracle"] = line["cpu_baseline"]["c4"]
+            line["cpu_baseline"]["c4"] = c4c
+        except Exception as exc:
+            if isinstance(line["cpu_baseline"].get("c4"), dict):
+                line["cpu_baseline"]["c4"]["c_port_error"] = str(exc)
         if isinstance(line.get("configs_4_c4"), dict):
             line["configs_4_c4"]["cpu_baseline"] = line["cpu_baseline"]["c4"]
     elif rank == 0 and world == 1 and not args.no_cpu_baseline and c4:
         try:
-            line["cpu_baseline"] = cpu_baseline_c4(args.cpu_budget, scene=args.c4_scene)
+            np_c4 = cpu_baseline_c4(args.cpu_budget, scene=args.c4_scene)
+            try:
+                line["cpu_baseline"] = cpu_baseline_c4_c_port(args.c4_scene)
+                line["cpu_baseline"]["numpy_oracle"] = np_c4
+            except Exception as exc:
+                line["cpu_baseline"] = dict(np_c4, c_port_error=str(exc))
         except Exception as exc:
             line["cpu_baseline"] = {"error": str(exc)}
     elif rank == 0:
