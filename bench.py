@@ -579,7 +579,7 @@ def cpu_baseline_c4_c_port(scene="under", D=16):
     x_obs, obs_r = c4_spheres(scene)
     b = CO.cbf_params(O.place_poles_chain([-2.2, -2.4]), [O.CF2P.MAX_THRUST, 10.0, 10.0, 10.0], 0.1, 1.0, x_obs, obs_r)
     out = {}
-    for tag, thr, E, steps in (("one_core", 1, 64, 200), ("all", cores, 64 * cores, 300)):
+    for tag, thr, E, steps in (("one_core", 1, 64, 200), ("all", cores, 64 * cores, 200)):
         xyz, rpy, P = c4_inputs(E, D, 123)
         CO.CbfLoopC(xyz[:cores], rpy[:cores], b).run(P[:cores], 2, threads=thr)      # thread pool and thread-local scratch up
         L = CO.CbfLoopC(xyz, rpy, b)
