@@ -1114,3 +1114,38 @@ def test_fused_loop_f64_matches_the_plain_c_oracle_1000_steps(mds):
         got = obs.double().cpu().numpy().reshape(-1, 20)
         assert np.abs(got[:, :16] - ref[:, :16]).max() < tol, dtype
         env.close()
+
+
+@pytest.mark.parametrize("E,D,phase,name", [(4096, 4, "c2", "C2"), (65536, 8, "c3", "C3")])
+def test_baseline_configs_2_and_3_at_full_size_every_drone_against_the_c_oracle(mds, E, D, phase, name):
+    """BASELINE configs 2 and 3 at their FULL size (4 096 x 4 and 65 536 x 8 drones), T = 1000 control steps, fp32: every
+    drone's final observation against the plain-C float64 oracle (oracle/c_oracle.c on the host cores: 0.5 G drone-steps for C3) --
+    north_star's 1e-5 on the 13 state components of all 524 288 drones, not of a sample -- through the C rollout loop the bench times
+    (two half-shard chains at C3) and, on a 1/16 slice, the 50-steps-per-launch kernel."""
+    from oracle import c_oracle as CO
+    steps = 1000
+    xyz, rpy, P = H.c2_setup(E, D, seed=1000, phase=phase)      # bench.py's generator and seed
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    ref, _ = CO.AviaryC(xyz.reshape(-1, 3), rpy.reshape(-1, 3), 100, 100).geometric_loop(P.reshape(-1, 7), steps, threads=threads)
+    env = make_env(mds, E, D, xyz, rpy, "float32")
+    env.set_trajectories(P)
+    env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype, device=env.device))
+    obs = env.rollout_geometric(0.0, steps, want_obs=True, obs_every_step=True)
+    got = obs.double().cpu().numpy().reshape(-1, 20)
+    err = np.abs(got[:, :16] - ref[:, :16])
+    rel_rpm = np.abs(got[:, 16:] / ref[:, 16:] - 1).max()
+    print(f"[{name} full size vs C oracle] {E * D} drones x {steps} steps: max |state err| {err.max():.3e} (mean {err.mean():.1e}), rpm rel {rel_rpm:.1e}")
+    assert err.max() < 1e-5 and rel_rpm < 1e-5
+    env.close()
+    Es = E // 16
+    env = make_env(mds, Es, D, xyz[:Es], rpy[:Es], "float32")
+    env.set_trajectories(P[:Es])
+    env.step(mds.torch.zeros((Es, D, 4), dtype=env.dtype, device=env.device))
+    t = 0.0
+    for _ in range(steps // 50):
+        last = env.rollout_geometric_fused(t, 50)
+        last = last[0] if isinstance(last, tuple) else last
+        t += 50 * env.CTRL_TIMESTEP
+    g2 = last.double().cpu().numpy().reshape(-1, 20)
+    assert np.abs(g2[:, :16] - ref[:Es * D, :16]).max() < 1e-5
+    env.close()
