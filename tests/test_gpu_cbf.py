@@ -961,9 +961,9 @@ def test_cbf_persistent_rollout_can_be_captured_into_a_hip_graph(mds):
         np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("dtype,tol,z,steps", [("float64", 1e-10, -3.0, 220), ("float32", 1e-5, -3.0, 220), ("float64", 1e-7, -3.0, 1000),
-                                                ("float64", 1e-5, 0.5, 220)])
-def test_c4_under_scene_512_envs_against_the_c_oracle_at_every_step(mds, dtype, tol, z, steps):
+@pytest.mark.parametrize("dtype,tol,z,steps,E", [("float64", 1e-10, -3.0, 220, 512), ("float32", 1e-5, -3.0, 220, 512), ("float64", 1e-7, -3.0, 1000, 512),
+                                                  ("float64", 1e-5, 0.5, 220, 512), ("float32", 1e-5, -3.0, 220, 16384)])
+def test_c4_under_scene_512_envs_against_the_c_oracle_at_every_step(mds, dtype, tol, z, steps, E):
     """The C4 headline scene on 512 envs of the bench's generator (16 drones, four spheres at z = -3) over the bench window, against the
     plain-C restatement (oracle/c_oracle.c: a second checker, fast enough for 1.8 M drone-steps): the persistent kernel's per-env
     statuses equal the oracle's at EVERY one of the 220 steps (all 0 over the window: the unique-minimiser branch), the state at step
@@ -971,7 +971,7 @@ def test_c4_under_scene_512_envs_against_the_c_oracle_at_every_step(mds, dtype, 
     most envs: 34 k infeasible env-steps, every status equal -- and on SURVEY 8d's `level` scene (z = 0.5: 23 k infeasible env-steps in
     the window, every status equal, the chaotic loop's state within 1e-5; measured 1.1e-14 / 2.7e-6 / 1.6e-10 / 1.7e-7)."""
     from oracle import c_oracle as CO
-    E, D = 512, 16
+    D = 16                                                      # E = 16 384: BASELINE config 4 at its FULL size, every env, every step
     xyz, rpy, P = H.c2_setup(E, D, seed=1000, phase="c3")       # bench.py's generator and seed
     P[..., 4] = 0.5 + 0.3 * np.arange(D)
     xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
@@ -982,7 +982,7 @@ def test_c4_under_scene_512_envs_against_the_c_oracle_at_every_step(mds, dtype, 
     env.set_trajectories(P)
     cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2, cbf_poles=np.array([-2.2, -2.4]))
     trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
-    ref, rst, its, _ = CO.CbfLoopC(xyz, rpy, CO.cbf_params(cbf.Kcbf.reshape(-1), cbf.umax, 0.1, 1.0, x_obs, obs_r)).run(P, steps, threads=8)
+    ref, rst, its, _ = CO.CbfLoopC(xyz, rpy, CO.cbf_params(cbf.Kcbf.reshape(-1), cbf.umax, 0.1, 1.0, x_obs, obs_r)).run(P, steps, threads=max(1, min(16, len(os.sched_getaffinity(0)))))
     assert its > 0
     if z < 0 and steps == 220:
         assert rst[20:].sum() == 0                              # the headline scene: feasible over the whole bench window
@@ -993,7 +993,7 @@ def test_c4_under_scene_512_envs_against_the_c_oracle_at_every_step(mds, dtype, 
     obs, _ = env.rollout_cbf_geometric_fused(0.0, steps, trk, x_obs, obs_r, steps_per_launch=44, status_log=slog)
     got_st = slog.cpu().numpy()
     bad_envs = np.unique(np.nonzero(got_st != rst)[1])
-    print(f"[c4 vs C oracle] {dtype} z={z} steps={steps}: envs with any status difference {bad_envs.size} of {E}, infeasible env-steps {int(rst.sum())}")
+    print(f"[c4 vs C oracle] {dtype} z={z} steps={steps} E={E}: envs with any status difference {bad_envs.size} of {E}, infeasible env-steps {int(rst.sum())}")
     np.testing.assert_array_equal(got_st, rst)
     got = obs.double().cpu().numpy().reshape(E, D, 20)
     err = np.abs(got[..., :16] - ref[..., :16]).max()
