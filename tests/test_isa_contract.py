@@ -70,3 +70,21 @@ def test_persistent_cbf_kernel_keeps_its_step_loop_free_of_scratch(isa):
     # in the step loop except the last-step-only stores of the state / RPM planes
     late = ops[bars[1]:]
     assert len([o for o in late if o.startswith("global_load") and ", off" in o and "s[" not in o]) <= 2
+
+
+def test_compare_models_kernel_streams_through_lds_with_full_occupancy(isa):
+    """k_compare_models<float, float> (simulations/CompareModels.py:48-56 as one launch): HBM-bound streaming -- 8 waves per SIMD
+    (<= 64 VGPRs, 20 KiB of LDS per 256-thread workgroup = 8 workgroups per CU), no scratch, no workgroup barrier (wave-scope staging),
+    rows in and out of memory as 16-byte chunks only, the dense 12 x 12 / 12 x 4 model matrices read as scalar operands (s_load), no MFMA."""
+    name = next(m.group(1) for m in re.finditer(r"\.name:\s+(_ZN3mds16k_compare_modelsIffEE\S+)", isa))
+    meta = isa[isa.index("amdhsa.kernels:"):]
+    blk = next(b for b in meta.split("\n  - ") if re.search(r"\.name:\s+" + re.escape(name) + r"\n", b))
+    assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 64
+    assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0
+    assert int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk).group(1)) == 256 * 20 * 4
+    ops = kernel_ops(isa, name)
+    assert not [o for o in ops if "mfma" in o or o.startswith("s_barrier") or o.startswith("scratch_")]
+    mem = [o for o in ops if o.startswith(("global_load", "global_store"))]
+    assert mem and all(o.startswith(("global_load_dwordx4", "global_store_dwordx4")) for o in mem), mem
+    assert len([o for o in ops if o.startswith("s_load_dwordx")]) >= 12          # 193 matrix / constant words through the scalar path
+    assert len([o for o in ops if o.startswith("ds_read_b128")]) >= 5 and len([o for o in ops if o.startswith("ds_write_b128")]) >= 5
