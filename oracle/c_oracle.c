@@ -309,6 +309,9 @@ void co_geometric_compute(const co_consts* c, int n, const double* obs, const do
 }
 /* env.step(action): st [n,20] in place, obs [n,20] out */
 void co_step(const co_consts* c, int n, double* st, const double* action, double* obs) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (n >= 4096)
+#endif
   for (int i = 0; i < n; ++i) {
     aviary_step(c, st + (size_t)i * CO_STATE, action + 4 * i);
     pack_obs(st + (size_t)i * CO_STATE, obs + (size_t)i * CO_OBS);

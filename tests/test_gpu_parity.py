@@ -889,6 +889,17 @@ def test_c5_full_size_properties(mds):
     gg = f[idx].double().cpu().numpy().reshape(-1, 20)
     # fp16 storage: 4e-3 m is one unit in the last place of a 5 m coordinate, and the stored state is re-rounded every step
     assert np.abs(gg[:, :3] - oo[:, :3]).max() < 5e-2 and np.abs(gg[:, 10:13] - oo[:, 10:13]).max() < 1e-1
+    # ... and EVERY one of the 524 288 drones against the plain-C oracle on the host cores (the same fp16-rounded commands)
+    from oracle import c_oracle as CO
+    av = CO.AviaryC(xyz.reshape(-1, 3), rpy.reshape(-1, 3), 240, 240)
+    a16 = [a.to(torch.float16).double().cpu().numpy().reshape(-1, 4) for a in acts]
+    for k in range(steps):
+        co = av.step(a16[k % 4])
+    ga = f.double().cpu().numpy().reshape(-1, 20)
+    ep, ev = np.abs(ga[:, :3] - co[:, :3]).max(), np.abs(ga[:, 10:13] - co[:, 10:13]).max()
+    print(f"[C5 full size vs C oracle] {E * D} drones x {steps} steps, fp16 storage: max |pos err| {ep:.2e} m, max |vel err| {ev:.2e} m/s")
+    assert ep < 5e-2 and ev < 1e-1
+    np.testing.assert_allclose(co[np.repeat(idx, D) * D + np.tile(np.arange(D), idx.size)], oo, rtol=0, atol=1e-10)   # the two oracles agree on the sample
 
 
 @pytest.mark.parametrize("name,physics,integrator", [("euler", "DYN", "euler"), ("rk4", "DYN", "rk4"), ("drag", "PYB_DRAG", "euler")])
