@@ -659,3 +659,104 @@ int co_cbf_loop(const co_consts* c, const co_cbf* b, int E, int D, int steps, do
   if (iter_total) *iter_total = total;
   return used;
 }
+
+/* ================================================================================================================================
+ * The scripts' DEFAULT controller (simulations/EnvGeometric.py:32, :425-427, :457): control/lqr/lqr_controller.py:73-113
+ * LQRController.compute on model/linearized.py -- x = obs_to_lin_model(obs) (rpy, ang_v, vel, pos); the error in the goal frame
+ * (euler of R_eq^T R = (roll, pitch, wrapped yaw - yaw_des) away from the gimbal; positions, velocities and rates rotated by R_eq^T,
+ * :92-99); u = -K e, u[0] += M G (:111-112); input_to_action (:113) -- with the wind of :463-467 as a constant world-frame force in
+ * env.step.  K [4,12] is the caller's (the host's continuous ARE, like the reference's constructor).
+ * ================================================================================================================================ */
+static void lqr12_compute(const co_consts* c, const double K[48], const double obs[20], const double des[11], double rpm[4]) {
+  const double yd = des[9], cy = cos(yd), sy = sin(yd);
+  double e[12];
+  e[0] = obs[7];
+  e[1] = obs[8];
+  const double dy = obs[9] - yd;
+  e[2] = atan2(sin(dy), cos(dy));
+  const double dw[3] = {obs[13], obs[14], obs[15] - des[10]};
+  const double dv[3] = {obs[10] - des[3], obs[11] - des[4], obs[12] - des[5]};
+  const double dp[3] = {obs[0] - des[0], obs[1] - des[1], obs[2] - des[2]};
+  const double* src[3] = {dw, dv, dp};
+  for (int b = 0; b < 3; ++b) {
+    e[3 + 3 * b] = cy * src[b][0] + sy * src[b][1];
+    e[4 + 3 * b] = -sy * src[b][0] + cy * src[b][1];
+    e[5 + 3 * b] = src[b][2];
+  }
+  double u[4];
+  for (int r = 0; r < 4; ++r) {
+    double a = 0.0;
+    for (int k = 0; k < 12; ++k) a += K[12 * r + k] * e[k];
+    u[r] = -a;
+  }
+  u[0] += c->M * c->G;
+  input_to_action(c, u, rpm);
+}
+
+/* env.step with a constant world-frame external force (p.applyExternalForce(..., WORLD_FRAME) every control step, :463-467): the same
+ * substep as aviary_step with wind / M added to the acceleration */
+static void aviary_step_wind(const co_consts* c, double st[CO_STATE], const double action[4], const double wind[3]) {
+  double rpm[4];
+  for (int k = 0; k < 4; ++k) rpm[k] = action[k] < 0.0 ? 0.0 : (action[k] > c->MAX_RPM ? c->MAX_RPM : action[k]);
+  double *pos = st, *quat = st + 3, *vel = st + 7, *rates = st + 10, *angv = st + 13;
+  const double dt = c->pyb_dt;
+  for (int s = 0; s < c->substeps; ++s) {
+    double R[9], f[4], zt[4];
+    quat_to_R_bullet(quat, R);
+    for (int k = 0; k < 4; ++k) {
+      f[k] = rpm[k] * rpm[k] * c->KF;
+      zt[k] = rpm[k] * rpm[k] * c->KM;
+    }
+    const double thrust = f[0] + f[1] + f[2] + f[3];
+    double tq[3] = {(f[1] - f[3]) * c->L, (-f[0] + f[2]) * c->L, -zt[0] + zt[1] - zt[2] + zt[3]};
+    double Jw[3], wJw[3];
+    for (int k = 0; k < 3; ++k) Jw[k] = c->J[k] * rates[k];
+    cross3(rates, Jw, wJw);
+    const double fw[3] = {R[2] * thrust + wind[0], R[5] * thrust + wind[1], R[8] * thrust - c->G * c->M + wind[2]};
+    for (int k = 0; k < 3; ++k) {
+      vel[k] += dt * (fw[k] / c->M);
+      rates[k] += dt * ((tq[k] - wJw[k]) / c->J[k]);
+    }
+    for (int k = 0; k < 3; ++k) pos[k] += dt * vel[k];
+    integrate_q(quat, rates, dt);
+    matvec3(R, rates, angv);
+  }
+  for (int k = 0; k < 4; ++k) st[16 + k] = rpm[k];
+}
+
+void co_lqr12_compute(const co_consts* c, int n, const double* K, const double* obs, const double* des, double* rpm) {
+  for (int i = 0; i < n; ++i) lqr12_compute(c, K, obs + 20 * i, des + 11 * i, rpm + 4 * i);
+}
+/* The do_control loop with controllers[0] = 'lqr' and the wind on from the first control step (EnvGeometric.py:431-473): as
+ * co_geometric_loop.  wind [3] (newtons, world frame) or NULL. */
+int co_lqr_loop(const co_consts* c, int n, int steps, double t0, int first_zero_step, const double* P, const double* K, const double* wind,
+                double* st, double* obs_out, int threads) {
+  int used = 1;
+  const double w0[3] = {wind ? wind[0] : 0.0, wind ? wind[1] : 0.0, wind ? wind[2] : 0.0};
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+  {
+#pragma omp single
+    used = omp_get_num_threads();
+  }
+#pragma omp parallel for schedule(static)
+#endif
+  for (int i = 0; i < n; ++i) {
+    double* s = st + (size_t)i * CO_STATE;
+    double obs[CO_OBS], des[11], rpm[4];
+    const double zero[4] = {0.0, 0.0, 0.0, 0.0};
+    if (first_zero_step) aviary_step(c, s, zero);                    /* :431, before the wind is on */
+    pack_obs(s, obs);
+    double t = t0;
+    for (int k = 0; k < steps; ++k) {
+      lemniscate(t, P + 7 * i, des);
+      lqr12_compute(c, K, obs, des, rpm);
+      aviary_step_wind(c, s, rpm, w0);
+      pack_obs(s, obs);
+      t += c->ctrl_dt;
+    }
+    memcpy(obs_out + (size_t)i * CO_OBS, obs, sizeof(obs));
+  }
+  return used;
+}

@@ -74,6 +74,28 @@ class AviaryC:
         return obs, used
 
 
+def lqr_loop(av, P, K, steps, wind=None, t0=0.0, first_zero_step=True, threads=1):
+    """The 'lqr' do_control loop of simulations/EnvGeometric.py on the AviaryC `av`: -> (last observation [n,20], threads used)."""
+    P = np.ascontiguousarray(np.asarray(P, dtype=np.float64).reshape(-1, 7))
+    K = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(4, 12))
+    w = None if wind is None else np.ascontiguousarray(np.asarray(wind, dtype=np.float64).reshape(3))
+    obs = np.zeros((av.n, 20))
+    lib().co_lqr_loop.restype = C.c_int
+    used = lib().co_lqr_loop(C.byref(av.c), C.c_int(av.n), C.c_int(steps), C.c_double(t0), C.c_int(1 if first_zero_step else 0), _dp(P), _dp(K),
+                             None if w is None else _dp(w), _dp(av.st), _dp(obs), C.c_int(threads))
+    return obs, used
+
+
+def lqr12_compute(obs, des, K, c=None):
+    obs = np.ascontiguousarray(np.asarray(obs, dtype=np.float64).reshape(-1, 20))
+    des = np.ascontiguousarray(np.asarray(des, dtype=np.float64).reshape(-1, 11))
+    K = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(4, 12))
+    rpm = np.zeros((obs.shape[0], 4))
+    c = c or consts()
+    lib().co_lqr12_compute(C.byref(c), C.c_int(obs.shape[0]), _dp(K), _dp(obs), _dp(des), _dp(rpm))
+    return rpm
+
+
 def lemniscate(t, P):
     P = np.ascontiguousarray(np.asarray(P, dtype=np.float64).reshape(-1, 7))
     des = np.zeros((P.shape[0], 11))

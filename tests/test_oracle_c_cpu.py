@@ -134,3 +134,22 @@ def test_c_oracle_cbf_loop_equals_numpy_oracle(D, nobs):
     got2, st2, _, _ = L2.run(P, steps, threads=3)
     np.testing.assert_array_equal(got2, got)
     np.testing.assert_array_equal(st2, st)
+
+
+def test_c_oracle_lqr_default_loop_matches_the_reference_fixtures():
+    """The scripts' default controller (LQRController on LinearizedModel) on the C restatement: operator against lqr12.npz (true and
+    'noisy' gains, min-thrust clips included), the loop with wind against closed_loop_lqr_ref_in_loop.npz (reference objects in the loop)."""
+    g = np.load(os.path.join(G, "lqr12.npz"))
+    des = np.zeros((g["obs"].shape[0], 11))
+    des[:, 0:3], des[:, 3:6], des[:, 9], des[:, 10] = g["pos_d"], g["vel_d"], g["yaw_d"], g["om_d"]
+    for tag in ("true", "noisy"):
+        np.testing.assert_allclose(CO.lqr12_compute(g["obs"], des, g["K_" + tag]), g["act_" + tag], rtol=1e-12)
+    f = np.load(os.path.join(G, "closed_loop_lqr_ref_in_loop.npz"))
+    P, every, D = f["params"], int(f["every"]), f["params"].shape[0]
+    av = CO.AviaryC(f["xyz"], np.zeros((D, 3)))
+    t, first = 0.0, True
+    for k in range(1, f["obs_log"].shape[0]):
+        obs, _ = CO.lqr_loop(av, P, f["K"], every, wind=f["wind"], t0=t, first_zero_step=first)
+        first = False
+        t = sum([0.01] * (k * every))
+        np.testing.assert_allclose(obs, f["obs_log"][k], rtol=0, atol=1e-7)
