@@ -590,13 +590,39 @@ static void thrust_omega_low_level(const co_consts* c, const double u[4], const 
 
 /* One control step of one env: st [D,20], pid [D,6], obs [D,20] (current on entry, next on exit), P [D,7].  Returns the status
  * (0 solved, 1 infeasible: modelled fallback) and the solver's iteration count through *iters. */
-static int cbf_env_step(const co_consts* c, const co_cbf* b, int D, double t, const double* P, double* st, double* pid, double* obs, int* iters) {
+/* control/lqr/lqr_omega_controller.py:90-119 LQROmegaController.compute(obs, skip_low_level=True): x = obs_to_lin_model(obs, 9); the error in
+ * the goal frame as lqr12_compute; u = -K e (K [4,9]), u[0] += M G, cap_u: u[0] clipped to [4 * 9440.3^2 KF, MAX_THRUST] -- the nominal
+ * controller simulations/CBFTest.py:290-293 builds by default (controllers[0] = 'lqr') */
+static void lqr_omega_compute(const co_consts* c, const double K[36], const double obs[20], const double des[11], double u[4]) {
+  const double yd = des[9], cy = cos(yd), sy = sin(yd);
+  double e[9];
+  e[0] = obs[7];
+  e[1] = obs[8];
+  const double dy = obs[9] - yd;
+  e[2] = atan2(sin(dy), cos(dy));
+  const double dv[3] = {obs[10] - des[3], obs[11] - des[4], obs[12] - des[5]};
+  const double dp[3] = {obs[0] - des[0], obs[1] - des[1], obs[2] - des[2]};
+  e[3] = cy * dv[0] + sy * dv[1]; e[4] = -sy * dv[0] + cy * dv[1]; e[5] = dv[2];
+  e[6] = cy * dp[0] + sy * dp[1]; e[7] = -sy * dp[0] + cy * dp[1]; e[8] = dp[2];
+  for (int r = 0; r < 4; ++r) {
+    double a = 0.0;
+    for (int k = 0; k < 9; ++k) a += K[9 * r + k] * e[k];
+    u[r] = -a;
+  }
+  u[0] += c->M * c->G;
+  const double lo = 4 * (9440.3 * 9440.3 * c->KF);
+  u[0] = u[0] < lo ? lo : (u[0] > c->MAX_THRUST ? c->MAX_THRUST : u[0]);
+}
+
+static int cbf_env_step(const co_consts* c, const co_cbf* b, int D, double t, const double* P, double* st, double* pid, double* obs, int* iters,
+                        const double* Klqr /* NULL: geometric nominal; [4,9]: LQR-omega nominal */) {
   double x[CO_MAXD * 9], xdes[CO_MAXD * 9], un[CO_MAXN], us[CO_MAXN];
   static __thread double G[CO_MAXM * CO_MAXN], h[CO_MAXM];
   for (int i = 0; i < D; ++i) {
     double des[11], om[4], rpm_unused[4];
     lemniscate(t, P + 7 * i, des);
-    geometric_compute_ex(c, obs + 20 * i, des, rpm_unused, om);
+    if (Klqr) lqr_omega_compute(c, Klqr, obs + 20 * i, des, om);
+    else geometric_compute_ex(c, obs + 20 * i, des, rpm_unused, om);
     un[4 * i] = om[0] - c->M * c->G;                                   /* CBFTest.py:339 */
     un[4 * i + 1] = om[1]; un[4 * i + 2] = om[2]; un[4 * i + 3] = om[3];
     const double* o = obs + 20 * i;                                    /* obs_to_lin_model(obs, 9): rpy, vel, pos */
@@ -628,9 +654,10 @@ int co_qp_project(int n, int m, const double* G, const double* h, double* u_io, 
   return qp_project(n, m, G, h, u_io, iters);
 }
 /* The C4 loop for E envs of D drones: env.step(first action) is the caller's (co_step); st [E*D,20], pid [E*D,6] (zeros at the start),
- * P [E*D,7]; `steps` control steps from t0; status_log [steps,E] (may be NULL), obs_out [E*D,20].  OpenMP over the envs. */
+ * P [E*D,7]; `steps` control steps from t0; status_log [steps,E] (may be NULL), obs_out [E*D,20]; Klqr NULL (geometric nominal) or the
+ * [4,9] gain of the LQR-omega nominal.  OpenMP over the envs. */
 int co_cbf_loop(const co_consts* c, const co_cbf* b, int E, int D, int steps, double t0, const double* P, double* st, double* pid, double* obs_out,
-                int* status_log, long long* iter_total, int threads) {
+                int* status_log, long long* iter_total, int threads, const double* Klqr) {
   if (D > CO_MAXD || b->n_obs > CO_MAXOBS) return -1;
   int used = 1;
   long long total = 0;
@@ -649,7 +676,7 @@ int co_cbf_loop(const co_consts* c, const co_cbf* b, int E, int D, int steps, do
     double t = t0;
     for (int k = 0; k < steps; ++k) {
       int it = 0;
-      const int stt = cbf_env_step(c, b, D, t, P + (size_t)e * D * 7, st + (size_t)e * D * CO_STATE, pid + (size_t)e * D * 6, obs, &it);
+      const int stt = cbf_env_step(c, b, D, t, P + (size_t)e * D * 7, st + (size_t)e * D * CO_STATE, pid + (size_t)e * D * 6, obs, &it, Klqr);
       if (status_log) status_log[(size_t)k * E + e] = stt;
       total += it;
       t += c->ctrl_dt;

@@ -174,15 +174,17 @@ class CbfLoopC:
         self.pid = np.zeros((self.E * self.D, 6))
         self.av.step(np.zeros((self.E * self.D, 4)))                        # env.step(zeros) before the loop (:296-300)
 
-    def run(self, P, steps, t0=0.0, threads=1):
-        """-> (obs [E,D,20], statuses [steps,E], solver iterations in all, threads used)"""
+    def run(self, P, steps, t0=0.0, threads=1, K_lqr_omega=None):
+        """-> (obs [E,D,20], statuses [steps,E], solver iterations in all, threads used).  K_lqr_omega [4,9]: the LQR-omega nominal
+        controller of simulations/CBFTest.py:290-293 instead of the geometric one."""
         P = np.ascontiguousarray(np.asarray(P, dtype=np.float64).reshape(-1, 7))
         obs = np.zeros((self.E * self.D, 20))
         st = np.zeros((steps, self.E), dtype=np.int32)
         tot = C.c_longlong(0)
         lib().co_cbf_loop.restype = C.c_int
         used = lib().co_cbf_loop(C.byref(self.av.c), C.byref(self.b), C.c_int(self.E), C.c_int(self.D), C.c_int(steps), C.c_double(t0), _dp(P),
-                                 _dp(self.av.st), _dp(self.pid), _dp(obs), st.ctypes.data_as(C.POINTER(C.c_int)), C.byref(tot), C.c_int(threads))
+                                 _dp(self.av.st), _dp(self.pid), _dp(obs), st.ctypes.data_as(C.POINTER(C.c_int)), C.byref(tot), C.c_int(threads),
+                                 None if K_lqr_omega is None else _dp(np.ascontiguousarray(np.asarray(K_lqr_omega, dtype=np.float64).reshape(4, 9))))
         if used < 0:
             raise ValueError("env larger than the C oracle's static bounds")
         return obs.reshape(self.E, self.D, 20), st, tot.value, used

@@ -1000,3 +1000,39 @@ def test_c4_under_scene_512_envs_against_the_c_oracle_at_every_step(mds, dtype, 
     print(f"[c4 vs C oracle] max |state error| at step {steps}: {err:.3e}")
     assert err < tol
     env.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-10), ("float32", 1e-5)])
+def test_cbftest_default_nominal_512_envs_against_the_c_oracle_at_every_step(mds, dtype, tol):
+    """simulations/CBFTest.py as it runs by default -- LQROmegaController nominal (:290-293), default CBF poles (-2.2, -2.4, -2.6 -> the
+    first two gains), one sphere at the lemniscate centre (:421-425) -- on 512 envs x 16 drones for 300 control steps against the plain-C
+    oracle: every status of every env at every step through the persistent kernel, every drone's state at the end (measured: 5.7
+    active-set iterations per env-step, 332 infeasible env-steps, all 153 600 statuses equal; state f64 1.2e-14, fp32 9.7e-7)."""
+    from multidronesim_amd.control.lqr.lqr_omega_controller import LQROmegaController
+    from oracle import c_oracle as CO
+    E, D, steps = 512, 16, 300
+    xyz, rpy, P = H.c2_setup(E, D, seed=77, phase="c3", omega=0.5)             # CBFTest.py:418: omega = 0.5
+    P[..., 4] = 0.5 + 0.3 * np.arange(D)
+    xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    x_obs, obs_r = [np.array([[0.0, 0.0, 0.5], [0, 0, 0]])], [0.1]
+    env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                         pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype)
+    env.set_trajectories(P)
+    ctrl = LQROmegaController(env, mds.LinearizedOmegaModel(env), None)
+    env.set_cbf_nominal("lqr_omega")
+    cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2)
+    trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+    ref, rst, its, _ = CO.CbfLoopC(xyz, rpy, CO.cbf_params(cbf.Kcbf.reshape(-1), cbf.umax, 0.1, 1.0, x_obs, obs_r)).run(
+        P, steps, threads=max(1, min(16, len(os.sched_getaffinity(0)))), K_lqr_omega=ctrl.K)
+    env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+    slog = mds.torch.empty((steps, E), dtype=mds.torch.int32, device=env.device)
+    obs, _ = env.rollout_cbf_geometric_fused(0.0, steps, trk, x_obs, obs_r, steps_per_launch=50, status_log=slog)
+    got_st = slog.cpu().numpy()
+    diff_envs = np.unique(np.nonzero(got_st != rst)[1]).size
+    err = np.abs(obs.double().cpu().numpy().reshape(E, D, 20)[..., :16] - ref[..., :16]).max()
+    print(f"[CBFTest default nominal vs C oracle] {dtype}: {int(rst.sum())} infeasible env-steps, {its / (E * steps):.2f} iterations per env-step, "
+          f"envs with any status difference {diff_envs}, max |state err| {err:.3e}")
+    assert its > 0
+    np.testing.assert_array_equal(got_st, rst)
+    assert err < tol
+    env.close()

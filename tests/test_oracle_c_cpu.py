@@ -114,6 +114,21 @@ def test_c_oracle_qp_equals_the_numpy_active_set_and_the_converged_interior_poin
     assert solved >= 30
 
 
+def test_c_oracle_cbf_loop_with_the_lqr_omega_nominal_equals_numpy_oracle():
+    """simulations/CBFTest.py's default nominal controller (LQROmegaController, :290-293) in the loop."""
+    E, D, steps = 3, 8, 150
+    xyz, rpy, P = H.c2_setup(E, D, phase="c3", offset=1.0)
+    P[..., 4] = 0.5 + 0.3 * np.arange(D)
+    xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    x_obs, obs_r = [np.array([[0.3, 0.2, 0.9], [0, 0, 0]])], [0.1]
+    Kcbf, umax = np.array([5.28, 4.6]), np.array([O.CF2P.MAX_THRUST, 10, 10, 10])
+    ref, hist = H.oracle_cbf_closed_loop(xyz, rpy, P, steps, Kcbf, umax, 0.1, 1.0, x_obs, obs_r, nominal="lqr_omega")
+    got, st, its, _ = CO.CbfLoopC(xyz, rpy, CO.cbf_params(Kcbf, umax, 0.1, 1.0, x_obs, obs_r)).run(P, steps, K_lqr_omega=O.lqr_omega_gain(O.CF2P))
+    np.testing.assert_array_equal(st, np.array(hist))
+    assert st.sum() > 50 and its > 500                              # the infeasible branch and many iterations are part of it
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9)
+
+
 @pytest.mark.parametrize("D,nobs", [(8, 1), (16, 4), (4, 0)])
 def test_c_oracle_cbf_loop_equals_numpy_oracle(D, nobs):
     """simulations/CBFTest.py:303-350 on both restatements: statuses equal at every step (infeasible env-steps included), states to 1e-9."""
