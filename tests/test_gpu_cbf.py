@@ -962,7 +962,7 @@ def test_cbf_persistent_rollout_can_be_captured_into_a_hip_graph(mds):
 
 
 @pytest.mark.parametrize("dtype,tol,z,steps,E", [("float64", 1e-10, -3.0, 220, 512), ("float32", 1e-5, -3.0, 220, 512), ("float64", 1e-7, -3.0, 1000, 512),
-                                                  ("float64", 1e-5, 0.5, 220, 512), ("float32", 1e-5, -3.0, 220, 16384)])
+                                                  ("float64", 1e-5, 0.5, 220, 512), ("float32", 1e-5, -3.0, 220, 16384), ("float64", 1e-4, 0.5, 220, 16384)])
 def test_c4_under_scene_512_envs_against_the_c_oracle_at_every_step(mds, dtype, tol, z, steps, E):
     """The C4 headline scene on 512 envs of the bench's generator (16 drones, four spheres at z = -3) over the bench window, against the
     plain-C restatement (oracle/c_oracle.c: a second checker, fast enough for 1.8 M drone-steps): the persistent kernel's per-env
