@@ -6,27 +6,20 @@ import numpy as np
 
 class CrazyflieModel:
     def __init__(self, env, debug=False):
-        self.mass = env.M
-        self.g = env.G
-        self.A = np.zeros((7, 7))
-        self.B = np.zeros((7, 4))
-        self.env = env
-        self.Ahat = np.zeros((7, 7))
-        self.Bhat = np.zeros((7, 4))
+        self.env, self.mass, self.g = env, env.M, env.G
         self.init_matrices()
         if debug:
-            print("A matrix: ")
-            print(self.A)
-            print("B matrix: ")
-            print(self.B)
+            print("A matrix: ", self.A, "B matrix: ", self.B, sep="\n")
 
     def init_matrices(self):
-        self.A[1:4, 4:7] = np.eye(3)
-        self.B[0, -1] = 1
-        self.B[-1, 0] = 1.0 / self.mass
-        self.B[1:3, 1:3] = np.array([[0, self.g], [-self.g, 0]])
-        self.Ahat = self.A.copy()
-        self.Bhat = self.B.copy()
+        """x = [yaw, x, y, z, vx, vy, vz], u = [f, pitch, roll, yaw_rate] (:40-52): positions integrate velocities, yaw integrates the
+        yaw-rate input, vz the thrust; pitch / roll act on the x / y rows through g (the reference's `B[1:3, 1:3] = [[0, g], [-g, 0]]`)."""
+        A, B = np.zeros((7, 7)), np.zeros((7, 4))
+        A[[1, 2, 3], [4, 5, 6]] = 1.0
+        B[0, 3], B[6, 0] = 1.0, 1.0 / self.mass
+        B[1, 2], B[2, 1] = self.g, -self.g
+        self.A, self.B = A, B
+        self.Ahat, self.Bhat = A.copy(), B.copy()
 
     def calc_xdot_from_obs(self, obs):
         return self.calc_xdot(None, None)

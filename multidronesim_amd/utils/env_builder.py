@@ -1,12 +1,14 @@
-"""utils/env_builder.py of the reference: ``Environment(G, M, MAX_THRUST, CTRL_TIMESTEP, DRONE_MODEL)`` -- the plain-attribute stand-in
-for an env the reference builds from a yaml file (:4-10).  Host data only."""
+"""utils/env_builder.py of the reference (:4-10): ``Environment(G, M, MAX_THRUST, CTRL_TIMESTEP, DRONE_MODEL)``, the plain-attribute
+stand-in for an env that the reference fills from a yaml file and hands to its models and controllers.  Host data only."""
+from dataclasses import dataclass
+
 from .enums import DroneModel
 
 
+@dataclass
 class Environment:
-    def __init__(self, G, M, MAX_THRUST, CTRL_TIMESTEP, DRONE_MODEL=DroneModel.CF2X):
-        self.G = G
-        self.M = M
-        self.MAX_THRUST = MAX_THRUST
-        self.CTRL_TIMESTEP = CTRL_TIMESTEP
-        self.DRONE_MODEL = DRONE_MODEL
+    G: float
+    M: float
+    MAX_THRUST: float
+    CTRL_TIMESTEP: float
+    DRONE_MODEL: DroneModel = DroneModel.CF2X
