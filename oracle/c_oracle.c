@@ -367,12 +367,13 @@ int co_geometric_loop(const co_consts* c, int n, int steps, double t0, int first
 #define CO_MAXD 16
 #define CO_MAXOBS 8
 #define CO_MAXN (4 * CO_MAXD)
-#define CO_MAXM (CO_MAXD * (CO_MAXD - 1) / 2 + 8 * CO_MAXD + CO_MAXD * CO_MAXOBS)
+#define CO_MAXM (CO_MAXD * (CO_MAXD - 1) / 2 + 10 * CO_MAXD + CO_MAXD * CO_MAXOBS)
 
 typedef struct {
-  double Kcbf[2], umax[4], safety_radius, zscale;       /* cbf/cbf.py:119-124, :566-572; DroneCBF(safety_radius, zscale) */
-  int n_obs;
+  double Kcbf[3], umax[4], safety_radius, zscale;       /* cbf/cbf.py:119-124, :566-572; DroneCBF(safety_radius, zscale); Kcbf[2]: order 3 only */
+  int n_obs, order;                                     /* order 2 (simulations/CBFTest.py) or 3 (CBFTestOrd3.py) */
   double obs_xyz[CO_MAXOBS][3], obs_r[CO_MAXOBS];       /* x_obs_list[j][0], obs_r_list[j] (simulations/CBFTest.py:421-425) */
+  double Fmin, Fmax;                                    /* order 3: thrust-state box, -M G and MAX_THRUST (cbf/cbf.py:564-565) */
 } co_cbf;
 
 int co_sizeof_cbf(void) { return (int)sizeof(co_cbf); }
@@ -785,5 +786,162 @@ int co_lqr_loop(const co_consts* c, int n, int steps, double t0, int first_zero_
     }
     memcpy(obs_out + (size_t)i * CO_OBS, obs, sizeof(obs));
   }
+  return used;
+}
+
+/* ================================================================================================================================
+ * The order-3 loop (simulations/CBFTestOrd3.py:306-352): LQRYankOmegaController nominal (control/lqr/lqr_YO_controller.py:99-124) on the
+ * 10-state x = obs_to_lin_model(obs, 10) = [rpy, F = calc_z_thrust(obs), vel, pos]; u_hat = (yank - M G, w) (:341: the M G is subtracted
+ * from the YANK and never added back, :350 -- kept); xdes = [0, 0, yaw, G M, vel, pos]; order-3 ECBF rows (cbf/cbf.py:135-283 with the
+ * slot quirk of custom_hdots :158-169, closed form of SURVEY.md 3.6, pinned by cbf_rows_o3.npz) incl. the thrust-state box rows with
+ * their column quirk (:446-464: column 4 i + 3); YankOmegaController low level (control/low_level/yank_omega_ctrl.py:39-55:
+ * thrust = calc_z_thrust(obs) + yank * dt, then the ThrustOmega PID).
+ * ================================================================================================================================ */
+static void cbf_pair_o3(const double* xi, const double* xj, const double* xdi, const double* xdj, double Ds, double zscale, const double K[3],
+                        double m, double g, double* hij, double Lg[4]) {
+  const double c4 = zscale * zscale * zscale * zscale;
+  const double ex = xi[7] - xj[7], ey = xi[8] - xj[8], ez = xi[9] - xj[9];
+  const double s = ex * ex + ey * ey, ezc = ez / zscale;
+  const double h = s * s + ezc * ezc * ezc * ezc - Ds * Ds * Ds * Ds;
+  const double gx = 4 * ex * s, gy = 4 * ey * s, gz = 4 * ez * ez * ez / c4;
+  const double Hxx = 12 * ex * ex + 4 * ey * ey, Hxy = 8 * ex * ey, Hyy = 4 * ex * ex + 12 * ey * ey, Hzz = 12 * ez * ez / c4;
+  double d[10];
+  for (int k = 0; k < 10; ++k) d[k] = (xi[k] - xdi[k]) - (xj[k] - xdj[k]);
+  const double dr = d[0], dp = d[1], dF = d[3], dvx = d[4], dvy = d[5], dvz = d[6];
+  const double dax = g * dp, day = -g * dr, daz = dF / m;
+  const double hdot = gx * dvx + gy * dvy + gz * dvz;
+  const double w0 = dF / m, w1 = dvx, w2 = dvy;                    /* custom_hdots i == 2: slots 6, 7, 8 of the 10-state (quirk kept) */
+  const double hddot_ref = g * (gy * dp - gz * dr) + (Hxx * w0 * w0 + 2 * Hxy * w0 * w1 + Hyy * w1 * w1 + Hzz * w2 * w2);
+  const double Hdv_da = Hxx * dvx * dax + Hxy * (dvx * day + dvy * dax) + Hyy * dvy * day + Hzz * dvz * daz;
+  const double T3 = 24 * ex * dvx * dvx * dvx + 24 * ey * dvx * dvx * dvy + 24 * ex * dvx * dvy * dvy + 24 * ey * dvy * dvy * dvy +
+                    (24 * ez / c4) * dvz * dvz * dvz;
+  *hij = K[0] * h + K[1] * hdot + K[2] * hddot_ref + (3 * Hdv_da + T3);
+  Lg[0] = gz / m; Lg[1] = -g * gy; Lg[2] = g * gx; Lg[3] = 0.0;
+}
+
+static int cbf_rows_o3(const co_consts* c, const co_cbf* b, int D, const double* x, const double* xdes, double* G, double* h) {
+  const int n = 4 * D;
+  int m = 0;
+  for (int i = 0; i < D - 1; ++i)
+    for (int j = i + 1; j < D; ++j) {
+      double hij, lg[4];
+      cbf_pair_o3(x + 10 * i, x + 10 * j, xdes + 10 * i, xdes + 10 * j, 2 * b->safety_radius, b->zscale, b->Kcbf, c->M, c->G, &hij, lg);
+      double* row = G + (size_t)m * n;
+      memset(row, 0, n * sizeof(double));
+      for (int k = 0; k < 4; ++k) { row[4 * i + k] = -lg[k]; row[4 * j + k] = lg[k]; }
+      h[m++] = hij;
+    }
+  for (int sgn = 0; sgn < 2; ++sgn)
+    for (int k = 0; k < n; ++k) {
+      double* row = G + (size_t)m * n;
+      memset(row, 0, n * sizeof(double));
+      row[k] = sgn ? -1.0 : 1.0;
+      h[m++] = b->umax[k & 3];
+    }
+  for (int i = 0; i < D; ++i)                                          /* thrust-state box (:446-464), column 4 i + 3 (quirk) */
+    for (int sgn = 0; sgn < 2; ++sgn) {
+      double* row = G + (size_t)m * n;
+      memset(row, 0, n * sizeof(double));
+      row[4 * i + 3] = sgn ? -1.0 : 1.0;
+      h[m++] = sgn ? b->Kcbf[2] * (x[10 * i + 3] - b->Fmin) : b->Kcbf[2] * (b->Fmax - x[10 * i + 3]);
+    }
+  for (int i = 0; i < D; ++i)
+    for (int j = 0; j < b->n_obs; ++j) {
+      double xo[10] = {0, 0, 0, 0, 0, 0, 0, b->obs_xyz[j][0], b->obs_xyz[j][1], b->obs_xyz[j][2]};
+      double hij, lg[4];
+      cbf_pair_o3(x + 10 * i, xo, xdes + 10 * i, xo, b->safety_radius + b->obs_r[j], b->zscale, b->Kcbf, c->M, c->G, &hij, lg);
+      double* row = G + (size_t)m * n;
+      memset(row, 0, n * sizeof(double));
+      for (int k = 0; k < 4; ++k) row[4 * i + k] = -lg[k];
+      h[m++] = hij;
+    }
+  return m;
+}
+
+static void lqr_yank_omega_compute(const co_consts* c, const double K[40], const double x[10], const double des[11], double u[4]) {
+  const double yd = des[9], cy = cos(yd), sy = sin(yd);
+  double e[10];
+  e[0] = x[0];
+  e[1] = x[1];
+  const double dy = x[2] - yd;
+  e[2] = atan2(sin(dy), cos(dy));
+  e[3] = x[3] - c->M * c->G;
+  const double dv[3] = {x[4] - des[3], x[5] - des[4], x[6] - des[5]};
+  const double dp[3] = {x[7] - des[0], x[8] - des[1], x[9] - des[2]};
+  e[4] = cy * dv[0] + sy * dv[1]; e[5] = -sy * dv[0] + cy * dv[1]; e[6] = dv[2];
+  e[7] = cy * dp[0] + sy * dp[1]; e[8] = -sy * dp[0] + cy * dp[1]; e[9] = dp[2];
+  for (int r = 0; r < 4; ++r) {
+    double a = 0.0;
+    for (int k = 0; k < 10; ++k) a += K[10 * r + k] * e[k];
+    u[r] = -a;
+  }
+}
+
+static int cbf3_env_step(const co_consts* c, const co_cbf* b, int D, double t, const double* P, double* st, double* pid, double* obs, int* iters,
+                         const double* Kyo) {
+  double x[CO_MAXD * 10], xdes[CO_MAXD * 10], un[CO_MAXN], us[CO_MAXN];
+  static __thread double G[CO_MAXM * CO_MAXN], h[CO_MAXM];
+  for (int i = 0; i < D; ++i) {
+    double des[11];
+    const double* o = obs + 20 * i;
+    lemniscate(t, P + 7 * i, des);
+    double* xi = x + 10 * i;                                           /* obs_to_lin_model(obs, 10): rpy, F = KF sum rpm^2, vel, pos */
+    xi[0] = o[7]; xi[1] = o[8]; xi[2] = o[9];
+    xi[3] = c->KF * (o[16] * o[16] + o[17] * o[17] + o[18] * o[18] + o[19] * o[19]);
+    xi[4] = o[10]; xi[5] = o[11]; xi[6] = o[12]; xi[7] = o[0]; xi[8] = o[1]; xi[9] = o[2];
+    lqr_yank_omega_compute(c, Kyo, xi, des, un + 4 * i);
+    un[4 * i] -= c->M * c->G;                                          /* CBFTestOrd3.py:341 */
+    double* xd = xdes + 10 * i;                                        /* [0, 0, yaw, G M, vel, pos] */
+    xd[0] = 0.0; xd[1] = 0.0; xd[2] = des[9]; xd[3] = c->G * c->M; xd[4] = des[3]; xd[5] = des[4]; xd[6] = des[5]; xd[7] = des[0]; xd[8] = des[1];
+    xd[9] = des[2];
+  }
+  const int n = 4 * D, m = cbf_rows_o3(c, b, D, x, xdes, G, h);
+  memcpy(us, un, n * sizeof(double));
+  const int ok = qp_project(n, m, G, h, us, iters);
+  if (!ok) memcpy(us, un, n * sizeof(double));
+  for (int i = 0; i < D; ++i) {
+    const double thrust = x[10 * i + 3] + us[4 * i] * c->ctrl_dt;      /* yank2thrust (yank_omega_ctrl.py:49-53); nothing added back (:350) */
+    const double u[4] = {thrust, us[4 * i + 1], us[4 * i + 2], us[4 * i + 3]};
+    double rpm[4];
+    thrust_omega_low_level(c, u, obs + 20 * i, c->ctrl_dt, pid + 6 * i, rpm);
+    aviary_step(c, st + (size_t)i * CO_STATE, rpm);
+    pack_obs(st + (size_t)i * CO_STATE, obs + 20 * i);
+  }
+  return ok ? 0 : 1;
+}
+
+int co_cbf_rows3(const co_consts* c, const co_cbf* b, int D, const double* x, const double* xdes, double* G, double* h) {
+  return cbf_rows_o3(c, b, D, x, xdes, G, h);
+}
+/* as co_cbf_loop, order 3: Kyo [4,10] the yank-omega LQR gain; the caller has stepped the env once with hover RPM (the thrust state is
+ * read from the observation's RPM echo) */
+int co_cbf3_loop(const co_consts* c, const co_cbf* b, int E, int D, int steps, double t0, const double* P, double* st, double* pid, double* obs_out,
+                 int* status_log, long long* iter_total, int threads, const double* Kyo) {
+  if (D > CO_MAXD || b->n_obs > CO_MAXOBS || !Kyo) return -1;
+  int used = 1;
+  long long total = 0;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+  {
+#pragma omp single
+    used = omp_get_num_threads();
+  }
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+#endif
+  for (int e = 0; e < E; ++e) {
+    double obs[CO_MAXD * 20];
+    for (int i = 0; i < D; ++i) pack_obs(st + (size_t)(e * D + i) * CO_STATE, obs + 20 * i);
+    double t = t0;
+    for (int k = 0; k < steps; ++k) {
+      int it = 0;
+      const int stt = cbf3_env_step(c, b, D, t, P + (size_t)e * D * 7, st + (size_t)e * D * CO_STATE, pid + (size_t)e * D * 6, obs, &it, Kyo);
+      if (status_log) status_log[(size_t)k * E + e] = stt;
+      total += it;
+      t += c->ctrl_dt;
+    }
+    memcpy(obs_out + (size_t)e * D * 20, obs, (size_t)D * 20 * sizeof(double));
+  }
+  if (iter_total) *iter_total = total;
   return used;
 }

@@ -117,15 +117,21 @@ CO_MAXOBS = 8
 
 
 class Cbf(C.Structure):
-    _fields_ = [("Kcbf", C.c_double * 2), ("umax", C.c_double * 4), ("safety_radius", C.c_double), ("zscale", C.c_double), ("n_obs", C.c_int),
-                ("obs_xyz", (C.c_double * 3) * CO_MAXOBS), ("obs_r", C.c_double * CO_MAXOBS)]
+    _fields_ = [("Kcbf", C.c_double * 3), ("umax", C.c_double * 4), ("safety_radius", C.c_double), ("zscale", C.c_double), ("n_obs", C.c_int),
+                ("order", C.c_int), ("obs_xyz", (C.c_double * 3) * CO_MAXOBS), ("obs_r", C.c_double * CO_MAXOBS), ("Fmin", C.c_double),
+                ("Fmax", C.c_double)]
 
 
-def cbf_params(Kcbf, umax, safety_radius, zscale, x_obs=None, obs_r=None):
+def cbf_params(Kcbf, umax, safety_radius, zscale, x_obs=None, obs_r=None, order=2, Fmin=None, Fmax=None):
     """x_obs as the reference passes it (simulations/CBFTest.py:421-425): one (order, 3) state per sphere, position in row 0."""
     assert lib().co_sizeof_cbf() == C.sizeof(Cbf), "co_cbf layout"
     b = Cbf()
-    b.Kcbf[:] = [float(k) for k in np.asarray(Kcbf).reshape(-1)[:2]]
+    kk = [float(k) for k in np.asarray(Kcbf).reshape(-1)[:3]]
+    b.Kcbf[:] = kk + [0.0] * (3 - len(kk))
+    b.order = int(order)
+    cc = consts()
+    b.Fmin = -cc.M * cc.G if Fmin is None else float(Fmin)
+    b.Fmax = cc.MAX_THRUST if Fmax is None else float(Fmax)
     b.umax[:] = [float(k) for k in np.asarray(umax).reshape(-1)[:4]]
     b.safety_radius, b.zscale = float(safety_radius), float(zscale)
     n = 0 if obs_r is None else len(obs_r)
@@ -139,14 +145,16 @@ def cbf_params(Kcbf, umax, safety_radius, zscale, x_obs=None, obs_r=None):
 
 
 def cbf_rows(x, xdes, b, c=None):
-    """CBF._build_ineq_const for one env: x, xdes [D,9] -> (G [m,4D], h [m]) in the reference's row order."""
-    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, 9))
-    xdes = np.ascontiguousarray(np.asarray(xdes, dtype=np.float64).reshape(-1, 9))
+    """CBF._build_ineq_const for one env: x, xdes [D,9] (order 2) or [D,10] (order 3) -> (G [m,4D], h [m]) in the reference's row order."""
+    xd = 9 if b.order == 2 else 10
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, xd))
+    xdes = np.ascontiguousarray(np.asarray(xdes, dtype=np.float64).reshape(-1, xd))
     D = x.shape[0]
-    mmax = D * (D - 1) // 2 + 8 * D + D * b.n_obs
+    mmax = D * (D - 1) // 2 + 8 * D + D * b.n_obs + (2 * D if b.order == 3 else 0)
     G, h = np.zeros((mmax, 4 * D)), np.zeros(mmax)
     c = c or consts()
-    m = lib().co_cbf_rows(C.byref(c), C.byref(b), C.c_int(D), _dp(x), _dp(xdes), _dp(G), _dp(h))
+    fn = lib().co_cbf_rows if b.order == 2 else lib().co_cbf_rows3
+    m = fn(C.byref(c), C.byref(b), C.c_int(D), _dp(x), _dp(xdes), _dp(G), _dp(h))
     assert m == mmax
     return G, h
 
@@ -166,13 +174,27 @@ def qp_project(uhat, G, h):
 class CbfLoopC:
     """simulations/CBFTest.py:303-350 for E envs of D drones on the C restatement (geometric nominal, order-2 filter, ThrustOmega low level)."""
 
-    def __init__(self, xyz, rpy, b, pyb_freq=100, ctrl_freq=100):
+    def __init__(self, xyz, rpy, b, pyb_freq=100, ctrl_freq=100, first_rpm=0.0):
         xyz = np.asarray(xyz, dtype=np.float64)
         self.E, self.D = xyz.shape[0], xyz.shape[1]
         self.av = AviaryC(xyz.reshape(-1, 3), np.asarray(rpy, dtype=np.float64).reshape(-1, 3), pyb_freq, ctrl_freq)
         self.b = b
         self.pid = np.zeros((self.E * self.D, 6))
-        self.av.step(np.zeros((self.E * self.D, 4)))                        # env.step(zeros) before the loop (:296-300)
+        self.av.step(np.full((self.E * self.D, 4), float(first_rpm)))       # env.step(zeros) before the loop (:296-300); order 3: hover RPM
+
+    def run3(self, P, steps, K_yank_omega, t0=0.0, threads=1):
+        """The order-3 loop (simulations/CBFTestOrd3.py:306-352) -> (obs [E,D,20], statuses [steps,E], solver iterations, threads used)."""
+        P = np.ascontiguousarray(np.asarray(P, dtype=np.float64).reshape(-1, 7))
+        K = np.ascontiguousarray(np.asarray(K_yank_omega, dtype=np.float64).reshape(4, 10))
+        obs = np.zeros((self.E * self.D, 20))
+        st = np.zeros((steps, self.E), dtype=np.int32)
+        tot = C.c_longlong(0)
+        lib().co_cbf3_loop.restype = C.c_int
+        used = lib().co_cbf3_loop(C.byref(self.av.c), C.byref(self.b), C.c_int(self.E), C.c_int(self.D), C.c_int(steps), C.c_double(t0), _dp(P),
+                                  _dp(self.av.st), _dp(self.pid), _dp(obs), st.ctypes.data_as(C.POINTER(C.c_int)), C.byref(tot), C.c_int(threads), _dp(K))
+        if used < 0:
+            raise ValueError("env larger than the C oracle's static bounds")
+        return obs.reshape(self.E, self.D, 20), st, tot.value, used
 
     def run(self, P, steps, t0=0.0, threads=1, K_lqr_omega=None):
         """-> (obs [E,D,20], statuses [steps,E], solver iterations in all, threads used).  K_lqr_omega [4,9]: the LQR-omega nominal

@@ -168,3 +168,34 @@ def test_c_oracle_lqr_default_loop_matches_the_reference_fixtures():
         first = False
         t = sum([0.01] * (k * every))
         np.testing.assert_allclose(obs, f["obs_log"][k], rtol=0, atol=1e-7)
+
+
+def test_c_oracle_order3_rows_and_loop():
+    """The order-3 (yank / body-rate) path on the C restatement: rows against the reference-minted (G, h) of cbf_rows_o3.npz (incl. the
+    slot quirk of custom_hdots and the column quirk of the thrust-state box), the CBFTestOrd3.py loop against the NumPy oracle."""
+    g = np.load(os.path.join(G, "cbf_rows_o3.npz"))
+    done = 0
+    for k in range(int(g["n_cases"])):
+        x, xd, xo, r, Gr, hr = (g[f"c{k}_{n}"] for n in ("x", "xdes", "xobs", "obsr", "G", "h"))
+        b = CO.cbf_params(g["Kcbf"], g["umax"], float(g["safety_radius"]), float(g["zscale"]), xo if len(r) else None, list(r) if len(r) else None,
+                          order=3, Fmin=float(g["Fmin"]), Fmax=float(g["Fmax"]))
+        Gc, hc = CO.cbf_rows(x, xd, b)
+        assert Gc.shape == Gr.shape
+        np.testing.assert_allclose(Gc, Gr, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(Gr).max()))
+        np.testing.assert_allclose(hc, hr, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(hr).max()))
+        done += 1
+    assert done >= 8
+    E, D, steps = 4, 4, 150
+    xyz, rpy, P = H.c2_setup(E, D, phase="c3", offset=0.0, omega=0.5)
+    xyz[..., 2] = 0.5 + 0.6 * np.arange(D)
+    P[..., 4] = 0.5 + 0.6 * np.arange(D)
+    x_obs, obs_r = [np.array([[0.0, 0.0, -0.3], [0, 0, 0], [0, 0, 0]])], [0.1]
+    c = O.CF2P
+    Kcbf, umax = O.place_poles_chain([-3.0, -3.6, -5.6]), np.array([c.MAX_THRUST / 0.01 / 100, 10, 10, 10])
+    ref, hist = H.oracle_cbf_closed_loop(xyz, rpy, P, steps, Kcbf, umax, 0.125, 2.0, x_obs, obs_r, nominal="lqr_yank_omega", order=3,
+                                         first_rpm=c.HOVER_RPM)
+    L = CO.CbfLoopC(xyz, rpy, CO.cbf_params(Kcbf, umax, 0.125, 2.0, x_obs, obs_r, order=3), first_rpm=c.HOVER_RPM)
+    got, st, its, _ = L.run3(P, steps, O.lqr_yank_omega_gain(c, 0.01))
+    np.testing.assert_array_equal(st, np.array(hist))
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9)
+    assert its > 100
