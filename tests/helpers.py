@@ -125,3 +125,22 @@ def oracle_cbf_closed_loop(xyz, rpy, P, steps, Kcbf, umax, safety_radius, zscale
     if record_at is not None:
         return obs.reshape(E, D, 20), np.array(hist), rec
     return obs.reshape(E, D, 20), np.array(hist)
+
+
+def oracle_threads():
+    """Host threads for the plain-C oracle (oracle/c_oracle.c): this process's CPU share, at most 16 (a GPU box gives one GPU 16 cores)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def full_size_or_slice(E):
+    """The full-size parity tests run the float64 C oracle on every unit of a BASELINE config (up to 0.5 G drone-steps): seconds on the
+    16 host cores of a GPU box.  On a host with fewer than 8 cores they keep the first eighth of the envs instead of taking minutes
+    (and say so): -> (envs to compare, note)."""
+    if oracle_threads() >= 8:
+        return E, ""
+    return max(64, E // 8), f" [only {oracle_threads()} host cores: the first {max(64, E // 8)} of {E} envs]"

@@ -972,6 +972,10 @@ def test_c4_under_scene_512_envs_against_the_c_oracle_at_every_step(mds, dtype, 
     the window, every status equal, the chaotic loop's state within 1e-5; measured 1.1e-14 / 2.7e-6 / 1.6e-10 / 1.7e-7)."""
     from oracle import c_oracle as CO
     D = 16                                                      # E = 16 384: BASELINE config 4 at its FULL size, every env, every step
+    if E > 512:
+        E, note = H.full_size_or_slice(E)                       # (a slice only on a host with few cores: the C oracle runs 58 M drone-steps)
+        if note:
+            print("[c4 vs C oracle]" + note)
     xyz, rpy, P = H.c2_setup(E, D, seed=1000, phase="c3")       # bench.py's generator and seed
     P[..., 4] = 0.5 + 0.3 * np.arange(D)
     xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
@@ -982,7 +986,7 @@ def test_c4_under_scene_512_envs_against_the_c_oracle_at_every_step(mds, dtype, 
     env.set_trajectories(P)
     cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2, cbf_poles=np.array([-2.2, -2.4]))
     trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
-    ref, rst, its, _ = CO.CbfLoopC(xyz, rpy, CO.cbf_params(cbf.Kcbf.reshape(-1), cbf.umax, 0.1, 1.0, x_obs, obs_r)).run(P, steps, threads=max(1, min(16, len(os.sched_getaffinity(0)))))
+    ref, rst, its, _ = CO.CbfLoopC(xyz, rpy, CO.cbf_params(cbf.Kcbf.reshape(-1), cbf.umax, 0.1, 1.0, x_obs, obs_r)).run(P, steps, threads=H.oracle_threads())
     assert its > 0
     if z < 0 and steps == 220:
         assert rst[20:].sum() == 0                              # the headline scene: feasible over the whole bench window
@@ -1023,7 +1027,7 @@ def test_cbftest_default_nominal_512_envs_against_the_c_oracle_at_every_step(mds
     cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2)
     trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
     ref, rst, its, _ = CO.CbfLoopC(xyz, rpy, CO.cbf_params(cbf.Kcbf.reshape(-1), cbf.umax, 0.1, 1.0, x_obs, obs_r)).run(
-        P, steps, threads=max(1, min(16, len(os.sched_getaffinity(0)))), K_lqr_omega=ctrl.K)
+        P, steps, threads=H.oracle_threads(), K_lqr_omega=ctrl.K)
     env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
     slog = mds.torch.empty((steps, E), dtype=mds.torch.int32, device=env.device)
     obs, _ = env.rollout_cbf_geometric_fused(0.0, steps, trk, x_obs, obs_r, steps_per_launch=50, status_log=slog)
@@ -1061,7 +1065,7 @@ def test_order3_loop_256_envs_against_the_c_oracle_at_every_step(mds, dtype, tol
     trk = mds.DroneQPTracker(cbf, order=3, num_robots=D, xdim=10, env=env)
     env.set_cbf_nominal("lqr_yank_omega")
     L = CO.CbfLoopC(xyz, rpy, CO.cbf_params(cbf.Kcbf.reshape(-1), cbf.umax, 0.125, 2.0, x_obs, obs_r, order=3), first_rpm=O.CF2P.HOVER_RPM)
-    ref, rst, its, _ = L.run3(P, steps, ctrl.K, threads=max(1, min(16, len(os.sched_getaffinity(0)))))
+    ref, rst, its, _ = L.run3(P, steps, ctrl.K, threads=H.oracle_threads())
     env.step(mds.torch.full((E, D, 4), O.CF2P.HOVER_RPM, dtype=env.dtype))
     t, hist = 0.0, []
     for k in range(steps):

@@ -436,7 +436,7 @@ def test_default_lqr_loop_at_config2_size_every_drone_against_the_c_oracle(gpu, 
     xyz, rpy, P = H.c2_setup(E, D, seed=1000, phase="c2")
     K = O.lqr12_gain(O.CF2P)
     wind = np.array([wind_force, 0.0, 0.0])
-    ref, _ = CO.lqr_loop(CO.AviaryC(xyz.reshape(-1, 3), rpy.reshape(-1, 3)), P, K, steps, wind=wind, threads=max(1, min(16, len(os.sched_getaffinity(0)))))
+    ref, _ = CO.lqr_loop(CO.AviaryC(xyz.reshape(-1, 3), rpy.reshape(-1, 3)), P, K, steps, wind=wind, threads=H.oracle_threads())
 
     def make():
         env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN, pyb_freq=100,
