@@ -23,30 +23,37 @@ def require_gpu(device_index: int) -> torch.device:
 def default_device_index() -> int:
     """The GPU a handle is created on when the caller names none.  The thread's current torch device when the caller has chosen
     one (torch.cuda.set_device / a device context: anything but device 0), so that helper handles (trajectory evaluation, DSLPID)
-    land beside an env created with an explicit ``device=``; else this rank's own GPU (LOCAL_RANK, one process per GPU) when the
-    process sees several; else device 0.  An env created with an explicit ``device=`` takes precedence over LOCAL_RANK."""
+    land beside an env created with an explicit ``device=``; else the GPU of the LIVE envs created with an explicit ``device=`` when
+    they all sit on one GPU (a process that drives several GPUs gives no such hint: its helpers take the fallback below, or the
+    caller selects the device with ``torch.cuda.device``); else this rank's own GPU (LOCAL_RANK, one process per GPU) when the
+    process sees several; else device 0."""
     import os
     if not torch.cuda.is_available():
         return 0
     cur = torch.cuda.current_device()
     if cur != 0:
         return cur
-    if _last_env_device is not None:          # the GPU of the env created last with an explicit device= (helpers serve that env)
-        return _last_env_device
+    hinted = set(_env_devices.values())
+    if len(hinted) == 1:                      # every live env with an explicit device= is on this GPU (helpers serve those envs)
+        return next(iter(hinted))
     if torch.cuda.device_count() > 1 and "LOCAL_RANK" in os.environ:
         return int(os.environ["LOCAL_RANK"]) % torch.cuda.device_count()
     return cur
 
 
-_last_env_device = None
+_env_devices = {}          # id(env) -> GPU index, for live envs created with an explicit device=
 
 
-def note_env_device(index: int) -> None:
+def note_env_device(env_key: int, index: int) -> None:
     """Called by the env constructor when the caller named its GPU: helper handles created afterwards without a device of their own
-    (trajectory evaluation, DSLPID) follow it instead of LOCAL_RANK (a rehearsal that puts every rank on device 0, or a process that
-    drives several GPUs, would otherwise get cross-device tensors)."""
-    global _last_env_device
-    _last_env_device = int(index)
+    (trajectory evaluation, DSLPID) follow it instead of LOCAL_RANK (a rehearsal that puts every rank on device 0 would otherwise get
+    cross-device tensors).  Keyed per env and dropped by ``forget_env_device`` on ``env.close()``: a closed env leaves no hint behind,
+    and envs on different GPUs cancel the hint instead of sending every helper to the GPU of the env created last."""
+    _env_devices[int(env_key)] = int(index)
+
+
+def forget_env_device(env_key: int) -> None:
+    _env_devices.pop(int(env_key), None)
 
 
 def stream_ptr(device: torch.device) -> int:

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .. import _capi as capi
-from .._device import DTYPE_BY_NAME, TORCH_DTYPE, default_device_index, note_env_device, require_gpu, stream_ptr, to_device
+from .._device import DTYPE_BY_NAME, TORCH_DTYPE, default_device_index, forget_env_device, note_env_device, require_gpu, stream_ptr, to_device
 from ..utils.enums import DroneModel, Physics
 
 __all__ = ["BaseAviary", "DroneModel", "Physics"]
@@ -70,7 +70,7 @@ class BaseAviary:
         if device is None:
             device = default_device_index()
         else:
-            note_env_device(device.index if isinstance(device, torch.device) else int(device))
+            note_env_device(id(self), device.index if isinstance(device, torch.device) else int(device))
         self.device = require_gpu(device)
         self._lib = lib
         self.DRONE_MODEL, self.PHYSICS = drone_model, physics
@@ -196,6 +196,7 @@ class BaseAviary:
                   "——— angular velocity {:+06.4f}, {:+06.4f}, {:+06.4f} ——— ".format(o[i, 13], o[i, 14], o[i, 15]))
 
     def close(self):
+        forget_env_device(id(self))
         if getattr(self, "_h", None) is not None:
             self._lib.mds_destroy(self._h)
             self._h = None

@@ -25,12 +25,11 @@ def parse_args(argv=None):
 
 
 class GeometricEnv(_cbf.GeometricEnv):
-    def do_control(self, trajs=None, render=False, computed_K=None, use_noisy_model=False):
+    def do_control(self, trajs=None, render=False, computed_K=None, use_noisy_model=True):          # the reference's default (:265)
         if computed_K is not None or self.args.controller == 'dlqr':
             raise NotImplementedError("controller 'dlqr' (a gain identified by fedCE): the FedCE / decentralised-LQR loop is outside the hot path")
-        if use_noisy_model:
-            # LQROmegaController(..., use_noisy_model=True) designs its gain on (Ahat, Bhat) (control/lqr/lqr_omega_controller.py:31-36)
-            self._noisy = True
+        # LQROmegaController(..., use_noisy_model=True) designs its gain on (Ahat, Bhat) (control/lqr/lqr_omega_controller.py:31-36)
+        self._noisy = bool(use_noisy_model)
         return super().do_control(trajs=trajs, render=render, qpTracker=None)
 
     def _nominal(self, env):

@@ -29,7 +29,7 @@ class GeometricEnv(_ord3.GeometricEnv):
     def __init__(self, args, circle_init=True):
         super().__init__(args, init_type='circle' if circle_init else None)
 
-    def do_control(self, trajs=None, render=False, computed_K=None, use_noisy_model=False):
+    def do_control(self, trajs=None, render=False, computed_K=None, use_noisy_model=True):      # the reference's default (:265)
         if computed_K is not None or self.args.controller == 'dlqr':
             raise NotImplementedError("controller 'dlqr' (a gain identified by fedCE): the FedCE / decentralised-LQR loop is outside the hot path")
         self._noisy = bool(use_noisy_model)
@@ -59,6 +59,6 @@ if __name__ == "__main__":
     geo = GeometricEnv(ARGS, circle_init=True)
     env = geo.create_env()
     trajs = [Lemniscate(center=np.array([0, 0, .5]), omega=1.5, yaw_rate=0) for _ in range(ARGS.num_drones)]      # noqa: F405  (:413)
-    geo.do_control(trajs=trajs, render=False)
+    geo.do_control(trajs=trajs, render=False, use_noisy_model=False)                                               # :432
     np.save("observations_omega.npy", geo.observations)                                                            # :415
     print("Wrote observations to observations_omega.npy", np.asarray(geo.observations).shape)

@@ -21,7 +21,9 @@ class Consts(C.Structure):
 def build(force=False):
     src = os.path.join(HERE, "c_oracle.c")
     if force or not os.path.exists(SO) or os.path.getmtime(src) > os.path.getmtime(SO):
-        subprocess.check_call(["make", "-C", HERE, "-B", "libc_oracle.so"], stdout=subprocess.DEVNULL)
+        r = subprocess.run(["make", "-C", HERE, "-B", "libc_oracle.so"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"make -C oracle failed ({r.returncode}):\n{r.stdout}")
     return SO
 
 

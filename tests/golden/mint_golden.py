@@ -680,31 +680,6 @@ def mint_compare_models(ref):
     print("compare_models", xdot_lin.shape, xdot_geo.shape, "clipped rpm entries", clipped, "quat w<0 rows", int((obs16[:, 6] < 0).sum()))
 
 
-def mint_crazyflie_model(ref):
-    """model/linear_crazyflie.py:27-52 (A, B, Ahat, Bhat of the 7-state model) from the reference file, its calc_xdot raising
-    (12-long state against the 7 x 7 A, :62-72), and what the reference's CrazyflieLQR constructor does with it
-    (control/lqr/crazyflie_lqr_controller.py:12-62 cannot be loaded -- it imports gym_pybullet_drones -- so that constructor's
-    formula is applied to the REFERENCE model's matrices here: Bryson weights + scipy's solve_continuous_are, which FAILS)."""
-    import scipy.linalg as la
-    cf = load("model.linear_crazyflie", REF + "/model/linear_crazyflie.py")
-    env = make_env()
-    m = cf.CrazyflieModel(env)
-    raised = False
-    try:
-        m.calc_xdot_from_obs(np.zeros(20))
-    except ValueError:
-        raised = True
-    R = np.diag([1 / env.MAX_THRUST ** 2, 1 / .0001 ** 2, 1 / .0001 ** 2, 1 / 0.1 ** 2])
-    Q = np.diag([1 / (np.pi / 40) ** 2] + [1 / .05 ** 2] * 3 + [1 / .15 ** 2] * 3)
-    are_fails = False
-    try:                                       # vx, vy have no input in this model (B[4:6] = 0) and sit on the imaginary axis: not stabilisable
-        la.solve_continuous_are(m.A, m.B, Q, R, e=None, s=None, balanced=True)
-    except np.linalg.LinAlgError:
-        are_fails = True
-    np.savez_compressed(OUT + "/crazyflie_model.npz", A=m.A, B=m.B, Ahat=m.Ahat, Bhat=m.Bhat, calc_xdot_raises=raised, are_fails=are_fails, **META)
-    print("crazyflie_model A", m.A.shape, "B", m.B.shape, "calc_xdot raises:", raised, "the constructor's ARE fails:", are_fails)
-
-
 def trajectory_cases(T):
     """The same constructor arguments are used for the reference classes (minting) and for the oracle /
     GPU classes (tests): T is a namespace with Lemniscate, Circle, Line, Wait, Compound, Rotate."""
@@ -766,6 +741,5 @@ if __name__ == "__main__":
     mint_lqr_yank_omega(ref)
     mint_lqr12(ref)
     mint_compare_models(ref)
-    mint_crazyflie_model(ref)
     sys.path.insert(0, REF)
     mint_trajectories()

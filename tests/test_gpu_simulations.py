@@ -394,7 +394,7 @@ def test_envgeometric_omega_and_yank_omega_scripts_match_oracle(gpu, which):
         geo.do_control(trajs=None, computed_K=np.zeros((4, 9)))
     P = np.array([[1.0, 0.5, 0, 0, 0.5 + 0.1 * k, 0.3, 0.4 * k] for k in range(D)])
     trajs = [S.Lemniscate(a=1.0, omega=0.5, center=P[k, 2:5], yaw_rate=0.3, phase_shift=0.4 * k) for k in range(D)]
-    geo.do_control(trajs=trajs, render=False)
+    geo.do_control(trajs=trajs, render=False, use_noisy_model=False)
     obs = np.asarray(geo.observations)
     assert obs.shape == (steps, D, 20) and len(geo.obs_ts) == steps
     c = O.CF2P
@@ -418,6 +418,18 @@ def test_envgeometric_omega_and_yank_omega_scripts_match_oracle(gpu, which):
     obs2 = np.asarray(geo2.observations)
     assert np.isfinite(obs2).all() and np.abs(obs2[-1][:, :3] - obs[-1][:, :3]).max() > (1e-6 if which == "omega" else 0.0)
     assert np.abs(obs2[-1][:, :3] - pos).max() < 0.6
+    # the reference's default is use_noisy_model=True (:265): a call without the argument is the explicit-True run, bit for bit; and the
+    # flag is per call, not sticky: False after True on the same object is the first run again
+    geo3 = S.GeometricEnv(args, circle_init=True)
+    geo3.INIT_XYZS[:, 2] = 0.5
+    geo3.create_env()
+    geo3.do_control(trajs=trajs, render=False)
+    np.testing.assert_array_equal(np.asarray(geo3.observations), obs2)
+    geo3.observations, geo3.obs_ts = [], []
+    geo3.INIT_XYZS[:, 2] = 0.5
+    geo3.create_env()
+    geo3.do_control(trajs=trajs, render=False, use_noisy_model=False)
+    np.testing.assert_array_equal(np.asarray(geo3.observations), obs)
 
 
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-10), ("float32", 1e-5)])
