@@ -14,8 +14,10 @@ streams for shards of 2^19 drones and more, see mds_set_rollout_streams).  Defau
 workload = BASELINE.json configs[2] ("C3": 65 536 envs x 8 drones, Lemniscate tracking), the
 configuration the metric's targets (>= 50 M drone-steps/s at >= 60 % of HBM roofline, 1/2/4/8
 GPU scaling) are quoted on; --workload c2 selects configs[1] (4 096 x 4), whose 3.5 MB working
-set is launch-latency bound.  Each rank owns its own envs (weak scaling, no collective on the
-data path).
+set is launch-latency bound.  Each rank owns its own envs (weak scaling, the default; no collective on the
+data path).  --scaling strong partitions the workload's OWN envs instead: rank g of G owns envs
+[g E / G, (g + 1) E / G) of the 1-GPU run's env set; --shard-of G runs one such shard
+alone on one GPU (the 1/2/4/8 curve predicted on one MI355X: profiles/tools/r04_shard_sweep.py).
 """
 from __future__ import annotations
 
@@ -73,6 +75,21 @@ def make_inputs(E, D, phase, seed):
     P[..., 0], P[..., 1], P[..., 2:5] = 1.0, 1.5, cen
     P[..., 6] = -(np.pi / 4) * (np.arange(D) - 1) if phase == "c2" else 2 * np.pi * np.arange(D) / (D + 0.25)
     return xyz, np.zeros((E, D, 3)), P
+
+
+def shard_inputs(E, D, phase, rank, world, scaling, seed=1000):
+    """This rank's envs.  weak (the default the driver times): every rank owns its OWN E envs (seed + rank) -- per-GPU work fixed as N
+    grows.  strong (BASELINE configs[2] "env-shard across 1/2/4/8"; the caller is simulations/EnvGeometric.py:434-469): the job is
+    the E envs of the 1-GPU run (same seed -> the same envs) and rank g owns the contiguous slice [g E / G, (g + 1) E / G), whole envs only.
+    Returns (xyz, rpy, P, (lo, hi))."""
+    if scaling == "strong":
+        if E % world:
+            raise SystemExit(f"bench.py: --scaling strong needs the env count ({E}) to be a multiple of the number of GPUs ({world})")
+        xyz, rpy, P = make_inputs(E, D, phase, seed)
+        lo, hi = rank * (E // world), (rank + 1) * (E // world)
+        return np.ascontiguousarray(xyz[lo:hi]), np.ascontiguousarray(rpy[lo:hi]), np.ascontiguousarray(P[lo:hi]), (lo, hi)
+    xyz, rpy, P = make_inputs(E, D, phase, seed + rank)
+    return xyz, rpy, P, (0, E)
 
 
 def dist_env():
@@ -674,6 +691,16 @@ def main(argv=None):
                     help="c4: mds_cbf_set_step_kernel(h, 1) -- nominal controller, QPs and low level + physics in ONE launch per control step "
                          "(the faster form when few envs iterate: the 'far' scene; slower on SURVEY 8d's)")
     ap.add_argument("--c5-log-gb", type=float, default=200.0, help="c5: size of the rollout log ring in GB (SURVEY 8d: sized for the 288 GB of HBM)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every rank its own envs_per_gpu envs.  strong: the job is the workload's envs (c3: 65 536 x 8) and "
+                         "rank g of G owns envs [g E / G, (g + 1) E / G) -- the same envs as the 1-GPU run (SURVEY 8e)")
+    ap.add_argument("--shard-of", type=int, default=0, metavar="G",
+                    help="one-GPU rehearsal of a strong-scaling shard: run rank --shard-rank's slice of a G-GPU job alone on this GPU (n_gpus "
+                         "stays 1, `value` is this shard's own rate); profiles/tools/r04_shard_sweep.py predicts the 1/2/4/8 curve with it")
+    ap.add_argument("--shard-rank", type=int, default=0)
+    ap.add_argument("--rollout-form", type=int, default=0, choices=[0, 1, 2],
+                    help="mds_set_rollout_form: 0 auto (by shard size), 1 one launch per control step, 2 the whole-rollout kernel in chunks")
+    ap.add_argument("--dry-run-envs", type=int, default=64, help=argparse.SUPPRESS)            # CPU test of the env partition
     ap.add_argument("--dry-run-cpu", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU tests of the N>1 path")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # CPU test of the exit-code relay
     ap.add_argument("--dry-run-build-file", default=None, help=argparse.SUPPRESS)              # CPU test of the collective build decision
@@ -719,6 +746,27 @@ def main(argv=None):
         elapsed = max_over_ranks(time.perf_counter() - t0, world, device)
         per_rank = gather_over_ranks(mine_s, world, device)
         starts, ends = gather_over_ranks(w0, world, device), gather_over_ranks(w1, world, device)
+        # the env partition: every rank builds its shard exactly as the GPU path does; rank 0 checks that the ranks' slices tile the
+        # job's env axis and (strong) that their union IS the 1-GPU run's env set
+        Ed = args.dry_run_envs
+        sx, sr, sP, (lo, hi) = shard_inputs(Ed, D, phase, rank, world, args.scaling)
+        shards = [None] * world
+        if world > 1:
+            torch.distributed.all_gather_object(shards, (lo, hi, sx, sr, sP))
+        else:
+            shards = [(lo, hi, sx, sr, sP)]
+        shard_rec = None
+        if rank == 0:
+            slices = [[int(a), int(b)] for a, b, *_ in shards]
+            if args.scaling == "strong":
+                fx, fr, fP = make_inputs(Ed, D, phase, 1000)
+                tiles = slices[0][0] == 0 and slices[-1][1] == Ed and all(slices[k][1] == slices[k + 1][0] for k in range(world - 1))
+                same = all(np.array_equal(np.concatenate([sh[j] for sh in shards]), full) for j, full in ((2, fx), (3, fr), (4, fP)))
+                shard_rec = {"scaling": "strong", "envs_total": Ed, "slices": slices, "slices_tile_the_env_axis": bool(tiles),
+                             "union_equals_one_gpu_set": bool(same)}
+            else:
+                distinct = all(not np.array_equal(shards[0][4], sh[4]) for sh in shards[1:])
+                shard_rec = {"scaling": "weak", "envs_total": Ed * world, "slices": slices, "ranks_own_distinct_envs": bool(distinct)}
         gathered = None
         if args.gather_obs:                    # the optional swarm all-gather, on CPU tensors over gloo
             from multidronesim_amd.swarm import all_gather_observations
@@ -728,7 +776,7 @@ def main(argv=None):
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "elapsed": elapsed, "ranks_seen": len(per_rank), "elapsed_per_rank": per_rank,
                               "value_per_rank": [1.0 / e for e in per_rank], "node_wall": max(ends) - min(starts), "built": built,
-                              "gathered": gathered}), flush=True)
+                              "gathered": gathered, "shard": shard_rec}), flush=True)
         if world > 1:
             torch.distributed.destroy_process_group()
         return 0
@@ -752,7 +800,14 @@ def main(argv=None):
     ensure_built(rank, world, local_rank, __graft_entry__.LIB, __graft_entry__.build, red_dev)
     from multidronesim_amd.envs.CtrlAviary import CtrlAviary, DroneModel, Physics
 
-    xyz, rpy, P = make_inputs(E, D, phase, 1000 + rank)          # every rank owns different envs
+    E_job = E
+    if args.shard_of:                       # one-GPU rehearsal of rank --shard-rank of a --shard-of-GPU strong-scaling job
+        if world != 1 or not 0 <= args.shard_rank < args.shard_of:
+            raise SystemExit("--shard-of G runs one shard alone: --gpus 1 and 0 <= --shard-rank < G")
+        xyz, rpy, P, env_slice = shard_inputs(E, D, phase, args.shard_rank, args.shard_of, "strong")
+    else:
+        xyz, rpy, P, env_slice = shard_inputs(E, D, phase, rank, world, args.scaling)       # weak: every rank owns different envs
+    E = xyz.shape[0]                        # envs on THIS GPU
     tracker = None
     c5 = args.workload == "c5"
     c4 = args.workload == "c4"
@@ -804,6 +859,7 @@ def main(argv=None):
     c_loop = not args.python_loop and not fused_T
     # The library's auto policy looks at the length of the call.  Fix it to what the TIMED call will do, so that the warm-up
     # goes through the same branch (same streams, same launch shapes) as the call that is timed.
+    env.set_rollout_form(args.rollout_form)                  # 0: the library picks the launch form by shard size (mds_set_rollout_form)
     env.set_rollout_streams(args.rollout_streams)
     planned = env.rollout_streams_for(args.steps, cbf=c4) if c_loop else 1
     env.set_rollout_streams(planned if c_loop else args.rollout_streams)
@@ -877,6 +933,8 @@ def main(argv=None):
     # `value` = units / the slowest rank's interval, the contract's MAX over ranks) do not see
     node_wall = max(gather_over_ranks(node_t1, world, red_dev)) - min(gather_over_ranks(node_t0, world, red_dev))
     used_streams = env.last_rollout_streams() if c_loop else 1
+    form_used = env.last_rollout_form() if (c_loop and geo) else 1       # 2: the whole-rollout kernel in chunks (small shards)
+    form_chunk = 50
     c4_kernel_ran = env.cbf_last_step_kernel() if c4 else None
 
     obs = c5_log[(c5_k[0] - 1) % c5_T] if c5 else env._obs
@@ -895,6 +953,8 @@ def main(argv=None):
         bytes_per = 24 * es + 26 * es / fused_T   # action row + obs row per step, state R/W once per launch
     elif fused_T and not c4:
         bytes_per = 20 * es + (33 * es + 20 * es) / fused_T     # obs row per step + (state R/W, params, final obs) once per launch
+    elif form_used == 2:
+        bytes_per = 20 * es + 33 * es / min(form_chunk, args.steps)   # obs row per step + (state R/W, params) once per launch of <= 50 steps
     achieved = bytes_per * n_local / (us_per_step * 1e-6) / 1e9
     split = used_streams == 2
     tname = {torch.float16: "_Float16", torch.float32: "float", torch.float64: "double"}[env.dtype]
@@ -903,10 +963,11 @@ def main(argv=None):
     line = {
         "metric": METRIC,
         "value": value, "unit": "drone-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": {"float32": "f32", "float64": "f64", "float16": "f16-storage/f32-math", "float32c": "f32 (compensated state accumulation)"}[args.dtype],
         "data": "synthetic",
-        "config": {"workload": desc, "envs_per_gpu": E, "drones_per_env": D, "pyb_freq": 100, "ctrl_freq": 100,
+        "config": {"workload": desc, "envs_per_gpu": E, "envs_total": E * world, "env_slice_rank0": list(env_slice), "drones_per_env": D,
+                   "pyb_freq": 100, "ctrl_freq": 100,
                    "physics": "DYN (explicit Euler)" if not rk4 else "DYN (RK4)",
                    "physics_note": "the reference's default Physics.PYB (Bullet multibody step + ground plane) is not reproduced: no PyBullet here, parity vs it is undemonstrated",
                    "parallelism": f"env-shard x{world}, no collective",
@@ -920,6 +981,22 @@ def main(argv=None):
         "node_wall": {"ms_per_step": node_wall * 1e3 / args.steps, "value": total_units / node_wall,
                       "what": "first rank's start .. last rank's finish (host clock of the node): `value` with the ranks' start skew counted"},
     }
+    if args.scaling == "strong" or args.shard_of:
+        G_ = args.shard_of or world
+        line["config"]["workload"] = (desc.replace(" per GPU", "") + f" -- STRONG scaling: the {E_job} envs of the 1-GPU run (same seed) partitioned over "
+                                      f"{G_} GPU(s), rank g owns envs [g E / G, (g + 1) E / G) = {E} envs")
+        line["config"]["parallelism"] = f"env-shard x{G_} of one {E_job}-env job, no collective"
+        if args.shard_of:
+            line["config"]["shard_of"] = {"G": args.shard_of, "rank": args.shard_rank,
+                                          "what": "ONE shard of a G-GPU strong-scaling job run alone on one GPU (a prediction of that rank's rate, not a multi-GPU measurement)"}
+    if form_used == 2:
+        line["config"]["launch"] = (f"C rollout loop in launch form 2 (mds_set_rollout_form auto: {n_local} drones are launch-bound one step per launch): the "
+                                    f"whole-rollout kernel, {form_chunk} control steps per launch, every step's observation written")
+        line["roofline"]["kernel"] = f"k_rollout_geometric<{cname},{tname},{'true' if rk4 else 'false'},false,0> ({form_chunk} control steps per launch)"
+        line["roofline"]["bytes_per_drone_step"] = bytes_per
+        line["roofline"]["note"] = ("algorithmic bytes of this form: the observation row per step + state and parameters once per launch; the kernel is "
+                                    "VALU / latency bound at this shard size, `frac` says how far from the HBM roofline that leaves it")
+    line["config"]["launch_form"] = form_used
     if split:
         # each stream runs `steps` half-shard launches inside the timed region, so us_per_step is also the average
         # launch period on either stream; `achieved` adds the two concurrent launches' bytes
@@ -927,7 +1004,7 @@ def main(argv=None):
                                  "launches": "two concurrent half-shard launches per control step, one per stream; "
                                              "achieved = 2 x bytes_per_launch / us_per_step"})
         line["config"]["launch"] = "C rollout loop, half shards on 2 streams"
-    if geo and args.dtype == "float32" and not fused_T and not rk4:   # (float32c: different traffic, no committed counters)
+    if geo and args.dtype == "float32" and not fused_T and not rk4 and form_used == 1:   # (float32c: different traffic, no committed counters)
         if args.workload == "c3big":
             line["roofline"]["residency"] = ("HBM-resident: 890 MB touched per control step (state 218 + parameters 117 + observations 335 MB written, "
                                              "state 218 MB rewritten), 3.5x the 256 MiB Infinity Cache")

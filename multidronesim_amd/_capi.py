@@ -77,6 +77,9 @@ PROTOTYPES = {
     "mds_set_rollout_streams": (C.c_int, [_P, C.c_int]),
     "mds_get_last_rollout_streams": (C.c_int, [_P]),
     "mds_rollout_streams_for": (C.c_int, [_P, C.c_int, C.c_int]),
+    "mds_set_rollout_form": (C.c_int, [_P, C.c_int, C.c_int]),
+    "mds_rollout_form_for": (C.c_int, [_P, C.c_int]),
+    "mds_get_last_rollout_form": (C.c_int, [_P]),
     "mds_rollout_step": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
     "mds_rollout_step_fused": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "mds_reset_async": (C.c_int, [_P, _P]),

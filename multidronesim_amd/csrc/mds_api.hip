@@ -111,6 +111,9 @@ struct mds_handle {
                                         // fork's own latency already starts chain 1 about half a kernel late: 20-step calls 17.3 vs 17.6 us)
   int split_min_steps = 0;              // auto policy: calls shorter than this stay on one stream (MDS_TUNE_SPLIT_MIN_STEPS, tuning only)
   int last_rollout_streams = 0;         // what the last mds_rollout_* call did (mds_get_last_rollout_streams)
+  int rollout_form = 0;                 // mds_set_rollout_form: 0 auto, 1 one launch per control step, 2 the whole-rollout kernel in chunks
+  int rollout_chunk = 50;               // control steps per launch of form 2
+  int last_rollout_form = 0;            // what the last mds_rollout_geometric did (mds_get_last_rollout_form)
   bool next_nom_ok[3] = {false, false, false};   // per env-range slot: the last low-level launch also left the nominal input of ...
   double next_nom_t[3] = {0.0, 0.0, 0.0};        // ... the control step at this time in the scratch (C rollout loops chain on it)
   bool cbf_hildreth = false;            // MDS_CBF_SOLVER=hildreth, read once by mds_cbf_configure
@@ -184,6 +187,26 @@ static int rollout_streams_policy(const mds_handle* h, int loop, int n_steps) {
   if (loop == 1) return (n >= kSplitMinDrones / 4 && n_steps >= min_steps) ? 2 : 1;
   const bool big = n >= 2 * kSplitMinDrones ? n_steps >= min_steps : (n >= kSplitMinDrones && n_steps >= 1000);
   return big ? 2 : 1;
+}
+
+// The launch form of the fused geometric loop (mds_set_rollout_form; mds_rollout_form_for reports it).  1: one launch per control step
+// (k_step_geometric; two chains on big shards, above).  2: the whole-rollout kernel in launches of `rollout_chunk` control steps
+// (k_rollout_geometric: state in registers, every step's observation still written).  Auto: shards of kFusedMinDrones .. kFusedMaxDrones
+// drones are launch-bound in form 1 -- a dependent launch costs ~4 us whatever it moves (C2, 16 384 drones: 3.9 us per step against 1.9;
+// one eighth of config 3 = 65 536 drones: profiles/r04_shard_sweep.json) -- and take form 2 for calls of kFusedMinSteps steps and more; larger
+// shards stream at 0.8-0.9 of the HBM roofline in form 1 and stay there.  fp16 storage stays in form 1 (form 2 rounds the state to fp16
+// once per launch instead of once per step: not the same arithmetic).
+#ifndef MDS_FUSED_MAX_DRONES
+#define MDS_FUSED_MAX_DRONES (size_t(1) << 17)
+#endif
+constexpr size_t kFusedMinDrones = size_t(1) << 13, kFusedMaxDrones = MDS_FUSED_MAX_DRONES;
+constexpr int kFusedMinSteps = 8;
+static int rollout_form_policy(const mds_handle* h, int n_steps) {
+  if (h->envfx || n_steps < 1) return 1;          // ground effect / downwash: env-mates interact every substep, no state-in-registers form
+  if (h->rollout_form) return h->rollout_form;
+  if (h->cfg.dtype == MDS_F16) return 1;
+  const size_t n = (size_t)h->n;
+  return (n >= kFusedMinDrones && n <= kFusedMaxDrones && n_steps >= kFusedMinSteps) ? 2 : 1;
 }
 
 // Set-up path (mds_create / mds_set_rollout_streams): the internal stream and the two events of the two-chain rollouts.
@@ -977,6 +1000,54 @@ int mds_step_geometric(mds_handle* h, double t, void* obs, void* act, void* stre
   return MDS_OK;
 }
 
+// One launch of the whole-rollout kernel: n_steps control steps with the state in registers.  ctrl: 0 GeometricControl, 1 LQRController
+// (12-state), 2 LQROmegaController + ThrustOmega, 3 LQRYankOmegaController + YankOmega.  Step k's observation goes to obs_log + k * log_stride
+// elements (log_stride = n * 20: a [n_steps, n, 20] log; 0: every step overwrites the same [n, 20] buffer, what a step-by-step loop with one
+// observation buffer does); obs_last (or NULL) receives the last step's.
+static void launch_rollout_kernel(mds_handle* h, int ctrl, double t0, int n_steps, void* obs_log, size_t log_stride, void* obs_last, hipStream_t st) {
+  const dim3 grid = grid_for(h->n, kBlock);
+  const double dt = 1.0 / h->cfg.ctrl_freq;
+  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
+  // the gain (up to 48 values) is read from its device copy: passing it by value would not fit beside Consts in SGPRs
+  const void* gain = ctrl >= 1 ? h->gain_dev[ctrl - 1] : nullptr;
+#define MDS_ROLL(RK4, DRAG, CTRL)                                                                                                  \
+  MDS_DISPATCH(h, (k_rollout_geometric<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, gain, h->n, h->ld, t0, dt,                       \
+                                                                                       n_steps, (S*)h->state, (const T*)h->lem,       \
+                                                                                       (T*)rpm_track(h), (S*)obs_log, log_stride, (S*)obs_last,   \
+                                                                                       (T*)h->ll, (const S*)obs_last, (S*)h->state_lo)))
+#define MDS_ROLLT(RK4, DRAG, CTRL)                                                                                                 \
+  MDS_DISPATCH(h, (k_rollout_traj<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, gain, h->n, h->ld, t0, dt,                                 \
+                                                                                  n_steps, (S*)h->state, (const T*)h->origin, SegTable{h->segs, h->nseg_total}, \
+                                                                                  h->tinfo, (T*)rpm_track(h), (S*)obs_log, log_stride, (S*)obs_last, (S*)h->state_lo)))
+#define MDS_ROLL_C(CTRL)                                                    \
+  do {                                                                      \
+    if (h->traj_mode == 2) {   /* general trajectories: segment tables */   \
+      if (rk4 && drag) MDS_ROLLT(true, true, CTRL);                         \
+      else if (rk4) MDS_ROLLT(true, false, CTRL);                           \
+      else if (drag) MDS_ROLLT(false, true, CTRL);                          \
+      else MDS_ROLLT(false, false, CTRL);                                   \
+    } else if (rk4 && drag) MDS_ROLL(true, true, CTRL);                     \
+    else if (rk4) MDS_ROLL(true, false, CTRL);                              \
+    else if (drag) MDS_ROLL(false, true, CTRL);                             \
+    else MDS_ROLL(false, false, CTRL);                                      \
+  } while (0)
+#define MDS_ROLL_LL(CTRL)                        \
+  do {                                           \
+    if (rk4 && drag) MDS_ROLL(true, true, CTRL); \
+    else if (rk4) MDS_ROLL(true, false, CTRL);   \
+    else if (drag) MDS_ROLL(false, true, CTRL);  \
+    else MDS_ROLL(false, false, CTRL);           \
+  } while (0)
+  if (ctrl == 3) MDS_ROLL_LL(3);
+  else if (ctrl == 2) MDS_ROLL_LL(2);
+  else if (ctrl == 1) MDS_ROLL_C(1);
+  else MDS_ROLL_C(0);
+#undef MDS_ROLL_LL
+#undef MDS_ROLL_C
+#undef MDS_ROLLT
+#undef MDS_ROLL
+}
+
 int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs, int obs_every_step, void* stream) {
   MDS_DEV(h);
   if (!h || n_steps < 0) return fail(MDS_EINVAL, "mds_rollout_geometric");
@@ -991,6 +1062,22 @@ int mds_rollout_geometric(mds_handle* h, double t0, int n_steps, void* obs, int 
     }
     return MDS_OK;
   }
+  if (rollout_form_policy(h, n_steps) == 2) {
+    // launch-bound shard sizes: the same loop through the whole-rollout kernel, rollout_chunk control steps per launch; every step's
+    // observation overwrites obs (obs_every_step) exactly as the per-step loop's launches do, or only the last step's is written
+    h->last_rollout_streams = 1;
+    h->last_rollout_form = 2;
+    for (int k = 0; k < n_steps;) {
+      const int chunk = n_steps - k < h->rollout_chunk ? n_steps - k : h->rollout_chunk;
+      const bool last = k + chunk == n_steps;
+      launch_rollout_kernel(h, 0, t0, chunk, obs_every_step ? obs : nullptr, 0, (!obs_every_step && last) ? obs : nullptr, (hipStream_t)stream);
+      for (int j = 0; j < chunk; ++j) t0 += dt;        // t accumulates step by step, as inside the kernel and in the reference loop
+      k += chunk;
+    }
+    MDS_HIP(hipGetLastError());
+    return MDS_OK;
+  }
+  h->last_rollout_form = 1;
   const unsigned nbatch = (unsigned)((h->n + kBlock - 1) / kBlock);
   const int streams = rollout_streams_policy(h, 0, n_steps);
   if (streams == 2 && nbatch >= 2) {
@@ -1149,6 +1236,23 @@ int mds_get_last_rollout_streams(const mds_handle* h) {
   return h->last_rollout_streams;
 }
 
+int mds_set_rollout_form(mds_handle* h, int form, int steps_per_launch) {
+  if (!h || form < 0 || form > 2 || steps_per_launch < 0) return fail(MDS_EINVAL, "mds_set_rollout_form: form 0 (auto), 1 or 2; steps_per_launch >= 0 (0: keep)");
+  h->rollout_form = form;
+  if (steps_per_launch > 0) h->rollout_chunk = steps_per_launch;
+  return MDS_OK;
+}
+
+int mds_rollout_form_for(const mds_handle* h, int n_steps) {
+  if (!h || n_steps < 0) return fail(MDS_EINVAL, "mds_rollout_form_for");
+  return rollout_form_policy(h, n_steps);
+}
+
+int mds_get_last_rollout_form(const mds_handle* h) {
+  if (!h) return fail(MDS_EINVAL, "mds_get_last_rollout_form: null handle");
+  return h->last_rollout_form;
+}
+
 struct EnvRange;
 static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream, bool with_filter,
                                  const char* who, const EnvRange* rg, bool have_nominal, bool want_next, double t_next);
@@ -1191,48 +1295,7 @@ static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, v
   }
   if (!aligned16(obs_log) || !aligned16(obs_last)) return fail(MDS_EALIGN, "mds_rollout_*_fused: obs buffers");
   if (n_steps == 0) return MDS_OK;
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid = grid_for(h->n, kBlock);
-  const double dt = 1.0 / h->cfg.ctrl_freq;
-  const bool rk4 = h->cfg.integrator == MDS_INTEGRATOR_RK4, drag = has_drag(h);
-  // the gain (up to 48 values) is read from its device copy: passing it by value would not fit beside Consts in SGPRs
-  const void* gain = ctrl >= 1 ? h->gain_dev[ctrl - 1] : nullptr;
-#define MDS_ROLL(RK4, DRAG, CTRL)                                                                                                  \
-  MDS_DISPATCH(h, (k_rollout_geometric<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, gain, h->n, h->ld, t0, dt,                       \
-                                                                                       n_steps, (S*)h->state, (const T*)h->lem,       \
-                                                                                       (T*)rpm_track(h), (S*)obs_log, (S*)obs_last,   \
-                                                                                       (T*)h->ll, (const S*)obs_last, (S*)h->state_lo)))
-#define MDS_ROLLT(RK4, DRAG, CTRL)                                                                                                 \
-  MDS_DISPATCH(h, (k_rollout_traj<T, S, RK4, DRAG, CTRL><<<grid, kBlock, 0, st>>>(C, gain, h->n, h->ld, t0, dt,                                 \
-                                                                                  n_steps, (S*)h->state, (const T*)h->origin, SegTable{h->segs, h->nseg_total}, \
-                                                                                  h->tinfo, (T*)rpm_track(h), (S*)obs_log, (S*)obs_last, (S*)h->state_lo)))
-#define MDS_ROLL_C(CTRL)                                                    \
-  do {                                                                      \
-    if (h->traj_mode == 2) {   /* general trajectories: segment tables */   \
-      if (rk4 && drag) MDS_ROLLT(true, true, CTRL);                         \
-      else if (rk4) MDS_ROLLT(true, false, CTRL);                           \
-      else if (drag) MDS_ROLLT(false, true, CTRL);                          \
-      else MDS_ROLLT(false, false, CTRL);                                   \
-    } else if (rk4 && drag) MDS_ROLL(true, true, CTRL);                     \
-    else if (rk4) MDS_ROLL(true, false, CTRL);                              \
-    else if (drag) MDS_ROLL(false, true, CTRL);                             \
-    else MDS_ROLL(false, false, CTRL);                                      \
-  } while (0)
-#define MDS_ROLL_LL(CTRL)                        \
-  do {                                           \
-    if (rk4 && drag) MDS_ROLL(true, true, CTRL); \
-    else if (rk4) MDS_ROLL(true, false, CTRL);   \
-    else if (drag) MDS_ROLL(false, true, CTRL);  \
-    else MDS_ROLL(false, false, CTRL);           \
-  } while (0)
-  if (ctrl == 3) MDS_ROLL_LL(3);
-  else if (ctrl == 2) MDS_ROLL_LL(2);
-  else if (lqr) MDS_ROLL_C(1);
-  else MDS_ROLL_C(0);
-#undef MDS_ROLL_LL
-#undef MDS_ROLL_C
-#undef MDS_ROLLT
-#undef MDS_ROLL
+  launch_rollout_kernel(h, ctrl, t0, n_steps, obs_log, (size_t)h->n * kObsDim, obs_last, (hipStream_t)stream);
   MDS_HIP(hipGetLastError());
   return MDS_OK;
 }

@@ -631,7 +631,7 @@ template <typename T, typename S, bool RK4, bool DRAG, int CTRL = 0>
 __global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c, const void* __restrict__ Kp, const int n, const size_t ld, double t,
                                                               const double ctrl_dt, const int n_steps, S* __restrict__ state,
                                                               const T* __restrict__ lem, T* __restrict__ last_rpm,
-                                                              S* __restrict__ obs_log, S* __restrict__ obs_last,
+                                                              S* __restrict__ obs_log, const size_t log_stride, S* __restrict__ obs_last,
                                                               T* __restrict__ ll = nullptr, const S* __restrict__ obs_prev = nullptr,
                                                               S* __restrict__ state_lo = nullptr) {
   __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_geometric(const Consts<T> c,
       else aviary_step<T, RK4, DRAG>(c, in.s, act, prev, clipped);
       if (want) pack_obs(in.s, V3<T>{in.P.cx, in.P.cy, in.P.cz}, clipped, o);
     }
-    if (obs_log != nullptr) write_obs_rows<S, T>(lds, obs_log + (size_t)k * n * kObsDim, n, i, valid, o);
+    if (obs_log != nullptr) write_obs_rows<S, T>(lds, obs_log + (size_t)k * log_stride, n, i, valid, o);
     if (obs_last != nullptr && k == n_steps - 1) write_obs_rows<S, T>(lds, obs_last, n, i, valid, o);
     t += ctrl_dt;
   }
@@ -704,7 +704,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout_traj(const Consts<T> c, cons
                                                          const double ctrl_dt, const int n_steps, S* __restrict__ state,
                                                          const T* __restrict__ origin, const SegTable segs,
                                                          const int* __restrict__ tinfo, T* __restrict__ last_rpm,
-                                                         S* __restrict__ obs_log, S* __restrict__ obs_last, S* __restrict__ state_lo = nullptr) {
+                                                         S* __restrict__ obs_log, const size_t log_stride, S* __restrict__ obs_last,
+                                                         S* __restrict__ state_lo = nullptr) {
   __shared__ __align__(16) unsigned char lds[kBlock * kObsDim * sizeof(S)];
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const bool valid = i < n;
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout_traj(const Consts<T> c, cons
       else aviary_step<T, RK4, DRAG>(c, s, act, prev, clipped);
       if (want) pack_obs(s, org, clipped, o);
     }
-    if (obs_log != nullptr) write_obs_rows<S, T>(lds, obs_log + (size_t)k * n * kObsDim, n, i, valid, o);
+    if (obs_log != nullptr) write_obs_rows<S, T>(lds, obs_log + (size_t)k * log_stride, n, i, valid, o);
     if (obs_last != nullptr && k == n_steps - 1) write_obs_rows<S, T>(lds, obs_last, n, i, valid, o);
     t += ctrl_dt;
   }

@@ -395,6 +395,21 @@ class BaseAviary:
         self._require_open()
         return int(self._lib.mds_rollout_streams_for(self._h, C.c_int(1 if cbf else 0), C.c_int(int(n_steps))))
 
+    def set_rollout_form(self, form: int = 0, steps_per_launch: int = 0):
+        """How rollout_geometric launches its steps (mds_set_rollout_form): 0 auto (by shard size), 1 one launch per control step
+        (bit-identical to step_geometric calls, independent of the sharding), 2 the whole-rollout kernel in launches of
+        ``steps_per_launch`` control steps (state in registers; results equal to rounding)."""
+        self._require_open()
+        capi.check(self._lib.mds_set_rollout_form(self._h, C.c_int(int(form)), C.c_int(int(steps_per_launch))), "mds_set_rollout_form")
+
+    def rollout_form_for(self, n_steps: int) -> int:
+        self._require_open()
+        return int(self._lib.mds_rollout_form_for(self._h, C.c_int(int(n_steps))))
+
+    def last_rollout_form(self) -> int:
+        self._require_open()
+        return int(self._lib.mds_get_last_rollout_form(self._h))
+
     def rollout_geometric_fused(self, t0: float, n_steps: int, log: bool = False, log_out: torch.Tensor | None = None,
                                 controller: str = "geometric"):
         """``n_steps`` fused control steps in ONE kernel launch (state stays in registers).  With

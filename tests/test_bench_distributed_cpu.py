@@ -123,3 +123,37 @@ def test_rank_zero_builds_while_the_others_wait(tmp_path):
         assert rec["built"] is (not pre_existing) and lib.exists()
         assert rec["ranks_seen"] == 2 and len(rec["value_per_rank"]) == 2 and len(rec["elapsed_per_rank"]) == 2
         assert rec["node_wall"] >= max(rec["elapsed_per_rank"]) - 1e-3      # first start .. last finish covers every rank's interval
+
+
+def test_strong_scaling_partition_is_the_one_gpu_env_set():
+    """--scaling strong (GPU g owns envs [g E / G, (g + 1) E / G) of config 3's env set): two gloo ranks build their shards
+    through the same function as the GPU path; their slices tile the env axis and their union is, bit for bit, the 1-GPU run's env set
+    (same seed).  Weak scaling (the default the driver times): the ranks own distinct envs."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29538", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--scaling", "strong", "--dry-run-envs", "48"]
+    out = subprocess.run(cmd, cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["shard"] == {"scaling": "strong", "envs_total": 48, "slices": [[0, 24], [24, 48]], "slices_tile_the_env_axis": True,
+                            "union_equals_one_gpu_set": True}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu"], cwd=ROOT, env=_clean_env(),
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["shard"]["scaling"] == "weak" and rec["shard"]["ranks_own_distinct_envs"] and rec["shard"]["slices"] == [[0, 64], [0, 64]]
+
+
+def test_shard_inputs_slices_and_refuses_a_ragged_partition():
+    sys.path.insert(0, ROOT)
+    import bench
+    import pytest
+    full = bench.make_inputs(64, 8, "c3", 1000)
+    for G in (1, 2, 4, 8):
+        parts = [bench.shard_inputs(64, 8, "c3", g, G, "strong") for g in range(G)]
+        assert [p[3] for p in parts] == [(g * 64 // G, (g + 1) * 64 // G) for g in range(G)]
+        for j in range(3):
+            np.testing.assert_array_equal(np.concatenate([p[j] for p in parts]), full[j])
+    with pytest.raises(SystemExit):
+        bench.shard_inputs(64, 8, "c3", 0, 3, "strong")
+    w = bench.shard_inputs(16, 8, "c3", 1, 2, "weak")
+    np.testing.assert_array_equal(w[2], bench.make_inputs(16, 8, "c3", 1001)[2])

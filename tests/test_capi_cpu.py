@@ -94,6 +94,7 @@ def test_null_handle_calls_return_einval(lib):
     assert lib.mds_set_rollout_streams(None, 2) == -1
     assert lib.mds_get_last_rollout_streams(None) == -1
     assert lib.mds_rollout_streams_for(None, 0, 100) == -1
+    assert lib.mds_set_rollout_form(None, 2, 50) == -1 and lib.mds_rollout_form_for(None, 100) == -1 and lib.mds_get_last_rollout_form(None) == -1
     assert lib.mds_cbf_last_iterations(None, None, None) == -1
     assert lib.mds_rollout_geometric(None, 0.0, 5, None, 1, None) == -1
     assert lib.mds_rollout_cbf_geometric(None, 0.0, 5, None, None, None) == -1

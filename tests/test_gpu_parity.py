@@ -515,6 +515,57 @@ def test_two_stream_rollout_is_bit_identical_and_stream_ordered(mds, dtype, phys
     env2.close()
 
 
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-11), ("float32", 1e-5)])
+def test_rollout_launch_form_policy_and_equivalence(mds, dtype, tol):
+    """mds_set_rollout_form: form 1 = one launch per control step (bit-identical to step_geometric calls), form 2 = the whole-rollout
+    kernel in launches of steps_per_launch control steps with every step's observation still written; auto picks form 2 for the
+    launch-bound shard sizes (2^13 .. 2^17 drones -- one eighth of config 3 is 65 536) and form 1 elsewhere.  Same arithmetic: the two
+    forms agree to rounding and both match the oracle; a call in form 2 continues a call in form 1 (t accumulates step by step)."""
+    torch = mds.torch
+    E, D, T = 1024, 8, 120                       # 8 192 drones: the lower edge of the auto window; 120 = 50 + 50 + 20 steps
+    xyz, rpy, P = H.c2_setup(E, D, phase="c3")
+    outs = {}
+    for form in (0, 1):
+        env = make_env(mds, E, D, xyz, rpy, dtype)
+        env.set_trajectories(P)
+        env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=env.device))
+        env.set_rollout_form(form)
+        assert env.rollout_form_for(T) == (2 if form == 0 else 1) and env.rollout_form_for(7) == 1 and env.last_rollout_form() == 0
+        o = env.rollout_geometric(0.0, T, obs_every_step=True).clone()
+        assert env.last_rollout_form() == (2 if form == 0 else 1) and env.last_rollout_streams() == 1
+        o2 = env.rollout_geometric(T * env.CTRL_TIMESTEP, 33, obs_every_step=False).clone()      # last observation only, chunk of 33
+        outs[form] = (o.double().cpu().numpy(), o2.double().cpu().numpy(), env.get_state())
+        env.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.isfinite(a).all()
+        np.testing.assert_allclose(a[..., :16] if a.shape[-1] == 20 else a, b[..., :16] if b.shape[-1] == 20 else b, atol=tol)
+    np.testing.assert_allclose(outs[0][0][..., 16:], outs[1][0][..., 16:], rtol=max(tol, 1e-9))
+    idx = np.arange(0, E, 16)
+    oobs, _ = H.oracle_closed_loop(xyz[idx], rpy[idx], P[idx], T)
+    assert np.abs(outs[0][0][idx].reshape(-1, 20)[:, :16] - oobs[:, :16]).max() < (1e-9 if dtype == "float64" else 1e-5)
+    # forced form 2 on a ragged little shard (3 x 5 = 15 drones), 7 steps per launch, against form 1 bit for bit in the TIME it hands
+    # the kernel: 23 steps = 7 + 7 + 7 + 2, then the step-by-step loop continues both
+    xs, rs, Ps = H.c2_setup(3, 5, phase="c3")
+    res = []
+    for form in (2, 1):
+        env = make_env(mds, 3, 5, xs, rs, dtype)
+        env.set_trajectories(Ps)
+        env.step(torch.zeros((3, 5, 4), dtype=env.dtype, device=env.device))
+        env.set_rollout_form(form, 7)
+        env.rollout_geometric(0.0, 23, obs_every_step=True)
+        assert env.last_rollout_form() == form
+        res.append(env.step_geometric(23 * env.CTRL_TIMESTEP).double().cpu().numpy())
+        env.close()
+    np.testing.assert_allclose(res[0][..., :16], res[1][..., :16], atol=tol)
+    # fp16 storage never leaves form 1 under the auto policy (form 2 rounds the state once per launch, not once per step)
+    env = make_env(mds, E, D, xyz, rpy, "float16")
+    env.set_trajectories(P)
+    assert env.rollout_form_for(1000) == 1
+    with pytest.raises(Exception):
+        env.set_rollout_form(3)
+    env.close()
+
+
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 def test_fused_rollout_equals_stepwise_and_logs_every_step(mds, dtype):
     """mds_rollout_geometric_fused (one launch, state in registers) == n calls of mds_step_geometric
