@@ -528,7 +528,10 @@ def measure_c5(CtrlAviary, DroneModel, Physics, torch, local_rank, device, steps
            "rollout_log_slots": slots, "rollout_log_GB": log.numel() * log.element_size() / 1e9, "state_sane": sane,
            "log_note": "a small ring (allocated in well under a second); `bench.py --workload c5` streams into a 200 GB log",
            "roofline": {"bound": "hbm", "bytes_per_drone_step": bpd, "achieved": gb, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBPS,
-                        "kernel": "k_step<float,_Float16,true,false,false>"}}
+                        "kernel": "k_step<float, _Float16, true, false, false, false>"}}
+    tr, src = _pmc_traffic("r04_pmc_traffic_c5_step.json", n_local // 2 if used == 2 else n_local)
+    if tr is not None:      # 112 B moved for 100 B algorithmic: the 12-byte fp32 origin (local frame) is read beside the fp16 state
+        out["roofline"].update({"traffic": tr, "traffic_source": src, "traffic_over_algorithmic": tr / (bpd * (n_local // 2 if used == 2 else n_local))})
     try:
         env.reset()
         env.rollout_step(act, 0, C5_EPISODE, log, episode_len=C5_EPISODE, steps_per_launch=fused_T)
@@ -539,7 +542,7 @@ def measure_c5(CtrlAviary, DroneModel, Physics, torch, local_rank, device, steps
         lastf = log[(C5_EPISODE * (reps + 1) - 1) % slots]
         out["fused_rollout"] = {"steps_per_launch": fused_T, "us_per_step": usf, "value": n_local / (usf * 1e-6), "bytes_per_drone_step": b2,
                                 "achieved_GBps": b2 * n_local / (usf * 1e-6) / 1e9, "bound": "VALU (state in registers)",
-                                "kernel": "k_rollout_step<float,_Float16,false,false>", "state_sane": bool(torch.isfinite(lastf).all().item())}
+                                "kernel": "k_rollout_step<float, _Float16, false, false>", "state_sane": bool(torch.isfinite(lastf).all().item())}
     except Exception as exc:
         out["fused_rollout"] = {"error": str(exc)}
     env.close()
@@ -1044,8 +1047,13 @@ def main(argv=None):
         line["roofline"]["traffic"] = None
         line["config"]["launch"] = f"fused rollout, {fused_T} steps per launch, obs log [T,n,20]"
     if c5:
-        line["roofline"]["kernel"] = "k_step<float,_Float16,true,false,false>"
+        line["roofline"]["kernel"] = "k_step<float, _Float16, true, false, false, false>"
         line["roofline"]["traffic"] = None
+        if args.dtype == "float32" and not rk4 and not args.python_loop:
+            per_launch = n_local // 2 if split else n_local
+            tr, src = _pmc_traffic("r04_pmc_traffic_c5_fused40.json" if fused_T == 40 else "r04_pmc_traffic_c5_step.json", per_launch) if fused_T in (0, 40) else (None, None)
+            if tr is not None:
+                line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr, src
         line["dtype"] = {"float16": "f16-storage/f32-math", "float32": "f32", "float64": "f64"}[str(env.dtype).split(".")[-1]]
         line["config"].update({"pyb_freq": 240, "ctrl_freq": 240,
                                "episode_steps": C5_EPISODE, "rollout_log_slots": c5_T, "rollout_log_GB": c5_T * slot_bytes / 1e9,
@@ -1055,6 +1063,8 @@ def main(argv=None):
         if fused_T:
             line["roofline"]["kernel"] = f"k_rollout_step<float,_Float16,false,false> ({fused_T} control steps per launch)"
             line["roofline"]["bound_note"] = "VALU (state in registers; the action table is read and the observation log written)"
+            line["roofline"]["us_per_launch"] = us_per_step * fused_T
+            line["roofline"]["bytes_per_launch"] = bytes_per * n_local * fused_T
             line["config"]["launch"] = f"C loop (mds_rollout_step_fused), {fused_T} steps per launch, obs -> rollout log slot"
     if c4:
         st = env._cbf_status
