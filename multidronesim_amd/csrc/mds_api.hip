@@ -13,13 +13,31 @@
 #include "../../include/mds.h"
 #include "mds_consts.hpp"
 #include "mds_kernels.hip"
-#include "mds_cbf_kernels.hip"
+#ifndef MDS_PART
+#define MDS_PART 3
+#endif
+#if MDS_PART & 2
+#include "mds_cbf_kernels.hip"      // (part 2 only: it defines a non-template kernel)
+#else
+#include "mds_cbf.hpp"
+#endif
 
 using namespace mds;
 
+// The library builds as one translation unit (MDS_PART 3, the default: `hipcc -shared mds_api.hip`) or as two compiled side by
+// side and linked (__graft_entry__.build(): -DMDS_PART=1 = handle management, the step / rollout / conversion entry points;
+// -DMDS_PART=2 = the ECBF filter, the LQR / DSLPID / low-level controllers and the CBF rollouts) -- the device code of ~200 kernel
+// instantiations compiles serially per unit, so two units halve the build and a change to the CBF kernels rebuilds one of them.
+namespace mds_detail {
+extern thread_local char g_err[512];            // last error text of the calling thread (mds_last_error): one copy for both parts
+#if MDS_PART & 1
+thread_local char g_err[512] = "";
+#endif
+}  // namespace mds_detail
+using mds_detail::g_err;
+
 namespace {
 
-thread_local char g_err[512] = "";
 
 int fail_hip(hipError_t e, const char* what) {
   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
@@ -331,6 +349,16 @@ static int upload_gain(mds_handle* h, int slot, const void* f32, size_t nf, cons
 
 extern "C" {
 
+// (C linkage like everything in this block; not part of include/mds.h)
+// helpers called across the two parts (defined once, in the part named)
+struct EnvRange;
+int step_env_plain(mds_handle* h, const void* action, void* obs, hipStream_t st, int first_substep, void* home = nullptr);              // part 1
+int step_env_ctrl(mds_handle* h, int ctrl, double t, const void* u_in, double thrust_offset, void* obs, void* act, hipStream_t st);     // part 1
+int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream, int ctrl, const char* who);       // part 1
+int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream, bool with_filter,            // part 2
+                          const char* who, const EnvRange* rgp = nullptr, bool have_nominal = false, bool want_next = false, double t_next = 0.0);
+
+#if MDS_PART & 1
 int mds_version(void) { return MDS_VERSION; }
 
 const char* mds_strerror(int status) {
@@ -693,7 +721,7 @@ static int envfx_return_home(mds_handle* h, void* home, hipStream_t st) {
   return MDS_OK;
 }
 
-static int step_env_plain(mds_handle* h, const void* action, void* obs, hipStream_t st, int first_substep, void* home = nullptr) {
+int step_env_plain(mds_handle* h, const void* action, void* obs, hipStream_t st, int first_substep, void* home) {
   const dim3 grid = grid_for(h->n, kBlock);
   const int K = h->cfg.pyb_freq / h->cfg.ctrl_freq, D = h->cfg.num_drones;
   void* rpm = rpm_track(h);
@@ -716,7 +744,7 @@ static int step_env_plain(mds_handle* h, const void* action, void* obs, hipStrea
 // One control step of a controller path under ground effect / downwash: k_step_ctrl_env (trajectory sample or given input ->
 // controller -> first substep), then the remaining substeps through k_step_env with the action it left in act_scratch.
 // ctrl 0 GeometricControl, 1 LQRController (12-state), 2 ThrustOmega low level on u_in, 3 YankOmega low level on u_in.
-static int step_env_ctrl(mds_handle* h, int ctrl, double t, const void* u_in, double thrust_offset, void* obs, void* act, hipStream_t st) {
+int step_env_ctrl(mds_handle* h, int ctrl, double t, const void* u_in, double thrust_offset, void* obs, void* act, hipStream_t st) {
   const dim3 grid = grid_for(h->n, kBlock);
   const int K = h->cfg.pyb_freq / h->cfg.ctrl_freq, D = h->cfg.num_drones;
   void* rpm = rpm_track(h);
@@ -1253,12 +1281,8 @@ int mds_get_last_rollout_form(const mds_handle* h) {
   return h->last_rollout_form;
 }
 
-struct EnvRange;
-static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream, bool with_filter,
-                                 const char* who, const EnvRange* rg, bool have_nominal, bool want_next, double t_next);
-
 // ctrl: 0 GeometricControl, 1 LQRController (12-state), 2 LQROmegaController + ThrustOmega, 3 LQRYankOmegaController + YankOmega
-static int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream, int ctrl, const char* who) {
+int rollout_fused(mds_handle* h, double t0, int n_steps, void* obs_log, void* obs_last, void* stream, int ctrl, const char* who) {
   if (!h || n_steps < 0) return fail(MDS_EINVAL, who);
   if (h->envfx) {
     // ground effect / downwash: env-mates interact every physics substep, so there is no state-in-registers form; the same loop
@@ -1433,6 +1457,8 @@ int mds_geo_model_to_obs(int dtype, int count, const void* x18, void* obs16, voi
   return MDS_OK;
 }
 
+#endif  // MDS_PART & 1
+#if MDS_PART & 2
 int mds_cbf_configure(mds_handle* h, const mds_cbf_params* p, const double* obstacles) {
   MDS_DEV(h);
   if (!h || !p) return fail(MDS_EINVAL, "mds_cbf_configure: null argument");
@@ -1955,9 +1981,8 @@ int mds_thrust_omega_from_rates(mds_handle* h, const void* u, const void* rates,
 // simulations/EnvGeometricOmega.py / EnvGeometricYankOmega.py (ctrl[j].compute(obs[j]) = LQR + low level, :314 / :319).
 // have_nominal: the previous step's low-level launch has already left this step's u_hat / xdes in the scratch (want_next of that call);
 // want_next: this step's low-level launch also computes the nominal input of the step at t_next (C rollout loops; nominal 0 / 1 only).
-static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream, bool with_filter,
-                                 const char* who, const EnvRange* rgp = nullptr, bool have_nominal = false, bool want_next = false,
-                                 double t_next = 0.0) {
+int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* status, void* action, void* stream, bool with_filter,
+                          const char* who, const EnvRange* rgp, bool have_nominal, bool want_next, double t_next) {
   EnvRange rg = rgp ? *rgp : EnvRange{0, -1, 0};
   if (!h->has_traj || h->traj_mode != 1) return fail(MDS_ESTATE, "mds_step_cbf_geometric / mds_step_nominal: call mds_set_lemniscate first");
   if (!aligned16(obs) || !aligned16(action)) return fail(MDS_EALIGN, "mds_step_cbf_geometric / mds_step_nominal: obs_dev/action_dev");
@@ -2086,7 +2111,7 @@ static int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* st
 // what k_cbf_rollout covers (mds_rollout_cbf_geometric_fused; mds_cbf_set_step_kernel(h, 2))
 static bool roll_fused_applies(const mds_handle* h) {
   const int D = h->cfg.num_drones;
-  const int m2 = D * (D - 1) / 2 + D * h->cbf.n_obs + 2 * D;
+  const int m2 = D * (D - 1) / 2 + (MDS_ROLL_BOUNDS ? 0 : D * h->cbf.n_obs) + 2 * D;      // (MDS_ROLL_BOUNDS: obstacle rows are per-drone bounds)
   return h->has_cbf && h->cbf.order == 2 && !h->cbf_hildreth && D >= 4 && D <= 16 && 64 % D == 0 && m2 <= 256 && !h->envfx &&
          h->cfg.integrator == MDS_INTEGRATOR_EULER && !has_drag(h) && h->cbf_nominal <= 1 && h->cfg.dtype != MDS_F16 &&
          h->cfg.pyb_freq == h->cfg.ctrl_freq && h->n <= (1 << 27);
@@ -2221,7 +2246,7 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
     ra.t = t; ra.ctrl_dt = dt; ra.n_steps = ks; ra.state = (T*)h->state; ra.state_lo = (T*)h->state_lo; ra.lem = (const T*)h->lem;                \
     ra.last_rpm = (T*)rpm; ra.ll = (T*)h->ll; ra.pair_ij = h->pair_ij; ra.obstacles = (const T*)h->obstacles; ra.obs_log = (T*)obs_log;           \
     ra.slot = slot; ra.n_slots = log_slots > 0 ? log_slots : 1; ra.obs_last = (T*)obs; ra.status = (int*)status; ra.status_log = (int*)slog;      \
-    ra.cost_io = h->cbf_cost; ra.max_iter = max_iter; ra.tol2 = (T)((TOL) * (TOL)); ra.stamps = stamps_dev;                                       \
+    ra.cost_io = h->cbf_cost; ra.max_iter = max_iter; ra.tol2 = (T)((TOL) * (TOL)); ra.tol = (T)(TOL); ra.stamps = stamps_dev;                   \
     k_cbf_rollout<T, NOM, COMP, (sizeof(T) == 8 ? NWD : NWF)><<<grid, 64 * nw, extra_lds, st>>>(ra);                                              \
   } while (0)
 #define MDS_CR_N(T, CC, CP, COMP, TOL)                        \
@@ -2282,5 +2307,7 @@ int mds_step_nominal(mds_handle* h, double t, void* obs, void* action, void* str
     return rollout_fused(h, t, 1, nullptr, obs, stream, h->cbf_nominal == 2 ? 3 : 2, "mds_step_nominal");
   return step_nominal_lowlevel(h, t, obs, nullptr, action, stream, false, "mds_step_nominal");
 }
+
+#endif  // MDS_PART & 2
 
 }  // extern "C"

@@ -421,7 +421,20 @@ template <typename T, int NV> struct CbfRow {
 // scratch.  ROWTAB: the selected row is fetched from an LDS copy of the rows (srow) by a uniform address; without it, from the owning
 // lane's registers (a select over its R rows + v_readlane) -- 16 bytes of LDS per row less.  Returns converged / iterations; su holds
 // the minimiser when converged.  Must be called with all 64 lanes active.
-template <typename T, int R, int NMAX, int NV, bool ROWTAB, int kQS>
+// SMALLQ > 0 (thrust-only QPs, NV == 1): active sets of up to SMALLQ rows live in REGISTERS as wave-uniform values -- a row of this QP
+// has at most two coefficients, so everything a step needs of the active set (d = N^T a, the Gram matrix N^T N of <= 3 x 3, r = its
+// solve in closed form, the multipliers, the drop bookkeeping) is arithmetic on uniform operands that every lane runs alike: no Q, R
+// or multipliers in LDS, no column reads, no back-substitution chain of v_readlane, one wave reduction (|z|^2) per step instead of
+// three.  The step is the dual active-set step of the general path (and of oracle/c_oracle.c qp_project, which solves the same Gram
+// system); a set that needs row SMALLQ + 1 is written out once as the thin QR the general path continues on.  The census of the C4
+// scenes: 0.76 tight pair rows per env-step on `under`, 2.6 iterations per env-step that iterates -- sets of 1-3 rows
+// are what the solver meets.  Unit-norm rows of this QP have coefficients +-1 (bounds) or +-1/sqrt2 (pairs): the Gram matrix of an
+// independent set is well conditioned (entries 0, +-1/2, +-1/sqrt2); should its determinant still come out tiny, the set is handed
+// to the QR path before the step is taken.
+#ifndef MDS_GI_SMALLQ
+#define MDS_GI_SMALLQ 0      // (measured on MI355X, round 4: 1 / 2 / 3 are 3 / 8 / 14 % SLOWER on C4 -- see DESIGN.md 4; kept for A/B)
+#endif
+template <typename T, int R, int NMAX, int NV, bool ROWTAB, int kQS, int SMALLQ = (NV == 1 ? MDS_GI_SMALLQ : 0)>
 __device__ __forceinline__ void gi_solve(const int lane, const int n, const int max_iter, const T tol2, const bool infeasible0,
                                          const T (&ca)[R][NV], const T (&cb)[R][NV], const T (&b)[R], const int (&ia)[R], const int (&ib)[R],
                                          const bool (&valid)[R], bool (&act)[R], T* __restrict__ su, T* __restrict__ sd,
@@ -430,13 +443,27 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
                                          int& q_out) {
   constexpr bool PRE = NMAX * sizeof(T) <= 128;   // a lane's rows of Q and R fit in registers: one LDS round trip per step instead of 2q
   static_assert(kQS == (PRE ? ((NMAX + 3) / 4 * 4 + 4) : NMAX + 1), "LDS row stride of Q and R");
+  static_assert(SMALLQ >= 0 && SMALLQ <= 3 && (SMALLQ == 0 || NV == 1), "register-resident active sets: thrust-only QPs, at most 3 rows");
   bool converged = false;
   bool infeasible = infeasible0;
   int q = 0, it = 0;
+  // the register-resident active set (uniform): row k < q is  ra[k] u[ri[k]] + rb[k] u[rj[k]] <= .. (rb = 0, rj = ri on a one-variable
+  // row), multiplier rl[k], row id rid[k] (lane + 64 slot of the owner); g..: its Gram matrix
+  constexpr int QR = SMALLQ > 0 ? SMALLQ : 1;
+  bool small = SMALLQ > 0;
+  T ra[QR], rb[QR], rl[QR];
+  int ri[QR], rj[QR], rid[QR];
+  T g00 = T(1), g11 = T(1), g22 = T(1), g01 = T(0), g02 = T(0), g12 = T(0);
+#pragma unroll
+  for (int k = 0; k < QR; ++k) {
+    ra[k] = rb[k] = rl[k] = T(0);
+    ri[k] = rj[k] = rid[k] = 0;
+  }
   while (!infeasible && it < max_iter) {
     // ---- most violated row outside the active set (distance^2 to its half-space) ----
     T best = T(0);
     int best_k = 0;
+
     T ua[R][NV], ub[R][NV];
 #pragma unroll
     for (int k = 0; k < R; ++k)
@@ -529,6 +556,145 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
 #pragma unroll
       for (int v = 0; v < NV; ++v) res = m_fma(wca[v], su[NV * wia + v], m_fma(two ? wcb[v] : T(0), su[NV * wib + v], res));
       const int ln = lane < NMAX ? lane : NMAX - 1;                                      // lanes >= n hold no row: clamp the address only
+      if constexpr (SMALLQ > 0) {
+        if (small) {
+          const T my_u = su[ln];
+          const T na = wca[0], nb = two ? wcb[0] : T(0);
+          auto ncoef = [&](int v) { return (v == wia ? na : T(0)) + ((two && v == wib) ? nb : T(0)); };   // the new row's coefficient at variable v
+          // d = N^T a, r = (N^T N)^-1 d
+          T d[QR], r[QR];
+#pragma unroll
+          for (int k = 0; k < QR; ++k) {
+            d[k] = k < q ? m_fma(ra[k], ncoef(ri[k]), (rj[k] != ri[k]) ? rb[k] * ncoef(rj[k]) : T(0)) : T(0);
+            r[k] = T(0);
+          }
+          T det = T(1);
+          if (q == 1) {
+            det = g00;
+            r[0] = d[0] * m_rcp(g00);
+          } else if (QR >= 2 && q == 2) {
+            det = m_fma(g00, g11, -(g01 * g01));
+            const T id = m_rcp(det);
+            r[0] = m_fma(g11, d[0], -(g01 * d[QR >= 2 ? 1 : 0])) * id;
+            r[QR >= 2 ? 1 : 0] = m_fma(g00, d[QR >= 2 ? 1 : 0], -(g01 * d[0])) * id;
+          } else if (QR >= 3 && q == 3) {
+            constexpr int i1 = QR >= 3 ? 1 : 0, i2 = QR >= 3 ? 2 : 0;
+            const T c00 = m_fma(g11, g22, -(g12 * g12)), c01 = m_fma(g02, g12, -(g01 * g22)), c02 = m_fma(g01, g12, -(g02 * g11));
+            const T c11 = m_fma(g00, g22, -(g02 * g02)), c12 = m_fma(g01, g02, -(g00 * g12)), c22 = m_fma(g00, g11, -(g01 * g01));
+            det = m_fma(g00, c00, m_fma(g01, c01, g02 * c02));
+            const T id = m_rcp(det);
+            r[0] = m_fma(c00, d[0], m_fma(c01, d[i1], c02 * d[i2])) * id;
+            r[i1] = m_fma(c01, d[0], m_fma(c11, d[i1], c12 * d[i2])) * id;
+            r[i2] = m_fma(c02, d[0], m_fma(c12, d[i1], c22 * d[i2])) * id;
+          }
+          // a set at capacity, or a Gram determinant that rounding could own: continue on the thin QR in LDS (below)
+          if (q == SMALLQ || !(det > T(sizeof(T) == 4 ? 1e-3 : 1e-6))) {
+            for (int j = 0; j < q; ++j) {                                                // Gram-Schmidt append of row j, as the general step's
+              T ja = ra[0], jb = rb[0], jl = rl[0];
+              int ji = ri[0], jj = rj[0], jid = rid[0];
+#pragma unroll
+              for (int k = 1; k < QR; ++k)
+                if (k == j) { ja = ra[k]; jb = rb[k]; jl = rl[k]; ji = ri[k]; jj = rj[k]; jid = rid[k]; }
+              const bool jtwo = jj != ji;
+              T dcj = m_fma(ja, sQ[ji][ln], jtwo ? jb * sQ[jj][ln] : T(0));
+              dcj = lane < j ? dcj : T(0);
+              T zj = T(0);
+              if (lane < n) {
+                zj = (lane == ji ? ja : T(0)) + ((jtwo && lane == jj) ? jb : T(0));
+                for (int c = 0; c < j; ++c) zj = m_fma(-sQ[lane][c], wv::get(dcj, c), zj);
+              }
+              const T zzj = wv::allreduce_n<ROW0>(zj * zj, wv::Add());
+              const T inzj = m_rsqrt(zzj), nzj = zzj * inzj;
+              MDS_WAVE_SYNC();
+              if (lane < n) sQ[lane][j] = zj * inzj;
+              if (lane < j) sR[lane][j] = dcj;
+              if (lane == 0) {
+                sR[j][j] = nzj;
+                sdi[j] = inzj;
+                slam[j] = jl;
+                sact[j] = jid;
+              }
+              MDS_WAVE_SYNC();
+            }
+            small = false;
+          } else {
+            T zv = T(0);
+            if (lane < n) {
+              zv = ncoef(lane);
+#pragma unroll
+              for (int k = 0; k < QR; ++k)
+                if (k < q) zv = m_fma(-r[k], (lane == ri[k] ? ra[k] : T(0)) + ((rj[k] != ri[k] && lane == rj[k]) ? rb[k] : T(0)), zv);
+            }
+            const T zz = wv::allreduce_n<ROW0>(zv * zv, wv::Add());
+            T rmax = T(0);
+#pragma unroll
+            for (int k = 0; k < QR; ++k) rmax = k < q ? m_max(rmax, m_abs(r[k])) : rmax;
+            T t1 = GiEps<T>::inf;
+            int drop = 0;
+#pragma unroll
+            for (int k = 0; k < QR; ++k)
+              if (k < q && r[k] > GiEps<T>::r * rmax && r[k] > T(0)) {
+                const T cand = m_max(rl[k], T(0)) * m_rcp(r[k]);
+                if (cand < t1) {                                                         // ties: lowest column
+                  t1 = cand;
+                  drop = k;
+                }
+              }
+            const bool has_z = zz > GiEps<T>::z;
+            const T t2 = has_z ? res * m_rcp(zz) : GiEps<T>::inf;
+            const T t = m_min(t1, t2);
+            if (!(t < GiEps<T>::inf)) {
+              infeasible = true;                                                         // no step possible: rows inconsistent
+              break;
+            }
+            const bool full = has_z && t2 <= t1;
+            MDS_WAVE_SYNC();
+            if (has_z && lane < n) su[lane] = m_fma(-t, zv, my_u);
+#pragma unroll
+            for (int k = 0; k < QR; ++k) rl[k] = k < q ? m_fma(-t, r[k], rl[k]) : rl[k];
+            lam_new += t;
+            if (full) {                                                                  // add: N <- [N a]
+              const T aa = m_fma(na, na, nb * nb);
+#pragma unroll
+              for (int k = 0; k < QR; ++k)
+                if (k == q) { ra[k] = na; rb[k] = nb; rl[k] = lam_new; ri[k] = wia; rj[k] = two ? wib : wia; rid[k] = wrow; }
+              if (q == 0) g00 = aa;
+              else if (q == 1) { g01 = d[0]; g11 = aa; }
+              else { g02 = d[0]; g12 = d[QR >= 2 ? 1 : 0]; g22 = aa; }
+              if (lane == owner) {
+#pragma unroll
+                for (int k = 0; k < R; ++k)
+                  if (k == kk) act[k] = true;
+              }
+              ++q;
+              MDS_WAVE_SYNC();
+              break;
+            }
+            // ---- drop active row `drop` (its multiplier reached zero) ----
+            int drow = rid[0];
+#pragma unroll
+            for (int k = 1; k < QR; ++k) drow = k == drop ? rid[k] : drow;
+            if (lane == (drow & 63)) {
+#pragma unroll
+              for (int k = 0; k < R; ++k)
+                if (k == (drow >> 6)) act[k] = false;
+            }
+            if (QR >= 3 && q == 3) {                                                     // the Gram matrix without row / column `drop`
+              if (drop == 0) { g00 = g11; g01 = g12; g11 = g22; }
+              else if (drop == 1) { g01 = g02; g11 = g22; }
+            } else if (q == 2 && drop == 0) {
+              g00 = g11;
+            }
+#pragma unroll
+            for (int k = 0; k + 1 < QR; ++k)
+              if (k >= drop) { ra[k] = ra[k + 1]; rb[k] = rb[k + 1]; rl[k] = rl[k + 1]; ri[k] = ri[k + 1]; rj[k] = rj[k + 1]; rid[k] = rid[k + 1]; }
+            --q;
+            MDS_WAVE_SYNC();
+            continue;
+          }
+        }
+        // (here: the set was just written out as a thin QR -- this step, same row and same count, runs on it below)
+      }
 #if !defined(MDS_TUNE_GI_NO_FIRST_STEP)
       if (q == 0) {
         // Empty active set (the first step of most solves, and the only one of more than half of them): the step runs along the
@@ -710,7 +876,9 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
   if (converged && it > 0) {
     // final certificate: EVERY row (active ones included) holds at the returned point.  Guards the
     // near-dependent / infeasible corner where a step along a numerically tiny z is taken.  (No iteration: the scan that
-    // declared convergence has just checked every row at the nominal point.)
+    // declared convergence has just checked every row at the nominal point.)  Round 4 tried folding it into the scan that declares
+    // convergence (a running maximum over all valid rows, one ballot at the exit: the same decision): 3 % SLOWER on every C4 scene --
+    // every env pays for the maximum in every scan, only the envs that iterated ever ran the certificate.
     T worst = T(0);
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -1214,6 +1382,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 && R == 4) ? 4 : 1) void k_cbf_
 #ifndef MDS_TUNE_ROLL_SKIP
 #define MDS_TUNE_ROLL_SKIP 0   // tuning aid (cost breakdown of stage B): 1 no row polynomial, 2 no normalisation, 4 no scan / solve, 8 no rows
 #endif
+#ifndef MDS_ROLL_BOUNDS
+#define MDS_ROLL_BOUNDS 1      // 1: obstacle and thrust-box rows folded into per-drone bounds in the drone-per-lane stage (round 4); 0: round 3's row layout (A/B)
+#endif
 struct RollSlot {       // row r = lane + 64 k of any env: what it is, as the row build consumes it (built once per launch by roll_slot_of)
   int a0;               // barrier rows: byte offset of agent i's record half 0 from the env's first record (swizzle applied); else 0
   int b0;               // pair rows: the same for agent j; other rows: byte offset of an obstacle record (obstacle o, or the first) in the
@@ -1226,8 +1397,10 @@ struct RollSlot {       // row r = lane + 64 k of any env: what it is, as the ro
 // sob / dso: byte offsets of the obstacle records and of the -Ds^4 table in the LDS block; wT: sizeof(T)
 template <typename T>
 __device__ __forceinline__ RollSlot roll_slot_of(const CbfParams<T>& P, const int* __restrict__ pair_ij, const int r, const int rec, const bool swz,
-                                                 const int sob, const int dso) {
-  const int D = P.num_drones, npairs = cbf_num_pairs(D), nobs_rows = D * P.n_obs, m = npairs + nobs_rows + 2 * D;
+                                                 const int sob, const int dso, const bool bounds = false) {
+  // bounds: the single-variable rows (obstacles, thrust box) are per-drone bounds made in stage A; the QP sees the pair rows, then
+  // D rows +u_var <= hi_var (kind 3) and D rows -u_var <= -lo_var (kind 4)
+  const int D = P.num_drones, npairs = cbf_num_pairs(D), nobs_rows = bounds ? 0 : D * P.n_obs, m = npairs + nobs_rows + 2 * D;
   auto half0 = [&](int ag) { return ag * rec + ((swz && ((ag >> 3) & 1)) ? 16 : 0); };
   RollSlot sl = {0, sob, dso, 0};
   if (r < npairs) {
@@ -1291,6 +1464,7 @@ template <typename T> struct RollArgs {
   int max_iter;
   T tol2;
   unsigned long long* stamps;
+  T tol;                          // sqrt(tol2): the distance by which a drone's bound interval may be empty before its env is infeasible
 };
 template <typename T> __device__ __forceinline__ const RollArgs<T> MDS_CONST_AS* fresh_args() {
   const RollArgs<T> MDS_CONST_AS* p = (const RollArgs<T> MDS_CONST_AS*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1310,7 +1484,8 @@ template <typename T, int NOM, bool COMP, int NW>
 __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout(const RollArgs<T>) {
 
   constexpr int NT = 64 * NW;
-  constexpr int R = 4, NMAX = 16, NV = 1;
+  constexpr bool kBounds = MDS_ROLL_BOUNDS != 0;
+  constexpr int R = kBounds ? 3 : 4, NMAX = 16, NV = 1;            // rows per lane: 120 pair rows + 32 bound rows <= 192 (round 3: 216 rows)
   constexpr int kQS = (NMAX + 3) / 4 * 4 + 4;
   constexpr int GBMAX = NT / 4;                                // envs per workgroup (D >= 4)
   // One drone's record: two 16-byte halves (px py e_pitch -e_roll | e_vx e_vy pz e_vz) -- the operand pairs of cbf_row_o2_pairs side
@@ -1344,6 +1519,12 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   T* const sDs = reinterpret_cast<T*>(raw + kDsOff);                  // -Ds^4: [0] pairs, [1 + o] obstacle o
   __shared__ T st[14][NT];                                     // the state and u_hat[0] across stage B (lane-contiguous planes: conflict-free)
   __shared__ T su_all[NT];                                     // thrust variable of every drone: u_hat[0] in, QP minimiser out
+  // Per-drone bounds of the thrust variable (kBounds): every obstacle row (cbf/cbf.py:369-398) and the thrust box (:400-412) of order 2
+  // constrain u[4 i] of drone i alone and depend on drone i's own state only, so stage A -- one drone per lane, state in registers --
+  // evaluates them and folds them into  u_i <= sbnd[0][i]  and  -u_i <= sbnd[1][i];  the QP of stage B sees the pair rows and these two
+  // rows per drone.  An obstacle row beyond the reach of the box, or an empty interval, writes -inf to both: the env is infeasible
+  // before any row of it is built.
+  __shared__ T sbnd[kBounds ? 2 : 1][kBounds ? NT : 1];
   __shared__ __align__(16) RollSlot stab[R][64];               // row slot table
   __shared__ int sconv[GBMAX], scost[GBMAX], sorder[GBMAX];    // per env of the workgroup: QP solved; iterations of its last solve; hand-out order
   __shared__ int sticket;
@@ -1391,7 +1572,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   {
     const CbfParams<T> P = load_const(&a0->p.P);
     const T* obstacles = a0->obstacles;
-  if (tid < R * 64) stab[tid >> 6][tid & 63] = roll_slot_of<T>(P, a0->pair_ij, (tid & 63) + 64 * (tid >> 6), kRec, kSwz && P.num_drones == 16, kSobOff, kDsOff);
+  if (tid < R * 64) stab[tid >> 6][tid & 63] = roll_slot_of<T>(P, a0->pair_ij, (tid & 63) + 64 * (tid >> 6), kRec, kSwz && P.num_drones == 16, kSobOff, kDsOff, kBounds);
   if (tid < kCbfMaxObs) {
     const bool on = tid < P.n_obs;
     for (int k = 0; k < 8; ++k) sobrec[tid][k] = T(0);
@@ -1437,6 +1618,40 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     const int sw = kSwz ? ((lq >> 3) & (D >> 4)) : 0;            // D = 16, agents 8..15: halves swapped
     *reinterpret_cast<V4*>(rc + 4 * sw) = V4{{s.p.x + Pl.cx, s.p.y + Pl.cy, rpy.y - T(0), -(rpy.x - T(0))}};
     *reinterpret_cast<V4*>(rc + 4 * (sw ^ 1)) = V4{{s.v.x - des.v.x, s.v.y - des.v.y, s.p.z + Pl.cz, s.v.z - des.v.z}};
+    if constexpr (kBounds) {
+      // the drone's single-variable rows -> its bounds.  Same operands as round 3's obstacle row slots (an obstacle is a record with
+      // zero tracking errors: x - 0 is exact), same row polynomial (contraction off), four obstacles side by side.
+      const CbfParams<T> Pb = load_const(&a->p.P);
+      const T wx = s.p.x + Pl.cx, wy = s.p.y + Pl.cy, wz = s.p.z + Pl.cz, evx = s.v.x - des.v.x, evy = s.v.y - des.v.y, evz = s.v.z - des.v.z;
+      T hi = Pb.umax[0], nlo = Pb.umax[0];
+      bool badl = false;
+      for (int o0 = 0; o0 < Pb.n_obs; o0 += 4) {                   // (uniform)
+        Pair<T> exy[4], dpr[4], dvxy[4], ezvz[4];
+        T nds4[4], hr[4], lg[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int o = o0 + j < kCbfMaxObs ? o0 + j : kCbfMaxObs - 1;
+          exy[j] = Pair<T>{wx - sobrec[o][0], wy - sobrec[o][1]};
+          dpr[j] = Pair<T>{rpy.y, -rpy.x};
+          dvxy[j] = Pair<T>{evx, evy};
+          ezvz[j] = Pair<T>{wz - sobrec[o][6], evz};
+          nds4[j] = sDs[1 + o];
+        }
+        cbf_row_o2_pairs<T, 4>(Pb, exy, dpr, dvxy, ezvz, nds4, hr, lg);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool on = o0 + j < Pb.n_obs;                       // (uniform)
+          const T aa = m_abs(lg[j]);                               // the row: -lg u <= hr
+          // beyond the reach of the box (round 3's test on the normalised row, b < -|a| umax): also the row 0 u <= hr < 0
+          badl = badl | (on & (hr[j] < -(aa * Pb.umax[0]) * (T(1) + T(sizeof(T) == 4 ? 1e-5 : 1e-10))));
+          const T bnd = hr[j] * m_rcp(aa);
+          hi = (on && lg[j] < T(0)) ? m_min(hi, bnd) : hi;         //  |lg| u <= hr
+          nlo = (on && lg[j] > T(0)) ? m_min(nlo, bnd) : nlo;      // -|lg| u <= hr
+        }
+      }
+      sbnd[0][tq] = badl ? -GiEps<T>::inf : hi;
+      sbnd[1][tq] = badl ? -GiEps<T>::inf : nlo;
+    }
     su_all[tq] = un0;
     st[13][tq] = un0;                                              // (su_all holds the QP's answer after stage B)
     st[0][tq] = s.p.x; st[1][tq] = s.p.y; st[2][tq] = s.p.z;
@@ -1462,7 +1677,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     stage_a(a0, c1, load_params(a0, (unsigned)i), t, tid);
   }
   const int log2D = 31 - __clz(D);                             // D is 4, 8 or 16
-  const int nbs = (cbf_num_pairs(D) + D * a0->p.P.n_obs + 63) >> 6;   // row slots that hold barrier rows
+  const int nbs = (cbf_num_pairs(D) + (kBounds ? 0 : D * a0->p.P.n_obs) + 63) >> 6;   // row slots that hold barrier rows
 
   for (int k = 0; k < n_steps; ++k) {
     if (wave == 0) {
@@ -1521,6 +1736,15 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         int ia[R], ib[R];
         bool vld[R], act[R];
         bool bad = false;
+        // kBounds: a drone whose single-variable rows leave no thrust value (stage A wrote -inf / -inf, or lo > hi) makes the env
+        // infeasible before any row is built -- the same decision as round 3's reach test while the rows were built, plus rows of one
+        // drone that contradict each other (round 3: found by the solver, "no step possible")
+        bool skip = false;
+        if constexpr (kBounds) {
+          const int lc = tl < D ? tl : D - 1;
+          const T h_l = sbnd[0][d0 + lc], n_l = sbnd[1][d0 + lc];
+          skip = __any(h_l + n_l < -ab->tol);
+        }
         // Rows r = lane + 64 k.  Slots below NBS hold barrier rows -- all of them in slots below NBS - 1, beside the first box rows in
         // slot NBS - 1: ONE straight-line body per slot, every lane runs the barrier arithmetic (lanes of other kinds on a harmless
         // record pair, their result replaced by a select), all slots' LDS reads issued together (one round trip per env).
@@ -1532,6 +1756,14 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         RollSlot sl[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) sl[r] = stab[r][tl];
+        T bndv[R];                                                 // kBounds: the right-hand side of a bound row (kind 3: hi, kind 4: -lo of its drone)
+#pragma unroll
+        for (int r = 0; r < R; ++r) bndv[r] = P.umax[0];
+        if constexpr (kBounds) {
+#pragma unroll
+          for (int r = NBS - 1; r < R; ++r)
+            bndv[r] = (&sbnd[0][0])[(((sl[r].kind & 255) == 4) ? NT : 0) + d0 + ((sl[r].kind >> 8) & 255)];
+        }
         using P2 = Pair<T>;
         P2 oa[NBS][4], ob[NBS][4];                                 // operand pairs of agent i / agent j or obstacle: (px py) (e_pitch -e_roll) (e_vx e_vy) (pz e_vz)
         T nds4[NBS];
@@ -1612,7 +1844,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
             const bool bar = kind == 1 || kind == 2;
             bad = bad | (bar & unreachable[r]);
             // +-u_var <= umax (cbf/cbf.py:400-412): unit norm as it stands
-            const T box_c = kind == 3 ? T(1) : (kind == 4 ? T(-1) : T(0)), box_b = kind >= 3 ? P.umax[0] : T(0);
+            const T box_c = kind == 3 ? T(1) : (kind == 4 ? T(-1) : T(0)), box_b = kind >= 3 ? bndv[r] : T(0);
             ca[r][0] = bar ? cak[r] : box_c;
             cb[r][0] = bar ? cbk[r] : T(0);
             b[r] = bar ? bk[r] : box_b;
@@ -1620,7 +1852,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
           } else {
             ca[r][0] = kind == 3 ? T(1) : (kind == 4 ? T(-1) : T(0));
             cb[r][0] = T(0);
-            b[r] = kind >= 3 ? P.umax[0] : T(0);
+            b[r] = kind >= 3 ? bndv[r] : T(0);
             vld[r] = kind >= 3;
           }
         }
@@ -1629,11 +1861,18 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         for (int r = 0; r < R; ++r) { ca[r][0] = cb[r][0] = b[r] = T(0); ia[r] = ib[r] = 0; vld[r] = act[r] = false; }
         if (false)
 #endif
-        switch (__builtin_amdgcn_readfirstlane(nbs)) {             // (wave-uniform; a scalar branch)
-          case 1: build_rows(wv::Ic<1>{}); break;
-          case 2: build_rows(wv::Ic<2>{}); break;
-          case 3: build_rows(wv::Ic<3>{}); break;
-          default: build_rows(wv::Ic<4>{}); break;
+        if (!skip) {
+          if constexpr (kBounds) {
+            if (__builtin_amdgcn_readfirstlane(nbs) <= 1) build_rows(wv::Ic<1>{});     // (wave-uniform; a scalar branch)
+            else build_rows(wv::Ic<2>{});
+          } else {
+            switch (__builtin_amdgcn_readfirstlane(nbs)) {
+              case 1: build_rows(wv::Ic<1>{}); break;
+              case 2: build_rows(wv::Ic<2>{}); break;
+              case 3: build_rows(wv::Ic<3>{}); break;
+              default: build_rows(wv::Ic<(R < 4 ? R : 4)>{}); break;
+            }
+          }
         }
         stamp_b(7);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)
@@ -1651,6 +1890,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         }
         if (false)
 #endif
+        if (!skip)
         gi_solve<T, R, NMAX, NV, false, kQS>(lane, D, max_iter, tol2, __any(bad), ca, cb, b, ia, ib, vld, act, &su_all[d0], S.sd, S.slam, S.sdi,
                                              S.sQ, S.sR, S.sact, nullptr, converged, it, q);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MDS_TUNE_NO_SETPRIO)

@@ -6,7 +6,7 @@ out = os.path.join(ROOT, "build", "isa")
 os.makedirs(out, exist_ok=True)
 asm = os.path.join(out, "mds_api.s")
 if "--no-build" not in sys.argv:
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-Wno-pass-failed", "-w", "-S", "--cuda-device-only",
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-Wno-pass-failed", "-w", "-DMDS_PART=2", "-S", "--cuda-device-only",
                            "-o", asm, os.path.join(ROOT, "multidronesim_amd", "csrc", "mds_api.hip")])
 s = open(asm).read()
 for m in re.finditer(r"\.name:\s+(\S*k_cbf_rollout\S*)", s):
