@@ -425,8 +425,8 @@ template <typename T, int NV> struct CbfRow {
 // has at most two coefficients, so everything a step needs of the active set (d = N^T a, the Gram matrix N^T N of <= 3 x 3, r = its
 // solve in closed form, the multipliers, the drop bookkeeping) is arithmetic on uniform operands that every lane runs alike: no Q, R
 // or multipliers in LDS, no column reads, no back-substitution chain of v_readlane, one wave reduction (|z|^2) per step instead of
-// three.  The step is the dual active-set step of the general path (and of oracle/c_oracle.c qp_project, which solves the same Gram
-// system); a set that needs row SMALLQ + 1 is written out once as the thin QR the general path continues on.  The census of the C4
+// three.  The step is the dual active-set step of the general path (solving the Gram system of the active normals directly, as the
+// plain-C checker of the tests does); a set that needs row SMALLQ + 1 is written out once as the thin QR the general path continues on.  The census of the C4
 // scenes: 0.76 tight pair rows per env-step on `under`, 2.6 iterations per env-step that iterates -- sets of 1-3 rows
 // are what the solver meets.  Unit-norm rows of this QP have coefficients +-1 (bounds) or +-1/sqrt2 (pairs): the Gram matrix of an
 // independent set is well conditioned (entries 0, +-1/2, +-1/sqrt2); should its determinant still come out tiny, the set is handed
