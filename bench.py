@@ -392,20 +392,25 @@ def c4_spheres(scene, z_override=None):
     return [np.array([[sx * xy, sy * xy, z], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)], [0.1] * 4
 
 
-def c4_inputs(E, D, seed):
-    """SURVEY 8d's C4 generator: the C3 swarm with trajectories / start heights stacked 0.3 m apart (with the omega linearisation the
-    barrier acts through e_z only)."""
+def c4_inputs(E, D, seed, generator="stacked"):
+    """The C4 swarm.  "stacked" (the bench's default): SURVEY 8d's generator MODIFIED -- the C3 swarm with start heights and trajectory
+    centres stacked 0.3 m apart instead of all at z = 0.5 (with the omega linearisation the barrier acts on the thrust through e_z
+    only: drones that share a plane have no authority over their pair rows).  "survey": SURVEY 8d's generator as written -- every
+    drone and every Lemniscate centre at z = 0.5."""
     xyz, rpy, P = make_inputs(E, D, "c3", seed)
-    P[..., 4] = 0.5 + 0.3 * np.arange(D)
-    xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    if generator == "stacked":
+        P[..., 4] = 0.5 + 0.3 * np.arange(D)
+        xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    elif generator != "survey":
+        raise ValueError(generator)
     return xyz, rpy, P
 
 
-def c4_make(CtrlAviary, DroneModel, Physics, E, D, seed, dtype, local_rank):
+def c4_make(CtrlAviary, DroneModel, Physics, E, D, seed, dtype, local_rank, generator="stacked"):
     from multidronesim_amd.cbf.cbf import DroneCBF
     from multidronesim_amd.cbf.qptracker import DroneQPTracker
     from multidronesim_amd.model.linear_omega import LinearizedOmegaModel
-    xyz, rpy, P = c4_inputs(E, D, seed)
+    xyz, rpy, P = c4_inputs(E, D, seed, generator)
     env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN,
                      pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype, device=local_rank)
     cbf = DroneCBF(env, [LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2,
@@ -458,12 +463,13 @@ def c4_pmc_traffic(scene, n_local, fused=False):
 
 
 def measure_c4(CtrlAviary, DroneModel, Physics, torch, local_rank, device, scene, dtype="float32", steps=200, warmup=20, fused_T=0,
-               one_launch=False, stats=True, seed=1000):
+               one_launch=False, stats=True, seed=1000, generator="stacked"):
     """BASELINE configs[3] on its own env: `warmup` untimed + `steps` timed control steps of the CBFTest.py:303-350 loop through the C
     rollout (or the K-steps-per-launch kernel), HIP events on the launch stream; then the untimed per-step census of the same window."""
     E, D, _, desc = WORKLOADS["c4"]
-    env, tracker = c4_make(CtrlAviary, DroneModel, Physics, E, D, seed, dtype, local_rank)
+    env, tracker = c4_make(CtrlAviary, DroneModel, Physics, E, D, seed, dtype, local_rank, generator)
     c4_obs, c4_r = c4_spheres(scene)
+    bpd = BYTES_PER_DRONE_STEP_C4 * (2 if dtype == "float64" else 1)         # 280 B in fp32 / f32c, 560 B in float64
     env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=device))
     dt = env.CTRL_TIMESTEP
     if one_launch:
@@ -483,17 +489,20 @@ def measure_c4(CtrlAviary, DroneModel, Physics, torch, local_rank, device, scene
     obs = env._obs
     sane = bool(torch.isfinite(obs).all().item()) and abs(float(obs[..., 3:7].norm(dim=-1).mean().item()) - 1.0) < 1e-3
     n_local = E * D
-    gb = BYTES_PER_DRONE_STEP_C4 * n_local / (us * 1e-6) / 1e9
-    out = {"workload": desc, "scene": scene, "scene_what": C4_SCENES[scene][2], "us_per_step": us, "value": n_local / (us * 1e-6),
+    gb = bpd * n_local / (us * 1e-6) / 1e9
+    out = {"workload": desc, "scene": scene, "scene_what": C4_SCENES[scene][2], "dtype": dtype,
+           "generator": ("SURVEY 8d's generator MODIFIED: start heights / trajectory centres stacked 0.3 m apart" if generator == "stacked" else
+                         "SURVEY 8d's generator as written: every drone and trajectory centre at z = 0.5"),
+           "us_per_step": us, "value": n_local / (us * 1e-6),
            "unit": "drone-steps/s", "steps": steps, "warmup": warmup, "streams": used, "state_sane": sane,
-           "step_kernel": (f"k_cbf_rollout ({fused_T} control steps per launch, state in registers)" if fused_T else
+           "step_kernel": (f"k_cbf_rollout<{'double' if dtype == 'float64' else 'float'}, ...> ({fused_T} control steps per launch, state in registers / LDS)" if fused_T else
                            ("k_cbf_step (one launch per step)" if env.cbf_last_step_kernel() == 1 else "k_cbf_filter_gi + k_lowlevel_step (two launches per step and env half)")),
-           "roofline": {"bound": "hbm", "bytes_per_drone_step": BYTES_PER_DRONE_STEP_C4, "achieved": gb, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "roofline": {"bound": "hbm", "bytes_per_drone_step": bpd, "achieved": gb, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": gb / HBM_PEAK_GBPS,
-                        "note": "algorithmic bytes of SURVEY 8d (280 B per drone-step); the path is VALU / latency bound, not HBM bound"}}
-    tr, src = c4_pmc_traffic(scene, n_local, bool(fused_T))
+                        "note": "algorithmic bytes of SURVEY 8d (280 B per drone-step in fp32, 560 B in float64); the path is VALU / latency bound, not HBM bound"}}
+    tr, src = c4_pmc_traffic(scene, n_local, bool(fused_T)) if (dtype == "float32" and generator == "stacked") else (None, None)
     if tr is not None:
-        out["roofline"].update({"traffic": tr, "traffic_source": src, "traffic_over_algorithmic": tr / (BYTES_PER_DRONE_STEP_C4 * n_local)})
+        out["roofline"].update({"traffic": tr, "traffic_source": src, "traffic_over_algorithmic": tr / (bpd * n_local)})
     if stats:
         try:
             out["window"] = c4_window_stats(torch, env, tracker, c4_obs, c4_r, warmup, steps)
@@ -549,12 +558,12 @@ def measure_c5(CtrlAviary, DroneModel, Physics, torch, local_rank, device, steps
     return out
 
 
-def cpu_baseline_c4(budget_s=8.0, E=2, D=16, scene="under"):
+def cpu_baseline_c4(budget_s=8.0, E=2, D=16, scene="under", generator="stacked"):
     """The oracle's C4 loop (geometric nominal -> cbf_filter: dense rows + exact QP per env -> ThrustOmega -> DYN step) on a bounded
     sample, one core."""
     from oracle import np_oracle as O
     c = O.CF2P
-    xyz, rpy, P = c4_inputs(E, D, 123)
+    xyz, rpy, P = c4_inputs(E, D, 123, generator)
     x_obs, obs_r = c4_spheres(scene)
     n = E * D
     Pf = P.reshape(-1, 7)
@@ -586,7 +595,7 @@ def cpu_baseline_c4(budget_s=8.0, E=2, D=16, scene="under"):
                       f"(dense 216-row G per env + exact active-set QP), {nfb} infeasible env-steps"}
 
 
-def cpu_baseline_c4_c_port(scene="under", D=16):
+def cpu_baseline_c4_c_port(scene="under", D=16, generator="stacked"):
     """The C4 loop on the plain-C restatement (oracle/c_oracle.c: dense 312-row G per env, exact dual active-set QP, ThrustOmega low
     level, DYN step; float64), OpenMP over the envs on every host core of this GPU's share and on one core.  Bounded samples."""
     from oracle import c_oracle as CO
@@ -600,7 +609,7 @@ def cpu_baseline_c4_c_port(scene="under", D=16):
     b = CO.cbf_params(O.place_poles_chain([-2.2, -2.4]), [O.CF2P.MAX_THRUST, 10.0, 10.0, 10.0], 0.1, 1.0, x_obs, obs_r)
     out = {}
     for tag, thr, E, steps in (("one_core", 1, 64, 200), ("all", cores, 64 * cores, 200)):
-        xyz, rpy, P = c4_inputs(E, D, 123)
+        xyz, rpy, P = c4_inputs(E, D, 123, generator)
         CO.CbfLoopC(xyz[:cores], rpy[:cores], b).run(P[:cores], 2, threads=thr)      # thread pool and thread-local scratch up
         L = CO.CbfLoopC(xyz, rpy, b)
         L.run(P, 20, threads=thr)                                                    # into the window the bench times (steps 20 ...)
@@ -689,7 +698,10 @@ def main(argv=None):
                          "4 m/s off its trajectory the row k0 h + k1 hdot + Lf2 h of a static sphere (x_des = x) turns hugely negative for "
                          "1 < r / |v_err| < 2.6 s whatever the thrust.  'far': the same four spheres 100 m away (r / |v_err| > 15 s): the 64 "
                          "obstacle rows are still built and scanned every step but stay positive; what remains is the 120 inter-agent rows")
-    ap.add_argument("--c4-z", type=float, default=None, help="c4: override the scene's sphere height (scene exploration)")
+    ap.add_argument("--c4-z", type=float, default=None, help="c4: override the scene's sphere height (scene exploration; the CPU baseline and the "
+                                                             "committed counter traffic still describe the un-overridden scene: use with --no-cpu-baseline)")
+    ap.add_argument("--c4-generator", default="stacked", choices=["stacked", "survey"],
+                    help="c4 swarm: 'stacked' = SURVEY 8d's generator modified (heights 0.3 m apart; the bench's default), 'survey' = 8d as written (all at z = 0.5)")
     ap.add_argument("--c4-one-launch", action="store_true",
                     help="c4: mds_cbf_set_step_kernel(h, 1) -- nominal controller, QPs and low level + physics in ONE launch per control step "
                          "(the faster form when few envs iterate: the 'far' scene; slower on SURVEY 8d's)")
@@ -722,6 +734,9 @@ def main(argv=None):
         args.warmup = args.steps // 10
 
     E, D, phase, desc = WORKLOADS[args.workload]
+    if args.c4_z is not None and not args.no_cpu_baseline:
+        raise SystemExit("--c4-z moves the spheres of the timed GPU run only: pass --no-cpu-baseline with it (the CPU baseline, the committed counter "
+                         "traffic and scene_what describe the named scene)")
     import torch
 
     if args.dry_run_cpu:
@@ -815,8 +830,9 @@ def main(argv=None):
     c5 = args.workload == "c5"
     c4 = args.workload == "c4"
     geo = args.workload in ("c2", "c3", "c3big")
-    if c4:
-        # trajectories / start heights stacked 0.3 m apart: with the omega linearisation the barrier acts through e_z only
+    if c4 and args.c4_generator == "stacked":
+        # SURVEY 8d's generator MODIFIED (c4_inputs): trajectories / start heights stacked 0.3 m apart -- with the omega linearisation
+        # the barrier acts through e_z only
         P[..., 4] = 0.5 + 0.3 * np.arange(D)
         xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
     if c5:
@@ -1071,20 +1087,23 @@ def main(argv=None):
         line["roofline"]["kernel"] = ("k_cbf_step (one launch per step and env half: nominal controller, 4 QPs per wave, low level + physics)" if c4_kernel_ran == 1 else
                                       "k_cbf_filter_gi + k_lowlevel_step (2 launches per step and env half from the second step on; the QP is issue/latency bound)")
         if fused_T:
-            line["roofline"]["kernel"] = f"k_cbf_rollout<float, 0, false, 8> ({fused_T} control steps per launch: a workgroup owns 32 envs; nominal controller, ticketed QPs, low level + physics; state in LDS / registers)"
+            line["roofline"]["kernel"] = (f"k_cbf_rollout<{cname}, 0, {'true' if args.dtype == 'float32c' else 'false'}, {4 if cname == 'double' else 8}> ({fused_T} control steps per launch: a workgroup "
+                                          "owns whole envs; nominal controller + per-drone bounds, ticketed QPs on the pair rows, low level + physics; state in LDS / registers)")
             line["roofline"]["us_per_launch"] = us_per_step * fused_T
-            line["roofline"]["bytes_per_launch"] = BYTES_PER_DRONE_STEP_C4 * n_local * fused_T
-            line["roofline"]["bytes_per_step"] = BYTES_PER_DRONE_STEP_C4 * n_local
-        line["roofline"]["bytes_per_drone_step"] = BYTES_PER_DRONE_STEP_C4
+            line["roofline"]["bytes_per_launch"] = bytes_per * n_local * fused_T
+            line["roofline"]["bytes_per_step"] = bytes_per * n_local
+        line["roofline"]["bytes_per_drone_step"] = bytes_per
         line["roofline"]["note"] = ("algorithmic bytes of SURVEY 8d (280 B per drone-step: the fused step's 212 + u_hat 16 + xdes 36 + u_safe 16); the path is "
                                     "VALU / latency bound, `frac` says how far from the HBM roofline that leaves it")
-        tr, src = c4_pmc_traffic(args.c4_scene, n_local, bool(fused_T))
+        tr, src = c4_pmc_traffic(args.c4_scene, n_local, bool(fused_T)) if (args.dtype == "float32" and args.c4_generator == "stacked" and args.c4_z is None) else (None, None)
         if tr is not None:
-            line["roofline"].update({"traffic": tr, "traffic_source": src, "traffic_over_algorithmic": tr / (BYTES_PER_DRONE_STEP_C4 * n_local)})
+            line["roofline"].update({"traffic": tr, "traffic_source": src, "traffic_over_algorithmic": tr / (bytes_per * n_local)})
         line["config"]["scene"] = args.c4_scene
-        line["config"]["scene_what"] = C4_SCENES[args.c4_scene][2]
-        line["config"]["parity_note"] = ("fp32 vs the float64 oracle on this loop: see tests/test_gpu_cbf.py (status equality and state error over "
-                                         "the bench window and 1000 steps)")
+        line["config"]["scene_what"] = C4_SCENES[args.c4_scene][2] + (f" -- sphere height overridden to z = {args.c4_z}" if args.c4_z is not None else "")
+        line["config"]["parity_note"] = ("fp32 vs the float64 oracle on this loop: north_star's 1e-5 holds to step 220 (the bench window) in fp32 and to step 1000 only in "
+                                         "float64; tests/test_gpu_cbf.py (status equality and state error over the bench window and 1000 steps)")
+        line["config"]["generator"] = ("SURVEY 8d's generator MODIFIED: start heights / trajectory centres stacked 0.3 m apart" if args.c4_generator == "stacked" else
+                                       "SURVEY 8d's generator as written: every drone and trajectory centre at z = 0.5")
         if extras and world == 1:
             try:
                 line["cbf_window"] = c4_window_stats(torch, env, tracker, c4_obs, c4_r, args.warmup, args.steps)
@@ -1190,6 +1209,25 @@ def main(argv=None):
                 except Exception as exc:
                     c4x["feasible_active_fused"] = {"error": str(exc)}
                 torch.cuda.empty_cache()
+                # the reference's own precision (float64: north_star's 1e-5 over 1000 steps holds on this loop only there), 560 B accounting
+                for key, scene in (("feasible_active_fused_f64", "under"), ("survey_8d_fused_f64", "level")):
+                    try:
+                        c4x[key] = measure_c4(CtrlAviary, DroneModel, Physics, torch, local_rank, device, scene, dtype="float64", fused_T=50, stats=False)
+                    except Exception as exc:
+                        c4x[key] = {"error": str(exc)}
+                    torch.cuda.empty_cache()
+                # SURVEY 8d's generator UNMODIFIED (every drone and centre at z = 0.5, spheres at z = 0.5): the scene the survey wrote, with
+                # its census (mostly pair rows without authority: drones that share a plane)
+                try:
+                    c4x["survey_8d_literal"] = measure_c4(CtrlAviary, DroneModel, Physics, torch, local_rank, device, "level", generator="survey")
+                    c4x["survey_8d_literal_fused"] = measure_c4(CtrlAviary, DroneModel, Physics, torch, local_rank, device, "level", fused_T=50, stats=False,
+                                                                generator="survey")
+                except Exception as exc:
+                    c4x["survey_8d_literal"] = {"error": str(exc)}
+                torch.cuda.empty_cache()
+            c4x["parity_note"] = ("north_star's 1e-5 against the float64 oracle holds on this loop in fp32 to step 220 (the bench window: 2.7e-6 on `under`) and to "
+                                  "step 1000 only in float64 (1.6e-10): the closed loop with the QP in it amplifies rounding 1e3-1e4 x, and past t = 4 s most envs turn "
+                                  "infeasible, where a status flips on a rounding error (tests/test_gpu_cbf.py, profiles/r04_c4_fp32_long.log)")
             line["configs_4_c4"] = c4x
             try:
                 line["configs_5_c5"] = dict(measure_c5(CtrlAviary, DroneModel, Physics, torch, local_rank, device), baseline_config_index=4)
@@ -1266,9 +1304,9 @@ def main(argv=None):
             line["configs_4_c4"]["cpu_baseline"] = line["cpu_baseline"]["c4"]
     elif rank == 0 and world == 1 and not args.no_cpu_baseline and c4:
         try:
-            np_c4 = cpu_baseline_c4(args.cpu_budget, scene=args.c4_scene)
+            np_c4 = cpu_baseline_c4(args.cpu_budget, scene=args.c4_scene, generator=args.c4_generator)
             try:
-                line["cpu_baseline"] = cpu_baseline_c4_c_port(args.c4_scene)
+                line["cpu_baseline"] = cpu_baseline_c4_c_port(args.c4_scene, generator=args.c4_generator)
                 line["cpu_baseline"]["numpy_oracle"] = np_c4
             except Exception as exc:
                 line["cpu_baseline"] = dict(np_c4, c_port_error=str(exc))

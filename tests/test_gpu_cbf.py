@@ -1006,6 +1006,54 @@ def test_c4_under_scene_512_envs_against_the_c_oracle_at_every_step(mds, dtype, 
     env.close()
 
 
+# gates of the long-horizon fp32 figures: the measurement (profiles/r04_c4_fp32_long.log) rounded up
+# (measured: step 220 2.6e-6 / 2.8e-6; 511 of 512 envs with all 1000 statuses equal, the first difference at step 976; step 1000 over those envs 1.2e-2 / 1.5e-2)
+C4_LONG_GATES = {"float32": dict(err220=1e-5, agree_min=500, err1000=5e-2), "float32c": dict(err220=1e-5, agree_min=500, err1000=5e-2)}
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float32c"])
+def test_c4_under_scene_512_envs_fp32_over_1000_steps_reported(mds, dtype):
+    """What fp32 keeps of north_star's "1e-5 over 1000 steps" on the CBF loop (BASELINE config 4's generator, `under` scene, 512 envs x 16
+    drones, the plain-C float64 oracle at every step): the closed loop with the QP in it amplifies rounding 1e3-1e4 x (float64 itself
+    ends 1.6e-10 from the oracle), and past t = 4 s the scene turns infeasible for most envs, where a status flips on a rounding error.
+    REPORTED, and gated at what is measured: the state error at step 220 (inside 1e-5), the envs whose 1000 statuses all equal the
+    oracle's, and the state error at step 1000 over those envs."""
+    from oracle import c_oracle as CO
+    E, D, steps = 512, 16, 1000
+    xyz, rpy, P = H.c2_setup(E, D, seed=1000, phase="c3")
+    P[..., 4] = 0.5 + 0.3 * np.arange(D)
+    xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    x_obs = [np.array([[sx * 0.5, sy * 0.5, -3.0], [0, 0, 0]]) for sx in (-1, 1) for sy in (-1, 1)]
+    obs_r = [0.1] * 4
+    env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                         pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype)
+    env.set_trajectories(P)
+    cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2, cbf_poles=np.array([-2.2, -2.4]))
+    trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
+    bpar = CO.cbf_params(cbf.Kcbf.reshape(-1), cbf.umax, 0.1, 1.0, x_obs, obs_r)
+    loop = CO.CbfLoopC(xyz, rpy, bpar)
+    ref220, rst220, _, _ = loop.run(P, 220, threads=H.oracle_threads())
+    ref, rst2, _, _ = loop.run(P, steps - 220, t0=2.2, threads=H.oracle_threads())
+    rst = np.concatenate([rst220, rst2])
+    env.step(mds.torch.zeros((E, D, 4), dtype=env.dtype))
+    slog = mds.torch.empty((steps, E), dtype=mds.torch.int32, device=env.device)
+    o220, _ = env.rollout_cbf_geometric_fused(0.0, 220, trk, x_obs, obs_r, steps_per_launch=44, status_log=slog[:220])
+    e220 = np.abs(o220.double().cpu().numpy().reshape(E, D, 20)[..., :16] - ref220[..., :16]).max()
+    obs, _ = env.rollout_cbf_geometric_fused(2.2, steps - 220, trk, x_obs, obs_r, steps_per_launch=52, status_log=slog[220:])
+    got_st = slog.cpu().numpy()
+    agree = (got_st == rst).all(axis=0)
+    first_diff = np.where(~agree, (got_st != rst).argmax(axis=0), steps)
+    err_env = np.abs(obs.double().cpu().numpy().reshape(E, D, 20)[..., :16] - ref[..., :16]).reshape(E, -1).max(axis=1)
+    e1000 = err_env[agree].max() if agree.any() else float("nan")
+    print(f"[c4 fp32 long horizon] {dtype}: |state err| at step 220 {e220:.3e} (all statuses of the window equal: {bool((got_st[:220] == rst[:220]).all())}); "
+          f"envs whose 1000 statuses all equal the oracle's: {int(agree.sum())} of {E} (first difference at step {int(first_diff.min())}, infeasible "
+          f"env-steps in the oracle {int(rst.sum())}); |state err| at step 1000 over those envs {e1000:.3e}, over all envs {err_env.max():.3e}")
+    g = C4_LONG_GATES[dtype]
+    assert (got_st[:220] == rst[:220]).all() and e220 < g["err220"]
+    assert agree.sum() >= g["agree_min"] and (not agree.any() or e1000 < g["err1000"])
+    env.close()
+
+
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-10), ("float32", 1e-5)])
 def test_cbftest_default_nominal_512_envs_against_the_c_oracle_at_every_step(mds, dtype, tol):
     """simulations/CBFTest.py as it runs by default -- LQROmegaController nominal (:290-293), default CBF poles (-2.2, -2.4, -2.6 -> the
