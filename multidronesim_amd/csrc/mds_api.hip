@@ -2112,7 +2112,7 @@ int step_nominal_lowlevel(mds_handle* h, double t, void* obs, int32_t* status, v
 static bool roll_fused_applies(const mds_handle* h) {
   const int D = h->cfg.num_drones;
   const int m2 = D * (D - 1) / 2 + (MDS_ROLL_BOUNDS ? 0 : D * h->cbf.n_obs) + 2 * D;      // (MDS_ROLL_BOUNDS: obstacle rows are per-drone bounds)
-  return h->has_cbf && h->cbf.order == 2 && !h->cbf_hildreth && D >= 4 && D <= 16 && 64 % D == 0 && m2 <= 256 && !h->envfx &&
+  return h->has_cbf && h->cbf.order == 2 && !h->cbf_hildreth && D >= 1 && D <= 16 && (MDS_ROLL_BOUNDS || 64 % D == 0) && m2 <= 256 && !h->envfx &&
          h->cfg.integrator == MDS_INTEGRATOR_EULER && !has_drag(h) && h->cbf_nominal <= 1 && h->cfg.dtype != MDS_F16 &&
          h->cfg.pyb_freq == h->cfg.ctrl_freq && h->n <= (1 << 27);
 }
@@ -2201,7 +2201,7 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
   const int m2 = D * (D - 1) / 2 + D * h->cbf.n_obs + 2 * D;
   // what the persistent kernel covers (everything else: mds_rollout_cbf_geometric, one or two launches per step)
   if (!roll_fused_applies(h))
-    return fail(MDS_EUNSUPPORTED, "mds_rollout_cbf_geometric_fused: order-2 CBF, D in {4, 8, 16}, <= 256 rows per env, explicit Euler at "
+    return fail(MDS_EUNSUPPORTED, "mds_rollout_cbf_geometric_fused: order-2 CBF, D <= 16, explicit Euler at "
                                   "pyb_freq == ctrl_freq without drag / ground effect / downwash, geometric or LQR-omega nominal, f32 / f32c / f64, "
                                   "at most 2^27 drones (32-bit byte offsets into the per-drone planes)");
   if (n_steps == 0) return MDS_OK;
@@ -2210,7 +2210,9 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
   // instantiation needs more than the 256 registers two wavefronts per SIMD would leave it)
   constexpr int NWF = MDS_CBF_ROLL_NW, NWD = 4;
   const int nw = h->cfg.dtype == MDS_F64 ? NWD : NWF;
-  const dim3 grid((unsigned)((h->n + 64 * nw - 1) / (64 * nw)));
+  // a workgroup owns 64 nw / Dp whole envs, Dp = the env width padded to 4, 8 or 16 lanes (any D <= 16)
+  const int Dp = D <= 4 ? 4 : (D <= 8 ? 8 : 16), envs_per_wg = 64 * nw / Dp;
+  const dim3 grid((unsigned)((h->cfg.num_envs + envs_per_wg - 1) / envs_per_wg));
   const int max_iter = h->cbf.max_iter > 0 ? h->cbf.max_iter : 64 * m2;
   const void* gain = h->cbf_nominal == 1 ? h->gain_dev[1] : nullptr;
   const double dt = 1.0 / h->cfg.ctrl_freq;

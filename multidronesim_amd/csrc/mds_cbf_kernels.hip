@@ -1561,18 +1561,22 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   };
   if (kStamps && stamps != nullptr && threadIdx.x < NW * 10) sst[threadIdx.x / 10][threadIdx.x % 10] = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int D = a0->p.P.num_drones, GB = NT / D;             // envs per workgroup
-  const int i = blockIdx.x * NT + tid;
-  const bool valid = i < a0->n;
-  const int env0 = (blockIdx.x * NT) / D;
-  const int nenv = min(GB, a0->E - env0);                          // envs this workgroup really owns (>= 1: the grid covers n)
+  // Any D <= 16 (round 4; the reference's own scripts run 2 and 7 drones: simulations/CBFTest.py:31, CBFTestOrd3.py:31): an env occupies
+  // Dp = 4, 8 or 16 consecutive lanes (the next power of two, at least 4), the lanes past its D drones idle.  Everything in LDS is indexed
+  // by the padded lane (records, state planes, bounds, su); global planes and observation rows by the drone's real index i = env D + d.
+  const int D = a0->p.P.num_drones;
+  const int log2P = D <= 4 ? 2 : (D <= 8 ? 3 : 4), Dp = 1 << log2P, GB = NT >> log2P;      // padded env width; envs per workgroup
+  const int env0 = blockIdx.x * GB;
+  const int i = (env0 + (tid >> log2P)) * D + (tid & (Dp - 1));
+  const bool valid = (tid & (Dp - 1)) < D && env0 + (tid >> log2P) < a0->E;
+  const int nenv = min(GB, a0->E - env0);                          // envs this workgroup really owns (>= 1: the grid covers E)
   auto slice_of = [&](int w) -> Slice& { return *reinterpret_cast<Slice*>(raw + (size_t)w * kObsWave); };
 
   // ---- once per launch ----
   {
     const CbfParams<T> P = load_const(&a0->p.P);
     const T* obstacles = a0->obstacles;
-  if (tid < R * 64) stab[tid >> 6][tid & 63] = roll_slot_of<T>(P, a0->pair_ij, (tid & 63) + 64 * (tid >> 6), kRec, kSwz && P.num_drones == 16, kSobOff, kDsOff, kBounds);
+  if (tid < R * 64) stab[tid >> 6][tid & 63] = roll_slot_of<T>(P, a0->pair_ij, (tid & 63) + 64 * (tid >> 6), kRec, kSwz && P.num_drones > 8, kSobOff, kDsOff, kBounds);
   if (tid < kCbfMaxObs) {
     const bool on = tid < P.n_obs;
     for (int k = 0; k < 8; ++k) sobrec[tid][k] = T(0);
@@ -1615,7 +1619,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     }
     // obs_to_lin_model(obs, 9) - xdes with obs = pack_obs(state): world position, roll, pitch, world velocity; xdes = [0, 0, yaw, v_des, p_des]
     T* rc = slice_of(wq).rec[lq];
-    const int sw = kSwz ? ((lq >> 3) & (D >> 4)) : 0;            // D = 16, agents 8..15: halves swapped
+    const int sw = kSwz ? ((lq >> 3) & (Dp >> 4)) : 0;           // Dp = 16, agents 8..15: halves swapped
     *reinterpret_cast<V4*>(rc + 4 * sw) = V4{{s.p.x + Pl.cx, s.p.y + Pl.cy, rpy.y - T(0), -(rpy.x - T(0))}};
     *reinterpret_cast<V4*>(rc + 4 * (sw ^ 1)) = V4{{s.v.x - des.v.x, s.v.y - des.v.y, s.p.z + Pl.cz, s.v.z - des.v.z}};
     if constexpr (kBounds) {
@@ -1676,7 +1680,6 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     const Consts<T> c1 = load_const(&a0->p.c);
     stage_a(a0, c1, load_params(a0, (unsigned)i), t, tid);
   }
-  const int log2D = 31 - __clz(D);                             // D is 4, 8 or 16
   const int nbs = (cbf_num_pairs(D) + (kBounds ? 0 : D * a0->p.P.n_obs) + 63) >> 6;   // row slots that hold barrier rows
 
   for (int k = 0; k < n_steps; ++k) {
@@ -1728,7 +1731,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         const CbfParams<T> P = load_const(&ab->p.P);
         const int max_iter = ab->max_iter;                         // (requested with them: the solver starts right after the scan)
         const T tol2 = ab->tol2;
-        const int d0 = el * D;
+        const int d0 = el << log2P;                                // the env's first (padded) lane
         const unsigned ebase = (unsigned)(d0 >> 6) * kObsWave + (unsigned)(d0 & 63) * kRec;   // the env's first record in the LDS block
         int tl = lane;
         asm volatile("" : "+v"(tl));                               // re-read per env: 4 LDS reads instead of 16 registers held across the stages
@@ -1934,11 +1937,11 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)tb), hi = __builtin_amdgcn_readfirstlane((unsigned)(tb >> 32));
       t = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
     }
-    unsigned wg0 = blockIdx.x * NT;
-    asm volatile("" : "+s"(wg0));                                  // the drone index is formed here (one add), not held -- spilled -- across the loop
+    unsigned eg0 = blockIdx.x * GB;
+    asm volatile("" : "+s"(eg0));                                  // the drone index is formed here, not held -- spilled -- across the loop
     int tq = tid;
     asm volatile("" : "+v"(tq));
-    const unsigned iu = wg0 + (unsigned)tq;
+    const unsigned iu = (eg0 + ((unsigned)tq >> log2P)) * (unsigned)D + ((unsigned)tq & (unsigned)(Dp - 1));
     const Consts<T> c = load_const(&ac->p.c);
     const CbfParams<T> P = load_const(&ac->p.P);
     constexpr int kRowBytes = kObsDim * (int)sizeof(T);
@@ -1958,7 +1961,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     {
       // Every lane runs the stage (a lane past the last drone on a clamped index, its stores skipped): no divergent region for the
       // compiler to sink the loads above into.
-      const int conv = sconv[tq >> log2D];
+      const int conv = sconv[tq >> log2P];
       const T safe = su_all[tq];
       T u[4];
       u[0] = (conv ? safe : st[13][tq]) + c.gravity;                                                // CBFTest.py:346
@@ -1989,8 +1992,12 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         pack_obs(s, V3<T>{Pl_next.cx, Pl_next.cy, Pl_next.cz}, clipped, o);                  // (the trajectory centre: this drone's, whatever the step)
         // the row goes to the wave's staging slice at once (20 values held across the rest of the stage were spilled to scratch)
         typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        // (row of the wave's staging slice: its envs' drones back to back -- the padded lanes of an env hold no row)
+        const int crow = (lq >> log2P) * D + (lq & (Dp - 1));
+        if ((lq & (Dp - 1)) < D) {
 #pragma unroll
-        for (int j = 0; j < kRowBytes / 16; ++j) reinterpret_cast<v4u*>(lds_wave + lq * kRowBytes)[j] = reinterpret_cast<const v4u*>(o)[j];
+          for (int j = 0; j < kRowBytes / 16; ++j) reinterpret_cast<v4u*>(lds_wave + crow * kRowBytes)[j] = reinterpret_cast<const v4u*>(o)[j];
+        }
       }
       if (valid && !more) store_state<T, T>(ac->state, ld, iu, s);
     }
@@ -2000,8 +2007,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       const int n = ac->n;
       T* dst = obs_log != nullptr ? obs_log + (size_t)slot * n * kObsDim : ac->obs_last;      // (log AND obs_last: the host copies the last slot)
       MDS_WAVE_SYNC();
-      const int wave_base = __builtin_amdgcn_readfirstlane((int)iu - lq);                  // uniform: scalar base + 32-bit lane offsets
-      const int rows = min(64, n - wave_base);
+      const int ew = __builtin_amdgcn_readfirstlane((int)eg0 + ((tq >> 6) << (6 - log2P)));  // the wave's first env (uniform)
+      const int wave_base = ew * D;                                                        // its first observation row: scalar base + 32-bit lane offsets
+      const int rows = (min(ew + (64 >> log2P), ac->E) - ew) * D;                          // (<= 0: no env of the shard in this wave)
       if (rows > 0) {
         const int bytes = rows * kRowBytes;
         unsigned char* gdst = reinterpret_cast<unsigned char*>(dst) + (size_t)wave_base * kRowBytes;

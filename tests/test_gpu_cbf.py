@@ -806,11 +806,12 @@ def test_cbf_persistent_rollout_matches_the_stepwise_loop(mds, nominal):
 
 
 def test_cbf_persistent_rollout_rejects_what_it_does_not_cover(mds):
-    """Order 3, RK4 and drone counts outside {4, 8, 16} return MDS_EUNSUPPORTED (the caller uses mds_rollout_cbf_geometric)."""
+    """RK4 / drag / env effects return MDS_EUNSUPPORTED (the caller uses mds_rollout_cbf_geometric); any drone count up to 16 is covered
+    (round 4; test_cbf_persistent_rollout_small_shapes)."""
     E, D = 4, 6
     xyz, rpy, P = H.c2_setup(E, D, phase="c3", offset=1.5)
     env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
-                         pyb_freq=100, ctrl_freq=100, num_envs=E, dtype="float32")
+                         pyb_freq=100, ctrl_freq=100, num_envs=E, dtype="float32", integrator="rk4")
     env.set_trajectories(P)
     cbf = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(D)], safety_radius=0.1, zscale=1.0, order=2)
     trk = mds.DroneQPTracker(cbf, num_robots=D, xdim=9, env=env)
@@ -823,12 +824,17 @@ def test_cbf_persistent_rollout_rejects_what_it_does_not_cover(mds):
     env.close()
 
 
-@pytest.mark.parametrize("D,n_obs,spl", [(4, 0, 1), (8, 2, 3), (4, 16, 7), (8, 0, 64)])
-def test_cbf_persistent_rollout_small_shapes(mds, D, n_obs, spl):
-    """The persistent kernel away from the C4 shape: 4 and 8 drones per env (128 / 64 envs per workgroup; with D = 4 and 16 obstacles the
-    barrier rows fill two row slots, with none a single one), no obstacles at all, one control step per launch and more steps per launch
-    than the call has, a single partial workgroup -- statuses equal to the step-by-step loop's at every step, state to rounding."""
-    E, steps = 11, 40
+@pytest.mark.parametrize("D,n_obs,spl,E", [(4, 0, 1, 11), (8, 2, 3, 11), (4, 16, 7, 11), (8, 0, 64, 11),
+                                             # any D <= 16 (an env padded to 4 / 8 / 16 lanes): the reference's own scripts run 2 and 7 drones
+                                             (2, 1, 5, 11), (3, 2, 50, 11), (7, 1, 9, 11), (5, 4, 4, 11), (12, 3, 13, 11), (1, 2, 6, 11), (16, 4, 10, 11),
+                                             # several workgroups, more than 64 envs per workgroup (D = 4: 128), a partial last workgroup
+                                             (4, 2, 10, 333), (8, 3, 10, 301), (7, 2, 10, 200), (2, 1, 10, 300)])
+def test_cbf_persistent_rollout_small_shapes(mds, D, n_obs, spl, E):
+    """The persistent kernel away from the C4 shape: any drone count up to 16 -- 4 and 8 drones per env (128 / 64 envs per workgroup), the
+    reference's own 2 (simulations/CBFTest.py:31) and 7 (CBFTestOrd3.py:31), 1, 3, 5, 12: an env occupies 4, 8 or 16 lanes, the rest
+    idle --, no obstacles and sixteen, one control step per launch and more steps per launch than the call has, a single partial
+    workgroup and several workgroups with a partial last one -- statuses equal to the step-by-step loop's at every step, state to rounding."""
+    steps = 40
     xyz, rpy, P = H.c2_setup(E, D, phase="c3", offset=1.0)
     P[..., 4] = 0.5 + 0.15 * np.arange(D)                         # 15 cm apart: closer than the pair distance, rows go active
     xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
@@ -859,8 +865,9 @@ def test_cbf_persistent_rollout_small_shapes(mds, D, n_obs, spl):
         env.close()
     np.testing.assert_array_equal(out["step"][1], out["fused"][1])
     np.testing.assert_array_equal(out["step"][3], out["fused"][3])
-    np.testing.assert_allclose(out["fused"][0][..., :16], out["step"][0][..., :16], rtol=0, atol=1e-4)
-    np.testing.assert_allclose(out["fused"][2], out["step"][2], rtol=0, atol=1e-4)
+    # (two fp32 kernels that contract FMAs differently, 40 steps of a crowded closed loop: 2.4e-4 in a body rate at D = 12)
+    np.testing.assert_allclose(out["fused"][0][..., :16], out["step"][0][..., :16], rtol=0, atol=1e-4 if D in (4, 8) and E == 11 else 1e-3)
+    np.testing.assert_allclose(out["fused"][2], out["step"][2], rtol=0, atol=1e-4 if D in (4, 8) and E == 11 else 1e-3)
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
@@ -910,7 +917,18 @@ def test_cbf_step_kernel_persistent_per_step(mds, dtype):
     np.testing.assert_array_equal(st.cpu().numpy(), s_ref)
     env.close()
 
-    env, _, trk = make(6)                       # D = 6: not covered -> form 0, no error
+    env, _, trk = make(6)                       # D = 6: covered since round 4 (an env padded to 8 lanes)
+    env.set_cbf_step_kernel(2)
+    env.step_cbf_geometric(0.0, trk, x_obs, obs_r)
+    assert env.cbf_last_step_kernel() == 2
+    env.close()
+    a, b, c = H.c2_setup(E, 6, phase="c3", offset=1.5)      # drag physics: not covered -> form 0, no error
+    env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=6, initial_xyzs=a, initial_rpys=b, physics=mds.Physics.PYB_DRAG,
+                         pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype)
+    env.set_trajectories(c)
+    cbf6 = mds.DroneCBF(env, [mds.LinearizedOmegaModel(env) for _ in range(6)], safety_radius=0.1, zscale=1.0, order=2)
+    trk = mds.DroneQPTracker(cbf6, num_robots=6, xdim=9, env=env)
+    env.step(mds.torch.zeros((E, 6, 4), dtype=env.dtype))
     env.set_cbf_step_kernel(2)
     env.step_cbf_geometric(0.0, trk, x_obs, obs_r)
     assert env.cbf_last_step_kernel() == 0
