@@ -475,9 +475,10 @@ int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs_d
  * boundary inside a launch.  obs_log_dev: NULL, or a ring [log_slots, n, 20] -- step k of this call writes its observation (the
  * reference's observations.append(obs), CBFTest.py:351) into slot (first_slot + k) % log_slots; without a log only the last step's
  * observation is materialised.  obs_dev [n,20]: the last step's observation (out).  status_dev [E]: the last step's statuses as
- * mds_cbf_filter; status_log_dev: NULL or [n_steps, E], every step's.  Covers order 2, D in {4, 8, 16}, <= 256 rows per env,
+ * mds_cbf_filter; status_log_dev: NULL or [n_steps, E], every step's.  Covers order 2, any D <= 16 (round 4: an env padded to 4, 8 or 16 lanes; obstacle and thrust-box rows folded into per-drone bounds),
  * explicit Euler at pyb_freq == ctrl_freq, DYN, geometric or LQR-omega nominal, f32 / f32c / f64, at most 2^27 drones per handle
- * (32-bit byte offsets into the per-drone planes); MDS_EUNSUPPORTED otherwise (use mds_rollout_cbf_geometric).  Same QP, statuses and iteration counts as the step-by-step loop; observations equal to rounding (the
+ * (32-bit byte offsets into the per-drone planes); MDS_EUNSUPPORTED otherwise (use mds_rollout_cbf_geometric).  Same feasible set, minimiser and statuses as the step-by-step loop
+ * (the single-variable rows enter as two bounds per drone, so a dominated row never counts as an iteration); observations equal to rounding (the
  * kernels contract FMAs differently, as the one-launch step does: mds_cbf_set_step_kernel).  The call only enqueues (kernel launches and one
  * device-to-device copy of the last ring slot): it may be captured into a hipGraph. */
 int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int steps_per_launch, void* obs_log_dev, int log_slots,

@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 && R == 4) ? 4 : 1) void k_cbf_
 }
 
 // ------------------------------------------------------------------------------------
-// n_steps CBF-filtered control steps of simulations/CBFTest.py:303-350 in ONE launch (order 2, D in {4, 8, 16}): the persistent form of
+// n_steps CBF-filtered control steps of simulations/CBFTest.py:303-350 in ONE launch (order 2, any D <= 16): the persistent form of
 // k_cbf_step.  A workgroup of NW wavefronts owns 64 NW drones = 64 NW / D whole envs for the whole launch and walks them through
 //   stage A, one drone per lane : trajs[j](t), nominal controller -> u_hat; the drone's record (world position, tracking errors in
 //                                 roll, pitch, velocity: what the rows need of obs_to_lin_model(obs) - xdes) into LDS;

@@ -64,7 +64,7 @@ class GeometricEnv(_base.GeometricEnv):
             steps = 0
         elif qpTracker is not None and not render:
             # nominal -> QP -> low level -> step (:303-350), the whole run through the persistent kernel where the library covers the
-            # configuration (order 2, 4 / 8 / 16 drones per env, Lemniscates, Euler DYN at pyb == ctrl): 50 control steps per launch,
+            # configuration (order 2, up to 16 drones per env, Lemniscates, Euler DYN at pyb == ctrl): 50 control steps per launch,
             # every step's observation into the log, every step's statuses into st_log.  MDS_EUNSUPPORTED: the step loop below.
             from .._capi import MdsError
             try:

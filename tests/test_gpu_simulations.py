@@ -67,10 +67,11 @@ def test_envgeometric_setpoint_and_batch(gpu):
         geo2.do_control()
 
 
-@pytest.mark.parametrize("nd,kernel", [(3, 0), (4, 2)])
+@pytest.mark.parametrize("nd,kernel", [(2, 2), (3, 2), (4, 2), (7, 2)])
 def test_cbftest_do_control_matches_oracle(gpu, nd, kernel):
-    """simulations/CBFTest.py __main__ (:414-427): LQR-omega nominal, one sphere at the lemniscate centre, order-2 filter.  With 3 drones
-    the loop runs step by step (QP launch + low-level launch), with 4 through the persistent rollout kernel (4 / 8 / 16 drones per env)."""
+    """simulations/CBFTest.py __main__ (:414-427): LQR-omega nominal, one sphere at the lemniscate centre, order-2 filter -- at the script's
+    own default of 2 drones (:31), and with 3, 4 and 7: the mirror's loop goes through the persistent rollout kernel (any drone count up
+    to 16 since round 4), statuses equal to the oracle loop's at every step."""
     from multidronesim_amd.simulations import CBFTest as S
     args = S.parse_args(["--num_drones", str(nd), "--duration_sec", "1", "--dtype", "float64"])
     assert args.controller == "lqr" and args.init_rad == .2
