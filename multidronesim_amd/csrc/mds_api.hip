@@ -288,25 +288,7 @@ static int split_join(mds_handle* h, hipStream_t st, int rc_body) {
 static inline dim3 grid_for(int n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 static inline bool is_comp(const mds_handle* h) { return h->cfg.dtype == MDS_F32C; }
 static inline bool is_f32(const mds_handle* h) { return h->cfg.dtype == MDS_F32 || h->cfg.dtype == MDS_F32C; }   // fp32 buffers
-template <typename T> static void fill_cbf(const mds_handle* h, const mds_cbf_params& p, CbfParams<T>& o) {
-  o.order = p.order;
-  o.n_obs = p.n_obs;
-  o.num_drones = h->cfg.num_drones;
-  for (int k = 0; k < 3; ++k) o.k[k] = (T)p.Kcbf[k];
-  for (int k = 0; k < 4; ++k) o.umax[k] = (T)p.umax[k];
-  o.Ds_pair = (T)(2.0 * p.safety_radius);
-  o.safety_radius = (T)p.safety_radius;
-  o.zscale = (T)p.zscale;
-  o.inv_zscale = (T)(1.0 / p.zscale);
-  o.obs_magic = p.n_obs > 0 ? (65536 + p.n_obs - 1) / p.n_obs : 0;
-  o.inv_c4 = (T)(1.0 / (p.zscale * p.zscale * p.zscale * p.zscale));
-  o.c4x4 = (T)(4.0 / (p.zscale * p.zscale * p.zscale * p.zscale));
-  o.c4x12 = (T)(12.0 / (p.zscale * p.zscale * p.zscale * p.zscale));
-  o.inv_m = (T)(1.0 / h->cfg.M);
-  o.g = (T)h->cfg.G;
-  o.Fmin = (T)p.Fmin;
-  o.Fmax = (T)p.Fmax;
-}
+template <typename T> static void fill_cbf(const mds_handle* h, const mds_cbf_params& p, CbfParams<T>& o) { fill_cbf_params(h->cfg, p, o); }
 
 template <typename T> static void fill_lin_model(const double* A, const double* B, double u_eq0, LinModel<T>& M) {
   for (int r = 0; r < 12; ++r) {

@@ -249,7 +249,20 @@ __global__ __launch_bounds__(256) void k_cbf_filter_o2(const CbfParams<T> P, con
 
 // keeps two loaded values live at this point (an empty asm the optimiser cannot look through): used to stop it from sinking LDS
 // reads into the conditional code that consumes them
-#define MDS_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+// MDS_KEEP_V / MDS_KEEP_S: an empty asm the optimiser cannot look through, on a vector / scalar register value.  In a host build (the
+// SIMT emulation of tests/emul/simt: these kernels under AddressSanitizer on the CPU) they are no-ops.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MDS_KEEP_V(x) asm volatile("" : "+v"(x))
+#define MDS_KEEP_S(x) asm volatile("" : "+s"(x))
+#else
+#define MDS_KEEP_V(x) ((void)0)
+#define MDS_KEEP_S(x) ((void)0)
+#endif
+#define MDS_PIN2(a, b) \
+  do {                 \
+    MDS_KEEP_V(a);     \
+    MDS_KEEP_V(b);     \
+  } while (0)
 namespace wv {
 // DPP controls (gfx9): quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140.
 // Must be called with all 64 lanes active (wave-uniform control flow): a disabled source lane leaves `old`.
@@ -1316,7 +1329,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 && R == 4) ? 4 : 1) void k_cbf_
   MDS_WAVE_SYNC();                                             // raw is the observation staging from here on
   const T* state2 = state;
   const T* lem2 = lem;
-  asm volatile("" : "+s"(state2), "+s"(lem2));
+  MDS_KEEP_S(state2); MDS_KEEP_S(lem2);
   GeoIn<T> in2;
   if (valid) {
     load_geo_in<T, T>(state2, lem2, ld, i, in2);
@@ -1426,7 +1439,11 @@ template <typename T> struct RollParams {
   Consts<T> c;
   CbfParams<T> P;
 };
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 #define MDS_CONST_AS __attribute__((address_space(4)))
+#else
+#define MDS_CONST_AS            // (host build of the SIMT emulation: a plain pointer)
+#endif
 // a by-value copy of a struct behind a constant-address-space pointer, word by word (the words that are used become scalar loads,
 // the others disappear)
 template <typename V> __device__ __forceinline__ V load_const(const V MDS_CONST_AS* p) {
@@ -1468,7 +1485,7 @@ template <typename T> struct RollArgs {
 };
 template <typename T> __device__ __forceinline__ const RollArgs<T> MDS_CONST_AS* fresh_args() {
   const RollArgs<T> MDS_CONST_AS* p = (const RollArgs<T> MDS_CONST_AS*)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(p));
+  MDS_KEEP_S(p);
   return p;
 }
 
@@ -1576,7 +1593,8 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   {
     const CbfParams<T> P = load_const(&a0->p.P);
     const T* obstacles = a0->obstacles;
-  if (tid < R * 64) stab[tid >> 6][tid & 63] = roll_slot_of<T>(P, a0->pair_ij, (tid & 63) + 64 * (tid >> 6), kRec, kSwz && P.num_drones > 8, kSobOff, kDsOff, kBounds);
+  for (int r = tid; r < R * 64; r += NT)                       // (a loop: NW = 1 or 2 -- the host emulation of the tests -- has fewer threads than slots)
+    stab[r >> 6][r & 63] = roll_slot_of<T>(P, a0->pair_ij, r, kRec, kSwz && P.num_drones > 8, kSobOff, kDsOff, kBounds);
   if (tid < kCbfMaxObs) {
     const bool on = tid < P.n_obs;
     for (int k = 0; k < 8; ++k) sobrec[tid][k] = T(0);
@@ -1595,6 +1613,10 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   s.q[0] = s.q[1] = s.q[2] = T(0);
   s.q[3] = T(1);
   if (valid) load_state<T, T>(a0->state, a0->ld, i, s);
+  // The obstacle records and -Ds^4 written above are read by the FIRST stage A below (the per-drone bounds), by every wave: a workgroup
+  // barrier per launch.  (Found by the host SIMT emulation of tests/emul/simt: without it the first control step of a launch raced --
+  // round 3 read these tables in stage B only, behind the step's own barrier.)
+  if (kBounds) __syncthreads();
   T un1 = T(0), un2 = T(0), un3 = T(0);                        // u_hat[1..3] of this step (stage A -> stage C, in registers across stage B; [0]: st[13])
 
   // stage A of drone i on the state in registers at time ta: u_hat, the record, the stash of the state
@@ -1734,7 +1756,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         const int d0 = el << log2P;                                // the env's first (padded) lane
         const unsigned ebase = (unsigned)(d0 >> 6) * kObsWave + (unsigned)(d0 & 63) * kRec;   // the env's first record in the LDS block
         int tl = lane;
-        asm volatile("" : "+v"(tl));                               // re-read per env: 4 LDS reads instead of 16 registers held across the stages
+        MDS_KEEP_V(tl);                               // re-read per env: 4 LDS reads instead of 16 registers held across the stages
         T ca[R][NV], cb[R][NV], b[R];
         int ia[R], ib[R];
         bool vld[R], act[R];
@@ -1785,10 +1807,10 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         for (int r = 0; r < NBS; ++r)                              // every slot's operands in ONE LDS round trip
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            asm volatile("" : "+v"(oa[r][c].x));
-            asm volatile("" : "+v"(oa[r][c].y));
-            asm volatile("" : "+v"(ob[r][c].x));
-            asm volatile("" : "+v"(ob[r][c].y));
+            MDS_KEEP_V(oa[r][c].x);
+            MDS_KEEP_V(oa[r][c].y);
+            MDS_KEEP_V(ob[r][c].x);
+            MDS_KEEP_V(ob[r][c].y);
           }
         // the barrier arithmetic of all NBS slots, statement by statement across the slots: NBS independent chains side by side
         Pair<T> exy[NBS], dpr[NBS], dvxy[NBS], ezvz[NBS];
@@ -1921,7 +1943,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     const double ctrl_dt = ac->ctrl_dt;
     {                                                              // the step's statuses, one coalesced store per workgroup
       int ts = tid;
-      asm volatile("" : "+v"(ts));                                 // (LDS addresses formed here, not held across the loop)
+      MDS_KEEP_V(ts);                                 // (LDS addresses formed here, not held across the loop)
       if (ts < nenv) {
         if (ac->status_log) ac->status_log[(size_t)k * ac->E + env0 + ts] = sconv[ts] ? 0 : 1;
         if (k == n_steps - 1) {
@@ -1938,9 +1960,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       t = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
     }
     unsigned eg0 = blockIdx.x * GB;
-    asm volatile("" : "+s"(eg0));                                  // the drone index is formed here, not held -- spilled -- across the loop
+    MDS_KEEP_S(eg0);                                  // the drone index is formed here, not held -- spilled -- across the loop
     int tq = tid;
-    asm volatile("" : "+v"(tq));
+    MDS_KEEP_V(tq);
     const unsigned iu = (eg0 + ((unsigned)tq >> log2P)) * (unsigned)D + ((unsigned)tq & (unsigned)(Dp - 1));
     const Consts<T> c = load_const(&ac->p.c);
     const CbfParams<T> P = load_const(&ac->p.P);
@@ -2028,7 +2050,7 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     slot = slot + 1 == ac->n_slots ? 0 : slot + 1;
     if (valid && more) {                                           // (the wave's own staging slice is drained: write_obs_rows ends with a wave sync)
       int ta2 = tid;
-      asm volatile("" : "+v"(ta2));
+      MDS_KEEP_V(ta2);
       const RollArgs<T> MDS_CONST_AS* aa = fresh_args<T>();
       stage_a(aa, c, Pl_next, t, ta2);
     }

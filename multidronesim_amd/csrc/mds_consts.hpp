@@ -5,6 +5,7 @@
 
 #include "../../include/mds.h"
 #include "mds_math.hpp"
+#include "mds_cbf.hpp"
 
 namespace mds {
 
@@ -63,6 +64,27 @@ template <typename T> inline void fill_envfx(const mds_config& cfg, EnvFx<T>& fx
     const double x[4] = {cfg.L, 0.0, -cfg.L, 0.0}, y[4] = {0.0, cfg.L, 0.0, -cfg.L};
     for (int k = 0; k < 4; ++k) { fx.prop_x[k] = (T)x[k]; fx.prop_y[k] = (T)y[k]; }
   }
+}
+
+// the ECBF parameter block of the CBF kernels (shared with the test-only SIMT emulation)
+template <typename T> inline void fill_cbf_params(const mds_config& cfg, const mds_cbf_params& p, CbfParams<T>& o) {
+  o.order = p.order;
+  o.n_obs = p.n_obs;
+  o.num_drones = cfg.num_drones;
+  for (int k = 0; k < 3; ++k) o.k[k] = (T)p.Kcbf[k];
+  for (int k = 0; k < 4; ++k) o.umax[k] = (T)p.umax[k];
+  o.Ds_pair = (T)(2.0 * p.safety_radius);
+  o.safety_radius = (T)p.safety_radius;
+  o.zscale = (T)p.zscale;
+  o.inv_zscale = (T)(1.0 / p.zscale);
+  o.obs_magic = p.n_obs > 0 ? (65536 + p.n_obs - 1) / p.n_obs : 0;
+  o.inv_c4 = (T)(1.0 / (p.zscale * p.zscale * p.zscale * p.zscale));
+  o.c4x4 = (T)(4.0 / (p.zscale * p.zscale * p.zscale * p.zscale));
+  o.c4x12 = (T)(12.0 / (p.zscale * p.zscale * p.zscale * p.zscale));
+  o.inv_m = (T)(1.0 / cfg.M);
+  o.g = (T)cfg.G;
+  o.Fmin = (T)p.Fmin;
+  o.Fmax = (T)p.Fmax;
 }
 
 }  // namespace mds

@@ -1,0 +1,95 @@
+"""TEST TOOLING ONLY: builds and runs tests/emul/simt/simt_cbf.cpp -- the CBF kernels of multidronesim_amd/csrc compiled as host C++ against
+the SIMT stand-in (one thread per lane) under AddressSanitizer + UndefinedBehaviorSanitizer.  The product never loads any of this."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
+CSRC = os.path.join(ROOT, "multidronesim_amd", "csrc")
+SRC = os.path.join(HERE, "simt_cbf.cpp")
+CLANG = os.environ.get("MDS_SIMT_CXX") or "/opt/rocm/lib/llvm/bin/clang++"
+EXE = {1: os.path.join(HERE, "simt_filter"), 2: os.path.join(HERE, "simt_rollout")}
+
+
+def available():
+    return os.path.exists(CLANG) or shutil.which("clang++") is not None
+
+
+def build(force=False):
+    """Two executables (the filter kernels / the persistent rollout kernel), compiled side by side: ~2 minutes the first time."""
+    cxx = CLANG if os.path.exists(CLANG) else shutil.which("clang++")
+    deps = [SRC, os.path.join(HERE, "hip", "hip_runtime.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    procs = []
+    for mode, exe in EXE.items():
+        if force or not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+            cmd = [cxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-pthread",
+                   f"-DSIMT_ONLY_MODE={mode}", "-I", HERE, "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-o", exe, SRC]
+            procs.append((cmd, subprocess.Popen(cmd, cwd=HERE, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("simt build failed: " + " ".join(cmd) + "\n" + out[-4000:])
+    return EXE
+
+
+def _structs(D, E, cbf_fields, pyb_freq=100, ctrl_freq=100):
+    from multidronesim_amd import _capi as capi
+    lib = capi.load_library()
+    cfg, gains, p = capi.MdsConfig(), capi.MdsGeometricGains(), capi.MdsCbfParams()
+    capi.check(lib.mds_default_config(capi.MDS_CF2P, C.byref(cfg)), "mds_default_config")
+    capi.check(lib.mds_default_geometric_gains(C.byref(gains)), "mds_default_geometric_gains")
+    cfg.num_envs, cfg.num_drones, cfg.pyb_freq, cfg.ctrl_freq, cfg.dtype = E, D, pyb_freq, ctrl_freq, capi.MDS_F64
+    for k, v in cbf_fields.items():
+        if isinstance(v, (list, tuple, np.ndarray)):
+            arr = getattr(p, k)
+            for j, x in enumerate(v):
+                arr[j] = float(x)
+        else:
+            setattr(p, k, v)
+    return cfg, gains, p
+
+
+def run(mode, dtype, E, D, n_steps, cbf_fields, obstacles, arrays, timeout=900):
+    """-> the bytes of out.bin.  obstacles: [n_obs, 4] (xyz, r).  arrays: the mode's float64 arrays, concatenated in order."""
+    exe = build()[mode]
+    cfg, gains, p = _structs(D, E, cbf_fields)
+    ob = np.zeros(64)
+    ob[:np.asarray(obstacles).size] = np.asarray(obstacles, dtype=np.float64).reshape(-1)
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(np.array([mode, 1 if dtype == "float64" else 0, E, D, n_steps, 0], dtype=np.int32).tobytes())
+            f.write(bytes(cfg)); f.write(bytes(gains)); f.write(bytes(p)); f.write(ob.tobytes())
+            for a in arrays:
+                f.write(np.ascontiguousarray(np.asarray(a, dtype=np.float64)).tobytes())
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+        r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=timeout, env=env)
+        if r.returncode != 0:
+            raise RuntimeError(f"simt_cbf (mode {mode}, {dtype}, E={E}, D={D}) exited {r.returncode}:\n{r.stderr[-6000:]}")
+        return open(fout, "rb").read(), r.stderr
+
+
+def filter_(dtype, obs, xdes, unom, cbf_fields, obstacles):
+    E, D = obs.shape[0], obs.shape[1]
+    raw, err = run(1, dtype, E, D, 0, cbf_fields, obstacles, [obs, xdes, unom])
+    n = E * D
+    us = np.frombuffer(raw[:n * 4 * 8], dtype=np.float64).reshape(E, D, 4)
+    st = np.frombuffer(raw[n * 32:n * 32 + 4 * E], dtype=np.int32)
+    it = np.frombuffer(raw[n * 32 + 4 * E:n * 32 + 8 * E], dtype=np.int32)
+    return us, st, it, err
+
+
+def rollout(dtype, t0, P, state13, steps, cbf_fields, obstacles):
+    E, D = P.shape[0], P.shape[1]
+    raw, err = run(2, dtype, E, D, steps, cbf_fields, obstacles, [np.array([t0]), P, state13])
+    n = E * D
+    obs = np.frombuffer(raw[:n * 20 * 8], dtype=np.float64).reshape(E, D, 20)
+    o = n * 160
+    slog = np.frombuffer(raw[o:o + 4 * steps * E], dtype=np.int32).reshape(steps, E)
+    it = np.frombuffer(raw[o + 4 * steps * E:o + 4 * steps * E + 4 * E], dtype=np.int32)
+    return obs, slog, it, err
