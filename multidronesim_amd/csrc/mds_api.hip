@@ -2231,7 +2231,8 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
     ra.last_rpm = (T*)rpm; ra.ll = (T*)h->ll; ra.pair_ij = h->pair_ij; ra.obstacles = (const T*)h->obstacles; ra.obs_log = (T*)obs_log;           \
     ra.slot = slot; ra.n_slots = log_slots > 0 ? log_slots : 1; ra.obs_last = (T*)obs; ra.status = (int*)status; ra.status_log = (int*)slog;      \
     ra.cost_io = h->cbf_cost; ra.max_iter = max_iter; ra.tol2 = (T)((TOL) * (TOL)); ra.tol = (T)(TOL); ra.stamps = stamps_dev;                   \
-    k_cbf_rollout<T, NOM, COMP, (sizeof(T) == 8 ? NWD : NWF)><<<grid, 64 * nw, extra_lds, st>>>(ra);                                              \
+    if (D == Dp) k_cbf_rollout<T, NOM, COMP, (sizeof(T) == 8 ? NWD : NWF), false><<<grid, 64 * nw, extra_lds, st>>>(ra);                          \
+    else k_cbf_rollout<T, NOM, COMP, (sizeof(T) == 8 ? NWD : NWF), true><<<grid, 64 * nw, extra_lds, st>>>(ra);                                   \
   } while (0)
 #define MDS_CR_N(T, CC, CP, COMP, TOL)                        \
   do {                                                        \

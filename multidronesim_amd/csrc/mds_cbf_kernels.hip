@@ -1497,7 +1497,9 @@ template <typename U> __device__ __forceinline__ U* lane_ptr(U* uniform_base, un
   return reinterpret_cast<U*>(reinterpret_cast<B*>(uniform_base) + idx * (unsigned)sizeof(U));
 }
 
-template <typename T, int NOM, bool COMP, int NW>
+// PAD: D is not 4, 8 or 16 -- an env is padded to the next of those widths (false: the padded and the real index coincide, and the
+// index arithmetic, the staging row and its guard fold away: the any-D form costs the C4 shape 2-3 %, measured).
+template <typename T, int NOM, bool COMP, int NW, bool PAD = true>
 __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout(const RollArgs<T>) {
 
   constexpr int NT = 64 * NW;
@@ -1584,8 +1586,8 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   const int D = a0->p.P.num_drones;
   const int log2P = D <= 4 ? 2 : (D <= 8 ? 3 : 4), Dp = 1 << log2P, GB = NT >> log2P;      // padded env width; envs per workgroup
   const int env0 = blockIdx.x * GB;
-  const int i = (env0 + (tid >> log2P)) * D + (tid & (Dp - 1));
-  const bool valid = (tid & (Dp - 1)) < D && env0 + (tid >> log2P) < a0->E;
+  const int i = PAD ? (env0 + (tid >> log2P)) * D + (tid & (Dp - 1)) : (int)(blockIdx.x * NT) + tid;
+  const bool valid = PAD ? ((tid & (Dp - 1)) < D && env0 + (tid >> log2P) < a0->E) : i < a0->n;
   const int nenv = min(GB, a0->E - env0);                          // envs this workgroup really owns (>= 1: the grid covers E)
   auto slice_of = [&](int w) -> Slice& { return *reinterpret_cast<Slice*>(raw + (size_t)w * kObsWave); };
 
@@ -1963,7 +1965,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     MDS_KEEP_S(eg0);                                  // the drone index is formed here, not held -- spilled -- across the loop
     int tq = tid;
     MDS_KEEP_V(tq);
-    const unsigned iu = (eg0 + ((unsigned)tq >> log2P)) * (unsigned)D + ((unsigned)tq & (unsigned)(Dp - 1));
+    unsigned wg0 = blockIdx.x * NT;
+    MDS_KEEP_S(wg0);
+    const unsigned iu = PAD ? (eg0 + ((unsigned)tq >> log2P)) * (unsigned)D + ((unsigned)tq & (unsigned)(Dp - 1)) : wg0 + (unsigned)tq;
     const Consts<T> c = load_const(&ac->p.c);
     const CbfParams<T> P = load_const(&ac->p.P);
     constexpr int kRowBytes = kObsDim * (int)sizeof(T);
@@ -2015,8 +2019,8 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
         // the row goes to the wave's staging slice at once (20 values held across the rest of the stage were spilled to scratch)
         typedef unsigned int v4u __attribute__((ext_vector_type(4)));
         // (row of the wave's staging slice: its envs' drones back to back -- the padded lanes of an env hold no row)
-        const int crow = (lq >> log2P) * D + (lq & (Dp - 1));
-        if ((lq & (Dp - 1)) < D) {
+        const int crow = PAD ? (lq >> log2P) * D + (lq & (Dp - 1)) : lq;
+        if (!PAD || (lq & (Dp - 1)) < D) {
 #pragma unroll
           for (int j = 0; j < kRowBytes / 16; ++j) reinterpret_cast<v4u*>(lds_wave + crow * kRowBytes)[j] = reinterpret_cast<const v4u*>(o)[j];
         }
@@ -2030,8 +2034,8 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       T* dst = obs_log != nullptr ? obs_log + (size_t)slot * n * kObsDim : ac->obs_last;      // (log AND obs_last: the host copies the last slot)
       MDS_WAVE_SYNC();
       const int ew = __builtin_amdgcn_readfirstlane((int)eg0 + ((tq >> 6) << (6 - log2P)));  // the wave's first env (uniform)
-      const int wave_base = ew * D;                                                        // its first observation row: scalar base + 32-bit lane offsets
-      const int rows = (min(ew + (64 >> log2P), ac->E) - ew) * D;                          // (<= 0: no env of the shard in this wave)
+      const int wave_base = PAD ? ew * D : __builtin_amdgcn_readfirstlane((int)iu - lq);   // its first observation row: scalar base + 32-bit lane offsets
+      const int rows = PAD ? (min(ew + (64 >> log2P), ac->E) - ew) * D : min(64, n - wave_base);   // (<= 0: no env of the shard in this wave)
       if (rows > 0) {
         const int bytes = rows * kRowBytes;
         unsigned char* gdst = reinterpret_cast<unsigned char*>(dst) + (size_t)wave_base * kRowBytes;

@@ -14,7 +14,7 @@ for m in re.finditer(r"\.name:\s+(\S*k_cbf_rollout\S*)", s):
     g = lambda k: (re.search(r"\." + k + r":\s+(\d+)", seg) or [None, "?"])[1]
     print(m.group(1)[:48], "vgpr", g("vgpr_count"), "spill", g("vgpr_spill_count"), "sgpr", g("sgpr_count"), "lds", g("group_segment_fixed_size"))
 lines = s.splitlines()
-name = "_ZN3mds13k_cbf_rolloutIfLi0ELb0ELi8EEE"
+name = "_ZN3mds13k_cbf_rolloutIfLi0ELb0ELi8ELb0EEE"
 st = [k for k, l in enumerate(lines) if l.startswith(name) and "@function" not in l and ": " in l][0]
 en = next(k for k in range(st, len(lines)) if "s_endpgm" in lines[k])
 body = lines[st + 1:en]
@@ -26,6 +26,6 @@ def mix(a, b, tag):
     c = collections.Counter(l.strip().split()[0] for l in body[a:b] if l.strip() and not l.strip().startswith((".", ";")) and not l.strip().endswith(":"))
     print(tag, a, b, "valu", sum(n for k, n in c.items() if k.startswith("v_")), "salu", sum(n for k, n in c.items() if k.startswith("s_")),
           "readlane", c["v_readlane_b32"], "writelane", c["v_writelane_b32"], "mov", c["v_mov_b32_e32"], "lshl_add_u64", c["v_lshl_add_u64"], "nop", c["s_nop"])
-bars = [k for k in marks if "s_barrier" in body[k]]
+bars = [k for k in marks if "s_barrier" in body[k]][-2:]
 mix(bars[0], bars[1], "B (all variants, solver included)")
 mix(bars[1], len(body), "C + A")

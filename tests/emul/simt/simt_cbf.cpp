@@ -131,7 +131,8 @@ template <typename T> static int run_rollout(const In& in, FILE* out) {
   for (int k0 = 0; k0 < steps; k0 += 7) {
     const int ks = steps - k0 < 7 ? steps - k0 : 7;
     ra.t = t; ra.n_steps = ks; ra.slot = slot; ra.status_log = slog.data() + (size_t)k0 * E;
-    simt::launch((unsigned)grid, 64 * NW, &ra, [&]() { k_cbf_rollout<T, 0, false, NW>(ra); });
+    if (D == Dp) simt::launch((unsigned)grid, 64 * NW, &ra, [&]() { k_cbf_rollout<T, 0, false, NW, false>(ra); });     // (as the library dispatches)
+    else simt::launch((unsigned)grid, 64 * NW, &ra, [&]() { k_cbf_rollout<T, 0, false, NW, true>(ra); });
     for (int j = 0; j < ks; ++j) t += ra.ctrl_dt;
     slot = (slot + ks) % 3;
   }
