@@ -477,7 +477,10 @@ int mds_rollout_cbf_geometric(mds_handle* h, double t0, int n_steps, void* obs_d
  * observation is materialised.  obs_dev [n,20]: the last step's observation (out).  status_dev [E]: the last step's statuses as
  * mds_cbf_filter; status_log_dev: NULL or [n_steps, E], every step's.  Covers order 2, any D <= 16 (round 4: an env padded to 4, 8 or 16 lanes; obstacle and thrust-box rows folded into per-drone bounds),
  * explicit Euler at pyb_freq == ctrl_freq, DYN, geometric or LQR-omega nominal, f32 / f32c / f64, at most 2^27 drones per handle
- * (32-bit byte offsets into the per-drone planes); MDS_EUNSUPPORTED otherwise (use mds_rollout_cbf_geometric).  Same feasible set, minimiser and statuses as the step-by-step loop
+ * (32-bit byte offsets into the per-drone planes); and ORDER 3 (round 4: the simulations/CBFTestOrd3.py:306-352 loop -- lqr-yank-omega nominal
+ * selected with mds_cbf_set_nominal(h, 2), YankOmega low level -- one wavefront per env, D <= 16, f32 / f64; obs_dev is then IN as well: the current
+ * observation, whose RPM echo starts the thrust state); MDS_EUNSUPPORTED otherwise (RK4, drag, ground effect / downwash, pyb_freq != ctrl_freq: use
+ * mds_rollout_cbf_geometric).  Same feasible set, minimiser and statuses as the step-by-step loop
  * (the single-variable rows enter as two bounds per drone, so a dominated row never counts as an iteration); observations equal to rounding (the
  * kernels contract FMAs differently, as the one-launch step does: mds_cbf_set_step_kernel).  The call only enqueues (kernel launches and one
  * device-to-device copy of the last ring slot): it may be captured into a hipGraph. */

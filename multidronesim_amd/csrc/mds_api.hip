@@ -2181,6 +2181,45 @@ int mds_rollout_cbf_geometric_fused(mds_handle* h, double t0, int n_steps, int s
   if (!aligned16(obs) || !aligned16(obs_log)) return fail(MDS_EALIGN, "mds_rollout_cbf_geometric_fused: obs buffers");
   const int D = h->cfg.num_drones;
   const int m2 = D * (D - 1) / 2 + D * h->cbf.n_obs + 2 * D;
+  if (h->cbf.order == 3) {
+    // the order-3 loop (simulations/CBFTestOrd3.py:306-352): k_cbf_rollout_o3, one wavefront per env, steps_per_launch steps per launch
+    if (!(h->cbf_nominal == 2 && h->has_lqr_yo && D <= 16 && !h->envfx && !h->cbf_hildreth && h->cfg.integrator == MDS_INTEGRATOR_EULER && !has_drag(h) &&
+          (h->cfg.dtype == MDS_F32 || h->cfg.dtype == MDS_F64) && h->cfg.pyb_freq == h->cfg.ctrl_freq))
+      return fail(MDS_EUNSUPPORTED, "mds_rollout_cbf_geometric_fused (order 3): lqr-yank-omega nominal, D <= 16, explicit Euler at pyb_freq == ctrl_freq "
+                                    "without drag / ground effect / downwash, f32 / f64");
+    if (n_steps == 0) return MDS_OK;
+    hipStream_t st3 = (hipStream_t)stream;
+    const int m3 = D * (D - 1) / 2 + D * h->cbf.n_obs + 6 * D, n3 = 3 * D;
+    const int max_iter3 = h->cbf.max_iter > 0 ? h->cbf.max_iter : 64 * m3;
+    const double dt3 = 1.0 / h->cfg.ctrl_freq, hover_sub = h->cfg.M * h->cfg.G;      // the hover force is subtracted from the yank on the way into the filter (:341)
+    void* rpm3 = rpm_track(h);
+    h->cbf_last_step_kernel = 2;
+    int slot3 = first_slot;
+    double t3 = t0;
+    for (int k0 = 0; k0 < n_steps; k0 += steps_per_launch) {
+      const int ks = n_steps - k0 < steps_per_launch ? n_steps - k0 : steps_per_launch;
+      int32_t* slog = status_log ? status_log + (size_t)k0 * h->cfg.num_envs : nullptr;
+#define MDS_O3(T, CC, CP, KK, RR, NM, TOL)                                                                                                   \
+  k_cbf_rollout_o3<T, RR, NM><<<dim3((unsigned)h->cfg.num_envs), 64, 0, st3>>>(CC, CP, KK, h->cfg.num_envs, h->ld, t3, dt3, ks, (T*)h->state,   \
+                                                                             (const T*)h->lem, (T*)rpm3, (T*)h->ll, h->pair_ij,              \
+                                                                             (const T*)h->obstacles, (T*)obs, (T*)obs_log, slot3,            \
+                                                                             log_slots > 0 ? log_slots : 1, (int*)status, (int*)slog,        \
+                                                                             h->cbf_cost, max_iter3, (T)((TOL) * (TOL)), (T)hover_sub)
+#define MDS_O3_S(T, CC, CP, KK, TOL)                 \
+  do {                                               \
+    if (n3 <= 24 && m3 <= 256) MDS_O3(T, CC, CP, KK, 4, 24, TOL); \
+    else MDS_O3(T, CC, CP, KK, 8, 48, TOL);          \
+  } while (0)
+      if (h->cfg.dtype == MDS_F64) MDS_O3_S(double, h->cd, h->cbf_d, h->lqr_yo_d, (h->cbf.tol > 0 ? h->cbf.tol : 1e-12));
+      else MDS_O3_S(float, h->cf, h->cbf_f, h->lqr_yo_f, (h->cbf.tol > 0 ? h->cbf.tol : 1e-6));
+#undef MDS_O3_S
+#undef MDS_O3
+      MDS_HIP(hipGetLastError());
+      for (int j = 0; j < ks; ++j) t3 += dt3;
+      if (obs_log) slot3 = (slot3 + ks) % log_slots;
+    }
+    return MDS_OK;
+  }
   // what the persistent kernel covers (everything else: mds_rollout_cbf_geometric, one or two launches per step)
   if (!roll_fused_applies(h))
     return fail(MDS_EUNSUPPORTED, "mds_rollout_cbf_geometric_fused: order-2 CBF, D <= 16, explicit Euler at "

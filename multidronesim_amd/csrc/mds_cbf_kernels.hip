@@ -917,13 +917,13 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
 #ifndef MDS_GI_MINWAVES
 #define MDS_GI_MINWAVES 1
 #endif
+// One env's QP on one wavefront (lane = threadIdx.x & 63, all 64 lanes active): its D x 20 observation block, D x xdim xdes block and
+// D x 4 nominal block in, its D x 4 u_safe block, status and iteration count out.  The blocks may live in global memory (k_cbf_filter_gi)
+// or in LDS (k_cbf_rollout_o3 stages them per control step); the LDS arrays of the solver are this function's own.
 template <typename T, typename S, int R, int NMAX, int ORDER>
-__global__ __launch_bounds__(64, MDS_GI_MINWAVES) void k_cbf_filter_gi(const CbfParams<T> P, const int E, const T kf, const int* __restrict__ pair_ij,
-                                                      const T* __restrict__ obstacles, const S* __restrict__ obs,
-                                                      const S* __restrict__ xdes, const S* __restrict__ unom,
-                                                      S* __restrict__ usafe, int* __restrict__ status, const int max_iter,
-                                                      const T tol2, const int* __restrict__ order_in,
-                                                      const int* __restrict__ count_in, int* __restrict__ cost_out) {
+__device__ __forceinline__ void cbf_filter_env(const CbfParams<T>& P, const int lane, const T kf, const int* __restrict__ pair_ij,
+                                               const T* __restrict__ obstacles, const S* obs, const S* xdes, const S* unom, S* usafe,
+                                               int* status_env, const int max_iter, const T tol2, int* cost_env) {
   constexpr int NV = ORDER == 2 ? 1 : 3;
   constexpr int XD = ORDER == 2 ? 9 : 10;
   constexpr bool PRE = NMAX * sizeof(T) <= 128;   // a lane's rows of Q and R fit in registers: one LDS round trip per step instead of 2q
@@ -943,28 +943,11 @@ __global__ __launch_bounds__(64, MDS_GI_MINWAVES) void k_cbf_filter_gi(const Cbf
   __shared__ __align__(16) CbfRow<T, NV> srow[(sizeof(S) * DMAX * 20 + sizeof(CbfRow<T, NV>) - 1) / sizeof(CbfRow<T, NV>)];
 #endif
   S* sraw = reinterpret_cast<S*>(srow);                     // the env's observation rows, staged before the rows are built
-  const int lane = threadIdx.x;
-  // Longest-first dispatch: the solve time of an env is ~ its number of active rows, which changes slowly from one
-  // control step to the next.  Every wave records its iteration count; every few launches k_cbf_order bins the envs into
-  // cost classes, and the launches walk the classes heaviest first, so the few long solves start at t = 0 instead of
-  // forming the kernel's tail.  (One atomic per wave on a shared counter would serialise: 12 ns each, measured.)
-  int env = blockIdx.x;
-  if (order_in) {
-    const int c0 = count_in[0], c1 = count_in[1];
-    const int b = blockIdx.x;
-    env = b < c0 ? order_in[b] : (b < c0 + c1 ? order_in[E + b - c0] : order_in[2 * E + b - c0 - c1]);
-#if !defined(MDS_TUNE_NO_SETPRIO)
-    // the envs that iterated last time: on the critical path from their first instruction
-    if (b < c0) __builtin_amdgcn_s_setprio(3);
-    else if (b < c0 + c1) __builtin_amdgcn_s_setprio(2);
-#endif
-  }
-  if (env >= E) return;
 #if defined(MDS_TUNE_ITERS)
   const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
   const int D = P.num_drones, n = NV * D;
-  const size_t base = (size_t)env * D;
+  constexpr size_t base = 0;                    // (the pointers are this env's blocks)
   const int npairs = cbf_num_pairs(D), nobs_rows = D * P.n_obs, m = npairs + nobs_rows + 2 * n;
 
   // ---- every global read of this env, issued back to back ----
@@ -1119,13 +1102,13 @@ __global__ __launch_bounds__(64, MDS_GI_MINWAVES) void k_cbf_filter_gi(const Cbf
 #if defined(MDS_TUNE_ITERS)   // tuning build: iteration count and final active-set size in the high bits of status
   {
     const int nbox = __popcll(__ballot(lane < q && sact[lane < NMAX ? lane : 0] >= npairs + nobs_rows));
-    if (lane == 0) status[env] = (converged ? 0 : 1) | ((it & 0x7f) << 1) | ((q & 0x1f) << 8) | ((nbox & 0x1f) << 13) |
+    if (lane == 0) *status_env = (converged ? 0 : 1) | ((it & 0x7f) << 1) | ((q & 0x1f) << 8) | ((nbox & 0x1f) << 13) |
                                  ((int)m_min<unsigned long long>((__builtin_amdgcn_s_memtime() - t_start) >> 8, 0x1fffull) << 18);
   }
 #else
-  if (lane == 0) status[env] = converged ? 0 : 1;
+  if (lane == 0) *status_env = converged ? 0 : 1;
 #endif
-  if (cost_out && lane == 0) cost_out[env] = it;
+  if (cost_env && lane == 0) *cost_env = it;
   MDS_WAVE_SYNC();
   // u_safe in the flat [D,4] layout of the nominal block that is still in registers
 #pragma unroll
@@ -1147,6 +1130,36 @@ __global__ __launch_bounds__(64, MDS_GI_MINWAVES) void k_cbf_filter_gi(const Cbf
       usafe[base * 4 + k] = (S)u;
     }
   }
+}
+
+template <typename T, typename S, int R, int NMAX, int ORDER>
+__global__ __launch_bounds__(64, MDS_GI_MINWAVES) void k_cbf_filter_gi(const CbfParams<T> P, const int E, const T kf, const int* __restrict__ pair_ij,
+                                                      const T* __restrict__ obstacles, const S* __restrict__ obs,
+                                                      const S* __restrict__ xdes, const S* __restrict__ unom,
+                                                      S* __restrict__ usafe, int* __restrict__ status, const int max_iter,
+                                                      const T tol2, const int* __restrict__ order_in,
+                                                      const int* __restrict__ count_in, int* __restrict__ cost_out) {
+  const int lane = threadIdx.x;
+  // Longest-first dispatch: the solve time of an env is ~ its number of active rows, which changes slowly from one
+  // control step to the next.  Every wave records its iteration count; every few launches k_cbf_order bins the envs into
+  // cost classes, and the launches walk the classes heaviest first, so the few long solves start at t = 0 instead of
+  // forming the kernel's tail.  (One atomic per wave on a shared counter would serialise: 12 ns each, measured.)
+  int env = blockIdx.x;
+  if (order_in) {
+    const int c0 = count_in[0], c1 = count_in[1];
+    const int b = blockIdx.x;
+    env = b < c0 ? order_in[b] : (b < c0 + c1 ? order_in[E + b - c0] : order_in[2 * E + b - c0 - c1]);
+#if !defined(MDS_TUNE_NO_SETPRIO)
+    // the envs that iterated last time: on the critical path from their first instruction
+    if (b < c0) __builtin_amdgcn_s_setprio(3);
+    else if (b < c0 + c1) __builtin_amdgcn_s_setprio(2);
+#endif
+  }
+  if (env >= E) return;
+  constexpr int XD = ORDER == 2 ? 9 : 10;
+  const size_t base = (size_t)env * P.num_drones;
+  cbf_filter_env<T, S, R, NMAX, ORDER>(P, lane, kf, pair_ij, obstacles, obs + base * 20, xdes + base * XD, unom + base * 4, usafe + base * 4, status + env,
+                                       max_iter, tol2, cost_out ? cost_out + env : nullptr);
 }
 
 // Row r of an order-2 env whose drones' world positions / tracking errors sit in LDS rows d0 .. d0 + D - 1 (k_cbf_step): the
@@ -2063,6 +2076,102 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
   if (kStamps && stamps != nullptr) {
     __syncthreads();
     if (threadIdx.x < NW * 10) stamps[(size_t)blockIdx.x * NW * 10 + threadIdx.x] = sst[threadIdx.x / 10][threadIdx.x % 10];
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// The order-3 loop of simulations/CBFTestOrd3.py:306-352 in launches of n_steps control steps -- the persistent form for the
+// reference's own order-3 shape (7 drones, one env: CBFTestOrd3.py:31, :452).  One wavefront per env, its drones on lanes 0 .. D - 1
+// with the state, the RPM echo (the thrust state is calc_z_thrust of it) and the low level's memory in registers for the whole launch.
+// Per step: every drone's current observation row, its nominal LQR-yank-omega input (yank - M G, w: :341) and xdes = [0, 0, yaw, M G,
+// v_des, p_des] (:345-347) go to LDS blocks; cbf_filter_env -- the body of the step-by-step filter kernel itself -- solves the env's
+// 3 D-variable QP on them; the drone lanes run the YankOmega low level on u_safe (the yank as it is: :350) and the physics step, and
+// write the observation row (slot (slot0 + k) % n_slots of the log ring, or only the last).  obs_io [n, 20]: in, the current observation
+// (its RPM echo starts the thrust state); out, the last step's.  t advances in double like the host loop.  Not tuned -- D of 64 lanes work
+// in the per-drone stages: the reference's order-3 scenes are a handful of drones -- but no launch, no u_hat / xdes / u_safe round
+// trip through HBM per control step.
+// ------------------------------------------------------------------------------------
+template <typename T, int R, int NMAX>
+__global__ __launch_bounds__(64) void k_cbf_rollout_o3(const Consts<T> c, const CbfParams<T> P, const LqrYoGain<T> K, const int E, const size_t ld, double t,
+                                                       const double ctrl_dt, const int n_steps, T* __restrict__ state, const T* __restrict__ lem,
+                                                       T* __restrict__ last_rpm, T* __restrict__ ll, const int* __restrict__ pair_ij,
+                                                       const T* __restrict__ obstacles, T* __restrict__ obs_io, T* __restrict__ obs_log, int slot,
+                                                       const int n_slots, int* __restrict__ status, int* __restrict__ status_log,
+                                                       int* __restrict__ cost, const int max_iter, const T tol2, const T hover_sub) {
+  constexpr int DMAX = NMAX / 3;
+  __shared__ __align__(16) T sobs[DMAX * kObsDim], sxdes[DMAX * 10], sunom[DMAX * 4], susafe[DMAX * 4];
+  __shared__ int sres[2];                                          // status, iterations of this step's solve
+  const int lane = threadIdx.x, env = blockIdx.x, D = P.num_drones;
+  const bool drone = lane < D;
+  const size_t i = (size_t)env * D + (drone ? lane : 0);           // (the other lanes: a clamped index, nothing stored)
+  const size_t n = (size_t)E * D;
+  GeoIn<T> in;
+  load_geo_in<T, T>(state, lem, ld, i, in);
+  LowLevelState<T> L;
+  L.last_omega = {ll[0 * ld + i], ll[1 * ld + i], ll[2 * ld + i]};
+  L.integral = {ll[3 * ld + i], ll[4 * ld + i], ll[5 * ld + i]};
+  T clipped[4];
+  load4<T, T>(obs_io + i * kObsDim + 16, clipped);
+  const V3<T> centre = {in.P.cx, in.P.cy, in.P.cz};
+  for (int k = 0; k < n_steps; ++k) {
+    if (drone) {
+      const Desired<T> des = lemniscate_local(in.P, t);
+      T u[4], o[kObsDim];
+      lqr_yank_omega_control<T>(c, K, euler_from_quat(in.s.q), clipped, in.s.v, in.s.p, des.p, des.v, des.yaw, u);
+      sunom[4 * lane] = u[0] - hover_sub; sunom[4 * lane + 1] = u[1]; sunom[4 * lane + 2] = u[2]; sunom[4 * lane + 3] = u[3];
+      T* xd = &sxdes[10 * lane];
+      xd[0] = T(0); xd[1] = T(0); xd[2] = des.yaw; xd[3] = c.gravity;
+      xd[4] = des.v.x; xd[5] = des.v.y; xd[6] = des.v.z;
+      xd[7] = des.p.x + in.P.cx; xd[8] = des.p.y + in.P.cy; xd[9] = des.p.z + in.P.cz;
+      pack_obs(in.s, centre, clipped, o);                          // the observation the previous step returned
+#pragma unroll
+      for (int j = 0; j < kObsDim; ++j) sobs[kObsDim * lane + j] = o[j];
+    }
+    MDS_WAVE_SYNC();
+    cbf_filter_env<T, T, R, NMAX, 3>(P, lane, c.kf, pair_ij, obstacles, sobs, sxdes, sunom, susafe, &sres[0], max_iter, tol2, &sres[1]);
+    MDS_WAVE_SYNC();
+    if (lane == 0) {
+      if (status_log) status_log[(size_t)k * E + env] = sres[0];
+      if (k == n_steps - 1) {
+        status[env] = sres[0];
+        if (cost) cost[env] = sres[1];
+      }
+    }
+    if (drone) {
+      const T u[4] = {susafe[4 * lane], susafe[4 * lane + 1], susafe[4 * lane + 2], susafe[4 * lane + 3]};
+      T act[4], prev[4] = {T(0), T(0), T(0), T(0)}, cl2[4];
+      Resid<T> rs;
+      resid_zero(rs);
+      yank_omega_control(c, (T)ctrl_dt, u, clipped, in.s.w, L, act);
+      aviary_step_any<T, false, false, false>(c, in.s, rs, act, prev, cl2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) clipped[j] = cl2[j];
+      const bool last = k == n_steps - 1;
+      if (obs_log != nullptr || last) {
+        T o[kObsDim];
+        pack_obs(in.s, centre, clipped, o);
+        if (obs_log != nullptr) {
+          T* dst = obs_log + ((size_t)slot * n + i) * kObsDim;
+#pragma unroll
+          for (int j = 0; j < kObsDim; j += 4) store4<T, T>(dst + j, o + j);
+        }
+        if (last) {
+          T* dst = obs_io + i * kObsDim;
+#pragma unroll
+          for (int j = 0; j < kObsDim; j += 4) store4<T, T>(dst + j, o + j);
+        }
+      }
+    }
+    MDS_WAVE_SYNC();                                               // the LDS blocks are rewritten by the next step
+    t += ctrl_dt;
+    slot = slot + 1 == n_slots ? 0 : slot + 1;
+  }
+  if (drone) {
+    store_state<T, T>(state, ld, i, in.s);
+    ll[0 * ld + i] = L.last_omega.x; ll[1 * ld + i] = L.last_omega.y; ll[2 * ld + i] = L.last_omega.z;
+    ll[3 * ld + i] = L.integral.x; ll[4 * ld + i] = L.integral.y; ll[5 * ld + i] = L.integral.z;
+    if (last_rpm != nullptr && n_steps > 0)
+      for (int j = 0; j < 4; ++j) last_rpm[j * ld + i] = clipped[j];
   }
 }
 

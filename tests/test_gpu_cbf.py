@@ -1108,8 +1108,9 @@ def test_cbftest_default_nominal_512_envs_against_the_c_oracle_at_every_step(mds
     env.close()
 
 
+@pytest.mark.parametrize("form", ["step", "persistent"])
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-8), ("float32", 5e-3)])
-def test_order3_loop_256_envs_against_the_c_oracle_at_every_step(mds, dtype, tol):
+def test_order3_loop_256_envs_against_the_c_oracle_at_every_step(mds, dtype, tol, form):
     """simulations/CBFTestOrd3.py's loop (yank-omega LQR nominal, order-3 ECBF with its 3 coupled QP variables per drone and the
     thrust-state box, YankOmega low level) on 256 envs x 8 drones x 200 steps against the plain-C oracle: the status of every env at
     every step, every drone's state at the end (float64: 2.7e-12, all 51 200 statuses equal; fp32: 3 borderline envs get another status
@@ -1133,16 +1134,22 @@ def test_order3_loop_256_envs_against_the_c_oracle_at_every_step(mds, dtype, tol
     L = CO.CbfLoopC(xyz, rpy, CO.cbf_params(cbf.Kcbf.reshape(-1), cbf.umax, 0.125, 2.0, x_obs, obs_r, order=3), first_rpm=O.CF2P.HOVER_RPM)
     ref, rst, its, _ = L.run3(P, steps, ctrl.K, threads=H.oracle_threads())
     env.step(mds.torch.full((E, D, 4), O.CF2P.HOVER_RPM, dtype=env.dtype))
-    t, hist = 0.0, []
-    for k in range(steps):
-        gobs, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
-        hist.append(st.clone())
-        t += env.CTRL_TIMESTEP
-    got_st = mds.torch.stack(hist).cpu().numpy()
+    if form == "persistent":      # k_cbf_rollout_o3 (round 4): the same loop, 37 control steps per launch (a ragged last one), statuses of every step
+        slog = mds.torch.full((steps, E), -1, dtype=mds.torch.int32, device=env.device)
+        gobs, st = env.rollout_cbf_geometric_fused(0.0, steps, trk, x_obs, obs_r, steps_per_launch=37, status_log=slog)
+        assert env.cbf_last_step_kernel() == 2
+        got_st = slog.cpu().numpy()
+    else:
+        t, hist = 0.0, []
+        for k in range(steps):
+            gobs, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
+            hist.append(st.clone())
+            t += env.CTRL_TIMESTEP
+        got_st = mds.torch.stack(hist).cpu().numpy()
     bad = np.unique(np.nonzero(got_st != rst)[1])
     good = np.setdiff1d(np.arange(E), bad)
     err = np.abs(gobs.double().cpu().numpy().reshape(E, D, 20)[good][..., :16] - ref[good][..., :16]).max()
-    print(f"[order 3 vs C oracle] {dtype}: {its / (E * steps):.2f} iterations per env-step, {int(rst.sum())} infeasible env-steps, "
+    print(f"[order 3 vs C oracle] {dtype} {form}: {its / (E * steps):.2f} iterations per env-step, {int(rst.sum())} infeasible env-steps, "
           f"envs with any status difference {bad.size}, max |state err| on the others {err:.3e}")
     assert its > 0
     if dtype == "float64":
@@ -1153,3 +1160,55 @@ def test_order3_loop_256_envs_against_the_c_oracle_at_every_step(mds, dtype, tol
         assert bad.size <= 8, bad
     assert err < tol
     env.close()
+
+
+@pytest.mark.parametrize("D,n_obs,E", [(7, 0, 1), (3, 1, 5), (16, 2, 9), (8, 16, 4)])
+def test_order3_persistent_rollout_small_shapes(mds, D, n_obs, E):
+    """k_cbf_rollout_o3 away from the 8-drone test shape: the reference's own 7 drones in one env (simulations/CBFTestOrd3.py:31), 3, and 16
+    drones (48 coupled variables), with and without spheres (16 of them: 280 rows per env), an observation ring that wraps, the call
+    continued by a second one -- statuses and solver iteration counts equal to the step-by-step loop's at every step, state to rounding."""
+    from multidronesim_amd.control import LQRYankOmegaController, YankOmegaController
+    steps = 30
+    xyz, rpy, P = H.c2_setup(E, D, seed=D, phase="c3", offset=2.0, omega=0.5)
+    xyz[..., 2] = 0.5 + 0.35 * np.arange(D)
+    P[..., 4] = 0.5 + 0.3 * np.arange(D)
+    rng = np.random.default_rng(D)
+    x_obs = [np.array([[*rng.uniform(-1.0, 1.0, size=2), rng.uniform(-0.5, 0.3)], [0, 0, 0], [0, 0, 0]]) for _ in range(n_obs)] or None
+    obs_r = [0.1] * n_obs if n_obs else None
+    out = {}
+    for form in ("step", "fused"):
+        env = mds.CtrlAviary(drone_model=mds.DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=mds.Physics.DYN,
+                             pyb_freq=100, ctrl_freq=100, num_envs=E, dtype="float64")
+        env.set_trajectories(P)
+        LQRYankOmegaController(env, mds.LinearizedYankOmegaModel(env), YankOmegaController(env))
+        cbf = mds.DroneCBF(env, [mds.LinearizedYankOmegaModel(env) for _ in range(D)], safety_radius=0.125, zscale=2.0, order=3,
+                           cbf_poles=np.array([-3.0, -3.6, -5.6]))
+        trk = mds.DroneQPTracker(cbf, order=3, num_robots=D, xdim=10, env=env)
+        env.set_cbf_nominal("lqr_yank_omega")
+        env.step(mds.torch.full((E, D, 4), O.CF2P.HOVER_RPM, dtype=env.dtype))
+        if form == "step":
+            t, hist, its = 0.0, [], []
+            for k in range(steps):
+                o, st = env.step_cbf_geometric(t, trk, x_obs, obs_r)
+                hist.append(st.cpu().numpy().copy())
+                its.append(cbf.last_iterations().cpu().numpy().copy())
+                t += env.CTRL_TIMESTEP
+            hist, ring = np.array(hist), None
+        else:
+            slog = mds.torch.full((steps, E), -1, dtype=mds.torch.int32, device=env.device)
+            ring = mds.torch.zeros((4, E, D, 20), dtype=env.dtype, device=env.device)
+            env.rollout_cbf_geometric_fused(0.0, 19, trk, x_obs, obs_r, steps_per_launch=8, status_log=slog[:19], obs_log=ring)
+            assert env.cbf_last_step_kernel() == 2
+            t19 = 0.0
+            for _ in range(19):
+                t19 += env.CTRL_TIMESTEP
+            o, st = env.rollout_cbf_geometric_fused(t19, steps - 19, trk, x_obs, obs_r, steps_per_launch=8, status_log=slog[19:], obs_log=ring, first_slot=19 % 4)
+            hist = slog.cpu().numpy()
+            its = [cbf.last_iterations().cpu().numpy().copy()]
+            np.testing.assert_array_equal(ring[(steps - 1) % 4].cpu().numpy(), o.cpu().numpy())      # the last slot of the ring is the observation returned
+        out[form] = (o.double().cpu().numpy().copy(), hist, env.get_state(), its[-1])
+        env.close()
+    np.testing.assert_array_equal(out["step"][1], out["fused"][1])
+    np.testing.assert_array_equal(out["step"][3], out["fused"][3])
+    np.testing.assert_allclose(out["fused"][0][..., :16], out["step"][0][..., :16], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(out["fused"][2], out["step"][2], rtol=0, atol=1e-9)

@@ -109,6 +109,7 @@ def test_cbftest_ord3_runs_the_yank_loop(gpu):
     geo.do_control(trajs=trajs, qpTracker=trk, x_obs_list=None, obs_r_list=None)
     obs = np.asarray(geo.observations)
     assert obs.shape == (100, 3, 20) and np.isfinite(obs).all()
+    assert geo.last_cbf_kernel == 2                                                    # the order-3 persistent kernel (k_cbf_rollout_o3, round 4)
     P = np.array([[1.0, 0.5, 0, 0, 0.5, 0.0, (2 * np.pi / (D + 0.25)) * num] for num in range(D)])
     oobs, ohist = H.oracle_cbf_closed_loop(geo.INIT_XYZS[None], geo.INIT_RPYS[None], P[None], 100, cbf.Kcbf.reshape(-1), cbf.umax, 0.125, 2.0,
                                            None, None, nominal="lqr_yank_omega", order=3, first_rpm=O.CF2P.HOVER_RPM)
