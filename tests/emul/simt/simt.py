@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
 CSRC = os.path.join(ROOT, "multidronesim_amd", "csrc")
 SRC = os.path.join(HERE, "simt_cbf.cpp")
 CLANG = os.environ.get("MDS_SIMT_CXX") or "/opt/rocm/lib/llvm/bin/clang++"
-EXE = {1: os.path.join(HERE, "simt_filter"), 2: os.path.join(HERE, "simt_rollout")}
+EXE = {1: os.path.join(HERE, "simt_filter"), 2: os.path.join(HERE, "simt_rollout")}          # (mode 3, the order-3 rollout, lives in simt_rollout)
 
 
 def available():
@@ -56,7 +56,7 @@ def _structs(D, E, cbf_fields, pyb_freq=100, ctrl_freq=100):
 
 def run(mode, dtype, E, D, n_steps, cbf_fields, obstacles, arrays, timeout=900):
     """-> the bytes of out.bin.  obstacles: [n_obs, 4] (xyz, r).  arrays: the mode's float64 arrays, concatenated in order."""
-    exe = build()[mode]
+    exe = build()[2 if mode == 3 else mode]
     cfg, gains, p = _structs(D, E, cbf_fields)
     ob = np.zeros(64)
     ob[:np.asarray(obstacles).size] = np.asarray(obstacles, dtype=np.float64).reshape(-1)
@@ -87,6 +87,18 @@ def filter_(dtype, obs, xdes, unom, cbf_fields, obstacles):
 def rollout(dtype, t0, P, state13, steps, cbf_fields, obstacles):
     E, D = P.shape[0], P.shape[1]
     raw, err = run(2, dtype, E, D, steps, cbf_fields, obstacles, [np.array([t0]), P, state13])
+    n = E * D
+    obs = np.frombuffer(raw[:n * 20 * 8], dtype=np.float64).reshape(E, D, 20)
+    o = n * 160
+    slog = np.frombuffer(raw[o:o + 4 * steps * E], dtype=np.int32).reshape(steps, E)
+    it = np.frombuffer(raw[o + 4 * steps * E:o + 4 * steps * E + 4 * E], dtype=np.int32)
+    return obs, slog, it, err
+
+
+def rollout_o3(dtype, t0, K, P, state13, rpm_echo, steps, cbf_fields, obstacles):
+    """k_cbf_rollout_o3: K [4,10] the LQR-yank-omega gain, rpm_echo [E,D,4] the current observation's clipped RPM."""
+    E, D = P.shape[0], P.shape[1]
+    raw, err = run(3, dtype, E, D, steps, cbf_fields, obstacles, [np.array([t0]), np.asarray(K).reshape(-1), P, state13, rpm_echo])
     n = E * D
     obs = np.frombuffer(raw[:n * 20 * 8], dtype=np.float64).reshape(E, D, 20)
     o = n * 160

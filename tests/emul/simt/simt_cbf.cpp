@@ -145,6 +145,64 @@ template <typename T> static int run_rollout(const In& in, FILE* out) {
   return 0;
 }
 
+// mode 3: k_cbf_rollout_o3 (one wavefront per env).  rest: t0, K[40] (the LQR-yank-omega gain), P[n*7], state13[n*13], rpm_echo[n*4]
+template <typename T> static int run_rollout_o3(const In& in, FILE* out) {
+  const int E = in.E, D = in.D, n = E * D, steps = in.n_steps;
+  if (in.cbf.order != 3 || D < 1 || D > 16 || in.rest.size() != (size_t)1 + 40 + (size_t)n * 24) return 3;
+  const double t0 = in.rest[0];
+  const double* Kd = in.rest.data() + 1;
+  const double* Pd = Kd + 40;
+  const double* st13 = Pd + (size_t)n * 7;
+  const double* echo = st13 + (size_t)n * 13;
+  const size_t ld = ((size_t)n + 255) / 256 * 256;
+  Consts<T> c;
+  fill_consts(in.cfg, in.gains, c);
+  CbfParams<T> P;
+  fill_cbf_params(in.cfg, in.cbf, P);
+  LqrYoGain<T> K;
+  for (int r = 0; r < 4; ++r)
+    for (int k = 0; k < 10; ++k) K.k[r][k] = (T)Kd[10 * r + k];
+  std::vector<T> state(13 * ld + 16, T(0)), lem(7 * ld + 16, T(0)), ll(6 * ld, T(0)), rpm(4 * ld, T(0)), obst = to_t<T>(in.obstacles, 64), obs((size_t)n * 20, T(0)),
+                 ring((size_t)3 * n * 20, T(0));
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < 7; ++k) lem[lidx(k, i, ld)] = (T)Pd[(size_t)7 * i + k];
+    const double* s = st13 + (size_t)13 * i;
+    for (int k = 0; k < 13; ++k) state[sidx(k, i, ld)] = (T)(k < 3 ? s[k] - Pd[(size_t)7 * i + 2 + k] : s[k]);
+    for (int k = 0; k < 4; ++k) obs[(size_t)20 * i + 16 + k] = (T)echo[(size_t)4 * i + k];       // the current observation's RPM echo (all the kernel reads of it)
+  }
+  std::vector<int> pair;
+  for (int i = 0; i < D - 1; ++i)
+    for (int j = i + 1; j < D; ++j) pair.push_back(i | (j << 8));
+  pair.push_back(0);
+  std::vector<int> status(E, -7), slog((size_t)steps * E, -7), cost(E, 0);
+  const double tol = in.cbf.tol > 0 ? in.cbf.tol : (sizeof(T) == 8 ? 1e-12 : 1e-6);
+  const int m3 = D * (D - 1) / 2 + D * in.cbf.n_obs + 6 * D, n3 = 3 * D, max_iter = in.cbf.max_iter > 0 ? in.cbf.max_iter : 64 * m3;
+  const double dt = 1.0 / in.cfg.ctrl_freq;
+  double t = t0;
+  int slot = 0;
+  for (int k0 = 0; k0 < steps; k0 += 5) {                          // launches of 5 steps, a 3-slot ring carried across them
+    const int ks = steps - k0 < 5 ? steps - k0 : 5;
+#define O3(RR, NM)                                                                                                                          \
+  simt::launch((unsigned)E, 64, nullptr, [&]() {                                                                                            \
+    k_cbf_rollout_o3<T, RR, NM>(c, P, K, E, ld, t, dt, ks, state.data(), lem.data(), rpm.data(), ll.data(), pair.data(), obst.data(), obs.data(), \
+                                ring.data(), slot, 3, status.data(), slog.data() + (size_t)k0 * E, cost.data(), max_iter, (T)(tol * tol),   \
+                                (T)(in.cfg.M * in.cfg.G));                                                                                  \
+  })
+    if (n3 <= 24 && m3 <= 256) O3(4, 24);
+    else O3(8, 48);
+#undef O3
+    for (int j = 0; j < ks; ++j) t += dt;
+    slot = (slot + ks) % 3;
+  }
+  std::vector<double> od(obs.begin(), obs.end());
+  for (size_t k = 0; k < od.size(); ++k)
+    if (od[k] != (double)ring[(size_t)((steps - 1) % 3) * n * 20 + k]) return 6;       // the ring's last slot is the observation returned
+  fwrite(od.data(), sizeof(double), od.size(), out);
+  fwrite(slog.data(), sizeof(int), slog.size(), out);
+  fwrite(cost.data(), sizeof(int), E, out);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc != 3) return 2;
   In in;
@@ -160,6 +218,7 @@ int main(int argc, char** argv) {
 #endif
 #if SIMT_ONLY_MODE != 1
   if (in.mode == 2) rc = in.dtype ? run_rollout<double>(in, out) : run_rollout<float>(in, out);
+  if (in.mode == 3) rc = in.dtype ? run_rollout_o3<double>(in, out) : run_rollout_o3<float>(in, out);
 #endif
   fclose(out);
   fprintf(stderr, "[simt] %ld wave collectives\n", simt::collectives);

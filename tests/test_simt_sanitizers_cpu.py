@@ -120,3 +120,25 @@ def test_persistent_rollout_kernel_under_asan_ubsan(built, D, E, steps, dtype, t
     np.testing.assert_array_equal(slog, rst)
     assert np.abs(obs[..., :16] - ref[..., :16]).max() < tol
     assert its > 0
+
+
+@pytest.mark.parametrize("D,E,steps,dtype,tol", [(7, 2, 12, "float64", 1e-8), (16, 2, 6, "float32", 1e-3)])
+def test_order3_persistent_rollout_kernel_under_asan_ubsan(built, D, E, steps, dtype, tol):
+    """k_cbf_rollout_o3<T, 4 | 8, 24 | 48>: the order-3 loop of simulations/CBFTestOrd3.py (7 drones there) -- the LDS blocks of the per-drone
+    stages around cbf_filter_env, launches of 5 steps with a 3-slot ring -- against the plain-C order-3 loop: every status, the final state."""
+    xyz, rpy, P = H.c2_setup(E, D, seed=5, phase="c3", offset=3.0, omega=0.5)
+    xyz[..., 2] = 0.5 + 0.4 * np.arange(D)
+    P[..., 4] = 0.5 + 0.4 * np.arange(D)
+    x_obs, obs_r = [np.array([[0.0, 0.0, -0.3], [0, 0, 0], [0, 0, 0]])], [0.1]
+    K3 = O.place_poles_chain([-3.0, -3.6, -5.6])
+    umax3 = [(O.CF2P.MAX_THRUST / 0.01) / 100, 10.0, 10.0, 10.0]
+    Kyo = O.lqr_yank_omega_gain(O.CF2P, 0.01)
+    loop = CO.CbfLoopC(xyz, rpy, CO.cbf_params(K3, umax3, 0.125, 2.0, x_obs, obs_r, order=3), first_rpm=O.CF2P.HOVER_RPM)
+    st0 = loop.av.st.reshape(E, D, 20).copy()
+    ref, rst, its, _ = loop.run3(P, steps, Kyo)
+    obs, slog, it, err = simt.rollout_o3(dtype, 0.0, Kyo, P, st0[..., :13], st0[..., 16:20], steps, _fields(3, 1, K3, umax3, 0.125, 2.0),
+                                         np.array([[0.0, 0.0, -0.3, 0.1]]))
+    assert "ERROR" not in err and "runtime error" not in err, err[-3000:]
+    print(f"[simt order-3 rollout] D={D} E={E} {dtype}: oracle iterations {its}, infeasible env-steps {int(rst.sum())}, max |state err| {np.abs(obs[..., :16] - ref[..., :16]).max():.2e}")
+    np.testing.assert_array_equal(slog, rst)
+    assert np.abs(obs[..., :16] - ref[..., :16]).max() < tol and its > 0
