@@ -453,7 +453,9 @@ def c4_window_stats(torch, env, tracker, c4_obs, c4_r, first, steps):
 def c4_pmc_traffic(scene, n_local, fused=False):
     """Counter traffic of ONE control step (all its launches), from the committed summary of the separate rocprofv3 --pmc passes
     (profiles/tools/r03_profile.sh): the step-by-step form (QP launch + low-level launch) or the persistent rollout kernel."""
-    path = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_c4_{scene}{'_fused' if fused else ''}.json")
+    path = os.path.join(ROOT, "profiles", f"r04_pmc_traffic_c4_{scene}_fused.json")          # (the persistent kernel's row layout changed in round 4)
+    if not fused or not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_c4_{scene}{'_fused' if fused else ''}.json")
     try:
         rec = json.load(open(path))
         per = rec["traffic_bytes_per_step"] / rec["drones_per_step_counted"]

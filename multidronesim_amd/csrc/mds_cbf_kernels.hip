@@ -1408,6 +1408,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 && R == 4) ? 4 : 1) void k_cbf_
 #ifndef MDS_TUNE_ROLL_SKIP
 #define MDS_TUNE_ROLL_SKIP 0   // tuning aid (cost breakdown of stage B): 1 no row polynomial, 2 no normalisation, 4 no scan / solve, 8 no rows
 #endif
+#ifndef MDS_ROLL_OBS_CHUNK
+#define MDS_ROLL_OBS_CHUNK 2
+#endif
 #ifndef MDS_ROLL_BOUNDS
 #define MDS_ROLL_BOUNDS 1      // 1: obstacle and thrust-box rows folded into per-drone bounds in the drone-per-lane stage (round 4); 0: round 3's row layout (A/B)
 #endif
@@ -1666,11 +1669,12 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       const T wx = s.p.x + Pl.cx, wy = s.p.y + Pl.cy, wz = s.p.z + Pl.cz, evx = s.v.x - des.v.x, evy = s.v.y - des.v.y, evz = s.v.z - des.v.z;
       T hi = Pb.umax[0], nlo = Pb.umax[0];
       bool badl = false;
-      for (int o0 = 0; o0 < Pb.n_obs; o0 += 4) {                   // (uniform)
-        Pair<T> exy[4], dpr[4], dvxy[4], ezvz[4];
-        T nds4[4], hr[4], lg[4];
+      constexpr int kOb = MDS_ROLL_OBS_CHUNK;                      // obstacle rows evaluated side by side (4: one scratch reload per step -- 128 VGPRs; 2: none)
+      for (int o0 = 0; o0 < Pb.n_obs; o0 += kOb) {                   // (uniform)
+        Pair<T> exy[kOb], dpr[kOb], dvxy[kOb], ezvz[kOb];
+        T nds4[kOb], hr[kOb], lg[kOb];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < kOb; ++j) {
           const int o = o0 + j < kCbfMaxObs ? o0 + j : kCbfMaxObs - 1;
           exy[j] = Pair<T>{wx - sobrec[o][0], wy - sobrec[o][1]};
           dpr[j] = Pair<T>{rpy.y, -rpy.x};
@@ -1678,9 +1682,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
           ezvz[j] = Pair<T>{wz - sobrec[o][6], evz};
           nds4[j] = sDs[1 + o];
         }
-        cbf_row_o2_pairs<T, 4>(Pb, exy, dpr, dvxy, ezvz, nds4, hr, lg);
+        cbf_row_o2_pairs<T, kOb>(Pb, exy, dpr, dvxy, ezvz, nds4, hr, lg);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < kOb; ++j) {
           const bool on = o0 + j < Pb.n_obs;                       // (uniform)
           const T aa = m_abs(lg[j]);                               // the row: -lg u <= hr
           // beyond the reach of the box (round 3's test on the normalised row, b < -|a| umax): also the row 0 u <= hr < 0

@@ -9,5 +9,5 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WA
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_c4f_${scene}_$i -- python3 bench.py --workload c4 --c4-scene $scene --steps 200 --warmup 50 --fused-rollout $T --no-cpu-baseline --no-extras > gpurun_out/pmc_c4f_${scene}_$i.log 2>&1 || echo "pass $i failed"
 done
-python3 profiles/tools/pmc_sum.py gpurun_out/pmc_c4f_${scene}_1 gpurun_out/pmc_c4f_${scene}_2 gpurun_out/pmc_c4f_${scene}_3 gpurun_out/pmc_c4f_${scene}_4 > gpurun_out/r03_pmc_c4_${scene}_fused_summary.txt
-cat gpurun_out/r03_pmc_c4_${scene}_fused_summary.txt
+python3 profiles/tools/pmc_sum.py gpurun_out/pmc_c4f_${scene}_1 gpurun_out/pmc_c4f_${scene}_2 gpurun_out/pmc_c4f_${scene}_3 gpurun_out/pmc_c4f_${scene}_4 > gpurun_out/${MDS_ROUND:-r04}_pmc_c4_${scene}_fused_summary.txt
+cat gpurun_out/${MDS_ROUND:-r04}_pmc_c4_${scene}_fused_summary.txt
