@@ -1181,14 +1181,22 @@ def main(argv=None):
                               pyb_freq=100, ctrl_freq=100, num_envs=E2, dtype=args.dtype, device=local_rank)
             env2.set_trajectories(P2)
             env2.step(torch.zeros((E2, D2, 4), dtype=env2.dtype, device=device))
+            env2.set_rollout_form(1)                   # one launch per control step (what the library did for every size before round 4)
             env2.rollout_geometric(0.0, 200, want_obs=True, obs_every_step=True)
             log2 = torch.empty((50, E2, D2, 20), dtype=env2.dtype, device=device)
             env2.rollout_geometric_fused(0.0, 50, log=True, log_out=log2)
             us_step = _timed_steps(device, lambda: env2.rollout_geometric(2.0, 2000, want_obs=True, obs_every_step=True), 2000)
             us_fused = _timed_steps(device, lambda: [env2.rollout_geometric_fused(22.0 + 0.5 * r_, 50, log=True, log_out=log2) for r_ in range(20)], 1000)
+            env2.set_rollout_form(0)                   # auto: this shard size is launch-bound, the library runs the loop through the whole-rollout kernel
+            env2.rollout_geometric(32.0, 200, want_obs=True, obs_every_step=True)
+            us_auto = _timed_steps(device, lambda: env2.rollout_geometric(34.0, 2000, want_obs=True, obs_every_step=True), 2000)
+            form_auto = env2.last_rollout_form()
             line["configs_1_c2"] = {"workload": WORKLOADS["c2"][3], "per_step": {"us_per_step": us_step, "value": E2 * D2 / (us_step * 1e-6),
                                                                                "frac": bytes_per * E2 * D2 / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                                                                               "bound": "kernel launch latency (3.5 MB per launch)"},
+                                                                               "bound": "kernel launch latency (3.5 MB per launch)", "launch_form": 1},
+                                    "auto": {"us_per_step": us_auto, "value": E2 * D2 / (us_auto * 1e-6), "launch_form": form_auto,
+                                             "what": "mds_rollout_geometric as the library issues it by itself (mds_set_rollout_form 0): 50 control steps per "
+                                                     "launch at this shard size, every step's observation written"},
                                     "fused_rollout_50": {"us_per_step": us_fused, "value": E2 * D2 / (us_fused * 1e-6)}, "unit": "drone-steps/s"}
             env2.close()
             del log2, env2
