@@ -1741,7 +1741,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
       if (lane == 0) sticket = 0;
     }
     if (kStamps && stamps != nullptr && k == 0) tk0 = __builtin_amdgcn_s_memtime();
+#if !(defined(MDS_TUNE_ROLL_NO_BAR) && (MDS_TUNE_ROLL_NO_BAR & 1))   // tuning aid: WRONG results (a race), only to bound what the barrier costs
     __syncthreads();
+#endif
     stamp(0);
 
     // ---- stage B: the workgroup's envs, one per wave at a time ----
@@ -1953,7 +1955,9 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout
     __builtin_amdgcn_s_setprio(MDS_TUNE_ROLL_PRIO_C);
 #endif
     stamp(1);
+#if !(defined(MDS_TUNE_ROLL_NO_BAR) && (MDS_TUNE_ROLL_NO_BAR & 2))   // tuning aid: WRONG results (a race), only to bound what the barrier costs
     __syncthreads();
+#endif
     stamp(2);
 
     // ---- stage C of this step, then stage A of the next: one drone per lane, state in registers ----
