@@ -15,13 +15,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def isa(tmp_path_factory):
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("isa") / "mds.s"
+    d = tmp_path_factory.mktemp("isa")
     import sys
     sys.path.insert(0, ROOT)
-    from __graft_entry__ import HIPCC_FLAGS
-    subprocess.check_call(["hipcc", *HIPCC_FLAGS, "-S", "--cuda-device-only", "-o", str(out),
-                           os.path.join(ROOT, "multidronesim_amd", "csrc", "mds_api.hip")], stderr=subprocess.DEVNULL)
-    return open(out).read()
+    from __graft_entry__ import HIPCC_FLAGS, PARTS
+    # the library's translation units (MDS_PART), compiled to assembly side by side like build() compiles them to objects
+    procs = [subprocess.Popen(["hipcc", *HIPCC_FLAGS, f"-DMDS_PART={k}", "-S", "--cuda-device-only", "-o", str(d / f"mds{k}.s"),
+                               os.path.join(ROOT, "multidronesim_amd", "csrc", "mds_api.hip")], stderr=subprocess.DEVNULL) for k in PARTS]
+    assert all(p.wait() == 0 for p in procs)
+    return "\n".join(open(d / f"mds{k}.s").read() for k in PARTS)
 
 
 def kernel_ops(isa, mangled):
