@@ -32,3 +32,17 @@ def test_driver_command_prints_the_contract_line():
     assert rf["traffic"] is not None and abs(rf["traffic"] / rf["bytes_per_launch"] - 1) < 0.01                      # PMC bytes = algorithmic bytes
     assert rf["frac"] > 0.6 and r["value"] > 2.2e10            # committed: 0.80-0.82, 2.96-3.02e10
     assert r["state_sane"] is True and r["ranks_seen"] == 1
+
+
+def test_strong_scaling_shard_line():
+    """`--scaling strong --shard-of 8`: rank 0's eighth of config 3's env set alone on this GPU -- the line says strong, names the slice,
+    and the library picked the whole-rollout launch form for this launch-bound shard size by itself (mds_set_rollout_form 0)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--scaling", "strong", "--shard-of", "8", "--steps", "200", "--warmup", "20",
+                          "--no-extras", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert r["scaling"] == "strong" and r["n_gpus"] == 1 and r["config"]["shard_of"]["G"] == 8
+    assert r["config"]["envs_per_gpu"] == 8192 and r["config"]["env_slice_rank0"] == [0, 8192] and "STRONG scaling" in r["config"]["workload"]
+    assert r["config"]["launch_form"] == 2 and "k_rollout_geometric" in r["roofline"]["kernel"]
+    assert abs(r["value"] - 8192 * 8 / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    assert r["state_sane"] is True and r["value"] > 1.5e10     # committed: 3.3e10 (1.97 us per step); one launch per step would be 1.4e10
