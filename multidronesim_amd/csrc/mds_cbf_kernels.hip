@@ -1408,6 +1408,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 && R == 4) ? 4 : 1) void k_cbf_
 #ifndef MDS_TUNE_ROLL_SKIP
 #define MDS_TUNE_ROLL_SKIP 0   // tuning aid (cost breakdown of stage B): 1 no row polynomial, 2 no normalisation, 4 no scan / solve, 8 no rows
 #endif
+#ifndef MDS_ROLL_F64_WAVES
+#define MDS_ROLL_F64_WAVES 2      // waves per SIMD the float64 instantiation is compiled for (2: <= 256 VGPRs, two 4-wave workgroups per CU run side by side)
+#endif
 #ifndef MDS_ROLL_OBS_CHUNK
 #define MDS_ROLL_OBS_CHUNK 2
 #endif
@@ -1516,7 +1519,7 @@ template <typename U> __device__ __forceinline__ U* lane_ptr(U* uniform_base, un
 // PAD: D is not 4, 8 or 16 -- an env is padded to the next of those widths (false: the padded and the real index coincide, and the
 // index arithmetic, the staging row and its guard fold away: the any-D form costs the C4 shape 2-3 %, measured).
 template <typename T, int NOM, bool COMP, int NW, bool PAD = true>
-__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : 1) void k_cbf_rollout(const RollArgs<T>) {
+__global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : MDS_ROLL_F64_WAVES) void k_cbf_rollout(const RollArgs<T>) {
 
   constexpr int NT = 64 * NW;
   constexpr bool kBounds = MDS_ROLL_BOUNDS != 0;
