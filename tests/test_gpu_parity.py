@@ -546,17 +546,22 @@ def test_rollout_launch_form_policy_and_equivalence(mds, dtype, tol):
     # forced form 2 on a ragged little shard (3 x 5 = 15 drones), 7 steps per launch, against form 1 bit for bit in the TIME it hands
     # the kernel: 23 steps = 7 + 7 + 7 + 2, then the step-by-step loop continues both
     xs, rs, Ps = H.c2_setup(3, 5, phase="c3")
-    res = []
-    for form in (2, 1):
-        env = make_env(mds, 3, 5, xs, rs, dtype)
-        env.set_trajectories(Ps)
-        env.step(torch.zeros((3, 5, 4), dtype=env.dtype, device=env.device))
-        env.set_rollout_form(form, 7)
-        env.rollout_geometric(0.0, 23, obs_every_step=True)
-        assert env.last_rollout_form() == form
-        res.append(env.step_geometric(23 * env.CTRL_TIMESTEP).double().cpu().numpy())
-        env.close()
-    np.testing.assert_allclose(res[0][..., :16], res[1][..., :16], atol=tol)
+    # ... also with the drag model (the kernel carries the previous step's RPM), two substeps per control step, and (fp32) the
+    # compensated dtype, whose rate residuals cross the launches
+    variants = [dict(), dict(physics=mds.Physics.PYB_DRAG, pyb=200)] + ([dict(dt="float32c")] if dtype == "float32" else [])
+    for kw in variants:
+        res = []
+        for form in (2, 1):
+            env = make_env(mds, 3, 5, xs, rs, kw.get("dt", dtype), kw.get("pyb", 100), 100, kw.get("physics"))
+            env.set_trajectories(Ps)
+            env.step(torch.zeros((3, 5, 4), dtype=env.dtype, device=env.device))
+            env.set_rollout_form(form, 7)
+            env.rollout_geometric(0.0, 23, obs_every_step=True)
+            assert env.last_rollout_form() == form
+            env.rollout_geometric(23 * env.CTRL_TIMESTEP, 9, want_obs=False)             # no observation wanted at all
+            res.append(env.step_geometric(32 * env.CTRL_TIMESTEP).double().cpu().numpy())
+            env.close()
+        np.testing.assert_allclose(res[0][..., :16], res[1][..., :16], atol=tol, err_msg=str(kw))
     # fp16 storage never leaves form 1 under the auto policy (form 2 rounds the state once per launch, not once per step)
     env = make_env(mds, E, D, xyz, rpy, "float16")
     env.set_trajectories(P)

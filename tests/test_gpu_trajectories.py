@@ -110,6 +110,17 @@ def test_whole_rollout_on_segment_tables_equals_stepwise():
         if k in (0, 70, T - 1):
             np.testing.assert_allclose(log[k].cpu().numpy(), o.cpu().numpy(), atol=1e-9)
     np.testing.assert_allclose(a.get_state(), b.get_state(), atol=1e-9)
+    # the same loop through mds_rollout_geometric in launch form 2 (mds_set_rollout_form: the whole-rollout kernel in launches of 40 steps,
+    # every step's observation into the one buffer), continuing both envs: == the step-by-step continuation
+    a.set_rollout_form(2, 40)
+    oa = a.rollout_geometric(T * a.CTRL_TIMESTEP, 90, obs_every_step=True)
+    assert a.last_rollout_form() == 2
+    t = T * b.CTRL_TIMESTEP
+    for k in range(90):
+        ob = b.step_geometric(t)
+        t += b.CTRL_TIMESTEP
+    np.testing.assert_allclose(oa.cpu().numpy(), ob.cpu().numpy(), atol=1e-9)
+    np.testing.assert_allclose(a.get_state(), b.get_state(), atol=1e-9)
     a.close(); b.close()
 
 
