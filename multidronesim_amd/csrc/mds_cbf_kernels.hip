@@ -569,9 +569,10 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
 #pragma unroll
       for (int v = 0; v < NV; ++v) res = m_fma(wca[v], su[NV * wia + v], m_fma(two ? wcb[v] : T(0), su[NV * wib + v], res));
       const int ln = lane < NMAX ? lane : NMAX - 1;                                      // lanes >= n hold no row: clamp the address only
+      const int lu = lane < n ? lane : n - 1;                                            // (u: inside this env's n variables -- past them lie another env's, which another wave may be writing)
       if constexpr (SMALLQ > 0) {
         if (small) {
-          const T my_u = su[ln];
+          const T my_u = su[lu];
           const T na = wca[0], nb = two ? wcb[0] : T(0);
           auto ncoef = [&](int v) { return (v == wia ? na : T(0)) + ((two && v == wib) ? nb : T(0)); };   // the new row's coefficient at variable v
           // d = N^T a, r = (N^T N)^-1 d
@@ -713,7 +714,7 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
         // Empty active set (the first step of most solves, and the only one of more than half of them): the step runs along the
         // row's own normal -- no Q, R or multipliers to read, no blocking row, no back substitution.  The general step below with
         // q = 0, operation for operation (same sums in the same order: same bits), at a third of its instructions.
-        const T my_u = su[ln];
+        const T my_u = su[lu];
         T zv = T(0);
         if (lane < n) {
           const int ag = lane / NV, vv = lane - ag * NV;
@@ -763,7 +764,7 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
         for (int v = 0; v < NV; ++v) dc = m_fma(wca[v], qa[v], m_fma(two ? wcb[v] : T(0), qb[v], dc));
         dc = lane < q ? dc : T(0);
       }
-      const T my_lam = slam[ln], my_di = sdi[ln], my_u = su[ln];
+      const T my_lam = slam[ln], my_di = sdi[ln], my_u = su[lu];
       T zv = T(0), rc = dc;
       if constexpr (PRE) {
         T qrow[NMAX], rrow[NMAX];

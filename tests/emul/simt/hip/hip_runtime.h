@@ -43,7 +43,7 @@ struct Ctx {
   const void* kernarg = nullptr;
 };
 inline thread_local Ctx ctx;
-inline long collectives = 0;      // (statistics only; racy by design: one writer per wave is enough of an estimate)
+inline std::atomic<long> collectives{0};      // (statistics only)
 
 // every lane publishes `mine`, then reads what f makes of the 64 published values; two barriers per collective
 template <typename F> inline uint64_t collective(uint64_t mine, F&& f) {
@@ -52,7 +52,7 @@ template <typename F> inline uint64_t collective(uint64_t mine, F&& f) {
   pthread_barrier_wait(&w.bar);
   const uint64_t r = f(w.xch);
   pthread_barrier_wait(&w.bar);
-  if (ctx.lane == 0) ++collectives;
+  if (ctx.lane == 0) collectives.fetch_add(1, std::memory_order_relaxed);
   return r;
 }
 inline int dpp_src(int lane, int ctrl) {

@@ -123,7 +123,10 @@ template <typename T> static int run_rollout(const In& in, FILE* out) {
   ra.state = state.data(); ra.state_lo = nullptr; ra.lem = lem.data(); ra.last_rpm = nullptr; ra.ll = ll.data(); ra.pair_ij = pair.data();
   ra.obstacles = obst.data(); ra.obs_log = ring.data(); ra.n_slots = 3; ra.obs_last = obs_last.data(); ra.status = status.data();
   ra.cost_io = cost.data(); ra.max_iter = in.cbf.max_iter > 0 ? in.cbf.max_iter : 64 * m2; ra.tol2 = (T)(tol * tol); ra.tol = (T)tol; ra.stamps = nullptr;
-  constexpr int NW = 1;                                          // one wavefront per workgroup: 64 threads own 64 / Dp whole envs
+#ifndef SIMT_NW
+#define SIMT_NW 1
+#endif
+  constexpr int NW = SIMT_NW;                                    // wavefronts per workgroup (1: 64 threads own 64 / Dp whole envs; the TSan build runs 2)
   const int Dp = D <= 4 ? 4 : (D <= 8 ? 8 : 16), envs_per_wg = 64 * NW / Dp, grid = (E + envs_per_wg - 1) / envs_per_wg;
   // launches of 7 steps (a ragged last one), the observation ring of 3 slots carried across them -- as mds_rollout_cbf_geometric_fused does
   double t = t0;
@@ -221,6 +224,6 @@ int main(int argc, char** argv) {
   if (in.mode == 3) rc = in.dtype ? run_rollout_o3<double>(in, out) : run_rollout_o3<float>(in, out);
 #endif
   fclose(out);
-  fprintf(stderr, "[simt] %ld wave collectives\n", simt::collectives);
+  fprintf(stderr, "[simt] %ld wave collectives\n", simt::collectives.load());
   return rc;
 }

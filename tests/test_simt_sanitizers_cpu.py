@@ -142,3 +142,28 @@ def test_order3_persistent_rollout_kernel_under_asan_ubsan(built, D, E, steps, d
     print(f"[simt order-3 rollout] D={D} E={E} {dtype}: oracle iterations {its}, infeasible env-steps {int(rst.sum())}, max |state err| {np.abs(obs[..., :16] - ref[..., :16]).max():.2e}")
     np.testing.assert_array_equal(slog, rst)
     assert np.abs(obs[..., :16] - ref[..., :16]).max() < tol and its > 0
+
+
+@pytest.mark.parametrize("D,E,steps,dtype,tol", [(16, 8, 6, "float64", 1e-9), (8, 16, 5, "float32", 1e-5)])
+def test_persistent_rollout_kernel_under_thread_sanitizer(D, E, steps, dtype, tol):
+    """k_cbf_rollout<T, 0, false, 2, false> under ThreadSanitizer, TWO wavefronts per workgroup: every LDS hand-off between lanes and
+    between waves (obstacle table -> stage A, records / bounds -> stage B, tickets, the solver's scratch, QP results -> stage C, observation
+    staging) sits behind a wave or workgroup barrier -- pthread barriers in the emulation, which TSan models; a pair of accesses it
+    cannot order would be a race on the GPU (or a missing wave-scope fence).  The race round 4 introduced and fixed shows up here
+    deterministically.  Full workgroups only: with a partial last workgroup the lanes past the last drone read the planes at a clamped
+    index they never use (the kernel's way of keeping every lane on one code path) while that drone's own lane writes them -- benign on
+    the GPU, a report here."""
+    xyz, rpy, P = H.c2_setup(E, D, phase="c3", offset=1.0)
+    P[..., 4] = 0.5 + 0.15 * np.arange(D)
+    xyz[..., 2] = 0.5 + 0.3 * np.arange(D)
+    x_obs = [np.array([[0.3, 0.2, 0.9], [0, 0, 0]]), np.array([[-0.4, 0.1, 1.4], [0, 0, 0]])]
+    obs_r = [0.1, 0.15]
+    K = O.place_poles_chain([-2.2, -2.4])
+    loop = CO.CbfLoopC(xyz, rpy, CO.cbf_params(K, UMAX2, 0.1, 1.0, x_obs, obs_r))
+    state13 = loop.av.st.reshape(E, D, 20)[..., :13].copy()
+    ref, rst, its, _ = loop.run(P, steps)
+    obst = np.array([[*xo[0], r] for xo, r in zip(x_obs, obs_r)])
+    obs, slog, it, err = simt.rollout(dtype, 0.0, P, state13, steps, _fields(2, 2, K, UMAX2, 0.1, 1.0), obst, tsan=True)
+    assert "ThreadSanitizer" not in err, err[-4000:]
+    np.testing.assert_array_equal(slog, rst)
+    assert np.abs(obs[..., :16] - ref[..., :16]).max() < tol and its > 0
