@@ -47,7 +47,7 @@ def build_tsan(force=False):
     cxx = CLANG if os.path.exists(CLANG) else shutil.which("clang++")
     deps = [SRC, os.path.join(HERE, "hip", "hip_runtime.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     if force or not os.path.exists(EXE_TSAN) or any(os.path.getmtime(d) > os.path.getmtime(EXE_TSAN) for d in deps):
-        cmd = [cxx, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-pthread", "-DSIMT_ONLY_MODE=2", "-DSIMT_NW=2", "-I", HERE,
+        cmd = [cxx, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-pthread", "-DSIMT_NW=2", "-I", HERE,
                "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-o", EXE_TSAN, SRC]
         r = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True)
         if r.returncode != 0:
@@ -93,9 +93,9 @@ def run(mode, dtype, E, D, n_steps, cbf_fields, obstacles, arrays, timeout=900, 
         return open(fout, "rb").read(), r.stderr
 
 
-def filter_(dtype, obs, xdes, unom, cbf_fields, obstacles):
+def filter_(dtype, obs, xdes, unom, cbf_fields, obstacles, tsan=False):
     E, D = obs.shape[0], obs.shape[1]
-    raw, err = run(1, dtype, E, D, 0, cbf_fields, obstacles, [obs, xdes, unom])
+    raw, err = run(1, dtype, E, D, 0, cbf_fields, obstacles, [obs, xdes, unom], tsan=tsan)
     n = E * D
     us = np.frombuffer(raw[:n * 4 * 8], dtype=np.float64).reshape(E, D, 4)
     st = np.frombuffer(raw[n * 32:n * 32 + 4 * E], dtype=np.int32)

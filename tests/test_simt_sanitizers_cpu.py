@@ -167,3 +167,19 @@ def test_persistent_rollout_kernel_under_thread_sanitizer(D, E, steps, dtype, to
     assert "ThreadSanitizer" not in err, err[-4000:]
     np.testing.assert_array_equal(slog, rst)
     assert np.abs(obs[..., :16] - ref[..., :16]).max() < tol and its > 0
+
+
+@pytest.mark.parametrize("order,D,dtype", [(2, 16, "float64"), (2, 5, "float32"), (3, 7, "float64"), (2, 32, "float32")])
+def test_qp_filter_kernels_under_thread_sanitizer(order, D, dtype):
+    """k_cbf_filter_gi (one wavefront per env) under ThreadSanitizer: the staging of the env's blocks, the row table, the solver's u / Q /
+    R / multiplier hand-offs between lanes all sit behind wave-scope fences (crowded scenes: 10-25 iterations with drops)."""
+    if order == 2:
+        obs, xdes, unom, x_obs, obs_r = c4_scene(3, D, seed=D, dz=0.2, vz=0.7)
+        K, um, sf, zs = O.place_poles_chain([-2.2, -2.4]), UMAX2, 0.1, 1.0
+    else:
+        obs, xdes, unom, x_obs, obs_r = c4_scene_o3(3, D, seed=D)
+        K, um, sf, zs = O.place_poles_chain([-3.0, -3.6, -5.6]), [(O.CF2P.MAX_THRUST / 0.01) / 100, 10.0, 10.0, 10.0], 0.125, 2.0
+    obst = np.array([[*np.asarray(xo).reshape(-1, 3)[0], r] for xo, r in zip(x_obs, obs_r)])
+    us, st, it, err = simt.filter_(dtype, obs, xdes, unom, _fields(order, len(obs_r), K, um, sf, zs), obst, tsan=True)
+    assert "ThreadSanitizer" not in err, err[-4000:]
+    assert it.max() >= 1 and np.isfinite(us).all()
