@@ -23,7 +23,7 @@ def available():
 def build(force=False):
     """Two executables (the filter kernels / the persistent rollout kernel), compiled side by side: ~2 minutes the first time."""
     cxx = CLANG if os.path.exists(CLANG) else shutil.which("clang++")
-    deps = [SRC, os.path.join(HERE, "hip", "hip_runtime.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps = [SRC, os.path.abspath(__file__), os.path.join(HERE, "hip", "hip_runtime.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     procs = []
     for mode, exe in EXE.items():
         if force or not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
@@ -45,7 +45,7 @@ def build_tsan(force=False):
     (records, bounds, tickets, solver scratch, observation staging) must all sit behind a wave or workgroup barrier -- pthread barriers
     here, which TSan understands; an unsynchronised pair of accesses is a race on the GPU too (or a missing wave-scope fence)."""
     cxx = CLANG if os.path.exists(CLANG) else shutil.which("clang++")
-    deps = [SRC, os.path.join(HERE, "hip", "hip_runtime.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps = [SRC, os.path.abspath(__file__), os.path.join(HERE, "hip", "hip_runtime.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     if force or not os.path.exists(EXE_TSAN) or any(os.path.getmtime(d) > os.path.getmtime(EXE_TSAN) for d in deps):
         cmd = [cxx, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-pthread", "-DSIMT_NW=2", "-I", HERE,
                "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-o", EXE_TSAN, SRC]
