@@ -444,6 +444,9 @@ template <typename T, int NV> struct CbfRow {
 // are what the solver meets.  Unit-norm rows of this QP have coefficients +-1 (bounds) or +-1/sqrt2 (pairs): the Gram matrix of an
 // independent set is well conditioned (entries 0, +-1/2, +-1/sqrt2); should its determinant still come out tiny, the set is handed
 // to the QR path before the step is taken.
+#ifndef MDS_TUNE_HASZ
+#define MDS_TUNE_HASZ 1
+#endif
 #ifndef MDS_GI_SMALLQ
 #define MDS_GI_SMALLQ 0      // (measured on MI355X, round 4: 1 / 2 / 3 are 3 / 8 / 14 % SLOWER on C4 -- see DESIGN.md 4; kept for A/B)
 #endif
@@ -654,7 +657,10 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
                   drop = k;
                 }
               }
-            const bool has_z = zz > GiEps<T>::z;
+            // a set of n independent normals spans the space: whatever is left of z is rounding, and a 'full step' along it would add a
+            // DEPENDENT row (q > n: past the thin QR's columns -- found by the host emulation under UBSan on an fp32 order-3 env that then
+            // cycled to the iteration cap); only the dual step is possible there
+            const bool has_z = zz > GiEps<T>::z && (MDS_TUNE_HASZ != 1 || q < n);
             const T t2 = has_z ? res * m_rcp(zz) : GiEps<T>::inf;
             const T t = m_min(t1, t2);
             if (!(t < GiEps<T>::inf)) {
@@ -812,7 +818,10 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
       if (lane < q && rc > GiEps<T>::r * rmax && rc > T(0)) t1v = m_max(my_lam, T(0)) * m_rcp(rc);
       const T t1 = wv::min_nonneg<ROW0>(t1v);
       const int drop = t1 < GiEps<T>::inf ? (int)__builtin_ctzll(__ballot(t1v == t1)) : 0;  // ties: lowest column
-      const bool has_z = zz > GiEps<T>::z;
+      // a set of n independent normals spans the space: whatever is left of z is rounding, and a 'full step' along it would add a
+            // DEPENDENT row (q > n: past the thin QR's columns -- found by the host emulation under UBSan on an fp32 order-3 env that then
+            // cycled to the iteration cap); only the dual step is possible there
+            const bool has_z = zz > GiEps<T>::z && (MDS_TUNE_HASZ != 1 || q < n);
       const T t2 = has_z ? res * m_rcp(zz) : GiEps<T>::inf;
       const T t = m_min(t1, t2);
       if (!(t < GiEps<T>::inf)) {
@@ -826,6 +835,10 @@ __device__ __forceinline__ void gi_solve(const int lane, const int n, const int 
       lam_new += t;
       if (!full) MDS_WAVE_SYNC();                                                        // the drop path reads slam / sact next; the add path only writes
       if (full) {                                                                        // add: N <- [N a]
+        if (MDS_TUNE_HASZ == 2 && q >= n) {
+          infeasible = true;
+          break;
+        }
         const T inz = m_rsqrt(zz), nz = zz * inz;
         if (lane < n) sQ[lane][q] = zv * inz;
         if (lane < q) sR[lane][q] = dc;
@@ -2103,6 +2116,20 @@ __global__ __launch_bounds__(64 * NW, sizeof(T) == 4 ? 4 : MDS_ROLL_F64_WAVES) v
 // in the per-drone stages: the reference's order-3 scenes are a handful of drones -- but no launch, no u_hat / xdes / u_safe round
 // trip through HBM per control step.
 // ------------------------------------------------------------------------------------
+// The filter body is CALLED here, not inlined (MDS_TUNE_O3_CALL 1).  Inlined into this kernel's step loop, the float64 instantiation
+// (390 registers incl. 134 AGPRs) came out of the compiler wrong as soon as gi_solve was touched: with the q == n guard -- or with an
+// equivalent guard placed elsewhere -- step 0 was exact and every env's status wrong from step 1 on, while the same sources pass on the
+// host emulation under ASan / UBSan / TSan / MSan, the fp32 instantiation passes, and the step-by-step kernel (the same body, inlined
+// into a kernel without a loop around it) passes.  As a call the solver is compiled once per (T, R, NMAX) on its own registers; this
+// kernel is not a tuned path.
+#ifndef MDS_TUNE_O3_CALL
+#define MDS_TUNE_O3_CALL 1
+#endif
+template <typename T, int R, int NMAX>
+__device__ __noinline__ void cbf_filter_env_o3_call(const CbfParams<T>* P, int lane, T kf, const int* pair_ij, const T* obstacles, const T* obs, const T* xdes,
+                                                    const T* unom, T* usafe, int* status_env, int max_iter, T tol2, int* cost_env) {
+  cbf_filter_env<T, T, R, NMAX, 3>(*P, lane, kf, pair_ij, obstacles, obs, xdes, unom, usafe, status_env, max_iter, tol2, cost_env);
+}
 template <typename T, int R, int NMAX>
 __global__ __launch_bounds__(64) void k_cbf_rollout_o3(const Consts<T> c, const CbfParams<T> P, const LqrYoGain<T> K, const int E, const size_t ld, double t,
                                                        const double ctrl_dt, const int n_steps, T* __restrict__ state, const T* __restrict__ lem,
@@ -2140,7 +2167,11 @@ __global__ __launch_bounds__(64) void k_cbf_rollout_o3(const Consts<T> c, const 
       for (int j = 0; j < kObsDim; ++j) sobs[kObsDim * lane + j] = o[j];
     }
     MDS_WAVE_SYNC();
+#if MDS_TUNE_O3_CALL
+    cbf_filter_env_o3_call<T, R, NMAX>(&P, lane, c.kf, pair_ij, obstacles, sobs, sxdes, sunom, susafe, &sres[0], max_iter, tol2, &sres[1]);
+#else
     cbf_filter_env<T, T, R, NMAX, 3>(P, lane, c.kf, pair_ij, obstacles, sobs, sxdes, sunom, susafe, &sres[0], max_iter, tol2, &sres[1]);
+#endif
     MDS_WAVE_SYNC();
     if (lane == 0) {
       if (status_log) status_log[(size_t)k * E + env] = sres[0];
@@ -2367,7 +2398,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 3 : 1) void k_cbf_filter_q4(co
     if (rl < q && rc > GiEps<T>::r * rmax && rc > T(0)) t1v = m_max(my_lam, T(0)) * m_rcp(rc);
     const T t1 = r16::allreduce(t1v, wv::Min());
     const int drop = t1 < GiEps<T>::inf ? r16::first(t1v == t1, lane) : 0;
-    const bool has_z = zz > GiEps<T>::z;
+    const bool has_z = zz > GiEps<T>::z && (MDS_TUNE_HASZ != 1 || q < n);                                                 // (q == n: only the dual step, as in gi_solve)
     const T t2 = has_z ? res * m_rcp(zz) : GiEps<T>::inf;
     const T t = m_min(t1, t2);
     const bool nostep = stepping && !(t < GiEps<T>::inf);                                         // rows inconsistent: falls back

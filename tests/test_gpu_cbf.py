@@ -1212,3 +1212,24 @@ def test_order3_persistent_rollout_small_shapes(mds, D, n_obs, E):
     np.testing.assert_array_equal(out["step"][3], out["fused"][3])
     np.testing.assert_allclose(out["fused"][0][..., :16], out["step"][0][..., :16], rtol=0, atol=1e-9)
     np.testing.assert_allclose(out["fused"][2], out["step"][2], rtol=0, atol=1e-9)
+
+
+def test_order3_degenerate_envs_do_not_run_to_the_iteration_cap(mds):
+    """tests/golden/o3_degenerate_envs.npz: three infeasible order-3 envs whose fp32 solve used to add dependent rows past a full active set
+    and cycle to the cap (5 376 iterations, 8 ms, LDS written out of bounds: found by the host emulation under UBSan) -- now status 1 after
+    a few dozen iterations, in fp32 and float64, through the filter kernel."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "o3_degenerate_envs.npz"))
+    D = 8
+    for dtype in ("float32", "float64"):
+        env = make_env(mds, 3, D, dtype)
+        cbf = mds.DroneCBF(env, [mds.LinearizedYankOmegaModel(env) for _ in range(D)], safety_radius=0.125, zscale=2.0, order=3,
+                           cbf_poles=np.array([-3.0, -3.6, -5.6]))
+        trk = mds.DroneQPTracker(cbf, order=3, num_robots=D, xdim=10, env=env)
+        obs = np.stack([d[f"obs{j}"] for j in range(3)])
+        xdes = np.stack([d[f"xdes{j}"] for j in range(3)])
+        unom = np.stack([d[f"unom{j}"] for j in range(3)])
+        us, st = trk.compute_control_batched(obs, xdes, unom, [np.array([[0.0, 0.0, -3.0], [0, 0, 0], [0, 0, 0]])], [0.1])
+        it = cbf.last_iterations().cpu().numpy()
+        assert (st.cpu().numpy() == 1).all() and it.max() < 100, (dtype, st, it)
+        np.testing.assert_allclose(us.double().cpu().numpy(), unom, atol=1e-6)
+        env.close()

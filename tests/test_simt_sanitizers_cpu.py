@@ -183,3 +183,24 @@ def test_qp_filter_kernels_under_thread_sanitizer(order, D, dtype):
     us, st, it, err = simt.filter_(dtype, obs, xdes, unom, _fields(order, len(obs_r), K, um, sf, zs), obst, tsan=True)
     assert "ThreadSanitizer" not in err, err[-4000:]
     assert it.max() >= 1 and np.isfinite(us).all()
+
+
+def test_order3_degenerate_envs_stop_at_a_full_active_set(built):
+    """Three envs caught on the MI355X in round 4 (tests/golden/o3_degenerate_envs.npz: the observation, xdes and u_hat of an 8-drone env of
+    the fp32 order-3 loop at the step where its solve ran to the iteration cap): infeasible QPs whose active set reaches n = 24 independent
+    rows; in fp32 the residual z of the next row is rounding noise above the threshold, and the "full step" along it used to ADD a 25th,
+    26th ... row -- past the thin QR's columns (UBSan: index 28 out of bounds for float[28]; on the GPU: LDS corruption and 5 376
+    iterations = 8 ms for that env).  With q == n only the dual step is taken: infeasible after a few dozen iterations, as the oracle."""
+    d = np.load(os.path.join(ROOT, "tests", "golden", "o3_degenerate_envs.npz"))
+    x_obs, obs_r = [np.array([[0.0, 0.0, -3.0], [0, 0, 0], [0, 0, 0]])], [0.1]
+    b = CO.cbf_params(d["Kcbf"], d["umax"], 0.125, 2.0, x_obs, obs_r, order=3)
+    for j in range(3):
+        obs, xdes, unom = d[f"obs{j}"][None], d[f"xdes{j}"][None], d[f"unom{j}"][None]
+        G, h = CO.cbf_rows(O.obs_to_lin_model(obs[0], 10), xdes[0], b)
+        ok, _, its = CO.qp_project(unom[0].reshape(-1), G, h)
+        assert not ok and int(d[f"its{j}"]) > 5000                      # infeasible; the GPU solve before the fix ran to the cap
+        for dtype in ("float32", "float64"):
+            us, st, it, err = simt.filter_(dtype, obs, xdes, unom, _fields(3, 1, d["Kcbf"], d["umax"], 0.125, 2.0), np.array([[0.0, 0.0, -3.0, 0.1]]))
+            assert "runtime error" not in err and "ERROR" not in err, err[-3000:]
+            assert st[0] == 1 and it[0] < 100, (j, dtype, st, it)
+            np.testing.assert_allclose(us[0], unom[0], atol=1e-6)        # the nominal input is kept
