@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
 CSRC = os.path.join(ROOT, "multidronesim_amd", "csrc")
 SRC = os.path.join(HERE, "simt_cbf.cpp")
 CLANG = os.environ.get("MDS_SIMT_CXX") or "/opt/rocm/lib/llvm/bin/clang++"
-EXE = {1: os.path.join(HERE, "simt_filter"), 2: os.path.join(HERE, "simt_rollout")}          # (mode 3, the order-3 rollout, lives in simt_rollout)
+EXE = {1: os.path.join(HERE, "simt_filter"), 2: os.path.join(HERE, "simt_rollout"),          # (mode 3, the order-3 rollout, lives in simt_rollout)
+       4: os.path.join(HERE, "simt_headline")}
 
 
 def available():
@@ -21,7 +22,8 @@ def available():
 
 
 def build(force=False):
-    """Two executables (the filter kernels / the persistent rollout kernel), compiled side by side: ~2 minutes the first time."""
+    """Three executables (the filter kernels / the persistent rollout kernels / the headline step and rollout kernels), compiled side by
+    side: ~2 minutes the first time."""
     cxx = CLANG if os.path.exists(CLANG) else shutil.which("clang++")
     deps = [SRC, os.path.abspath(__file__), os.path.join(HERE, "hip", "hip_runtime.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     procs = []
@@ -72,7 +74,10 @@ def _structs(D, E, cbf_fields, pyb_freq=100, ctrl_freq=100):
     return cfg, gains, p
 
 
-def run(mode, dtype, E, D, n_steps, cbf_fields, obstacles, arrays, timeout=900, tsan=False):
+DTYPE_CODE = {"float32": 0, "float64": 1, "float16": 2, "float32c": 3}
+
+
+def run(mode, dtype, E, D, n_steps, cbf_fields, obstacles, arrays, timeout=900, tsan=False, nominal=0):
     """-> the bytes of out.bin.  obstacles: [n_obs, 4] (xyz, r).  arrays: the mode's float64 arrays, concatenated in order."""
     exe = build_tsan() if tsan else build()[2 if mode == 3 else mode]
     cfg, gains, p = _structs(D, E, cbf_fields)
@@ -81,7 +86,7 @@ def run(mode, dtype, E, D, n_steps, cbf_fields, obstacles, arrays, timeout=900, 
     with tempfile.TemporaryDirectory() as td:
         fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
         with open(fin, "wb") as f:
-            f.write(np.array([mode, 1 if dtype == "float64" else 0, E, D, n_steps, 0], dtype=np.int32).tobytes())
+            f.write(np.array([mode, DTYPE_CODE[dtype], E, D, n_steps, nominal], dtype=np.int32).tobytes())
             f.write(bytes(cfg)); f.write(bytes(gains)); f.write(bytes(p)); f.write(ob.tobytes())
             for a in arrays:
                 f.write(np.ascontiguousarray(np.asarray(a, dtype=np.float64)).tobytes())
@@ -124,3 +129,16 @@ def rollout_o3(dtype, t0, K, P, state13, rpm_echo, steps, cbf_fields, obstacles,
     slog = np.frombuffer(raw[o:o + 4 * steps * E], dtype=np.int32).reshape(steps, E)
     it = np.frombuffer(raw[o + 4 * steps * E:o + 4 * steps * E + 4 * E], dtype=np.int32)
     return obs, slog, it, err
+
+
+def headline(dtype, form, t0, P, state13, steps, actions=None, tsan=False):
+    """Mode 4: form 0 k_step_geometric per step, 1 k_rollout_geometric, 2 k_step on an action table [3, E, D, 4], 3 k_rollout_step.
+    -> (obs [E,D,20], state13 [E,D,13] world, action_out [E,D,4] (form 0), stderr)"""
+    E, D = P.shape[0], P.shape[1]
+    arrays = [np.array([t0]), P, state13] + ([actions] if form >= 2 else [])
+    raw, err = run(4, dtype, E, D, steps, {"order": 2}, np.zeros((0, 4)), arrays, tsan=tsan, nominal=form)
+    n = E * D
+    obs = np.frombuffer(raw[:n * 160], dtype=np.float64).reshape(E, D, 20)
+    st = np.frombuffer(raw[n * 160:n * 264], dtype=np.float64).reshape(E, D, 13)
+    act = np.frombuffer(raw[n * 264:n * 296], dtype=np.float64).reshape(E, D, 4)
+    return obs, st, act, err

@@ -6,7 +6,7 @@
 // against the plain-C oracle.  Never part of the product (the product path is the HIP library only).
 //
 //   simt_cbf <in.bin> <out.bin>
-// in.bin : int32 mode (1 filter, 2 rollout), dtype (0 f32, 1 f64), E, D, n_steps, nominal; mds_config, mds_geometric_gains, mds_cbf_params
+// in.bin : int32 mode (1 filter, 2 rollout, 3 order-3 rollout, 4 the headline step / rollout kernels), dtype (0 f32, 1 f64), E, D, n_steps, nominal; mds_config, mds_geometric_gains, mds_cbf_params
 //          (raw structs); double obstacles[16*4]; then  filter: obs[n*20], xdes[n*xd], unom[n*4]   rollout: t0, P[n*7], state13[n*13] (world)
 // out.bin: filter: double usafe[n*4], int32 status[E], iters[E]      rollout: double obs[n*20], int32 status_log[steps*E], iters[E]
 #include <stdio.h>
@@ -206,6 +206,96 @@ template <typename T> static int run_rollout_o3(const In& in, FILE* out) {
   return 0;
 }
 
+// mode 4: the headline kernels (BASELINE configs 1-3 and 5), 256-thread workgroups with a partial last one.  `nominal` picks the launch
+// form: 0 k_step_geometric per control step in two half-shard launches (batch0), 1 k_rollout_geometric in launches of 7 steps (log ring
+// of 7 slots + obs_last), 2 k_step per control step on an action table, 3 k_rollout_step in launches of 5 steps (3 action sets, 4-slot ring).
+// dtype: 0 fp32, 1 fp64, 2 fp16 storage (fp32 arithmetic), 3 fp32 with compensated accumulation (forms 0 / 1).
+// rest: t0, P[n*7], state13[n*13] (world), forms 2 / 3: actions[3*n*4].   out: double obs[n*20], state13[n*13] (world), act[n*4] (form 0)
+template <typename T, typename S, bool COMP> static int run_headline(const In& in, FILE* out) {
+  const int E = in.E, D = in.D, n = E * D, steps = in.n_steps, form = in.nominal, A = 3;
+  const bool table = form >= 2;
+  if (steps < 1 || in.rest.size() != (size_t)1 + (size_t)n * 20 + (table ? (size_t)A * n * 4 : 0)) return 3;
+  const double t0 = in.rest[0];
+  const double* Pd = in.rest.data() + 1;
+  const double* st13 = Pd + (size_t)n * 7;
+  const double* actd = st13 + (size_t)n * 13;
+  const size_t ld = ((size_t)n + 255) / 256 * 256;
+  Consts<T> c;
+  fill_consts(in.cfg, in.gains, c);
+  // exact-size buffers: a store past drone n - 1 (the partial wave of the last workgroup) lands in a red zone
+  std::vector<S> state(13 * ld, S(0)), lo(4 * ld, S(0)), obs((size_t)n * 20, S(0)), ring((size_t)7 * n * 20, S(0)), act_out((size_t)n * 4, S(0)), actions;
+  std::vector<T> lem(7 * ld, T(0)), origin(3 * ld, T(0)), rpm(4 * ld, T(0));
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < 7; ++k) lem[lidx(k, i, ld)] = (T)Pd[(size_t)7 * i + k];
+    for (int k = 0; k < 3; ++k) origin[k * ld + i] = (T)Pd[(size_t)7 * i + 2 + k];
+    const double* s = st13 + (size_t)13 * i;
+    for (int k = 0; k < 13; ++k) state[sidx(k, i, ld)] = (S)(T)(k < 3 ? s[k] - Pd[(size_t)7 * i + 2 + k] : s[k]);
+  }
+  if (table) {
+    actions.resize((size_t)A * n * 4);
+    for (size_t k = 0; k < actions.size(); ++k) actions[k] = (S)(T)actd[k];
+  }
+  S* lop = COMP ? lo.data() : nullptr;
+  const unsigned grid = (unsigned)(ld / 256), g0 = (grid + 1) / 2;
+  const double dt = 1.0 / in.cfg.ctrl_freq;
+  double t = t0;
+  int last_slot = 0;
+  if (form == 0) {
+    for (int k = 0; k < steps; ++k, t += dt) {
+      simt::launch(g0, 256, nullptr, [&]() {
+        k_step_geometric<T, S, true, true, false, false, COMP>(c, n, ld, t, state.data(), lem.data(), rpm.data(), obs.data(), act_out.data(), 0, lop);
+      });
+      if (grid > g0)
+        simt::launch(grid - g0, 256, nullptr, [&]() {
+          k_step_geometric<T, S, true, true, false, false, COMP>(c, n, ld, t, state.data(), lem.data(), rpm.data(), obs.data(), act_out.data(), (int)g0, lop);
+        });
+    }
+  } else if (form == 1) {
+    for (int k0 = 0; k0 < steps; k0 += 7) {
+      const int ks = steps - k0 < 7 ? steps - k0 : 7;
+      simt::launch(grid, 256, nullptr, [&]() {
+        k_rollout_geometric<T, S, false, false, 0>(c, nullptr, n, ld, t, dt, ks, state.data(), lem.data(), rpm.data(), ring.data(), (size_t)n * 20, obs.data(),
+                                                   nullptr, nullptr, lop);
+      });
+      for (int j = 0; j < ks; ++j) t += dt;
+      last_slot = ks - 1;
+    }
+    for (size_t k = 0; k < obs.size(); ++k)
+      if ((double)obs[k] != (double)ring[(size_t)last_slot * n * 20 + k]) return 6;       // obs_last = the log's last written slot
+  } else if (form == 2) {
+    if (COMP) return 4;
+    for (int k = 0; k < steps; ++k)
+      simt::launch(grid, 256, nullptr, [&]() {
+        k_step<T, S, true, false, false>(c, n, ld, state.data(), origin.data(), rpm.data(), actions.data() + (size_t)(k % A) * n * 4, obs.data(), 0);
+      });
+  } else {
+    if (COMP) return 4;
+    int a0 = 0, s0 = 0;
+    ring.resize((size_t)4 * n * 20);
+    for (int k0 = 0; k0 < steps; k0 += 5) {
+      const int ks = steps - k0 < 5 ? steps - k0 : 5;
+      simt::launch(grid, 256, nullptr, [&]() {
+        k_rollout_step<T, S, false, false>(c, n, ld, state.data(), origin.data(), rpm.data(), actions.data(), a0, A, ring.data(), s0, 4, ks);
+      });
+      a0 = (a0 + ks) % A;
+      s0 = (s0 + ks) % 4;
+    }
+    last_slot = (s0 + 3) % 4;
+    for (size_t k = 0; k < obs.size(); ++k) obs[k] = ring[(size_t)last_slot * n * 20 + k];
+  }
+  std::vector<double> od(obs.begin(), obs.end()), sd((size_t)n * 13), ad(act_out.begin(), act_out.end());
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 13; ++k)
+      sd[(size_t)13 * i + k] = (double)(T)state[sidx(k, i, ld)] + (COMP && k >= 10 ? (double)(T)lo[ridx(k, i)] : 0.0) + (k < 3 ? Pd[(size_t)7 * i + 2 + k] : 0.0);
+  for (int i = 0; i < n; ++i)                                               // the clipped RPM the kernel kept = the observation's echo
+    for (int k = 0; k < 4; ++k)
+      if ((double)(S)rpm[k * ld + i] != od[(size_t)20 * i + 16 + k]) return 7;
+  fwrite(od.data(), sizeof(double), od.size(), out);
+  fwrite(sd.data(), sizeof(double), sd.size(), out);
+  fwrite(ad.data(), sizeof(double), ad.size(), out);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc != 3) return 2;
   In in;
@@ -214,14 +304,20 @@ int main(int argc, char** argv) {
   if (!out) return 2;
   int rc = 5;
 #ifndef SIMT_ONLY_MODE
-#define SIMT_ONLY_MODE 0        // 1 / 2: compile one mode only (tests/emul/simt/simt.py builds the two side by side)
+#define SIMT_ONLY_MODE 0        // 1 / 2 / 4: compile one group of modes only (tests/emul/simt/simt.py builds them side by side)
 #endif
-#if SIMT_ONLY_MODE != 2
+#if SIMT_ONLY_MODE == 0 || SIMT_ONLY_MODE == 1
   if (in.mode == 1) rc = in.dtype ? run_filter<double>(in, out) : run_filter<float>(in, out);
 #endif
-#if SIMT_ONLY_MODE != 1
+#if SIMT_ONLY_MODE == 0 || SIMT_ONLY_MODE == 2
   if (in.mode == 2) rc = in.dtype ? run_rollout<double>(in, out) : run_rollout<float>(in, out);
   if (in.mode == 3) rc = in.dtype ? run_rollout_o3<double>(in, out) : run_rollout_o3<float>(in, out);
+#endif
+#if SIMT_ONLY_MODE == 0 || SIMT_ONLY_MODE == 4
+  if (in.mode == 4)
+    rc = in.dtype == 0 ? run_headline<float, float, false>(in, out)
+                       : (in.dtype == 1 ? run_headline<double, double, false>(in, out)
+                                        : (in.dtype == 2 ? run_headline<float, half_t, false>(in, out) : run_headline<float, float, true>(in, out)));
 #endif
   fclose(out);
   fprintf(stderr, "[simt] %ld wave collectives\n", simt::collectives.load());

@@ -204,3 +204,77 @@ def test_order3_degenerate_envs_stop_at_a_full_active_set(built):
             assert "runtime error" not in err and "ERROR" not in err, err[-3000:]
             assert st[0] == 1 and it[0] < 100, (j, dtype, st, it)
             np.testing.assert_allclose(us[0], unom[0], atol=1e-6)        # the nominal input is kept
+
+
+def _headline_case(E, D, steps, yaw_rate=0.3):
+    xyz, rpy, P = H.c2_setup(E, D, seed=3, yaw_rate=yaw_rate)
+    rng = np.random.default_rng(11)
+    rpy = rng.uniform(-0.2, 0.2, size=(E, D, 3))
+    av = CO.AviaryC(xyz, rpy)
+    av.step(np.zeros((E * D, 4)))                                   # EnvGeometric.py:431
+    return P, av, av.st.reshape(E, D, 20)[..., :13].copy()
+
+
+HEADLINE_TOL = {"float64": 1e-11, "float32": 2e-5, "float32c": 2e-5, "float16": 2e-2}
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32", "float16", "float32c"])
+@pytest.mark.parametrize("form", [0, 1])
+def test_headline_geometric_kernels_under_asan_ubsan(built, dtype, form):
+    """k_step_geometric (two half-shard launches per control step, as the library's form 1) and k_rollout_geometric (launches of 7 steps,
+    log ring + obs_last: form 2) on 256-thread workgroups, 37 envs x 8 drones = one full workgroup and one of 40 drones (a partial
+    wave, three empty ones) with exact-size buffers: every state / Lemniscate / RPM plane access and the LDS-staged observation rows of
+    the partial wave under AddressSanitizer, every index and conversion under UBSan -- in fp64, fp32, fp16 storage and the compensated
+    fp32 -- against the plain-C loop (co_geometric_loop) on the same inputs."""
+    E, D, steps = 37, 8, 16
+    P, av, state13 = _headline_case(E, D, steps)
+    ref, _ = av.geometric_loop(P, steps, first_zero_step=False)
+    obs, st, act, err = simt.headline(dtype, form, 0.0, P, state13, steps)
+    assert "ERROR" not in err and "runtime error" not in err, err[-3000:]
+    ref = ref.reshape(E, D, 20)
+    e_obs = np.abs(obs[..., :16] - ref[..., :16]).max()
+    e_st = np.abs(st - av.st.reshape(E, D, 20)[..., :13]).max()
+    print(f"[simt headline] form {form + 1} {dtype}: max |obs err| {e_obs:.2e}, |state err| {e_st:.2e}")
+    assert e_obs < HEADLINE_TOL[dtype] and e_st < HEADLINE_TOL[dtype]
+    assert np.abs(obs[..., 16:] / ref[..., 16:] - 1).max() < (1e-2 if dtype == "float16" else 1e-4)
+    if form == 0 and dtype == "float64":
+        np.testing.assert_allclose(act, ref[..., 16:], rtol=0, atol=1e-6)      # action_out of the last step = the RPM it applied (clipped: equal in range)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32", "float16"])
+@pytest.mark.parametrize("form", [2, 3])
+def test_headline_step_kernels_under_asan_ubsan(built, dtype, form):
+    """k_step per control step and k_rollout_step (launches of 5 steps, 3 action sets, a 4-slot observation ring) -- BASELINE config 5's
+    kernels -- with a partial last workgroup under ASan + UBSan, against co_step on the same action table."""
+    E, D, steps = 29, 10, 11
+    P, av, state13 = _headline_case(E, D, steps)
+    rng = np.random.default_rng(2)
+    actions = O.CF2P.HOVER_RPM * (1 + 0.05 * rng.uniform(-1, 1, size=(3, E, D, 4)))
+    actions[1, 0, 0] = [0.0, 5e4, -3.0, 1e4]                       # the clip on both sides
+    for k in range(steps):
+        ref = av.step(actions[k % 3])
+    obs, st, _, err = simt.headline(dtype, form, 0.0, P, state13, steps, actions=actions)
+    assert "ERROR" not in err and "runtime error" not in err, err[-3000:]
+    ref = ref.reshape(E, D, 20)
+    e_obs = np.abs(obs[..., :16] - ref[..., :16]).max()
+    print(f"[simt headline] form {form} {dtype}: max |obs err| {e_obs:.2e}")
+    assert e_obs < HEADLINE_TOL[dtype] * 5
+    assert np.abs(st - av.st.reshape(E, D, 20)[..., :13]).max() < HEADLINE_TOL[dtype] * 5
+
+
+@pytest.mark.parametrize("dtype,form", [("float32", 0), ("float32", 1), ("float16", 1), ("float32", 3)])
+def test_headline_kernels_under_thread_sanitizer(dtype, form):
+    """The same kernels under ThreadSanitizer (4 wavefronts per workgroup, full workgroups only -- see the note on clamped reads above):
+    each wave stages its observation rows in its own LDS slice behind wave-scope barriers; no wave touches another's slice or rows."""
+    E, D, steps = 64, 8, 6
+    P, av, state13 = _headline_case(E, D, steps)
+    rng = np.random.default_rng(2)
+    actions = O.CF2P.HOVER_RPM * (1 + 0.05 * rng.uniform(-1, 1, size=(3, E, D, 4)))
+    if form >= 2:
+        for k in range(steps):
+            ref = av.step(actions[k % 3])
+    else:
+        ref, _ = av.geometric_loop(P, steps, first_zero_step=False)
+    obs, st, _, err = simt.headline(dtype, form, 0.0, P, state13, steps, actions=actions, tsan=True)
+    assert "ThreadSanitizer" not in err, err[-4000:]
+    assert np.abs(obs[..., :16] - ref.reshape(E, D, 20)[..., :16]).max() < HEADLINE_TOL[dtype] * 5
