@@ -363,9 +363,22 @@ def _pmc_traffic(name, drones_per_launch):
         return None, None
 
 
-def extra_c3_variant(CtrlAviary, DroneModel, Physics, torch, local_rank, device, E, D, phase, seed, dtype, integrator, steps, streams):
+def _pmc_step_traffic(name, drones):
+    """(HBM bytes per control step scaled to `drones`, source) from a committed per-step PMC summary (profiles/<name>), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        per = rec["traffic_bytes_per_step"] / rec["drones_per_step_counted"]
+        return per * drones, f"profiles/{name} (separate rocprofv3 --pmc passes: 2 x FETCH_SIZE + WRITE_SIZE KiB; scaled to this shard)"
+    except Exception:
+        return None
+
+
+def extra_c3_variant(CtrlAviary, DroneModel, Physics, torch, local_rank, device, E, D, phase, seed, dtype, integrator, steps, streams, forms=(1,)):
     """The same fused step on another instantiation of the kernel (RK4 integrator, float64) or another shard size: its own env,
-    `steps` control steps through the C rollout loop after an untimed pass of the same length; microseconds per control step."""
+    `steps` control steps through the C rollout loop after an untimed pass of the same length; microseconds per control step in
+    launch form 1 (one launch per control step; the figure returned first) and, with forms=(1, 2), in form 2 beside it."""
     xyz, rpy, P = make_inputs(E, D, phase, seed)
     env = CtrlAviary(drone_model=DroneModel.CF2P, num_drones=D, initial_xyzs=xyz, initial_rpys=rpy, physics=Physics.DYN,
                      pyb_freq=100, ctrl_freq=100, num_envs=E, dtype=dtype, integrator=integrator, device=local_rank)
@@ -375,13 +388,19 @@ def extra_c3_variant(CtrlAviary, DroneModel, Physics, torch, local_rank, device,
     env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=device))
     env.set_rollout_streams(streams)
     dt = env.CTRL_TIMESTEP
-    env.rollout_geometric(0.0, steps, want_obs=True, obs_every_step=True)
-    us = _timed_steps(device, lambda: env.rollout_geometric(steps * dt, steps, want_obs=True, obs_every_step=True), steps)
-    used = env.last_rollout_streams()
+    res = []
+    for k, form in enumerate(forms):
+        env.set_rollout_form(form)
+        env.rollout_geometric(2 * k * steps * dt, steps, want_obs=True, obs_every_step=True)
+        us = _timed_steps(device, lambda: env.rollout_geometric((2 * k + 1) * steps * dt, steps, want_obs=True, obs_every_step=True), steps)
+        assert env.last_rollout_form() == form
+        res.append((us, env.last_rollout_streams()))
     obs = env._obs
     sane = bool(torch.isfinite(obs).all().item()) and abs(float(obs[..., 3:7].norm(dim=-1).mean().item()) - 1.0) < 1e-3
     env.close()
-    return us, used, sane
+    if len(forms) == 1:
+        return res[0][0], res[0][1], sane
+    return res[0][0], res[0][1], sane, res[1][0]
 
 
 def c4_spheres(scene, z_override=None):
@@ -880,7 +899,9 @@ def main(argv=None):
     c_loop = not args.python_loop and not fused_T
     # The library's auto policy looks at the length of the call.  Fix it to what the TIMED call will do, so that the warm-up
     # goes through the same branch (same streams, same launch shapes) as the call that is timed.
-    env.set_rollout_form(args.rollout_form)                  # 0: the library picks the launch form by shard size (mds_set_rollout_form)
+    env.set_rollout_form(args.rollout_form)                  # 0: the library picks the launch form by shard size and call length (mds_set_rollout_form)
+    if c_loop and geo and not c4 and not c5:
+        env.set_rollout_form(env.rollout_form_for(args.steps))     # (a 5-step warm-up alone would be issued step by step)
     env.set_rollout_streams(args.rollout_streams)
     planned = env.rollout_streams_for(args.steps, cbf=c4) if c_loop else 1
     env.set_rollout_streams(planned if c_loop else args.rollout_streams)
@@ -1011,12 +1032,27 @@ def main(argv=None):
             line["config"]["shard_of"] = {"G": args.shard_of, "rank": args.shard_rank,
                                           "what": "ONE shard of a G-GPU strong-scaling job run alone on one GPU (a prediction of that rank's rate, not a multi-GPU measurement)"}
     if form_used == 2:
-        line["config"]["launch"] = (f"C rollout loop in launch form 2 (mds_set_rollout_form auto: {n_local} drones are launch-bound one step per launch): the "
-                                    f"whole-rollout kernel, {form_chunk} control steps per launch, every step's observation written")
+        line["config"]["launch"] = (f"C rollout loop (mds_rollout_geometric) in launch form 2 -- the library's own choice (mds_set_rollout_form 0) from 8 192 drones and "
+                                    f"8 steps on: the whole-rollout kernel, <= {form_chunk} control steps per launch, the state in registers between them, every "
+                                    "step's observation written; `per_step` carries launch form 1 (one launch per control step) in the same run")
         line["roofline"]["kernel"] = f"k_rollout_geometric<{cname},{tname},{'true' if rk4 else 'false'},false,0> ({form_chunk} control steps per launch)"
         line["roofline"]["bytes_per_drone_step"] = bytes_per
-        line["roofline"]["note"] = ("algorithmic bytes of this form: the observation row per step + state and parameters once per launch; the kernel is "
-                                    "VALU / latency bound at this shard size, `frac` says how far from the HBM roofline that leaves it")
+        line["roofline"]["steps_per_launch"] = min(form_chunk, args.steps)
+        line["roofline"]["us_per_launch"] = us_per_step * min(form_chunk, args.steps)
+        line["roofline"]["bytes_per_launch"] = bytes_per * n_local * min(form_chunk, args.steps)
+        line["roofline"]["note"] = ("algorithmic bytes of this form: the 20-value observation row per drone-step + state (read, written) and trajectory parameters once "
+                                    "per launch -- SURVEY 8d's 212 B per drone-step count the state through HBM twice per step, which this form does not do.  The "
+                                    "kernel is VALU-bound (~1 000 VALU instructions per drone-step at ~0.85 of the issue rate, DESIGN.md section 4); `frac` says how far "
+                                    "from the HBM roofline that leaves it")
+        if args.workload != "c3big":
+            line["roofline"]["residency"] = (f"Infinity-Cache-assisted: the step's {bytes_per * n_local / 1e6:.3g} MB are the observation rows, written to the same "
+                                             "[n, 20] array every step (as the step-by-step loop does), which fits the 256 MiB Infinity Cache -- `frac` is an effective "
+                                             "bandwidth fraction, not an HBM one")
+        if args.dtype == "float32" and not rk4 and args.workload in ("c3", "c3big"):
+            rec_ = _pmc_step_traffic("r04_pmc_traffic_c3_form2.json", n_local)
+            if rec_ is not None:
+                line["roofline"]["traffic"], line["roofline"]["traffic_source"] = rec_
+                line["roofline"]["traffic_what"] = "HBM bytes per control step of the shard (the launch's counters / its control steps)"
     line["config"]["launch_form"] = form_used
     if split:
         # each stream runs `steps` half-shard launches inside the timed region, so us_per_step is also the average
@@ -1128,6 +1164,29 @@ def main(argv=None):
         except Exception as exc:
             line["cbf_iterations_last_step"] = {"error": str(exc)}
     # ---- secondary measurements, same run (never part of `value`) -------------------------------------------------------
+    # launch form 1 beside a form-2 headline: one launch of k_step_geometric per control step, the state through HBM every step (SURVEY 8d's
+    # 212 B per drone-step), the library's stream policy -- 200 steps after an untimed call of the same length
+    if form_used == 2 and geo and not c4 and not c5 and extras and rank == 0:
+        try:
+            env.set_rollout_form(1)
+            env.set_rollout_streams(0)
+            env.rollout_geometric(0.0, 200, want_obs=True, obs_every_step=True)
+            us1 = _timed_steps(device, lambda: env.rollout_geometric(200 * dt, 200, want_obs=True, obs_every_step=True), 200)
+            b1 = BYTES_PER_DRONE_STEP * es // 4 + (32 if args.dtype == "float32c" else 0)
+            used1 = env.last_rollout_streams()
+            line["per_step"] = {"what": "launch form 1 (mds_set_rollout_form 1): one launch of the fused step kernel per control step, bit-identical to mds_step_geometric "
+                                        "calls; 200 steps after an untimed call of the same length, HIP events",
+                                "kernel": line["roofline"]["kernel"] if form_used == 1 else
+                                f"k_step_geometric<{cname}, {tname}, true, false, {'true' if rk4 else 'false'}, false, {'true' if args.dtype == 'float32c' else 'false'}>",
+                                "us_per_step": us1, "value": n_local / (us1 * 1e-6), "unit": "drone-steps/s", "bytes_per_drone_step": b1, "streams": used1,
+                                "achieved": b1 * n_local / (us1 * 1e-6) / 1e9, "frac": b1 * n_local / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBPS, "launch_form": 1}
+            if args.dtype == "float32" and not rk4 and args.workload == "c3":
+                tr1, src1 = _pmc_traffic("r03_pmc_traffic_c3.json", n_local // 2 if used1 == 2 else n_local)
+                if tr1 is not None:
+                    line["per_step"]["traffic_per_launch"], line["per_step"]["traffic_source"] = tr1, src1
+            env.set_rollout_form(2)
+        except Exception as exc:
+            line["per_step"] = {"error": str(exc)}
     # the whole-rollout kernel, 50 control steps per launch with every step's observation streamed to a [50,n,20] log
     if args.workload in ("c2", "c3") and not fused_T and not args.python_loop and extras and not rk4:
         T2 = 50
@@ -1192,7 +1251,7 @@ def main(argv=None):
             us_auto = _timed_steps(device, lambda: env2.rollout_geometric(34.0, 2000, want_obs=True, obs_every_step=True), 2000)
             form_auto = env2.last_rollout_form()
             line["configs_1_c2"] = {"workload": WORKLOADS["c2"][3], "per_step": {"us_per_step": us_step, "value": E2 * D2 / (us_step * 1e-6),
-                                                                               "frac": bytes_per * E2 * D2 / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                                                               "frac": (BYTES_PER_DRONE_STEP * es // 4) * E2 * D2 / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                                                                                "bound": "kernel launch latency (3.5 MB per launch)", "launch_form": 1},
                                     "auto": {"us_per_step": us_auto, "value": E2 * D2 / (us_auto * 1e-6), "launch_form": form_auto,
                                              "what": "mds_rollout_geometric as the library issues it by itself (mds_set_rollout_form 0): 50 control steps per "
@@ -1247,7 +1306,8 @@ def main(argv=None):
             # the same kernel beyond the Infinity Cache, north_star's integrator, and the reference's own precision, each on its own env
             try:
                 EB, DB, phB, _ = WORKLOADS["c3big"]
-                us, used, sane = extra_c3_variant(CtrlAviary, DroneModel, Physics, torch, local_rank, device, EB, DB, phB, 2000, "float32", "euler", 50, 0)
+                us, used, sane, us_f2 = extra_c3_variant(CtrlAviary, DroneModel, Physics, torch, local_rank, device, EB, DB, phB, 2000, "float32", "euler", 50, 0,
+                                                         forms=(1, 2))
                 gb = BYTES_PER_DRONE_STEP * EB * DB / (us * 1e-6) / 1e9
                 nl = EB * DB // 2 if used == 2 else EB * DB
                 tr, src = _pmc_traffic("r02_pmc_traffic_c3big.json", nl)
@@ -1255,22 +1315,31 @@ def main(argv=None):
                 line["roofline"]["hbm_resident"] = {"workload": WORKLOADS["c3big"][3], "drones": EB * DB, "steps": 50, "us_per_step": us,
                                                     "value": EB * DB / (us * 1e-6), "achieved": gb, "unit": "GB/s", "frac": gb / HBM_PEAK_GBPS,
                                                     "frac_of_achievable_6300": gb / 6300.0, "bytes_per_step": BYTES_PER_DRONE_STEP * EB * DB,
-                                                    "streams": used, "traffic": tr, "traffic_source": src, "state_sane": sane}
+                                                    "streams": used, "traffic": tr, "traffic_source": src, "state_sane": sane, "launch_form": 1,
+                                                    "kernel": "k_step_geometric<float, float, true, false, false, false, false>",
+                                                    "form_2": {"us_per_step": us_f2, "value": EB * DB / (us_f2 * 1e-6), "bytes_per_drone_step": 20 * 4 + 33 * 4 / 50,
+                                                               "frac": (20 * 4 + 33 * 4 / 50) * EB * DB / (us_f2 * 1e-6) / 1e9 / HBM_PEAK_GBPS}}
             except Exception as exc:
                 line["roofline"]["hbm_resident"] = {"error": str(exc)}
             torch.cuda.empty_cache()
             for key, dty, integ, bpd in (("rk4", "float32", "rk4", BYTES_PER_DRONE_STEP), ("f64", "float64", "euler", 2 * BYTES_PER_DRONE_STEP),
                                          ("f32c", "float32c", "euler", BYTES_PER_DRONE_STEP + 32)):
                 try:
-                    us, used, sane = extra_c3_variant(CtrlAviary, DroneModel, Physics, torch, local_rank, device, E, D, phase, 1000, dty, integ, 200, 0)
+                    us, used, sane, us_f2 = extra_c3_variant(CtrlAviary, DroneModel, Physics, torch, local_rank, device, E, D, phase, 1000, dty, integ, 200, 0,
+                                                             forms=(1, 2))
                     gb = bpd * n_local / (us * 1e-6) / 1e9
+                    es_ = 8 if dty == "float64" else 4
+                    b_f2 = 20 * es_ + (33 * es_ + (32 if dty == "float32c" else 0)) / 50
                     line[key] = {"what": {"rk4": "same C3 step with the classical RK4 integrator (north_star's), fp32",
                                           "f64": "same C3 step in float64 (the reference's precision), explicit Euler",
                                           "f32c": "same C3 step in fp32 with compensated accumulation (MDS_F32C: two-sum inside the step, the residuals of the "
                                                   "three body rates kept between steps, +32 B per drone-step; open-loop 1000-step error 6e-6 instead of "
                                                   "1.4e-5: north_star's 1e-5 tolerance without a controller in the loop)"}[key],
                                  "us_per_step": us, "value": n_local / (us * 1e-6), "unit": "drone-steps/s", "bytes_per_drone_step": bpd,
-                                 "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBPS, "streams": used, "steps": 200, "state_sane": sane}
+                                 "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBPS, "streams": used, "steps": 200, "state_sane": sane, "launch_form": 1,
+                                 "form_2": {"what": "the same 200 steps as the library issues them by itself: the whole-rollout kernel, 50 control steps per launch",
+                                            "us_per_step": us_f2, "value": n_local / (us_f2 * 1e-6), "bytes_per_drone_step": b_f2,
+                                            "frac": b_f2 * n_local / (us_f2 * 1e-6) / 1e9 / HBM_PEAK_GBPS}}
                 except Exception as exc:
                     line[key] = {"error": str(exc)}
                 torch.cuda.empty_cache()

@@ -248,14 +248,16 @@ int mds_get_last_rollout_streams(const mds_handle* h);
 int mds_rollout_streams_for(const mds_handle* h, int loop, int n_steps);
 
 /* The LAUNCH FORM of mds_rollout_geometric (the loop of simulations/EnvGeometric.py:434-469; SURVEY 8e: an env shard of config 3 on
- * G GPUs is E / G envs per GPU, and below ~2^17 drones a dependent launch per control step costs more than the step moves).
+ * G GPUs is E / G envs per GPU; below ~2^17 drones a dependent launch per control step costs more than the step moves, and above it a
+ * launch per step streams the state through HBM twice per step where one launch per 50 steps keeps it in registers).
  * form 1 = one launch of the fused step kernel per control step (on two chains where mds_set_rollout_streams says so): bit-identical to
  * n_steps calls of mds_step_geometric.  form 2 = the whole-rollout kernel (mds_rollout_geometric_fused's) in launches of steps_per_launch
  * control steps (default 50): the state stays in registers between the steps of a launch, every step's observation is still written to
  * obs_dev when obs_every_step != 0; same arithmetic, results agree with form 1 to rounding (the two kernels contract FMAs differently;
- * each is parity-tested against the oracle).  form 0 = auto: form 2 for shards of 2^13 .. 2^17 drones and calls of 8 steps and more
- * (measured: profiles/r04_shard_sweep.json), form 1 otherwise and always with fp16 storage or ground effect / downwash.  A caller that
- * needs results independent of how the envs are sharded over GPUs selects form 1.  steps_per_launch 0 keeps the current value. */
+ * each is parity-tested against the oracle).  form 0 = auto: form 2 for shards of 2^13 drones and more (float64: 2^13 .. 2^17) and calls of
+ * 8 steps and more -- the faster form at every such size (measured: profiles/r04_shard_sweep.json, r04_form_sweep.json) --, form 1 otherwise
+ * and always with fp16 storage or ground effect / downwash.  A caller that needs results bit-identical to mds_step_geometric calls, whatever the shard
+ * size and call length, selects form 1.  steps_per_launch 0 keeps the current value. */
 int mds_set_rollout_form(mds_handle* h, int form, int steps_per_launch);
 /* 1 or 2: what an mds_rollout_geometric call of n_steps would do under the current setting; what the most recent one did (0: none yet). */
 int mds_rollout_form_for(const mds_handle* h, int n_steps);

@@ -209,22 +209,27 @@ static int rollout_streams_policy(const mds_handle* h, int loop, int n_steps) {
 
 // The launch form of the fused geometric loop (mds_set_rollout_form; mds_rollout_form_for reports it).  1: one launch per control step
 // (k_step_geometric; two chains on big shards, above).  2: the whole-rollout kernel in launches of `rollout_chunk` control steps
-// (k_rollout_geometric: state in registers, every step's observation still written).  Auto: shards of kFusedMinDrones .. kFusedMaxDrones
-// drones are launch-bound in form 1 -- a dependent launch costs ~4 us whatever it moves (C2, 16 384 drones: 3.9 us per step against 1.9;
-// one eighth of config 3 = 65 536 drones: profiles/r04_shard_sweep.json) -- and take form 2 for calls of kFusedMinSteps steps and more; larger
-// shards stream at 0.8-0.9 of the HBM roofline in form 1 and stay there.  fp16 storage stays in form 1 (form 2 rounds the state to fp16
-// once per launch instead of once per step: not the same arithmetic).
+// (k_rollout_geometric: state in registers, every step's observation still written).  Auto: form 2 for every shard of kFusedMinDrones drones
+// and more and calls of kFusedMinSteps steps and more -- it is the faster form at every size measured (profiles/r04_shard_sweep.json,
+// r04_form_sweep.json): below 2^18 drones form 1 is launch-bound (a dependent launch costs ~4 us whatever it moves: C2, 16 384 drones, 3.9 us
+// per step against 1.9; one eighth of config 3, 65 536 drones, 4.75 against 1.97), above it form 1 streams the 13-value state through HBM
+// twice per step (212 B per drone-step at 0.8-0.93 of the roofline: config 3 15.4 us per step) where form 2 moves the observation row only
+// (82.6 B: 9.0 us, VALU-bound).  MDS_FUSED_MAX_DRONES (compile time) caps the window for A/B builds.  float64 takes form 2 up to 2^17 drones only
+// (below).  fp16 storage stays in form 1 (form 2 rounds the state to fp16 once per launch instead of once per step: not the same arithmetic).
 #ifndef MDS_FUSED_MAX_DRONES
-#define MDS_FUSED_MAX_DRONES (size_t(1) << 17)
+#define MDS_FUSED_MAX_DRONES (~size_t(0))
 #endif
-constexpr size_t kFusedMinDrones = size_t(1) << 13, kFusedMaxDrones = MDS_FUSED_MAX_DRONES;
+constexpr size_t kFusedMinDrones = size_t(1) << 13, kFusedMaxDrones = MDS_FUSED_MAX_DRONES, kFusedF64MaxDrones = size_t(1) << 17;
 constexpr int kFusedMinSteps = 8;
 static int rollout_form_policy(const mds_handle* h, int n_steps) {
   if (h->envfx || n_steps < 1) return 1;          // ground effect / downwash: env-mates interact every substep, no state-in-registers form
   if (h->rollout_form) return h->rollout_form;
   if (h->cfg.dtype == MDS_F16) return 1;
   const size_t n = (size_t)h->n;
-  return (n >= kFusedMinDrones && n <= kFusedMaxDrones && n_steps >= kFusedMinSteps) ? 2 : 1;
+  // float64: the whole-rollout kernel is arithmetic-bound (software sin / cos / atan2 / asin, divisions) and loses to the streaming form once the
+  // shard is big enough for that one to stream (config 3: 33.8 us per step against 31.6; 2 M drones 135 against 130): launch-bound sizes only
+  const size_t nmax = h->cfg.dtype == MDS_F64 ? (kFusedF64MaxDrones < kFusedMaxDrones ? kFusedF64MaxDrones : kFusedMaxDrones) : kFusedMaxDrones;
+  return (n >= kFusedMinDrones && n <= nmax && n_steps >= kFusedMinSteps) ? 2 : 1;
 }
 
 // Set-up path (mds_create / mds_set_rollout_streams): the internal stream and the two events of the two-chain rollouts.

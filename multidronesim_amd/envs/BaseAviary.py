@@ -396,8 +396,8 @@ class BaseAviary:
         return int(self._lib.mds_rollout_streams_for(self._h, C.c_int(1 if cbf else 0), C.c_int(int(n_steps))))
 
     def set_rollout_form(self, form: int = 0, steps_per_launch: int = 0):
-        """How rollout_geometric launches its steps (mds_set_rollout_form): 0 auto (by shard size), 1 one launch per control step
-        (bit-identical to step_geometric calls, independent of the sharding), 2 the whole-rollout kernel in launches of
+        """How rollout_geometric launches its steps (mds_set_rollout_form): 0 auto (form 2 from 8 192 drones and 8 steps on), 1 one launch per control step
+        (bit-identical to step_geometric calls at every shard size), 2 the whole-rollout kernel in launches of
         ``steps_per_launch`` control steps (state in registers; results equal to rounding)."""
         self._require_open()
         capi.check(self._lib.mds_set_rollout_form(self._h, C.c_int(int(form)), C.c_int(int(steps_per_launch))), "mds_set_rollout_form")
