@@ -363,18 +363,6 @@ def _pmc_traffic(name, drones_per_launch):
         return None, None
 
 
-def _pmc_step_traffic(name, drones):
-    """(HBM bytes per control step scaled to `drones`, source) from a committed per-step PMC summary (profiles/<name>), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-        per = rec["traffic_bytes_per_step"] / rec["drones_per_step_counted"]
-        return per * drones, f"profiles/{name} (separate rocprofv3 --pmc passes: 2 x FETCH_SIZE + WRITE_SIZE KiB; scaled to this shard)"
-    except Exception:
-        return None
-
-
 def extra_c3_variant(CtrlAviary, DroneModel, Physics, torch, local_rank, device, E, D, phase, seed, dtype, integrator, steps, streams, forms=(1,)):
     """The same fused step on another instantiation of the kernel (RK4 integrator, float64) or another shard size: its own env,
     `steps` control steps through the C rollout loop after an untimed pass of the same length; microseconds per control step in
@@ -1044,15 +1032,28 @@ def main(argv=None):
                                     "per launch -- SURVEY 8d's 212 B per drone-step count the state through HBM twice per step, which this form does not do.  The "
                                     "kernel is VALU-bound (~1 000 VALU instructions per drone-step at ~0.85 of the issue rate, DESIGN.md section 4); `frac` says how far "
                                     "from the HBM roofline that leaves it")
-        if args.workload != "c3big":
-            line["roofline"]["residency"] = (f"Infinity-Cache-assisted: the step's {bytes_per * n_local / 1e6:.3g} MB are the observation rows, written to the same "
-                                             "[n, 20] array every step (as the step-by-step loop does), which fits the 256 MiB Infinity Cache -- `frac` is an effective "
-                                             "bandwidth fraction, not an HBM one")
+        line["roofline"]["residency"] = (f"cache-assisted: the step's {bytes_per * n_local / 1e6:.3g} MB are the observation rows, written to the SAME [n, 20] array every step (as the "
+                                         "step-by-step loop does) with default-policy stores, so a rewritten line that is still in the XCD's L2 / the Infinity Cache never "
+                                         "travels: `traffic` (L2 -> fabric bytes per launch, PMC) is about a quarter of the algorithmic bytes; `frac` is an effective "
+                                         "bandwidth fraction, not an HBM one.  `fused_rollout` is the same kernel with every step's rows going to their own slot of a "
+                                         "[50, n, 20] log (non-temporal stores, traffic = algorithmic)")
         if args.dtype == "float32" and not rk4 and args.workload in ("c3", "c3big"):
-            rec_ = _pmc_step_traffic("r04_pmc_traffic_c3_form2.json", n_local)
-            if rec_ is not None:
-                line["roofline"]["traffic"], line["roofline"]["traffic_source"] = rec_
-                line["roofline"]["traffic_what"] = "HBM bytes per control step of the shard (the launch's counters / its control steps)"
+            # (the committed counters are per launch of 50 steps -- the long runs -- and of 20 steps -- the driver's command)
+            tr, src = _pmc_traffic(f"r04_pmc_traffic_c3_form2_L{min(form_chunk, args.steps)}.json", n_local)
+            if tr is not None:
+                line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr, src
+                line["roofline"]["traffic_over_algorithmic"] = tr / line["roofline"]["bytes_per_launch"]
+            try:      # what actually bounds this kernel: VALU issue (committed SQ_INSTS_VALU of the same kernel; 0.96 ns per wave64 fp32 instruction and SIMD,
+                      # profiles/tools/ubench/valu_rate.hip)
+                with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_c3_form2_L50.json")) as f_:
+                    vi = json.load(f_)["valu_wave_instructions_per_drone_step"]
+                per_simd = vi * (n_local / 64) / 1024
+                line["roofline"]["valu"] = {"wave_instructions_per_drone_step": vi, "ns_per_instruction_and_simd": us_per_step * 1e3 / per_simd,
+                                            "peak_ns_per_instruction_and_simd": 0.96, "frac_of_issue_rate": 0.96 * per_simd / (us_per_step * 1e3),
+                                            "what": "SQ_INSTS_VALU per drone-step (PMC, committed) x wavefronts per SIMD / the measured step time, against the issue rate of "
+                                                    "independent wave64 fp32 instructions measured on this chip: the bound this kernel actually runs into"}
+            except Exception:
+                pass
     line["config"]["launch_form"] = form_used
     if split:
         # each stream runs `steps` half-shard launches inside the timed region, so us_per_step is also the average

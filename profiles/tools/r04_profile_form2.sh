@@ -22,30 +22,37 @@ for c in FETCH_SIZE WRITE_SIZE; do pmc c3_form2 $c --gpus 1 --steps 2000 --warmu
 pmc c3_form2 "SQ_INSTS_VALU SQ_WAVES" --gpus 1 --steps 2000 --warmup 200
 pmc c3_form2 "SQ_BUSY_CYCLES SQ_WAVE_CYCLES" --gpus 1 --steps 2000 --warmup 200
 pmc c3_form2 "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" --gpus 1 --steps 2000 --warmup 200
+for c in FETCH_SIZE WRITE_SIZE; do pmc c3_form2_driver $c --gpus 1 --steps 20 --warmup 5; done
 python3 - <<'PY'
 import glob, csv, json
 O = "gpurun_out/r04f2"
-n, steps = 524288, 2200
-rec = {"source": "profiles/tools/r04_profile_form2.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), bench.py --gpus 1 --steps 2000 --warmup 200 (launch form 2: k_rollout_geometric<float, float, false, false, 0>, 50 control steps per launch, every step's observation written to the same [n, 20] array)",
-       "unit_note": "counter unit = KiB; FETCH_SIZE x2 as for 16-byte-per-lane streaming reads (MI355X_MICROARCH.md section HBM)",
-       "drones_per_step_counted": n, "control_steps_counted": steps}
-sq = {}
-for d in glob.glob(f"{O}/pmc_c3_form2_*"):
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "k_rollout_geometric" in r["Kernel_Name"]:
-                sq.setdefault(r["Counter_Name"], [0.0, 0])
-                sq[r["Counter_Name"]][0] += float(r["Counter_Value"]); sq[r["Counter_Name"]][1] += 1
-for c, (tot, k) in sq.items():
-    rec[c + "_total"], rec[c + "_launches"] = tot, k
-if "FETCH_SIZE" in sq and "WRITE_SIZE" in sq:
-    rec["read_bytes_per_step_corrected"] = sq["FETCH_SIZE"][0] * 1024 * 2 / steps
-    rec["write_bytes_per_step"] = sq["WRITE_SIZE"][0] * 1024 / steps
-    rec["traffic_bytes_per_step"] = rec["read_bytes_per_step_corrected"] + rec["write_bytes_per_step"]
-    rec["algorithmic_bytes_per_step"] = (80 + 132 / 50) * n
-if "SQ_INSTS_VALU" in sq:
-    rec["valu_wave_instructions_per_drone_step"] = sq["SQ_INSTS_VALU"][0] / steps / (n / 64)
-json.dump(rec, open(f"{O}/r04_pmc_traffic_c3_form2.json", "w"), indent=1)
-print(json.dumps({k: v for k, v in rec.items() if k not in ("source", "unit_note")}, indent=1))
+n = 524288
+def collect(tag):
+    sq = {}
+    for d in glob.glob(f"{O}/pmc_{tag}_*"):
+        if not d.endswith(".log") and ("_driver_" in d) == tag.endswith("_driver"):
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "k_rollout_geometric" in r["Kernel_Name"]:
+                        sq.setdefault(r["Counter_Name"], []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    return {c: [v for _, v in sorted(rows)] for c, rows in sq.items()}
+for tag, L, cmd, pick in (("c3_form2", 50, "--gpus 1 --steps 2000 --warmup 200", slice(None)), ("c3_form2_driver", 20, "--gpus 1 --steps 20 --warmup 5", slice(-1, None))):
+    sq = collect(tag)
+    rec = {"source": f"profiles/tools/r04_profile_form2.sh: rocprofv3 --pmc <counter> --kernel-trace (separate passes), bench.py {cmd} --no-extras (launch form 2: k_rollout_geometric<float, float, false, false, 0>, {L} control steps per launch, every step's observation written to the same [n, 20] array)" + ("; the timed 20-step launch only (the 5-step warm-up launch left out)" if L == 20 else ""),
+           "unit_note": "FETCH_SIZE / WRITE_SIZE: counter unit = KiB; FETCH_SIZE x2 as for 16-byte-per-lane streaming reads (MI355X_MICROARCH.md section HBM)",
+           "drones_per_launch_counted": n, "control_steps_per_launch": L}
+    for c, vals in sq.items():
+        v = vals[pick]
+        rec[c + "_per_launch"], rec[c + "_launches"] = sum(v) / len(v), len(v)
+    if "FETCH_SIZE" in sq and "WRITE_SIZE" in sq:
+        rec["read_bytes_per_launch_corrected"] = rec["FETCH_SIZE_per_launch"] * 1024 * 2
+        rec["write_bytes_per_launch"] = rec["WRITE_SIZE_per_launch"] * 1024
+        rec["traffic_bytes_per_launch"] = rec["read_bytes_per_launch_corrected"] + rec["write_bytes_per_launch"]
+        rec["algorithmic_bytes_per_launch"] = (80 * L + 132) * n
+        rec["traffic_over_algorithmic"] = rec["traffic_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"]
+    if "SQ_INSTS_VALU" in sq:
+        rec["valu_wave_instructions_per_drone_step"] = rec["SQ_INSTS_VALU_per_launch"] / L / (n / 64)
+    json.dump(rec, open(f"{O}/r04_pmc_traffic_c3_form2_L{L}.json", "w"), indent=1)
+    print(json.dumps({k: v for k, v in rec.items() if k not in ("source", "unit_note")}, indent=1))
 PY
 for n in driver_form2 long_form2 driver_form1; do tail -1 $O/trace_$n.json | python3 -c "import json,sys; r=json.loads(sys.stdin.read()); print('$n', '%.4g' % r['value'], 'us/step %.2f' % r['roofline']['us_per_step'], 'frac %.3f' % r['roofline']['frac'], r['roofline'].get('streams'), r['config'].get('launch_form'))"; done
