@@ -21,16 +21,28 @@ def available():
     return os.path.exists(CLANG) or shutil.which("clang++") is not None
 
 
-def build(force=False):
-    """Three executables (the filter kernels / the persistent rollout kernels / the headline step and rollout kernels), compiled side by
-    side: ~2 minutes the first time."""
+EXE_TSAN = os.path.join(HERE, "simt_rollout_tsan")
+_COMMON = ["-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-pthread", "-I", HERE, "-Wno-unknown-attributes", "-Wno-ignored-attributes"]
+
+
+def _jobs():
+    """(executable, compile flags): three ASan + UBSan executables (the filter kernels / the persistent rollout kernels / the headline step and
+    rollout kernels) and the ThreadSanitizer build of everything with two wavefronts per workgroup in the persistent kernels."""
+    jobs = [(exe, ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", f"-DSIMT_ONLY_MODE={mode}"]) for mode, exe in EXE.items()]
+    jobs.append((EXE_TSAN, ["-fsanitize=thread", "-DSIMT_NW=2"]))
+    return jobs
+
+
+def build(force=False, only=None):
+    """All four executables compiled side by side (~2 minutes the first time on 4 cores); `only`: restrict to these executables."""
     cxx = CLANG if os.path.exists(CLANG) else shutil.which("clang++")
     deps = [SRC, os.path.abspath(__file__), os.path.join(HERE, "hip", "hip_runtime.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     procs = []
-    for mode, exe in EXE.items():
+    for exe, flags in _jobs():
+        if only is not None and exe not in only:
+            continue
         if force or not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
-            cmd = [cxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-pthread",
-                   f"-DSIMT_ONLY_MODE={mode}", "-I", HERE, "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-o", exe, SRC]
+            cmd = [cxx, *_COMMON, *flags, "-o", exe, SRC]
             procs.append((cmd, subprocess.Popen(cmd, cwd=HERE, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for cmd, p in procs:
         out, _ = p.communicate()
@@ -39,21 +51,11 @@ def build(force=False):
     return EXE
 
 
-EXE_TSAN = os.path.join(HERE, "simt_rollout_tsan")
-
-
 def build_tsan(force=False):
-    """The rollout kernels once more under ThreadSanitizer, two wavefronts per workgroup: the LDS hand-offs between lanes and between waves
-    (records, bounds, tickets, solver scratch, observation staging) must all sit behind a wave or workgroup barrier -- pthread barriers
-    here, which TSan understands; an unsynchronised pair of accesses is a race on the GPU too (or a missing wave-scope fence)."""
-    cxx = CLANG if os.path.exists(CLANG) else shutil.which("clang++")
-    deps = [SRC, os.path.abspath(__file__), os.path.join(HERE, "hip", "hip_runtime.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    if force or not os.path.exists(EXE_TSAN) or any(os.path.getmtime(d) > os.path.getmtime(EXE_TSAN) for d in deps):
-        cmd = [cxx, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-pthread", "-DSIMT_NW=2", "-I", HERE,
-               "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-o", EXE_TSAN, SRC]
-        r = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("simt tsan build failed:\n" + (r.stdout + r.stderr)[-4000:])
+    """The kernels once more under ThreadSanitizer, two wavefronts per workgroup in the persistent kernels: the LDS hand-offs between lanes and
+    between waves (records, bounds, tickets, solver scratch, observation staging) must all sit behind a wave or workgroup barrier -- pthread
+    barriers here, which TSan understands; an unsynchronised pair of accesses is a race on the GPU too (or a missing wave-scope fence)."""
+    build(force, only=(EXE_TSAN,))
     return EXE_TSAN
 
 

@@ -29,7 +29,7 @@ UMAX2 = [O.CF2P.MAX_THRUST, 10.0, 10.0, 10.0]
 
 @pytest.fixture(scope="module")
 def built():
-    return simt.build()          # ~2 minutes the first time (two executables compiled side by side), cached by mtime afterwards
+    return simt.build()          # ~2 minutes the first time (four executables compiled side by side), cached by mtime afterwards
 
 
 def _fields(order, n_obs, K, umax, safety, zscale):
@@ -98,7 +98,7 @@ def test_qp_filter_kernel_order3_under_asan_ubsan(built, D, dtype, E, tol):
     assert n_act >= 1
 
 
-@pytest.mark.parametrize("D,E,steps,dtype,tol", [(16, 5, 10, "float64", 1e-9), (7, 9, 8, "float32", 1e-5), (2, 3, 8, "float64", 1e-9), (4, 5, 6, "float32", 1e-5)])
+@pytest.mark.parametrize("D,E,steps,dtype,tol", [(16, 5, 8, "float64", 1e-9), (7, 9, 8, "float32", 1e-5), (2, 3, 8, "float64", 1e-9), (4, 5, 6, "float32", 1e-5)])
 def test_persistent_rollout_kernel_under_asan_ubsan(built, D, E, steps, dtype, tol):
     """k_cbf_rollout<T, 0, false, 1>: the whole persistent kernel, one wavefront per workgroup (64 / Dp envs each, a partial last workgroup),
     launches of 7 steps with a 3-slot observation ring -- per-drone bounds in stage A, the row-slot table, the ticket loop, the solver in
