@@ -134,10 +134,11 @@ def rollout_o3(dtype, t0, K, P, state13, rpm_echo, steps, cbf_fields, obstacles,
 
 
 def headline(dtype, form, t0, P, state13, steps, actions=None, tsan=False):
-    """Mode 4: form 0 k_step_geometric per step, 1 k_rollout_geometric, 2 k_step on an action table [3, E, D, 4], 3 k_rollout_step.
+    """Mode 4: form 0 k_step_geometric per step, 1 k_rollout_geometric (log ring), 2 k_step on an action table [3, E, D, 4], 3 k_rollout_step,
+    4 k_rollout_geometric rewriting one [n, 20] array every step.
     -> (obs [E,D,20], state13 [E,D,13] world, action_out [E,D,4] (form 0), stderr)"""
     E, D = P.shape[0], P.shape[1]
-    arrays = [np.array([t0]), P, state13] + ([actions] if form >= 2 else [])
+    arrays = [np.array([t0]), P, state13] + ([actions] if form in (2, 3) else [])
     raw, err = run(4, dtype, E, D, steps, {"order": 2}, np.zeros((0, 4)), arrays, tsan=tsan, nominal=form)
     n = E * D
     obs = np.frombuffer(raw[:n * 160], dtype=np.float64).reshape(E, D, 20)

@@ -208,12 +208,13 @@ template <typename T> static int run_rollout_o3(const In& in, FILE* out) {
 
 // mode 4: the headline kernels (BASELINE configs 1-3 and 5), 256-thread workgroups with a partial last one.  `nominal` picks the launch
 // form: 0 k_step_geometric per control step in two half-shard launches (batch0), 1 k_rollout_geometric in launches of 7 steps (log ring
-// of 7 slots + obs_last), 2 k_step per control step on an action table, 3 k_rollout_step in launches of 5 steps (3 action sets, 4-slot ring).
+// of 7 slots + obs_last), 2 k_step per control step on an action table, 3 k_rollout_step in launches of 5 steps (3 action sets, 4-slot ring),
+// 4 k_rollout_geometric with every step's rows rewritten in place (log stride 0: the default-policy-store path).
 // dtype: 0 fp32, 1 fp64, 2 fp16 storage (fp32 arithmetic), 3 fp32 with compensated accumulation (forms 0 / 1).
 // rest: t0, P[n*7], state13[n*13] (world), forms 2 / 3: actions[3*n*4].   out: double obs[n*20], state13[n*13] (world), act[n*4] (form 0)
 template <typename T, typename S, bool COMP> static int run_headline(const In& in, FILE* out) {
   const int E = in.E, D = in.D, n = E * D, steps = in.n_steps, form = in.nominal, A = 3;
-  const bool table = form >= 2;
+  const bool table = form == 2 || form == 3;
   if (steps < 1 || in.rest.size() != (size_t)1 + (size_t)n * 20 + (table ? (size_t)A * n * 4 : 0)) return 3;
   const double t0 = in.rest[0];
   const double* Pd = in.rest.data() + 1;
@@ -262,6 +263,14 @@ template <typename T, typename S, bool COMP> static int run_headline(const In& i
     }
     for (size_t k = 0; k < obs.size(); ++k)
       if ((double)obs[k] != (double)ring[(size_t)last_slot * n * 20 + k]) return 6;       // obs_last = the log's last written slot
+  } else if (form == 4) {                                      // mds_rollout_geometric's own use of the kernel: every step rewrites the same [n, 20] array
+    for (int k0 = 0; k0 < steps; k0 += 7) {
+      const int ks = steps - k0 < 7 ? steps - k0 : 7;
+      simt::launch(grid, 256, nullptr, [&]() {
+        k_rollout_geometric<T, S, false, false, 0>(c, nullptr, n, ld, t, dt, ks, state.data(), lem.data(), rpm.data(), obs.data(), 0, nullptr, nullptr, nullptr, lop);
+      });
+      for (int j = 0; j < ks; ++j) t += dt;
+    }
   } else if (form == 2) {
     if (COMP) return 4;
     for (int k = 0; k < steps; ++k)

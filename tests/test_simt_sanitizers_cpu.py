@@ -218,14 +218,14 @@ def _headline_case(E, D, steps, yaw_rate=0.3):
 HEADLINE_TOL = {"float64": 1e-11, "float32": 2e-5, "float32c": 2e-5, "float16": 2e-2}
 
 
-@pytest.mark.parametrize("dtype", ["float64", "float32", "float16", "float32c"])
-@pytest.mark.parametrize("form", [0, 1])
+@pytest.mark.parametrize("dtype,form", [(d, f) for f in (0, 1) for d in ("float64", "float32", "float16", "float32c")] + [("float32", 4), ("float64", 4)])
 def test_headline_geometric_kernels_under_asan_ubsan(built, dtype, form):
     """k_step_geometric (two half-shard launches per control step, as the library's form 1) and k_rollout_geometric (launches of 7 steps,
     log ring + obs_last: form 2) on 256-thread workgroups, 37 envs x 8 drones = one full workgroup and one of 40 drones (a partial
     wave, three empty ones) with exact-size buffers: every state / Lemniscate / RPM plane access and the LDS-staged observation rows of
     the partial wave under AddressSanitizer, every index and conversion under UBSan -- in fp64, fp32, fp16 storage and the compensated
-    fp32 -- against the plain-C loop (co_geometric_loop) on the same inputs."""
+    fp32 -- against the plain-C loop (co_geometric_loop) on the same inputs.  form 4: the whole-rollout kernel as mds_rollout_geometric
+    launches it, every step's rows rewritten in place (the default-policy-store instantiation of the staging)."""
     E, D, steps = 37, 8, 16
     P, av, state13 = _headline_case(E, D, steps)
     ref, _ = av.geometric_loop(P, steps, first_zero_step=False)
@@ -234,7 +234,7 @@ def test_headline_geometric_kernels_under_asan_ubsan(built, dtype, form):
     ref = ref.reshape(E, D, 20)
     e_obs = np.abs(obs[..., :16] - ref[..., :16]).max()
     e_st = np.abs(st - av.st.reshape(E, D, 20)[..., :13]).max()
-    print(f"[simt headline] form {form + 1} {dtype}: max |obs err| {e_obs:.2e}, |state err| {e_st:.2e}")
+    print(f"[simt headline] form {form} {dtype}: max |obs err| {e_obs:.2e}, |state err| {e_st:.2e}")
     assert e_obs < HEADLINE_TOL[dtype] and e_st < HEADLINE_TOL[dtype]
     assert np.abs(obs[..., 16:] / ref[..., 16:] - 1).max() < (1e-2 if dtype == "float16" else 1e-4)
     if form == 0 and dtype == "float64":
