@@ -254,7 +254,7 @@ int mds_rollout_streams_for(const mds_handle* h, int loop, int n_steps);
  * n_steps calls of mds_step_geometric.  form 2 = the whole-rollout kernel (mds_rollout_geometric_fused's) in launches of steps_per_launch
  * control steps (default 50): the state stays in registers between the steps of a launch, every step's observation is still written to
  * obs_dev when obs_every_step != 0; same arithmetic, results agree with form 1 to rounding (the two kernels contract FMAs differently;
- * each is parity-tested against the oracle).  form 0 = auto: form 2 for shards of 2^13 drones and more (float64: 2^13 .. 2^17) and calls of
+ * each is parity-tested against the oracle).  form 0 = auto: form 2 for shards of 2^13 drones and more and calls of
  * 8 steps and more -- the faster form at every such size (measured: profiles/r04_shard_sweep.json, r04_form_sweep.json) --, form 1 otherwise
  * and always with fp16 storage or ground effect / downwash.  A caller that needs results bit-identical to mds_step_geometric calls, whatever the shard
  * size and call length, selects form 1.  steps_per_launch 0 keeps the current value. */

@@ -214,21 +214,20 @@ static int rollout_streams_policy(const mds_handle* h, int loop, int n_steps) {
 // r04_form_sweep.json): below 2^18 drones form 1 is launch-bound (a dependent launch costs ~4 us whatever it moves: C2, 16 384 drones, 3.9 us
 // per step against 1.9; one eighth of config 3, 65 536 drones, 4.75 against 1.97), above it form 1 streams the 13-value state through HBM
 // twice per step (212 B per drone-step at 0.8-0.93 of the roofline: config 3 15.4 us per step) where form 2 moves the observation row only
-// (82.6 B: 9.0 us, VALU-bound).  MDS_FUSED_MAX_DRONES (compile time) caps the window for A/B builds.  float64 takes form 2 up to 2^17 drones only
-// (below).  fp16 storage stays in form 1 (form 2 rounds the state to fp16 once per launch instead of once per step: not the same arithmetic).
+// (82.6 B: 7.5-9.0 us, VALU-bound).  float64 likewise (config 3: 32.7 -> 30.9 us per step, 4 M drones 330 -> 246; its whole-rollout kernel is
+// arithmetic-bound -- software sin / cos / atan2 / asin, divisions -- and wins by less).  MDS_FUSED_MAX_DRONES (compile time) caps the window for A/B
+// builds.  fp16 storage stays in form 1 (form 2 rounds the state to fp16 once per launch instead of once per step: not the same arithmetic).
 #ifndef MDS_FUSED_MAX_DRONES
 #define MDS_FUSED_MAX_DRONES (~size_t(0))
 #endif
-constexpr size_t kFusedMinDrones = size_t(1) << 13, kFusedMaxDrones = MDS_FUSED_MAX_DRONES, kFusedF64MaxDrones = size_t(1) << 17;
+constexpr size_t kFusedMinDrones = size_t(1) << 13, kFusedMaxDrones = MDS_FUSED_MAX_DRONES;
 constexpr int kFusedMinSteps = 8;
 static int rollout_form_policy(const mds_handle* h, int n_steps) {
   if (h->envfx || n_steps < 1) return 1;          // ground effect / downwash: env-mates interact every substep, no state-in-registers form
   if (h->rollout_form) return h->rollout_form;
   if (h->cfg.dtype == MDS_F16) return 1;
   const size_t n = (size_t)h->n;
-  // float64: the whole-rollout kernel is arithmetic-bound (software sin / cos / atan2 / asin, divisions) and loses to the streaming form once the
-  // shard is big enough for that one to stream (config 3: 33.8 us per step against 31.6; 2 M drones 135 against 130): launch-bound sizes only
-  const size_t nmax = h->cfg.dtype == MDS_F64 ? (kFusedF64MaxDrones < kFusedMaxDrones ? kFusedF64MaxDrones : kFusedMaxDrones) : kFusedMaxDrones;
+  const size_t nmax = kFusedMaxDrones;
   return (n >= kFusedMinDrones && n <= nmax && n_steps >= kFusedMinSteps) ? 2 : 1;
 }
 

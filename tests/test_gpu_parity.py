@@ -519,7 +519,7 @@ def test_two_stream_rollout_is_bit_identical_and_stream_ordered(mds, dtype, phys
 def test_rollout_launch_form_policy_and_equivalence(mds, dtype, tol):
     """mds_set_rollout_form: form 1 = one launch per control step (bit-identical to step_geometric calls), form 2 = the whole-rollout
     kernel in launches of steps_per_launch control steps with every step's observation still written; auto picks form 2 from 2^13
-    drones and 8 steps on (float64: up to 2^17 drones, where its whole-rollout kernel stops winning) and form 1 elsewhere.  Same arithmetic:
+    drones and 8 steps on and form 1 elsewhere.  Same arithmetic:
     the two forms agree to rounding and both match the oracle; a call in form 2 continues a call in form 1 (t accumulates step by step)."""
     torch = mds.torch
     E, D, T = 1024, 8, 120                       # 8 192 drones: the lower edge of the auto window; 120 = 50 + 50 + 20 steps
@@ -569,11 +569,11 @@ def test_rollout_launch_form_policy_and_equivalence(mds, dtype, tol):
     with pytest.raises(Exception):
         env.set_rollout_form(3)
     env.close()
-    # a quarter of a million drones: fp32 keeps the state in registers (form 2), float64 streams it (form 1)
+    # a quarter of a million drones: the state stays in registers (form 2) whatever the precision
     Eb = 32768
     xb, rb, Pb = H.c2_setup(Eb, D, phase="c3")
     env = make_env(mds, Eb, D, xb, rb, dtype)
-    assert env.rollout_form_for(20) == (2 if dtype == "float32" else 1) and env.rollout_form_for(7) == 1
+    assert env.rollout_form_for(20) == 2 and env.rollout_form_for(7) == 1
     env.close()
 
 
