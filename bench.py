@@ -1023,20 +1023,22 @@ def main(argv=None):
         line["config"]["launch"] = (f"C rollout loop (mds_rollout_geometric) in launch form 2 -- the library's own choice (mds_set_rollout_form 0) from 8 192 drones and "
                                     f"8 steps on: the whole-rollout kernel, <= {form_chunk} control steps per launch, the state in registers between them, every "
                                     "step's observation written; `per_step` carries launch form 1 (one launch per control step) in the same run")
-        line["roofline"]["kernel"] = f"k_rollout_geometric<{cname},{tname},{'true' if rk4 else 'false'},false,0> ({form_chunk} control steps per launch)"
+        line["roofline"]["kernel"] = (f"k_rollout_geometric<{cname},{tname},{'true' if rk4 else 'false'},false,0> ({min(form_chunk, args.steps)} control steps per launch"
+                                      + (f"; {form_chunk} in calls of {form_chunk} steps and more)" if args.steps < form_chunk else ")"))
         line["roofline"]["bytes_per_drone_step"] = bytes_per
         line["roofline"]["steps_per_launch"] = min(form_chunk, args.steps)
         line["roofline"]["us_per_launch"] = us_per_step * min(form_chunk, args.steps)
         line["roofline"]["bytes_per_launch"] = bytes_per * n_local * min(form_chunk, args.steps)
         line["roofline"]["note"] = ("algorithmic bytes of this form: the 20-value observation row per drone-step + state (read, written) and trajectory parameters once "
                                     "per launch -- SURVEY 8d's 212 B per drone-step count the state through HBM twice per step, which this form does not do.  The "
-                                    "kernel is VALU-bound (~1 000 VALU instructions per drone-step at ~0.85 of the issue rate, DESIGN.md section 4); `frac` says how far "
-                                    "from the HBM roofline that leaves it")
+                                    "kernel is VALU-issue bound (~730 VALU wave-instructions per drone-step, `valu`; DESIGN.md section 4); `frac` says how far from the HBM "
+                                    "roofline that leaves it")
         line["roofline"]["residency"] = (f"cache-assisted: the step's {bytes_per * n_local / 1e6:.3g} MB are the observation rows, written to the SAME [n, 20] array every step (as the "
                                          "step-by-step loop does) with default-policy stores, so a rewritten line that is still in the XCD's L2 / the Infinity Cache never "
                                          "travels: `traffic` (L2 -> fabric bytes per launch, PMC) is about a quarter of the algorithmic bytes; `frac` is an effective "
                                          "bandwidth fraction, not an HBM one.  `fused_rollout` is the same kernel with every step's rows going to their own slot of a "
-                                         "[50, n, 20] log (non-temporal stores, traffic = algorithmic)")
+                                         "[50, n, 20] log (non-temporal stores, traffic = algorithmic)"
+                                         + ("; `frac_hbm_resident` is this kernel on a 4 M-drone shard, whose 335 MB of rows per step do not fit the caches" if args.workload == "c3" else ""))
         if args.dtype == "float32" and not rk4 and args.workload in ("c3", "c3big"):
             # (the committed counters are per launch of 50 steps -- the long runs -- and of 20 steps -- the driver's command)
             tr, src = _pmc_traffic(f"r04_pmc_traffic_c3_form2_L{min(form_chunk, args.steps)}.json", n_local)
@@ -1312,7 +1314,8 @@ def main(argv=None):
                 gb = BYTES_PER_DRONE_STEP * EB * DB / (us * 1e-6) / 1e9
                 nl = EB * DB // 2 if used == 2 else EB * DB
                 tr, src = _pmc_traffic("r02_pmc_traffic_c3big.json", nl)
-                line["roofline"]["frac_hbm_resident"] = gb / HBM_PEAK_GBPS
+                f2_frac = (20 * 4 + 33 * 4 / 50) * EB * DB / (us_f2 * 1e-6) / 1e9 / HBM_PEAK_GBPS
+                line["roofline"]["frac_hbm_resident"] = f2_frac if form_used == 2 else gb / HBM_PEAK_GBPS    # the headline's kernel on the 4 M-drone shard
                 line["roofline"]["hbm_resident"] = {"workload": WORKLOADS["c3big"][3], "drones": EB * DB, "steps": 50, "us_per_step": us,
                                                     "value": EB * DB / (us * 1e-6), "achieved": gb, "unit": "GB/s", "frac": gb / HBM_PEAK_GBPS,
                                                     "frac_of_achievable_6300": gb / 6300.0, "bytes_per_step": BYTES_PER_DRONE_STEP * EB * DB,
