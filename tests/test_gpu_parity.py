@@ -539,6 +539,16 @@ def test_rollout_launch_form_policy_and_equivalence(mds, dtype, tol):
     for a, b in zip(outs[0], outs[1]):
         assert np.isfinite(a).all()
         np.testing.assert_allclose(a[..., :16] if a.shape[-1] == 20 else a, b[..., :16] if b.shape[-1] == 20 else b, atol=tol)
+    # form 2 rewrites ONE [n, 20] array step after step (default-policy stores); the same kernel writing every step's rows to their own slot of a
+    # [T, n, 20] log (non-temporal stores) must leave, bit for bit, the same last rows and the same state
+    env = make_env(mds, E, D, xyz, rpy, dtype)
+    env.set_trajectories(P)
+    env.step(torch.zeros((E, D, 4), dtype=env.dtype, device=env.device))
+    last, log = env.rollout_geometric_fused(0.0, T, log=True)
+    np.testing.assert_array_equal(log[-1].double().cpu().numpy(), outs[0][0])
+    np.testing.assert_array_equal(last.double().cpu().numpy(), outs[0][0])
+    assert np.abs(log[T // 2].double().cpu().numpy() - outs[0][0]).max() > 1e-3          # (the log's slots are different steps)
+    env.close()
     np.testing.assert_allclose(outs[0][0][..., 16:], outs[1][0][..., 16:], rtol=max(tol, 1e-9))
     idx = np.arange(0, E, 16)
     oobs, _ = H.oracle_closed_loop(xyz[idx], rpy[idx], P[idx], T)
