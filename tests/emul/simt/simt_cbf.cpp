@@ -128,11 +128,12 @@ template <typename T> static int run_rollout(const In& in, FILE* out) {
 #endif
   constexpr int NW = SIMT_NW;                                    // wavefronts per workgroup (1: 64 threads own 64 / Dp whole envs; the TSan build runs 2)
   const int Dp = D <= 4 ? 4 : (D <= 8 ? 8 : 16), envs_per_wg = 64 * NW / Dp, grid = (E + envs_per_wg - 1) / envs_per_wg;
-  // launches of 7 steps (a ragged last one), the observation ring of 3 slots carried across them -- as mds_rollout_cbf_geometric_fused does
+  // launches of 7 steps (4 in runs of <= 5; a ragged last one), the observation ring of 3 slots carried across them -- as mds_rollout_cbf_geometric_fused does
   double t = t0;
   int slot = 0;
-  for (int k0 = 0; k0 < steps; k0 += 7) {
-    const int ks = steps - k0 < 7 ? steps - k0 : 7;
+  const int per_launch = steps <= 5 ? 4 : 7;                   // (short runs still cross a launch boundary)
+  for (int k0 = 0; k0 < steps; k0 += per_launch) {
+    const int ks = steps - k0 < per_launch ? steps - k0 : per_launch;
     ra.t = t; ra.n_steps = ks; ra.slot = slot; ra.status_log = slog.data() + (size_t)k0 * E;
     if (D == Dp) simt::launch((unsigned)grid, 64 * NW, &ra, [&]() { k_cbf_rollout<T, 0, false, NW, false>(ra); });     // (as the library dispatches)
     else simt::launch((unsigned)grid, 64 * NW, &ra, [&]() { k_cbf_rollout<T, 0, false, NW, true>(ra); });

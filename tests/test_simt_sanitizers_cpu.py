@@ -98,7 +98,7 @@ def test_qp_filter_kernel_order3_under_asan_ubsan(built, D, dtype, E, tol):
     assert n_act >= 1
 
 
-@pytest.mark.parametrize("D,E,steps,dtype,tol", [(16, 5, 8, "float64", 1e-9), (7, 9, 8, "float32", 1e-5), (2, 3, 8, "float64", 1e-9), (4, 5, 6, "float32", 1e-5)])
+@pytest.mark.parametrize("D,E,steps,dtype,tol", [(16, 5, 5, "float64", 1e-9), (7, 9, 8, "float32", 1e-5), (2, 3, 8, "float64", 1e-9), (4, 5, 6, "float32", 1e-5)])
 def test_persistent_rollout_kernel_under_asan_ubsan(built, D, E, steps, dtype, tol):
     """k_cbf_rollout<T, 0, false, 1>: the whole persistent kernel, one wavefront per workgroup (64 / Dp envs each, a partial last workgroup),
     launches of 7 steps with a 3-slot observation ring -- per-drone bounds in stage A, the row-slot table, the ticket loop, the solver in
@@ -144,7 +144,7 @@ def test_order3_persistent_rollout_kernel_under_asan_ubsan(built, D, E, steps, d
     assert np.abs(obs[..., :16] - ref[..., :16]).max() < tol and its > 0
 
 
-@pytest.mark.parametrize("D,E,steps,dtype,tol", [(16, 8, 6, "float64", 1e-9), (8, 16, 5, "float32", 1e-5)])
+@pytest.mark.parametrize("D,E,steps,dtype,tol", [(16, 8, 5, "float64", 1e-9), (8, 16, 5, "float32", 1e-5)])
 def test_persistent_rollout_kernel_under_thread_sanitizer(D, E, steps, dtype, tol):
     """k_cbf_rollout<T, 0, false, 2, false> under ThreadSanitizer, TWO wavefronts per workgroup: every LDS hand-off between lanes and
     between waves (obstacle table -> stage A, records / bounds -> stage B, tickets, the solver's scratch, QP results -> stage C, observation
