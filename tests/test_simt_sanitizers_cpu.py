@@ -218,7 +218,7 @@ def _headline_case(E, D, steps, yaw_rate=0.3):
 HEADLINE_TOL = {"float64": 1e-11, "float32": 2e-5, "float32c": 2e-5, "float16": 2e-2}
 
 
-@pytest.mark.parametrize("dtype,form", [(d, f) for f in (0, 1) for d in ("float64", "float32", "float16", "float32c")] + [("float32", 4), ("float64", 4)])
+@pytest.mark.parametrize("dtype,form", [(d, f) for f in (0, 1) for d in ("float64", "float32", "float16", "float32c")] + [("float32", 4), ("float64", 4), ("float16", 4)])
 def test_headline_geometric_kernels_under_asan_ubsan(built, dtype, form):
     """k_step_geometric (two half-shard launches per control step, as the library's form 1) and k_rollout_geometric (launches of 7 steps,
     log ring + obs_last: form 2) on 256-thread workgroups, 37 envs x 8 drones = one full workgroup and one of 40 drones (a partial
